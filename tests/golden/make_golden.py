@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING THE REFERENCE (build container only).
+
+Run from the repo root:   python tests/golden/make_golden.py
+Needs /root/reference (read-only mount); nothing else in the repo reads it.  The
+reference modules are imported under a stub parent package:
+`scldm.layers`, `scldm.nnets`, `scldm.stochastic_layers`, `scldm.vae`,
+`scldm.transport` depend only on torch/numpy once `scvi.distributions.NegativeBinomial`
+and `torchdiffeq.odeint` exist as import-time stubs.
+
+Only DATA is written (inputs, expected outputs, state_dict key/shape lists) to
+tests/golden/*.npz.  Weights are NOT stored: both sides rebuild them from
+`oracle.weights.make_state_dict(shapes, seed)`.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SCLDM_REFERENCE", "/root/reference/src/scldm")
+
+
+def _install_stubs():
+    pkg = types.ModuleType("scldm")
+    pkg.__path__ = [REF]
+    sys.modules["scldm"] = pkg
+    scvi = types.ModuleType("scvi")
+    scvid = types.ModuleType("scvi.distributions")
+
+    class NegativeBinomial:  # plain holder; the reference only constructs it (vae.py:87)
+        def __init__(self, mu, theta):
+            self.mu, self.theta = mu, theta
+
+    scvid.NegativeBinomial = NegativeBinomial
+    scvi.distributions = scvid
+    sys.modules["scvi"] = scvi
+    sys.modules["scvi.distributions"] = scvid
+    td = types.ModuleType("torchdiffeq")
+    td.odeint = None  # never called: fixed-step parity is unpinned (see oracle/transport.py)
+    sys.modules["torchdiffeq"] = td
+
+
+_install_stubs()
+from scldm.layers import InputTransformerVAE  # noqa: E402
+from scldm.nnets import Decoder, DiT, Encoder  # noqa: E402
+from scldm.stochastic_layers import NegativeBinomialTransformerLayer  # noqa: E402
+from scldm.transport import create_transport  # noqa: E402
+from scldm.vae import TransformerVAE  # noqa: E402
+
+from oracle.weights import make_state_dict, shapes_of  # noqa: E402
+
+DIT_CASES = {
+    # name: (kwargs, batch, seed)
+    "dit_tiny": (dict(n_embed=64, n_embed_input=16, n_layer=2, n_head=4, seq_len=16, class_vocab_sizes={"a": 5},
+                      condition_strategy="mutually_exclusive"), 4, 101),
+    "dit_base": (dict(n_embed=256, n_embed_input=16, n_layer=8, n_head=8, seq_len=16,
+                      class_vocab_sizes={"clusters": 14}, condition_strategy="mutually_exclusive"), 2, 102),
+    "dit_joint": (dict(n_embed=256, n_embed_input=16, n_layer=8, n_head=8, seq_len=16,
+                       class_vocab_sizes={"cell_type": 18, "cytokine": 91}, condition_strategy="joint"), 2, 103),
+    "dit_me2": (dict(n_embed=64, n_embed_input=16, n_layer=2, n_head=4, seq_len=16,
+                     class_vocab_sizes={"a": 5, "b": 7}, condition_strategy="mutually_exclusive"), 3, 104),
+}
+COMMON = dict(dropout=0.0, bias=True, norm_layer="layernorm", multiple_of=4, layernorm_eps=1e-8, cfg_dropout_prob=0.8)
+
+
+def build_dit(kwargs, seed):
+    m = DiT(**kwargs, **COMMON)
+    shapes = shapes_of(m)
+    m.load_state_dict(make_state_dict(shapes, seed), strict=True)
+    m.eval()
+    return m, shapes
+
+
+def gen_dit(name, kwargs, B, seed):
+    m, shapes = build_dit(kwargs, seed)
+    rng = np.random.default_rng(seed + 1000)
+    S, C = kwargs["seq_len"], kwargs["n_embed_input"]
+    out = {"shapes_json": np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+           "kwargs_json": np.array(json.dumps({**kwargs, **COMMON})), "seed": np.array(seed)}
+    # ---- plain forward with per-sample t and labels (single-class dicts for mutually_exclusive) ----
+    x = rng.standard_normal((B, S, C)).astype(np.float32)
+    t = rng.uniform(0, 1, (B,)).astype(np.float32)
+    labels = {k: rng.integers(0, v, (B,)).astype(np.int64) for k, v in kwargs["class_vocab_sizes"].items()}
+    out["fwd_x"], out["fwd_t"] = x, t
+    for k, v in labels.items():
+        out[f"fwd_label_{k}"] = v
+    taps = {}
+    blk = m.blocks[0]
+    hooks = [
+        blk.attn.register_forward_hook(lambda mod, i, o: taps.__setitem__("block0.attn_out", o.detach().numpy().copy())),
+        blk.attn.register_forward_pre_hook(lambda mod, i: taps.__setitem__("block0.mod1", i[0].detach().numpy().copy())),
+        blk.mlp.register_forward_pre_hook(lambda mod, i: taps.__setitem__("block0.mod2", i[0].detach().numpy().copy())),
+        blk.mlp.register_forward_hook(lambda mod, i, o: taps.__setitem__("block0.mlp_out", o.detach().numpy().copy())),
+        blk.register_forward_hook(lambda mod, i, o: taps.__setitem__("block0.out", o.detach().numpy().copy())),
+    ]
+    names = sorted(kwargs["class_vocab_sizes"])
+    with torch.no_grad():
+        if kwargs["condition_strategy"] == "joint":
+            cond = {k: torch.from_numpy(v) for k, v in labels.items()}
+        else:
+            cond = {names[0]: torch.from_numpy(labels[names[0]])}  # one available class -> deterministic (nnets.py:395)
+        y = m(torch.from_numpy(x), torch.from_numpy(t), cond, force_drop_ids=False)
+    for h in hooks:
+        h.remove()
+    out["fwd_out"] = y.numpy()
+    out["fwd_classes"] = np.array(json.dumps(sorted(cond.keys())))
+    for k, v in taps.items():
+        out[f"tap_{k}"] = v
+    # ---- forward_with_cfg on a doubled batch, scalar-broadcast t (integrators.py:103-104) ----
+    z = rng.standard_normal((B, S, C)).astype(np.float32)
+    x2 = np.concatenate([z, z], 0)
+    t2 = np.full((2 * B,), 0.37, np.float32)
+    lab2 = {k: np.concatenate([v, v]) for k, v in labels.items()}
+    out["cfg_x"], out["cfg_t"] = x2, t2
+    for k, v in lab2.items():
+        out[f"cfg_label_{k}"] = v
+    for tag, scales in (("s1", {k: 1.0 for k in names}), ("s2", {k: 2.0 - 0.5 * i for i, k in enumerate(names)})):
+        with torch.no_grad():
+            y = m.forward_with_cfg(torch.from_numpy(x2), torch.from_numpy(t2),
+                                   condition={k: torch.from_numpy(v) for k, v in lab2.items()}, cfg_scale=scales)
+        out[f"cfg_out_{tag}"] = y.numpy()
+        out[f"cfg_scales_{tag}"] = np.array(json.dumps(scales))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, "fwd |y|max", float(np.abs(out["fwd_out"]).max()), "cfg |y|max", float(np.abs(out["cfg_out_s2"]).max()))
+    return m
+
+
+def gen_transport(m, kwargs, seed):
+    """Transport.training_losses (Linear/velocity) with x0, t injected."""
+    tr = create_transport(path_type="Linear", prediction="velocity", loss_weight="velocity", train_eps=1e-5, sample_eps=1e-5)
+    assert tr.train_eps == 0 and tr.sample_eps == 0
+    rng = np.random.default_rng(seed + 2000)
+    B, S, C = 3, kwargs["seq_len"], kwargs["n_embed_input"]
+    x1 = rng.standard_normal((B, S, C)).astype(np.float32)
+    x0 = rng.standard_normal((B, S, C)).astype(np.float32)
+    t = rng.uniform(0, 1, (B,)).astype(np.float32)
+    lab = rng.integers(0, 5, (B,)).astype(np.int64)
+    tr.sample = lambda x1_: (torch.from_numpy(t), torch.from_numpy(x0), x1_)  # replaces the RNG draws (transport.py:97-108)
+    with torch.no_grad():
+        terms = tr.training_losses(lambda xt, tt, **kw: m(xt, tt, kw["condition"], force_drop_ids=False),
+                                   torch.from_numpy(x1), {"condition": {"a": torch.from_numpy(lab)}})
+    np.savez_compressed(os.path.join(HERE, "transport_tiny.npz"), x1=x1, x0=x0, t=t, label_a=lab,
+                        pred=terms["pred"].numpy(), loss=terms["loss"].numpy())
+    print("transport loss", terms["loss"].numpy())
+
+
+VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
+
+
+def gen_vae(name, n_genes, G, S, B, seed):
+    enc = Encoder(n_layer=8, n_inducing_points=16, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, dropout=0.0,
+                  bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", positional_encoding=True)
+    dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, n_inducing_points=16,
+                  dropout=0.0, bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
+                  use_adaln=False)
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm",
+                                            layernorm_eps=1e-8)
+    inp = InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p")
+    vae = TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=inp)
+    shapes = shapes_of(vae)
+    vae.load_state_dict(make_state_dict(shapes, seed), strict=True)
+    vae.eval()
+    rng = np.random.default_rng(seed + 1000)
+    genes = np.stack([rng.permutation(n_genes)[:G] for _ in range(B)]).astype(np.int64)
+    counts = rng.poisson(0.7, (B, G)).astype(np.float32)
+    sub = np.stack([np.sort(rng.permutation(G)[:S]) for _ in range(B)])
+    genes_subset = np.take_along_axis(genes, sub, 1)
+    counts_subset = np.take_along_axis(counts, sub, 1)
+    lib = counts.sum(1, keepdims=True).astype(np.float32) + 1.0
+    with torch.no_grad():
+        z = vae.encode(torch.from_numpy(counts), torch.from_numpy(genes), torch.from_numpy(counts_subset),
+                       torch.from_numpy(genes_subset))
+        nb = vae.decode(z, torch.from_numpy(genes), torch.from_numpy(lib))
+        zrand = torch.from_numpy(rng.standard_normal((B, 16, 16)).astype(np.float32))
+        nb2 = vae.decode(zrand, torch.from_numpy(genes), torch.from_numpy(lib))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"),
+                        shapes_json=np.array(json.dumps({k: list(v) for k, v in shapes.items()})), seed=np.array(seed),
+                        n_genes=np.array(n_genes), genes=genes, counts=counts, genes_subset=genes_subset,
+                        counts_subset=counts_subset, library_size=lib, z=z.numpy(), mu=nb.mu.numpy(), theta=nb.theta.numpy(),
+                        zrand=zrand.numpy(), mu_rand=nb2.mu.numpy())
+    print(name, "z absmax", float(z.abs().max()), "mu rowsum", nb.mu.sum(1).numpy(), "lib", lib[:, 0])
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    models = {}
+    for name, (kw, B, seed) in DIT_CASES.items():
+        models[name] = gen_dit(name, kw, B, seed)
+    gen_transport(models["dit_tiny"], DIT_CASES["dit_tiny"][0], 101)
+    for name, (kw, G, S, B, seed) in VAE_CASES.items():
+        gen_vae(name, kw["n_genes"], G, S, B, seed)
