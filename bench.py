@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py - cells/sec of CFG flow-matching sampling with the MI355X DiT path (one JSON line on rank 0).
+
+step     = one full sampling pass of the per-GPU batch: noise (already resident in HBM) -> final guided latents,
+           n_evals DiT-with-CFG evaluations (3 sample-forwards per requested cell per evaluation), fused in one
+           C call (scldm_sample_ode); for N > 1 followed by the single RCCL all-gather of the generated latents.
+value    = whole-job requested cells per second = N * B_per_gpu / (time per step), max over ranks.
+roofline = the fused DiT block kernel (dominant): algorithmic FLOPs per launch / mean launch duration measured
+           with HIP events on the launch stream inside the timed region, against the dense MFMA peak.
+cpu_baseline = the CPU oracle ("port" of the reference algorithm) on this box's host cores, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # north_star target row: dentate_gyrus shape, batch 4096 x 100 Euler evaluations on one MI355X, bf16
+    "dentate_b4096_euler100": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=4096, evals=100, method="euler", scale=1.0),
+    # BASELINE.json configs[1]
+    "dentate_b512_euler50": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=512, evals=50, method="euler", scale=1.0),
+    # configs[2]: 100 Heun steps = 200 evaluations, guidance 2.0
+    "hlca_b2048_heun100": dict(vocab={"cell_type": 50}, strategy="mutually_exclusive", B=2048, evals=200, method="heun", scale=2.0),
+    # configs[3]: 8192 cells over 8 GPUs = 1024 per GPU, joint conditioning
+    "parse1m_b1024_euler100": dict(vocab={"cell_type": 18, "cytokine": 91}, strategy="joint", B=1024, evals=100, method="euler", scale=1.0),
+}
+FLOPS_PER_SAMPLE_FWD = 210_763_776
+FLOPS_PER_SAMPLE_BLOCK = 26_247_168 - 2 * 256 * 1536  # fused block kernel: everything of a block except the adaLN projection
+PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md:41-42
+
+
+def make_model(wl, precision, device, seed=0):
+    from scldm_amd.nnets import DiT
+    m = DiT(n_embed=256, n_embed_input=16, n_layer=8, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+            multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes=wl["vocab"], cfg_dropout_prob=0.8,
+            condition_strategy=wl["strategy"])
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():  # random-init weights of the reference architecture (no checkpoints offline);
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)  # adaLN-Zero init would make the network output zeros
+    m = m.to(device).eval()
+    m.precision = precision
+    return m
+
+
+def make_inputs(wl, B, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    z0 = torch.randn(B, 16, 16, generator=g)
+    labels = {k: torch.randint(0, v, (B,), generator=g) for k, v in wl["vocab"].items()}
+    z2 = torch.cat([z0, z0]).to(device)
+    cond2 = {k: torch.cat([v, v]).to(device) for k, v in labels.items()}
+    scales = {k: wl["scale"] for k in wl["vocab"]}
+    return z2, cond2, scales
+
+
+def n_passes(wl):
+    return 1 if wl["strategy"] == "joint" else len(wl["vocab"])
+
+
+def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world):
+    out = None
+    for _ in range(steps):
+        out = m.sample_ode_cfg(z2, cond2, scales, wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1, wl["method"])
+        if dist_on:
+            import torch.distributed as dist
+            gathered = torch.empty((world,) + tuple(out.shape), device=out.device, dtype=out.dtype)
+            dist.all_gather_into_tensor(gathered, out)
+            out = gathered
+    return out
+
+
+def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_blocks):
+    z2, cond2, scales = make_inputs(wl, wl["B"], device, seed=1234 + rank)
+    run_steps(m, wl, z2, cond2, scales, warmup, dist_on, world)
+    if time_blocks:
+        m.block_timing(True)
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(m, wl, z2, cond2, scales, steps, dist_on, world)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    blocks = m.block_timing() if time_blocks else None
+    if time_blocks:
+        m.block_timing(False)
+    if dist_on:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, blocks
+
+
+def cpu_baseline(m, wl, budget_cells=128, evals=2):
+    """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on this
+    box's host cores over a bounded sample: `budget_cells` cells x `evals` Euler evaluations with CFG."""
+    from oracle.dit import DiTConfig, dit_forward_with_cfg
+    from oracle.transport import sample_ode_fixed
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = DiTConfig(class_vocab_sizes=wl["vocab"], condition_strategy=wl["strategy"])
+    z2, cond2, scales = make_inputs(wl, budget_cells, "cpu", seed=99)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    f = lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales)
+    sample_ode_fixed(z2[:8].repeat(1, 1, 1), lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, {k: v[:8] for k, v in cond2.items()}, scales), 2, "euler")
+    t0 = time.perf_counter()
+    sample_ode_fixed(z2, f, evals + 1, "euler")
+    dt = time.perf_counter() - t0
+    per_eval = dt / evals
+    n_evals_full = wl["evals"]
+    return {"value": budget_cells / (per_eval * n_evals_full), "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{budget_cells} cells x {evals} of {n_evals_full} CFG evaluations (fp32, torch CPU ops), per-evaluation time "
+                      f"{per_eval:.3f}s scaled to {n_evals_full} evaluations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short extra-workload measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    m = make_model(wl, args.precision, device)
+    dt, blocks = time_workload(m, wl, device, args.steps, args.warmup, dist_on, world, rank, time_blocks=True)
+    ms_per_step = 1e3 * dt / args.steps
+    cells = world * wl["B"]
+    value = cells / (dt / args.steps)
+    n_fwd = (2 + n_passes(wl)) * wl["B"]
+    evals = wl["evals"]
+    dit_flops_step = n_fwd * FLOPS_PER_SAMPLE_FWD * evals
+    result = {
+        "metric": "cells/sec (whole node) @100 Euler steps; DiT-fwd MFMA util % of peak",
+        "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": cells, "cfg_evaluations": evals,
+                   "method": wl["method"], "guidance_scale": wl["scale"], "condition_strategy": wl["strategy"],
+                   "class_vocab_sizes": wl["vocab"], "sample_forwards_per_evaluation_per_gpu": n_fwd,
+                   "parallelism": f"batch-sharded x{world}, one all-gather of latents" if dist_on else "single GPU"},
+        "dit_fwd_tflops_per_gpu": dit_flops_step / (dt / args.steps) / 1e12,
+        "dit_fwd_mfma_frac": dit_flops_step / (dt / args.steps) / PEAK[args.precision],
+    }
+    if blocks and blocks[0] > 0:
+        n_launch, tot_ms = blocks
+        avg_s = tot_ms / n_launch / 1e3
+        ach = n_fwd * FLOPS_PER_SAMPLE_BLOCK / avg_s / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "dit_block_kernel", "achieved": ach, "peak": PEAK[args.precision] / 1e12,
+                              "unit": "TFLOP/s", "frac": ach / (PEAK[args.precision] / 1e12), "traffic": None,
+                              "launches": n_launch, "avg_launch_us": avg_s * 1e6,
+                              "algorithmic_flops_per_launch": n_fwd * FLOPS_PER_SAMPLE_BLOCK}
+    if rank == 0 and not dist_on:
+        if not args.no_extra:
+            extra = []
+            for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100"):
+                if name == args.workload:
+                    continue
+                w2 = dict(WORKLOADS[name])
+                m2 = make_model(w2, args.precision, device)
+                d2, _ = time_workload(m2, w2, device, 1, 1, False, 1, 0, time_blocks=False)
+                nf2 = (2 + n_passes(w2)) * w2["B"]
+                extra.append({"workload": name, "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2,
+                              "dit_fwd_mfma_frac": nf2 * FLOPS_PER_SAMPLE_FWD * w2["evals"] / d2 / PEAK[args.precision]})
+                del m2
+            result["other_workloads"] = extra
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(m, wl)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

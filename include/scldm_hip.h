@@ -1,0 +1,142 @@
+/*
+ * scldm_hip.h - C ABI of libscldm_hip.so: the MI355X (gfx950) implementation of the scLDM
+ * latent-diffusion hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (czi-ai/scldm) has no FFI: its seam is Hydra `_target_` instantiation of
+ * nn.Modules.  Each entry point below therefore cites the reference
+ * Python method it replaces; the ctypes binding a maintainer would add is shown in INTEGRATION.md
+ * and implemented in scldm_amd/_lib.py.
+ *
+ * Conventions
+ *  - every pointer named `d_*` or documented "device" is a device (HBM) pointer; tensors are
+ *    contiguous, row-major, fp32 unless stated; labels are int64 (torch.long);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it;
+ *  - no hidden allocation in hot calls: the caller provides `ws` of at least
+ *    scldm_dit_workspace_bytes(...) bytes (256-byte aligned);
+ *  - return value: 0 on success, SCLDM_ERR_* (<0) otherwise; scldm_last_error() returns a
+ *    thread-local message;
+ *  - a handle belongs to one device and one host thread at a time.
+ */
+#ifndef SCLDM_HIP_H
+#define SCLDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCLDM_OK 0
+#define SCLDM_ERR_SHAPE (-1)   /* unsupported / inconsistent shape or argument */
+#define SCLDM_ERR_HIP (-2)     /* HIP runtime error (text in scldm_last_error) */
+#define SCLDM_ERR_STATE (-3)   /* e.g. weights not loaded */
+
+#define SCLDM_MAX_CLASSES 8
+
+#define SCLDM_PREC_FP32 0  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): parity path, <=1e-4 vs reference */
+#define SCLDM_PREC_BF16 1  /* bf16 operands, fp32 accumulate / LN / softmax / residual: throughput path */
+
+#define SCLDM_METHOD_EULER 0
+#define SCLDM_METHOD_HEUN 1
+
+typedef struct scldm_dit scldm_dit;
+
+/* Mirror of scldm.nnets.DiT.__init__ kwargs (reference src/scldm/nnets.py:219-234).
+ * Classes are listed in SORTED NAME ORDER (the reference iterates sorted(class_vocab_sizes), :393,:404,:438). */
+typedef struct {
+  int n_embed;        /* 256 (only supported value this round) */
+  int n_embed_input;  /* latent channels, <= 64 */
+  int n_layer;
+  int n_head;         /* 8 (head_dim 32) */
+  int seq_len;        /* 16 */
+  int hidden_dim;     /* SwiGLU hidden (684 for n_embed 256, multiple_of 4), layers.py:165-167 */
+  float layernorm_eps;
+  int n_classes;
+  int class_vocab[SCLDM_MAX_CLASSES]; /* vocab size per class; the null token index equals it */
+} scldm_dit_config;
+
+/* Device pointers to the reference's parameters in their PyTorch layouts (Linear.weight is (out,in)).
+ * state_dict keys: SURVEY.md section 8b.  Per-layer arrays are HOST arrays of n_layer device pointers. */
+typedef struct {
+  const float* pos_embed;                 /* pos_embed (1,S,D) */
+  const float* t_w0; const float* t_b0;   /* t_embedder.mlp.0 (D,256),(D) */
+  const float* t_w2; const float* t_b2;   /* t_embedder.mlp.2 (D,D),(D) */
+  const float* in_w; const float* in_b;   /* input_proj (D,Din),(D) */
+  const float* fin_w; const float* fin_b; /* final_layer.linear (Din,D),(Din) */
+  const float* fin_ada_w; const float* fin_ada_b; /* final_layer.adaln_modulation.1 (2D,D),(2D) */
+  const float* const* class_emb;          /* n_classes x class_embeddings.<name>.weight (vocab+1,D), sorted-name order */
+  const float* const* attn_w; const float* const* attn_b;   /* blocks.i.attn.c_attn (3D,D),(3D) */
+  const float* const* proj_w; const float* const* proj_b;   /* blocks.i.attn.c_proj (D,D),(D) */
+  const float* const* w1; const float* const* w2;           /* blocks.i.mlp.w1/w2 (H,D) */
+  const float* const* cproj;                                /* blocks.i.mlp.c_proj (D,H) */
+  const float* const* ada_w; const float* const* ada_b;     /* blocks.i.adaln_modulation.1 (6D,D),(6D) */
+} scldm_dit_weights;
+
+const char* scldm_last_error(void);
+int scldm_version(void);
+
+int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out);
+void scldm_dit_destroy(scldm_dit* h);
+
+/* Re-pack weights from the caller's parameter tensors into MFMA fragment streams (fp32 and bf16
+ * copies).  Call again after an optimiser step.  Sources stay owned by the caller. */
+int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream);
+
+/* Floats per conditioning row: n_layer*6*D + 2*D (all adaLN vectors of all layers + final layer). */
+int scldm_dit_mod_width(const scldm_dit* h);
+
+/* Workspace bytes for calls that process up to n_fwd sample-forwards, n_rows conditioning rows and
+ * an ODE state of n_state samples (0 when not sampling). */
+size_t scldm_dit_workspace_bytes(const scldm_dit* h, int n_fwd, int n_rows, int n_state);
+
+/* Conditioning rows: c = TimestepEmbedder(t) + sum_classes Embedding(label or null), then
+ * SiLU(c) W_adaLN^T + b for every block and the final layer in one pass.
+ * Replaces layers.py:351-364, nnets.py:283-288,380-456 and the nine adaln_modulation Linears
+ * (layers.py:206,214-216,395,398).  t: device (n_rows) with t_stride 1, or one device float with
+ * t_stride 0.  labels[c]: device (n_rows) int64, or NULL => class c uses its null token.
+ * mod_out: device (n_rows, mod_width). */
+int scldm_dit_cond_rows(scldm_dit* h, const float* t, int t_stride, const int64_t* const* labels, int n_rows,
+                        float* mod_out, void* ws, void* stream);
+
+/* DiT trunk on prepared conditioning: input_proj + pos_embed, n_layer fused blocks, final layer
+ * (nnets.py:290-296).  Sample-forward s < n_direct reads latent x[s]; s >= n_direct re-reads the last
+ * `rep` latents (x[n_direct - rep + (s - n_direct) % rep]) - the conditional CFG passes.
+ * row_index[s] selects the conditioning row of `mod`.  out: device (n_fwd, S, Din). */
+int scldm_dit_forward_rows(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd, const float* mod,
+                           const int32_t* row_index, float* out, int precision, void* ws, void* stream);
+
+/* DiT.forward in eval mode (nnets.py:273-297): x (n,S,Din), t (n), labels[c] (n) or NULL. */
+int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, const int64_t* const* labels, float* out, int n,
+                      int precision, void* ws, void* stream);
+
+/* DiT.forward_with_cfg (nnets.py:336-378) in one call.  x, out: (2B,S,Din).  t: (2B) with t_stride 1 or a
+ * single device float with t_stride 0 (the ODE solver broadcasts one scalar, integrators.py:103-104).
+ * The unconditional pass covers all 2B rows; conditional pass p re-runs the second half with the classes
+ * in pass_mask[p] (bit c = class c keeps its labels, others null) and is blended with pass_scale[p]:
+ *   joint:              n_pass = 1, mask = all classes, scale = mean(cfg_scale)        (:364-369)
+ *   mutually_exclusive: one pass per cfg_scale entry, mask = that class, scale = its value (:372-376)
+ * Conditional labels are given for n_urows UNIQUE label rows (ulabels[c]: device (n_urows) int64) and
+ * cell_row (device (B) int32, or NULL when n_urows == B) maps each cell of the second half to its row.
+ * With t_stride 1 the rows must be per-cell (n_urows == B, cell_row NULL). */
+int scldm_dit_forward_cfg(scldm_dit* h, const float* x, const float* t, int t_stride, const int64_t* const* ulabels,
+                          int n_urows, const int32_t* cell_row, int B, int n_pass, const uint32_t* pass_mask,
+                          const float* pass_scale, float* out, int precision, void* ws, void* stream);
+
+/* Fixed-grid ODE sampling of dz/dt = forward_with_cfg(z, t) from t=0 to 1 (transport.py:324-369,
+ * integrators.py:100-112 with sampling_method euler|heun): t_i = i/n_steps, h = 1/n_steps;
+ * euler: one evaluation per step; heun: two (k1 at t_i, k2 at t_i+h).  z (2B,S,Din) is updated in place
+ * (first B rows unconditional, last B guided - models.py:801-812).  `n_steps` = reference num_steps - 1. */
+int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int n_urows, const int32_t* cell_row, int B,
+                     int n_pass, const uint32_t* pass_mask, const float* pass_scale, int n_steps, int method,
+                     int precision, void* ws, void* stream);
+
+/* Timing hook for bench.py: when enabled, every fused-block launch is bracketed by HIP events on its
+ * own stream; scldm_dit_block_timing drains them (synchronises) and returns launches and total ms. */
+void scldm_dit_block_timing_enable(scldm_dit* h, int enable);
+int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCLDM_HIP_H */

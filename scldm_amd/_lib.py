@@ -1,0 +1,92 @@
+"""ctypes binding of libscldm_hip.so (C ABI in include/scldm_hip.h).
+
+There is NO CPU fallback: importing the product without the built HIP library raises.
+Build it with `./build.sh` (hipcc --offload-arch=gfx950) or `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscldm_hip.so")
+
+MAX_CLASSES = 8
+PREC_FP32, PREC_BF16 = 0, 1
+METHOD_EULER, METHOD_HEUN = 0, 1
+PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16}
+METHODS = {"euler": METHOD_EULER, "heun": METHOD_HEUN}
+
+c_float_p = C.POINTER(C.c_float)
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("n_embed", C.c_int), ("n_embed_input", C.c_int), ("n_layer", C.c_int), ("n_head", C.c_int),
+                ("seq_len", C.c_int), ("hidden_dim", C.c_int), ("layernorm_eps", C.c_float), ("n_classes", C.c_int),
+                ("class_vocab", C.c_int * MAX_CLASSES)]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos_embed", "t_w0", "t_b0", "t_w2", "t_b2", "in_w", "in_b", "fin_w", "fin_b",
+                                          "fin_ada_w", "fin_ada_b")] + \
+               [(n, c_void_pp) for n in ("class_emb", "attn_w", "attn_b", "proj_w", "proj_b", "w1", "w2", "cproj", "ada_w", "ada_b")]
+
+
+class ScldmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build the HIP extension first (./build.sh). "
+                          "scldm_amd has no CPU fallback by design.")
+    L = C.CDLL(LIB_PATH)
+    L.scldm_last_error.restype = C.c_char_p
+    L.scldm_version.restype = C.c_int
+    L.scldm_dit_create.argtypes = [C.POINTER(DitConfig), C.POINTER(C.c_void_p)]
+    L.scldm_dit_destroy.argtypes = [C.c_void_p]
+    L.scldm_dit_destroy.restype = None
+    L.scldm_dit_load_weights.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p]
+    L.scldm_dit_mod_width.argtypes = [C.c_void_p]
+    L.scldm_dit_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.scldm_dit_workspace_bytes.restype = C.c_size_t
+    L.scldm_dit_cond_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, c_void_pp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.scldm_dit_forward_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_dit_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, c_void_pp, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p]
+    L.scldm_dit_forward_cfg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_void_pp, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.POINTER(C.c_uint32), c_float_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_sample_ode.argtypes = [C.c_void_p, C.c_void_p, c_void_pp, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                   C.POINTER(C.c_uint32), c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_dit_block_timing_enable.argtypes = [C.c_void_p, C.c_int]
+    L.scldm_dit_block_timing_enable.restype = None
+    L.scldm_dit_block_timing.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
+           "scldm_dit_mod_width", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
+           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
+           "scldm_dit_block_timing"]
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise ScldmError(f"{what} failed (code {rc}): {lib().scldm_last_error().decode()}")
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (None -> NULL)."""
+    arr = (C.c_void_p * max(len(ptrs), 1))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

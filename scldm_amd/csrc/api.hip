@@ -1,0 +1,507 @@
+// C ABI of libscldm_hip.so (see include/scldm_hip.h).  gfx950 only; no torch dependency.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/scldm_hip.h"
+#include "dit_aux.hpp"
+#include "dit_block.hpp"
+
+using namespace scldm;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(SCLDM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define LAUNCH_CHECK()                                                                             \
+  do {                                                                                             \
+    hipError_t e_ = hipGetLastError();                                                             \
+    if (e_ != hipSuccess) return fail(SCLDM_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 128-token tile
+
+struct LayerPack {
+  void* stream[2];  // [precision] packed weight stream of the layer (+ ring over-read slack)
+  float* b_qkv;
+  float* b_proj;
+};
+
+struct scldm_dit {
+  scldm_dit_config cfg;
+  int n_chunks;   // padded hidden / 128
+  int mod_w;
+  bool loaded;
+  std::vector<LayerPack> layers;
+  float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
+  float* emb;                      // concatenated class tables
+  int emb_row0[SCLDM_MAX_CLASSES];
+  float *ada_t, *ada_b;            // (256, mod_w), (mod_w)
+  float *in_wt, *in_b, *pos;       // (Din,256), (256), (16,256)
+  float *fin_w, *fin_b;            // (Din,256), (Din)
+  // timing hook
+  bool timing;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  int force_ntt;
+};
+
+extern "C" const char* scldm_last_error(void) { return g_err; }
+extern "C" int scldm_version(void) { return 1; }
+
+static size_t esize(int prec) { return prec == SCLDM_PREC_BF16 ? 2 : 4; }
+
+extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
+  if (!cfg || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (cfg->n_embed != 256 || cfg->n_head != 8 || cfg->seq_len != 16)
+    return fail(SCLDM_ERR_SHAPE, "fused DiT block supports n_embed=256, n_head=8, seq_len=16 (got %d,%d,%d)", cfg->n_embed,
+                cfg->n_head, cfg->seq_len);
+  if (cfg->n_embed_input < 1 || cfg->n_embed_input > 64) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be in [1,64]");
+  if (cfg->n_layer < 1 || cfg->hidden_dim < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / hidden_dim");
+  if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
+  scldm_dit* h = new scldm_dit();
+  h->cfg = *cfg;
+  h->n_chunks = (cfg->hidden_dim + kHC - 1) / kHC;
+  h->mod_w = cfg->n_layer * 6 * kD + 2 * kD;
+  h->loaded = false;
+  h->timing = false;
+  h->ev_used = 0;
+  h->force_ntt = 0;
+  if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
+  h->layers.resize(cfg->n_layer);
+  auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
+  const int L = cfg->n_layer, din = cfg->n_embed_input, nc = h->n_chunks;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < L && e == hipSuccess; ++i) {
+    LayerPack& lp = h->layers[i];
+    for (int p = 0; p < 2 && e == hipSuccess; ++p) {
+      const size_t es = esize(p);
+      const size_t elems = ((size_t)4 * units_per_wave(nc) + kMaxPF) * 1024;  // + slack for the ring's over-read
+      if ((e = alloc(&lp.stream[p], elems * es)) != hipSuccess) break;
+      if ((e = hipMemset(lp.stream[p], 0, elems * es)) != hipSuccess) break;
+    }
+    if (e == hipSuccess) e = alloc((void**)&lp.b_qkv, 768 * 4);
+    if (e == hipSuccess) e = alloc((void**)&lp.b_proj, 256 * 4);
+  }
+  int emb_rows = 0;
+  for (int c = 0; c < cfg->n_classes; ++c) {
+    h->emb_row0[c] = emb_rows;
+    emb_rows += cfg->class_vocab[c] + 1;
+  }
+  if (e == hipSuccess) e = alloc((void**)&h->w0t, 256 * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->b0, 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->w2t, 256 * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->b2, 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->emb, (size_t)(emb_rows > 0 ? emb_rows : 1) * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->ada_t, (size_t)256 * h->mod_w * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->ada_b, (size_t)h->mod_w * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->in_wt, (size_t)din * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->fin_w, (size_t)din * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
+  if (e != hipSuccess) {
+    int rc = fail(SCLDM_ERR_HIP, "hipMalloc failed in scldm_dit_create: %s", hipGetErrorString(e));
+    scldm_dit_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SCLDM_OK;
+}
+
+extern "C" void scldm_dit_destroy(scldm_dit* h) {
+  if (!h) return;
+  for (auto& lp : h->layers) {
+    for (int p = 0; p < 2; ++p) {
+      if (lp.stream[p]) (void)hipFree(lp.stream[p]);
+    }
+    if (lp.b_qkv) (void)hipFree(lp.b_qkv);
+    if (lp.b_proj) (void)hipFree(lp.b_proj);
+  }
+  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_b, h->pos, h->fin_w, h->fin_b};
+  for (float* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
+  delete h;
+}
+
+extern "C" int scldm_dit_mod_width(const scldm_dit* h) { return h ? h->mod_w : 0; }
+
+extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream_) {
+  if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_dit_config& c = h->cfg;
+  const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, nc = h->n_chunks, mw = h->mod_w;
+  const int T = 256;
+  for (int i = 0; i < L; ++i) {
+    LayerPack& lp = h->layers[i];
+    const long long npk = (long long)4 * units_per_wave(nc) * 1024;
+    pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
+                                                          (float*)lp.stream[0], H, nc);
+    pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
+                                                           (__bf16*)lp.stream[1], H, nc);
+    copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], lp.b_qkv, 768);
+    copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], lp.b_proj, 256);
+    // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
+    transpose_kernel<<<cdiv(1536 * 256, T), T, 0, st>>>(w->ada_w[i], h->ada_t, 1536, 256, mw, i * 1536);
+    copy_kernel<<<cdiv(1536, T), T, 0, st>>>(w->ada_b[i], h->ada_b + i * 1536, 1536);
+  }
+  transpose_kernel<<<cdiv(512 * 256, T), T, 0, st>>>(w->fin_ada_w, h->ada_t, 512, 256, mw, L * 1536);
+  copy_kernel<<<cdiv(512, T), T, 0, st>>>(w->fin_ada_b, h->ada_b + L * 1536, 512);
+  transpose_kernel<<<cdiv(256 * 256, T), T, 0, st>>>(w->t_w0, h->w0t, 256, 256, 256, 0);
+  transpose_kernel<<<cdiv(256 * 256, T), T, 0, st>>>(w->t_w2, h->w2t, 256, 256, 256, 0);
+  copy_kernel<<<1, T, 0, st>>>(w->t_b0, h->b0, 256);
+  copy_kernel<<<1, T, 0, st>>>(w->t_b2, h->b2, 256);
+  transpose_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_wt, 256, din, 256, 0);
+  copy_kernel<<<1, T, 0, st>>>(w->in_b, h->in_b, 256);
+  copy_kernel<<<cdiv(16 * 256, T), T, 0, st>>>(w->pos_embed, h->pos, 16 * 256);
+  copy_kernel<<<cdiv(din * 256, T), T, 0, st>>>(w->fin_w, h->fin_w, din * 256);
+  copy_kernel<<<1, T, 0, st>>>(w->fin_b, h->fin_b, din);
+  for (int ci = 0; ci < c.n_classes; ++ci) {
+    const int n = (c.class_vocab[ci] + 1) * 256;
+    copy_kernel<<<cdiv(n, T), T, 0, st>>>(w->class_emb[ci], h->emb + (size_t)h->emb_row0[ci] * 256, n);
+  }
+  LAUNCH_CHECK();
+  h->loaded = true;
+  return SCLDM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Ws {
+  float* h;       // (n_fwd*16, 256)
+  float* v;       // (n_fwd, 16*din)
+  float* mod;     // (n_rows, mod_w)
+  float* silu;    // (n_rows, 256)
+  int32_t* ridx;  // (n_fwd)
+  float* dz;      // (n_state, e)
+  float* k2;      // (n_state, e)
+  float* ztmp;    // (n_state, e)
+  size_t total;
+};
+static Ws carve(const scldm_dit* h, void* base, int n_fwd, int n_rows, int n_state) {
+  Ws w;
+  char* p = (char*)base;
+  size_t off = 0;
+  const size_t e = (size_t)16 * h->cfg.n_embed_input;
+  auto take = [&](size_t bytes) { char* r = p + off; off += align256(bytes); return r; };
+  w.h = (float*)take((size_t)pad8(n_fwd) * 16 * 256 * 4);  // whole 128-token tiles
+  w.v = (float*)take((size_t)n_fwd * e * 4);
+  w.mod = (float*)take((size_t)n_rows * h->mod_w * 4);
+  w.silu = (float*)take((size_t)(n_rows + 1) * 256 * 4);  // +1 spare row (device scalar t)
+  w.ridx = (int32_t*)take((size_t)n_fwd * 4);
+  w.dz = (float*)take((size_t)n_state * e * 4);
+  w.k2 = (float*)take((size_t)n_state * e * 4);
+  w.ztmp = (float*)take((size_t)n_state * e * 4);
+  w.total = off;
+  return w;
+}
+extern "C" size_t scldm_dit_workspace_bytes(const scldm_dit* h, int n_fwd, int n_rows, int n_state) {
+  if (!h) return 0;
+  return carve(h, nullptr, n_fwd, n_rows, n_state).total;
+}
+
+// conditioning rows -> silu_c rows [row0, row0+rows)
+static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t* const* labels, uint32_t mask, int rows,
+                       float* silu_c, hipStream_t st) {
+  if (rows <= 0) return SCLDM_OK;
+  CondArgs a;
+  a.t = t;
+  a.t_stride = t_stride;
+  a.w0t = h->w0t; a.b0 = h->b0; a.w2t = h->w2t; a.b2 = h->b2;
+  a.emb = h->emb;
+  a.n_classes = h->cfg.n_classes;
+  for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
+    a.emb_row0[c] = c < a.n_classes ? h->emb_row0[c] : 0;
+    a.null_tok[c] = c < a.n_classes ? h->cfg.class_vocab[c] : 0;
+    a.labels[c] = (c < a.n_classes && labels && labels[c] && ((mask >> c) & 1u)) ? labels[c] : nullptr;
+  }
+  a.silu_c = silu_c;
+  a.rows = rows;
+  cond_embed_kernel<<<rows, 256, 0, st>>>(a);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st) {
+  dim3 grid(cdiv(h->mod_w, 256), cdiv(rows, kAdaRU));
+  adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+template <typename OP, int NTT>
+static int launch_block_t(scldm_dit* h, const BlockArgs& a, hipStream_t st) {
+  using L = BlockLayout<OP, NTT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)dit_block_kernel<OP, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+    attr_set = true;
+  }
+  const int grid = cdiv((long long)a.n_fwd * 16, L::TM);
+  dit_block_kernel<OP, NTT><<<grid, 256, L::LDS_BYTES, st>>>(a);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+static int pick_ntt(const scldm_dit* h, int n_fwd, int prec) {
+  if (prec == SCLDM_PREC_FP32) return 2;
+  if (h->force_ntt == 2 || h->force_ntt == 4) return h->force_ntt;
+  // 128-token tiles once they fill the 256 CUs at least twice; 64-token tiles (2 workgroups / CU) below that
+  return ((long long)n_fwd * 16 >= 2LL * 256 * 128) ? 4 : 2;
+}
+
+static int launch_block(scldm_dit* h, const BlockArgs& a, int prec, hipStream_t st) {
+  const int ntt = pick_ntt(h, a.n_fwd, prec);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->timing && h->ev_used + 2 <= 40000) {
+    while (h->ev.size() < h->ev_used + 2) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreate(&ev));
+      h->ev.push_back(ev);
+    }
+    e0 = h->ev[h->ev_used];
+    e1 = h->ev[h->ev_used + 1];
+    h->ev_used += 2;
+    HIP_TRY(hipEventRecord(e0, st));
+  }
+  int rc;
+  if (prec == SCLDM_PREC_FP32) rc = launch_block_t<OpF32, 2>(h, a, st);
+  else if (ntt == 4) rc = launch_block_t<OpBF16, 4>(h, a, st);
+  else rc = launch_block_t<OpBF16, 2>(h, a, st);
+  if (rc != SCLDM_OK) return rc;
+  if (e1) HIP_TRY(hipEventRecord(e1, st));
+  return SCLDM_OK;
+}
+
+static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd, const float* mod, const int32_t* ridx,
+                 float* hbuf, float* out, int prec, hipStream_t st) {
+  const scldm_dit_config& c = h->cfg;
+  input_proj_kernel<<<pad8(n_fwd), 256, 0, st>>>(x, h->in_wt, h->in_b, h->pos, hbuf, c.n_embed_input, n_direct, rep, n_fwd);
+  LAUNCH_CHECK();
+  for (int i = 0; i < c.n_layer; ++i) {
+    const LayerPack& lp = h->layers[i];
+    BlockArgs a;
+    a.x = hbuf;
+    a.mod = mod;
+    a.row_index = ridx;
+    a.w_stream = lp.stream[prec];
+    a.b_qkv = lp.b_qkv; a.b_proj = lp.b_proj;
+    a.n_fwd = n_fwd;
+    a.mod_stride = h->mod_w;
+    a.mod_offset = i * kModBlock;
+    a.n_chunks = h->n_chunks;
+    a.eps = c.layernorm_eps;
+    a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
+    int rc = launch_block(h, a, prec, st);
+    if (rc != SCLDM_OK) return rc;
+  }
+  const int n_tok = n_fwd * 16;
+  final_layer_kernel<<<cdiv(n_tok, 4), 256, 0, st>>>(hbuf, mod, ridx, h->mod_w, c.n_layer * kModBlock, h->fin_w, h->fin_b, out,
+                                                      n_tok, c.n_embed_input, c.layernorm_eps);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+static int check_ready(const scldm_dit* h, int prec) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_dit_load_weights has not been called");
+  if (prec != SCLDM_PREC_FP32 && prec != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", prec);
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_dit_cond_rows(scldm_dit* h, const float* t, int t_stride, const int64_t* const* labels, int n_rows,
+                                   float* mod_out, void* ws_, void* stream_) {
+  int rc = check_ready(h, 0);
+  if (rc) return rc;
+  if (n_rows <= 0 || !t || !mod_out || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  Ws w = carve(h, ws_, 0, n_rows, 0);
+  if ((rc = launch_cond(h, t, t_stride, labels, 0xffffffffu, n_rows, w.silu, st))) return rc;
+  return launch_adaln(h, w.silu, mod_out, n_rows, st);
+}
+
+extern "C" int scldm_dit_forward_rows(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd, const float* mod,
+                                      const int32_t* row_index, float* out, int precision, void* ws_, void* stream_) {
+  int rc = check_ready(h, precision);
+  if (rc) return rc;
+  if (n_fwd <= 0 || n_direct <= 0 || n_direct > n_fwd || (n_fwd > n_direct && (rep <= 0 || rep > n_direct)))
+    return fail(SCLDM_ERR_SHAPE, "bad n_fwd/n_direct/rep (%d,%d,%d)", n_fwd, n_direct, rep);
+  if (!x || !mod || !row_index || !out || !ws_) return fail(SCLDM_ERR_SHAPE, "null pointer argument");
+  Ws w = carve(h, ws_, n_fwd, 0, 0);
+  return trunk(h, x, n_direct, rep > 0 ? rep : 1, n_fwd, mod, row_index, w.h, out, precision, (hipStream_t)stream_);
+}
+
+extern "C" int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, const int64_t* const* labels, float* out,
+                                 int n, int precision, void* ws_, void* stream_) {
+  int rc = check_ready(h, precision);
+  if (rc) return rc;
+  if (n <= 0 || !x || !t || !out || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  Ws w = carve(h, ws_, n, n, 0);
+  if ((rc = launch_cond(h, t, 1, labels, 0xffffffffu, n, w.silu, st))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, n, st))) return rc;
+  iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(w.ridx, n);
+  LAUNCH_CHECK();
+  return trunk(h, x, n, 1, n, w.mod, w.ridx, w.h, out, precision, st);
+}
+
+// One CFG evaluation: dz (2B, e) = forward_with_cfg(z, t); t_dev/t_stride describe the device-side t.
+struct CfgPlan {
+  int B, P, U, uncond_rows, n_fwd, n_rows;
+  const int64_t* const* ulabels;
+  const int32_t* cell_row;
+  uint32_t mask[SCLDM_MAX_CLASSES];
+  float scale[SCLDM_MAX_CLASSES];
+};
+
+__global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_t* __restrict__ cell_row, int n_direct,
+                                          int uncond_rows, int B, int U, int P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_direct + P * B) return;
+  if (s < n_direct) { ri[s] = (uncond_rows == 1) ? 0 : s; return; }
+  const int p = (s - n_direct) / B, i = (s - n_direct) % B;
+  ri[s] = uncond_rows + p * U + (cell_row ? cell_row[i] : i);
+}
+__global__ void set_scalar_kernel(float* p, float v) { *p = v; }
+
+static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
+                    float* dz, int prec, hipStream_t st) {
+  int rc;
+  // unconditional rows: every class null
+  if ((rc = launch_cond(h, t_dev, t_stride, nullptr, 0u, pl.uncond_rows, w.silu, st))) return rc;
+  for (int p = 0; p < pl.P; ++p) {
+    const float* tp = (t_stride == 0) ? t_dev : t_dev + pl.B;  // second half of t
+    if ((rc = launch_cond(h, tp, t_stride, pl.ulabels, pl.mask[p], pl.U, w.silu + (size_t)(pl.uncond_rows + p * pl.U) * 256, st)))
+      return rc;
+  }
+  if ((rc = launch_adaln(h, w.silu, w.mod, pl.n_rows, st))) return rc;
+  if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;
+  CfgArgs ca;
+  ca.v = w.v;
+  ca.dz = dz;
+  ca.B = pl.B;
+  ca.e = 16 * h->cfg.n_embed_input;
+  ca.P = pl.P;
+  for (int p = 0; p < SCLDM_MAX_CLASSES; ++p) ca.scale[p] = p < pl.P ? pl.scale[p] : 0.f;
+  const size_t n = (size_t)2 * pl.B * ca.e;
+  cfg_blend_kernel<<<cdiv(n, 256), 256, 0, st>>>(ca);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, int n_urows, const int32_t* cell_row, int B,
+                     int n_pass, const uint32_t* pass_mask, const float* pass_scale, int t_stride) {
+  if (B <= 0) return fail(SCLDM_ERR_SHAPE, "B must be positive");
+  if (n_pass < 0 || n_pass > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_pass out of range");
+  if (n_pass > 0 && (!ulabels || !pass_mask || !pass_scale || n_urows <= 0)) return fail(SCLDM_ERR_SHAPE, "conditional passes need labels/masks/scales");
+  if (n_pass > 0 && !cell_row && n_urows != B) return fail(SCLDM_ERR_SHAPE, "cell_row is NULL but n_urows (%d) != B (%d)", n_urows, B);
+  if (t_stride != 0 && n_pass > 0 && (cell_row || n_urows != B))
+    return fail(SCLDM_ERR_SHAPE, "per-sample t (t_stride=1) requires per-cell label rows (n_urows == B, cell_row NULL)");
+  pl.B = B;
+  pl.P = n_pass;
+  pl.U = n_pass > 0 ? n_urows : 0;
+  pl.uncond_rows = (t_stride == 0) ? 1 : 2 * B;
+  pl.n_fwd = 2 * B + n_pass * B;
+  pl.n_rows = pl.uncond_rows + pl.P * pl.U;
+  pl.ulabels = ulabels;
+  pl.cell_row = cell_row;
+  for (int p = 0; p < n_pass; ++p) {
+    pl.mask[p] = pass_mask[p];
+    pl.scale[p] = pass_scale[p];
+  }
+  (void)h;
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_dit_forward_cfg(scldm_dit* h, const float* x, const float* t, int t_stride, const int64_t* const* ulabels,
+                                     int n_urows, const int32_t* cell_row, int B, int n_pass, const uint32_t* pass_mask,
+                                     const float* pass_scale, float* out, int precision, void* ws_, void* stream_) {
+  int rc = check_ready(h, precision);
+  if (rc) return rc;
+  if (!x || !t || !out || !ws_) return fail(SCLDM_ERR_SHAPE, "null pointer argument");
+  if (t_stride != 0 && t_stride != 1) return fail(SCLDM_ERR_SHAPE, "t_stride must be 0 or 1");
+  CfgPlan pl;
+  if ((rc = make_plan(h, pl, ulabels, n_urows, cell_row, B, n_pass, pass_mask, pass_scale, t_stride))) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  Ws w = carve(h, ws_, pl.n_fwd, pl.n_rows, 0);
+  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, pl.uncond_rows, B, pl.U, pl.P);
+  LAUNCH_CHECK();
+  return cfg_eval(h, pl, x, t, t_stride, w, out, precision, st);
+}
+
+// torch.linspace(0, 1, steps) in fp32 (integrators.py:95): symmetric fill from both ends.
+static float linspace01(int idx, int steps) {
+  const float step = 1.0f / (float)(steps - 1);
+  return (idx < steps / 2) ? step * (float)idx : 1.0f - step * (float)(steps - idx - 1);
+}
+
+extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int n_urows, const int32_t* cell_row,
+                                int B, int n_pass, const uint32_t* pass_mask, const float* pass_scale, int n_steps, int method,
+                                int precision, void* ws_, void* stream_) {
+  int rc = check_ready(h, precision);
+  if (rc) return rc;
+  if (!z || !ws_) return fail(SCLDM_ERR_SHAPE, "null pointer argument");
+  if (n_steps < 1) return fail(SCLDM_ERR_SHAPE, "n_steps must be >= 1");
+  if (method != SCLDM_METHOD_EULER && method != SCLDM_METHOD_HEUN) return fail(SCLDM_ERR_SHAPE, "unknown method %d", method);
+  CfgPlan pl;
+  if ((rc = make_plan(h, pl, ulabels, n_urows, cell_row, B, n_pass, pass_mask, pass_scale, 0))) return rc;
+  hipStream_t st = (hipStream_t)stream_;
+  Ws w = carve(h, ws_, pl.n_fwd, pl.n_rows, 2 * B);
+  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, 1, B, pl.U, pl.P);
+  LAUNCH_CHECK();
+  const size_t n = (size_t)2 * B * 16 * h->cfg.n_embed_input;
+  const int steps = n_steps + 1;
+  float* tscal = w.silu + (size_t)pl.n_rows * 256;  // device scalar t: the spare row carve() reserves after the silu rows
+  for (int i = 0; i < n_steps; ++i) {
+    const float t0 = linspace01(i, steps), t1 = linspace01(i + 1, steps);
+    const float hs = t1 - t0;
+    set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t0);
+    if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st))) return rc;
+    if (method == SCLDM_METHOD_EULER) {
+      axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, z, hs, n);
+    } else {
+      axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.ztmp, hs, n);
+      set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t1);
+      if ((rc = cfg_eval(h, pl, w.ztmp, tscal, 0, w, w.k2, precision, st))) return rc;
+      heun_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.k2, 0.5f * hs, n);
+    }
+    LAUNCH_CHECK();
+  }
+  return SCLDM_OK;
+}
+
+extern "C" void scldm_dit_block_timing_enable(scldm_dit* h, int enable) {
+  if (!h) return;
+  h->timing = enable != 0;
+  h->ev_used = 0;
+}
+extern "C" int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  double tot = 0;
+  int n = 0;
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += ms;
+    ++n;
+  }
+  if (n_launches) *n_launches = n;
+  if (total_ms) *total_ms = tot;
+  h->ev_used = 0;
+  return SCLDM_OK;
+}

@@ -1,0 +1,86 @@
+// Shared device helpers for the scLDM gfx950 kernels (MI355X / CDNA4 only).
+//
+// MFMA conventions used everywhere in this directory (cdna_hip_programming.md section 3):
+//   v_mfma_f32_32x32x16_bf16 / 8 x v_mfma_f32_32x32x2_f32 compute D[32x32] += A[32xK16] * B[K16x32]
+//   A operand: lane l holds 8 k-values of row (l & 31), k-group (l >> 5)
+//   B operand: lane l holds 8 k-values of col (l & 31), k-group (l >> 5)
+//   C/D      : lane l holds col (l & 31); register r holds row (r&3) + 8*(r>>2) + 4*(l>>5)
+// A and B layouts are symmetric, so swapping the operands yields the transposed product,
+// and ANY k permutation is legal as long as A and B use the same one.  We exploit both.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scldm {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) - well inside the 1e-4 parity budget
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+
+__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand-precision policies.  E = element type stored in LDS / packed weights,
+// Frag = one lane's 8 k-values.  `mma` accumulates a 32x32 tile over 16 k-values.
+// ---------------------------------------------------------------------------------------------
+struct OpBF16 {
+  using E = __bf16;
+  using Frag = bf16x8;
+  using Quad = bf16x4;  // 4 consecutive elements (one accumulator register group)
+  static constexpr bool kIsBF16 = true;
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ Frag pack8(const float* v) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (__bf16)v[i];
+    return f;
+  }
+  static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
+    Quad q;
+    q[0] = (__bf16)a; q[1] = (__bf16)b; q[2] = (__bf16)c; q[3] = (__bf16)d;
+    return q;
+  }
+};
+
+struct OpF32 {
+  using E = float;
+  using Frag = f32x8;
+  using Quad = f32x4;
+  static constexpr bool kIsBF16 = false;
+  // exact fp32: 8 x v_mfma_f32_32x32x2_f32 (each contracts k-groups 0 and 1 of one element slot)
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], c, 0, 0, 0);
+    return c;
+  }
+  static __device__ __forceinline__ Frag pack8(const float* v) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = v[i];
+    return f;
+  }
+  static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
+    Quad q = {a, b, c, d};
+    return q;
+  }
+};
+
+}  // namespace scldm

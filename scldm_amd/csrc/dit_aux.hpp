@@ -1,0 +1,252 @@
+// Small kernels around the fused block: weight packing, conditioning (timestep MLP + class embeddings
+// + all-layer adaLN projection), input projection, final layer, CFG blend and ODE state update.
+#pragma once
+#include "common.hpp"
+#include "dit_block.hpp"
+
+namespace scldm {
+
+// ------------------------------------------------------------------------------------------------
+// Weight packing: PyTorch (out, in) row-major fp32 -> one contiguous MFMA-fragment stream per wave
+// (layout documented at WStream in dit_block.hpp).  Element (unit gu, tile ft, lane l, j) lives at
+// ((gu*2 + ft)*64 + l)*8 + j; its k index inside the unit's k-step is (l>>5)*8 + j; its row is l&31.
+//   units 0-47 : c_attn rows p*256 + w*64 + ft*32 + r          (p = q,k,v)       attn.c_attn.weight (768,256)
+//   units 48-63: c_proj rows w*64 + ft*32 + r                                      attn.c_proj.weight (256,256)
+//   chunk c, units 0-15: tile rows 0-15 = w1[hid], rows 16-31 = w2[hid], hid = c*128 + w*32 + ft*16 + (r&15)
+//   chunk c, units 16-23: mlp.c_proj rows w*64 + ft*32 + r, k = hidden index c*128 + ks*16 + ...
+// Hidden indices >= H are zero (exact padding of 684 -> 768).
+// ------------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* __restrict__ Wproj, const float* __restrict__ W1,
+                                  const float* __restrict__ W2, const float* __restrict__ Wcp, E* __restrict__ out, int H,
+                                  int n_chunks) {
+  const int UW = units_per_wave(n_chunks);
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)4 * UW * 1024) return;
+  const int j = idx & 7, l = (idx >> 3) & 63, ft = (idx >> 9) & 1;
+  const int gu = (int)(idx >> 10), w = gu / UW, u = gu % UW;
+  const int r = l & 31, k8 = (l >> 5) * 8 + j;
+  float val;
+  if (u < 48) {
+    const int p = u >> 4, ks = u & 15;
+    val = Wqkv[(size_t)(p * 256 + w * 64 + ft * 32 + r) * 256 + ks * 16 + k8];
+  } else if (u < 64) {
+    const int ks = u - 48;
+    val = Wproj[(size_t)(w * 64 + ft * 32 + r) * 256 + ks * 16 + k8];
+  } else {
+    const int v = u - 64, c = v / kUnitsPerChunk, vv = v % kUnitsPerChunk;
+    if (vv < 16) {
+      const int hid = c * kHC + w * 32 + ft * 16 + (r & 15);
+      const float* src = (r < 16) ? W1 : W2;
+      val = (hid < H) ? src[(size_t)hid * 256 + vv * 16 + k8] : 0.f;
+    } else {
+      const int hid = c * kHC + (vv - 16) * 16 + k8;
+      val = (hid < H) ? Wcp[(size_t)(w * 64 + ft * 32 + r) * H + hid] : 0.f;
+    }
+  }
+  out[idx] = (E)val;
+}
+
+// out[k*ldo + col0 + n] = W[n*K + k]  (transpose so that consecutive threads read consecutive floats)
+__global__ void transpose_kernel(const float* __restrict__ W, float* __restrict__ out, int N, int K, int ldo, int col0) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * K) return;
+  const int n = idx % N, k = idx / N;
+  out[(size_t)k * ldo + col0 + n] = W[(size_t)n * K + k];
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) dst[idx] = src[idx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conditioning.  One workgroup (256 threads = 256 features) per conditioning row.
+//   c = t_mlp(sinusoid(t)) + sum_classes emb_c[label or null]    (layers.py:351-364, nnets.py:380-456)
+// writes silu(c) (the input of every adaLN projection, layers.py:206,395).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxClasses = 8;
+struct CondArgs {
+  const float* t;          // (rows) or scalar when t_stride == 0
+  int t_stride;
+  const float* w0t;        // (256,256) transposed t_embedder.mlp.0.weight  [k][n]
+  const float* b0;
+  const float* w2t;        // transposed t_embedder.mlp.2.weight
+  const float* b2;
+  const float* emb;        // concatenated class tables, (sum(vocab+1), 256)
+  int n_classes;
+  int emb_row0[kMaxClasses];   // first row of class c in `emb`
+  int null_tok[kMaxClasses];   // vocab size of class c (= index of its null token)
+  const int64_t* labels[kMaxClasses];  // (rows) or nullptr => null token for every row
+  float* silu_c;           // (rows,256)
+  int rows;
+};
+
+__global__ __launch_bounds__(256) void cond_embed_kernel(const CondArgs a) {
+  __shared__ float te[256];
+  __shared__ float h1[256];
+  const int u = blockIdx.x, n = threadIdx.x;
+  const float t = a.t[(size_t)u * a.t_stride];
+  {
+    const int k = n & 127;
+    const float freq = expf(-9.210340371976184f * (float)k / 128.0f);  // exp(-ln(10000) k / half)
+    const float arg = t * freq;
+    te[n] = (n < 128) ? cosf(arg) : sinf(arg);  // [cos | sin], cos first
+  }
+  __syncthreads();
+  float s = a.b0[n];
+#pragma unroll 8
+  for (int k = 0; k < 256; ++k) s += a.w0t[k * 256 + n] * te[k];
+  h1[n] = silu_f(s);
+  __syncthreads();
+  float c = a.b2[n];
+#pragma unroll 8
+  for (int k = 0; k < 256; ++k) c += a.w2t[k * 256 + n] * h1[k];
+  for (int ci = 0; ci < a.n_classes; ++ci) {
+    int tok = a.null_tok[ci];
+    if (a.labels[ci] != nullptr) tok = (int)a.labels[ci][u];
+    c += a.emb[(size_t)(a.emb_row0[ci] + tok) * 256 + n];
+  }
+  a.silu_c[(size_t)u * 256 + n] = silu_f(c);
+}
+
+// mod[u][n] = bias[n] + sum_k wt[k][n] * silu_c[u][k] for ALL layers at once (n < mod_w).
+// RU rows per workgroup share each weight read.
+constexpr int kAdaRU = 8;
+__global__ __launch_bounds__(256) void adaln_all_kernel(const float* __restrict__ silu_c, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ mod,
+                                                        int rows, int mod_w) {
+  __shared__ float sc[kAdaRU][256];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int u0 = blockIdx.y * kAdaRU;
+  for (int i = threadIdx.x; i < kAdaRU * 256; i += 256) {
+    const int u = u0 + (i >> 8);
+    sc[i >> 8][i & 255] = (u < rows) ? silu_c[(size_t)u * 256 + (i & 255)] : 0.f;
+  }
+  __syncthreads();
+  if (n >= mod_w) return;
+  float acc[kAdaRU];
+  const float b = bias[n];
+#pragma unroll
+  for (int r = 0; r < kAdaRU; ++r) acc[r] = b;
+#pragma unroll 4
+  for (int k = 0; k < 256; ++k) {
+    const float w = wt[(size_t)k * mod_w + n];
+#pragma unroll
+    for (int r = 0; r < kAdaRU; ++r) acc[r] += w * sc[r][k];
+  }
+#pragma unroll
+  for (int r = 0; r < kAdaRU; ++r)
+    if (u0 + r < rows) mod[(size_t)(u0 + r) * mod_w + n] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input projection + positional embedding (nnets.py:290-291).  One workgroup per sample-forward.
+// Sample-forward s reads latent row (s < n_direct ? s : s - ((s - n_direct) / rep + 1) * rep ... ) -
+// expressed generally through src_row = s < n_direct ? s : n_direct - rep + (s - n_direct) % rep,
+// i.e. every extra (conditional) pass re-reads the LAST `rep` rows of the state (the guided half).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ z, const float* __restrict__ wt /*[din][256]*/,
+                                                         const float* __restrict__ b, const float* __restrict__ pos,
+                                                         float* __restrict__ h, int din, int n_direct, int rep, int n_fwd) {
+  __shared__ float xs[16 * 64];
+  const int s = blockIdx.x, n = threadIdx.x;
+  if (s >= n_fwd) {  // tile padding: finite (zero) rows so that 0 * pad never produces NaN inside shared MFMA tiles
+    for (int tok = 0; tok < 16; ++tok) h[((size_t)s * 16 + tok) * 256 + n] = 0.f;
+    return;
+  }
+  const int src = (s < n_direct) ? s : (n_direct - rep + (s - n_direct) % rep);
+  for (int i = n; i < 16 * din; i += 256) xs[i] = z[(size_t)src * 16 * din + i];
+  __syncthreads();
+  const float bn = b[n];
+  for (int tok = 0; tok < 16; ++tok) {
+    float acc = bn + pos[tok * 256 + n];
+    for (int k = 0; k < din; ++k) acc += wt[k * 256 + n] * xs[tok * din + k];
+    h[((size_t)s * 16 + tok) * 256 + n] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final layer (layers.py:397-401): LN (no affine) -> *(1+scale)+shift with (shift, scale) = chunks
+// (0, 1) of the final adaLN vector (conventional order) -> Linear 256 -> din.  One wave per token.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ h, const float* __restrict__ mod,
+                                                          const int32_t* __restrict__ row_index, int mod_stride, int fin_off,
+                                                          const float* __restrict__ w /*[din][256]*/, const float* __restrict__ b,
+                                                          float* __restrict__ out, int n_tok, int din, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tok) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(h + (size_t)tok * 256 + lane * 4);
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256);
+  float d[4], ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d[i] = v[i] - mean;
+    ss += d[i] * d[i];
+  }
+  const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * (1.0f / 256) + eps);
+  const float* mrow = mod + (size_t)row_index[tok >> 4] * mod_stride + fin_off;
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(mrow + lane * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + 256 + lane * 4);
+  float y[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = d[i] * rstd * (1.0f + sc[i]) + sh[i];
+  for (int j = 0; j < din; ++j) {
+    const f32x4 wj = *reinterpret_cast<const f32x4*>(w + j * 256 + lane * 4);
+    float p = y[0] * wj[0] + y[1] * wj[1] + y[2] * wj[2] + y[3] * wj[3];
+    p = wave_sum(p);
+    if (lane == 0) out[(size_t)tok * din + j] = p + b[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CFG blend (nnets.py:356-378) + explicit ODE state updates.
+// v holds n_direct = 2B unconditional outputs followed by P conditional passes of B rows each.
+//   dz[i]      = v[i]                                   i <  B
+//   dz[B + i]  = v[B+i] + sum_p scale[p] * (v[2B + pB + i] - v[B+i])
+// ------------------------------------------------------------------------------------------------
+struct CfgArgs {
+  const float* v;
+  float* dz;       // (2B, e) may alias nothing else
+  int B, e, P;     // e = elements per sample (16*din)
+  float scale[kMaxClasses];
+};
+__global__ void cfg_blend_kernel(const CfgArgs a) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t half = (size_t)a.B * a.e;
+  if (idx >= 2 * half) return;
+  float r = a.v[idx];
+  if (idx >= half) {
+    const float u = r;
+    for (int p = 0; p < a.P; ++p) r += a.scale[p] * (a.v[2 * half + (size_t)p * half + (idx - half)] - u);
+  }
+  a.dz[idx] = r;
+}
+
+// out = z + h * k
+__global__ void axpy_kernel(const float* __restrict__ z, const float* __restrict__ k, float* __restrict__ out, float h, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = z[idx] + h * k[idx];
+}
+// z += hh * (k1 + k2)   (Heun corrector, hh = h/2)
+__global__ void heun_kernel(float* __restrict__ z, const float* __restrict__ k1, const float* __restrict__ k2, float hh, size_t n) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) z[idx] = z[idx] + hh * (k1[idx] + k2[idx]);
+}
+
+__global__ void fill_row_index_kernel(int32_t* __restrict__ ri, const int32_t* __restrict__ cell_row, int n_direct, int B,
+                                      int U, int P) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_direct + P * B) return;
+  if (s < n_direct) { ri[s] = 0; return; }
+  const int p = (s - n_direct) / B, i = (s - n_direct) % B;
+  ri[s] = 1 + p * U + (cell_row ? cell_row[i] : i);
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ ri, int n) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) ri[s] = s;
+}
+
+}  // namespace scldm

@@ -1,0 +1,353 @@
+"""Networks with the reference's API (src/scldm/nnets.py) whose forward runs on MI355X HIP kernels.
+
+`DiT` keeps `scldm.nnets.DiT`'s constructor kwargs, attributes, method signatures and state_dict
+keys (nnets.py:216-297,336-378), so `hydra.utils.instantiate` with `_target_: scldm_amd.nnets.DiT`
+and `load_state_dict(strict=True)` of reference checkpoints work unchanged.  All arithmetic goes
+through libscldm_hip.so (include/scldm_hip.h); there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Literal
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import Block, FinalLayerDit, TimestepEmbedder, sincos_pos_embed, swiglu_hidden
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA (ROCm) tensor: scldm_amd runs only on the MI355X HIP path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class DiT(nn.Module):
+    """Diffusion Transformer (adaLN-Zero) - drop-in for scldm.nnets.DiT.
+
+    Extra (non-reference) knobs: `precision` ("fp32" exact-fp32 MFMA parity path, or "bf16"
+    throughput path; default from $SCLDM_PRECISION, else "fp32").
+    """
+
+    def __init__(
+        self,
+        n_embed: int,
+        n_embed_input: int,
+        n_layer: int,
+        n_head: int,
+        seq_len: int,
+        dropout: float,
+        bias: bool,
+        norm_layer: str,
+        multiple_of: int,
+        layernorm_eps: float,
+        class_vocab_sizes: dict[str, int],
+        cfg_dropout_prob: float = 0.1,
+        condition_strategy: Literal["mutually_exclusive", "joint"] = "mutually_exclusive",
+    ):
+        super().__init__()
+        if not bias:
+            raise NotImplementedError("the fused DiT block expects bias=True (ldm_base.yaml:22)")
+        self.class_vocab_sizes = dict(class_vocab_sizes)
+        self.cfg_dropout_prob = cfg_dropout_prob
+        self.condition_strategy = condition_strategy
+        self.class_embeddings = nn.ModuleDict()
+        for name, vocab in self.class_vocab_sizes.items():
+            self.class_embeddings[name] = nn.Embedding(vocab + int(cfg_dropout_prob > 0), n_embed)
+        self.t_embedder = TimestepEmbedder(n_embed)
+        self.pos_embed = nn.Parameter(torch.zeros(1, seq_len, n_embed), requires_grad=False)
+        self.blocks = nn.ModuleList([
+            Block(n_embed=n_embed, n_head=n_head, dropout=dropout, bias=bias, norm_layer=norm_layer, multiple_of=multiple_of,
+                  layernorm_eps=layernorm_eps, use_adaln=True, elementwise_affine=False) for _ in range(n_layer)
+        ])
+        self.n_embed, self.seq_len = n_embed, seq_len
+        self.n_embed_input, self.n_layer, self.n_head = n_embed_input, n_layer, n_head
+        self.layernorm_eps, self.multiple_of = layernorm_eps, multiple_of
+        self.input_proj = nn.Linear(n_embed_input, n_embed, bias=bias)
+        self.final_layer = FinalLayerDit(n_embed, n_embed_input, bias, layernorm_eps)
+        self.precision = os.environ.get("SCLDM_PRECISION", "fp32")
+        self._handle = None
+        self._weights_key = None
+        self._ws = None
+        self._dedup_cache = {}
+        self.initialize_weights()
+
+    # ------------------------------------------------------------------ init (nnets.py:458-492)
+    def initialize_weights(self):
+        def _basic(m):
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+        self.apply(_basic)
+        self.pos_embed.data.copy_(torch.from_numpy(sincos_pos_embed(self.n_embed, self.seq_len)).float().unsqueeze(0))
+        for emb in self.class_embeddings.values():
+            nn.init.normal_(emb.weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        for blk in self.blocks:  # adaLN-Zero
+            nn.init.zeros_(blk.adaln_modulation[-1].weight)
+            nn.init.zeros_(blk.adaln_modulation[-1].bias)
+        nn.init.zeros_(self.final_layer.adaln_modulation[-1].weight)
+        nn.init.zeros_(self.final_layer.adaln_modulation[-1].bias)
+        nn.init.zeros_(self.final_layer.linear.weight)
+        nn.init.zeros_(self.final_layer.linear.bias)
+
+    # ------------------------------------------------------------------ native handle management
+    @property
+    def _class_names(self) -> list[str]:
+        return sorted(self.class_vocab_sizes.keys())
+
+    def _native(self):
+        L = _lib.lib()
+        dev = self.pos_embed.device
+        if dev.type != "cuda":
+            raise RuntimeError("DiT parameters must live on a CUDA (ROCm) device; call .cuda() first. There is no CPU path.")
+        if self._handle is None:
+            names = self._class_names
+            if len(names) > _lib.MAX_CLASSES:
+                raise ValueError(f"at most {_lib.MAX_CLASSES} condition classes are supported")
+            cfg = _lib.DitConfig(n_embed=self.n_embed, n_embed_input=self.n_embed_input, n_layer=self.n_layer, n_head=self.n_head,
+                                 seq_len=self.seq_len, hidden_dim=swiglu_hidden(self.n_embed, self.multiple_of),
+                                 layernorm_eps=self.layernorm_eps, n_classes=len(names))
+            for i, n in enumerate(names):
+                cfg.class_vocab[i] = self.class_vocab_sizes[n]
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(L.scldm_dit_create(C.byref(cfg), C.byref(h)), "scldm_dit_create")
+            self._handle = h
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key != self._weights_key:
+            self._load_weights(L)
+            self._weights_key = key
+        return L, self._handle
+
+    def _load_weights(self, L):
+        for p in self.parameters():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("DiT parameters must be contiguous fp32 (master weights); bf16 copies are derived internally")
+        dp = lambda t: t.data_ptr()
+        blocks = list(self.blocks)
+        keep = [
+            _lib.ptr_array([dp(self.class_embeddings[n].weight) for n in self._class_names]),
+            _lib.ptr_array([dp(b.attn.c_attn.weight) for b in blocks]), _lib.ptr_array([dp(b.attn.c_attn.bias) for b in blocks]),
+            _lib.ptr_array([dp(b.attn.c_proj.weight) for b in blocks]), _lib.ptr_array([dp(b.attn.c_proj.bias) for b in blocks]),
+            _lib.ptr_array([dp(b.mlp.w1.weight) for b in blocks]), _lib.ptr_array([dp(b.mlp.w2.weight) for b in blocks]),
+            _lib.ptr_array([dp(b.mlp.c_proj.weight) for b in blocks]),
+            _lib.ptr_array([dp(b.adaln_modulation[1].weight) for b in blocks]),
+            _lib.ptr_array([dp(b.adaln_modulation[1].bias) for b in blocks]),
+        ]
+        cast = lambda a: C.cast(a, _lib.c_void_pp)
+        w = _lib.DitWeights(
+            pos_embed=dp(self.pos_embed), t_w0=dp(self.t_embedder.mlp[0].weight), t_b0=dp(self.t_embedder.mlp[0].bias),
+            t_w2=dp(self.t_embedder.mlp[2].weight), t_b2=dp(self.t_embedder.mlp[2].bias), in_w=dp(self.input_proj.weight),
+            in_b=dp(self.input_proj.bias), fin_w=dp(self.final_layer.linear.weight), fin_b=dp(self.final_layer.linear.bias),
+            fin_ada_w=dp(self.final_layer.adaln_modulation[1].weight), fin_ada_b=dp(self.final_layer.adaln_modulation[1].bias),
+            class_emb=cast(keep[0]), attn_w=cast(keep[1]), attn_b=cast(keep[2]), proj_w=cast(keep[3]), proj_b=cast(keep[4]),
+            w1=cast(keep[5]), w2=cast(keep[6]), cproj=cast(keep[7]), ada_w=cast(keep[8]), ada_b=cast(keep[9]))
+        with torch.cuda.device(self.pos_embed.device):
+            _lib.check(L.scldm_dit_load_weights(self._handle, C.byref(w), _stream_ptr()), "scldm_dit_load_weights")
+
+    def _workspace(self, L, n_fwd: int, n_rows: int, n_state: int) -> int:
+        need = L.scldm_dit_workspace_bytes(self._handle, n_fwd, n_rows, n_state)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.pos_embed.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.pos_embed.device)
+        return self._ws.data_ptr()
+
+    def _prec(self) -> int:
+        try:
+            return _lib.PRECISIONS[self.precision]
+        except KeyError:
+            raise ValueError(f"precision must be one of {list(_lib.PRECISIONS)}") from None
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().scldm_dit_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ label handling (nnets.py:380-456)
+    def _eval_label_ptrs(self, condition: dict[str, torch.Tensor], n: int):
+        """Device label pointers per class (sorted-name order) for an EVAL-mode forward; None -> null token."""
+        names = self._class_names
+        available = [c for c in names if c in condition]
+        if not available:
+            raise ValueError("condition must contain at least one known class (reference raises StopIteration/KeyError here)")
+        keep = []
+        if self.condition_strategy == "joint":
+            missing = [c for c in names if c not in condition]
+            if missing:
+                raise KeyError(missing[0])  # the reference indexes condition[class_name] for every class (nnets.py:449)
+            chosen = set(names)
+        else:
+            # the reference draws the selected class with torch.randint even in eval (nnets.py:395)
+            sel = int(torch.randint(0, len(available), ()).item()) if len(available) > 1 else 0
+            chosen = {available[sel]}
+        ptrs = []
+        for c in names:
+            if c in chosen:
+                lab = condition[c]
+                if lab.shape[0] != n:
+                    raise ValueError(f"Condition '{c}' length ({lab.shape[0]}) must match batch size ({n})")
+                lab = lab.to(device=self.pos_embed.device, dtype=torch.long).contiguous()
+                keep.append(lab)
+                ptrs.append(lab.data_ptr())
+            else:
+                ptrs.append(None)
+        return _lib.ptr_array(ptrs), keep
+
+    # ------------------------------------------------------------------ forward (nnets.py:273-297)
+    def forward(self, x: torch.Tensor, t: torch.Tensor, condition: dict[str, torch.Tensor],
+                force_drop_ids: bool | None = None) -> torch.Tensor:
+        if force_drop_ids is None:
+            force_drop_ids = self.training
+        if not self.training:
+            assert not force_drop_ids, "force_drop_ids must be False when not training"
+        if self.training or force_drop_ids:
+            raise NotImplementedError("training-mode forward (CFG label dropout + backward) is not built yet: "
+                                      "SURVEY.md section 8 row T1 / config 5 is a later round. Use .eval().")
+        L, h = self._native()
+        x = _require_cuda_f32("x", x)
+        t = _require_cuda_f32("t", t)
+        n = x.shape[0]
+        if x.shape[1:] != (self.seq_len, self.n_embed_input) or t.shape != (n,):
+            raise ValueError(f"expected x (B,{self.seq_len},{self.n_embed_input}) and t (B,), got {tuple(x.shape)}, {tuple(t.shape)}")
+        labels, keep = self._eval_label_ptrs(condition, n)
+        out = torch.empty_like(x)
+        ws = self._workspace(L, n, n, 0)
+        with torch.cuda.device(x.device):
+            _lib.check(L.scldm_dit_forward(h, x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), out.data_ptr(), n,
+                                           self._prec(), ws, _stream_ptr()), "scldm_dit_forward")
+        del keep
+        return out
+
+    # ------------------------------------------------------------------ CFG plan shared by forward_with_cfg / sample_ode_cfg
+    def _cfg_plan(self, condition, cfg_scale, B: int, dedup: bool):
+        """Returns (ulabel_ptrs, n_urows, cell_row_ptr, n_pass, masks, scales, keepalive)."""
+        names = self._class_names
+        if condition is None or cfg_scale is None:
+            return None, 0, None, 0, None, None, []
+        half = {}
+        for k, v in condition.items():
+            if v.shape[0] != 2 * B:
+                raise ValueError(f"Condition '{k}' length ({v.shape[0]}) must match batch size ({2 * B})")
+            half[k] = v[B:].to(device=self.pos_embed.device, dtype=torch.long)
+        if self.condition_strategy == "joint":
+            for c in names:
+                if c not in half:
+                    raise KeyError(c)
+            used = list(names)
+            masks = [sum(1 << i for i in range(len(names)))]
+            scales = [sum(cfg_scale.values()) / len(cfg_scale)]  # nnets.py:368
+        else:
+            used = [c for c in cfg_scale.keys()]
+            for c in used:
+                if c not in half:
+                    raise KeyError(c)
+                if c not in names:
+                    raise KeyError(c)
+            masks = [1 << names.index(c) for c in used]
+            scales = [float(cfg_scale[c]) for c in used]
+        keep = []
+        cell_row_ptr = None
+        n_u = B
+        cols = {c: half[c].contiguous() for c in used}
+        if dedup and used:
+            key = tuple((c, cols[c].data_ptr(), cols[c]._version, B) for c in used)
+            hit = self._dedup_cache.get(key)
+            if hit is None:
+                stacked = torch.stack([cols[c] for c in used], dim=1)
+                uniq, inv = torch.unique(stacked, dim=0, return_inverse=True)
+                hit = ({c: uniq[:, i].contiguous() for i, c in enumerate(used)}, inv.to(torch.int32).contiguous(), [cols[c] for c in used])
+                self._dedup_cache.clear()
+                self._dedup_cache[key] = hit
+            ucols, inv, _ = hit
+            if ucols[used[0]].shape[0] < B:
+                cols, n_u, cell_row_ptr = ucols, ucols[used[0]].shape[0], inv.data_ptr()
+                keep.append(inv)
+        ptrs = []
+        for c in names:
+            if c in cols:
+                keep.append(cols[c])
+                ptrs.append(cols[c].data_ptr())
+            else:
+                ptrs.append(None)
+        n_pass = len(masks)
+        m = (C.c_uint32 * max(n_pass, 1))(*masks)
+        s = (C.c_float * max(n_pass, 1))(*scales)
+        return _lib.ptr_array(ptrs), n_u, cell_row_ptr, n_pass, m, s, keep
+
+    # ------------------------------------------------------------------ forward_with_cfg (nnets.py:336-378)
+    def forward_with_cfg(self, x: torch.Tensor, t: torch.Tensor, condition: dict[str, torch.Tensor] | None = None,
+                         cfg_scale: dict[str, float] | None = None) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("forward_with_cfg is an inference path; call .eval() first")
+        L, h = self._native()
+        uniform_t = getattr(t, "_scldm_uniform_t", False)  # set by scldm_amd.transport's ODE loop (scalar t broadcast)
+        x = _require_cuda_f32("x", x)
+        tt = _require_cuda_f32("t", t)
+        n = x.shape[0]
+        B = n // 2
+        if n != 2 * B or x.shape[1:] != (self.seq_len, self.n_embed_input) or tt.shape != (n,):
+            raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(x.shape)}, {tuple(tt.shape)}")
+        ul, n_u, cell_row, n_pass, masks, scales, keep = self._cfg_plan(condition, cfg_scale, B, dedup=uniform_t)
+        out = torch.empty_like(x)
+        t_stride = 0 if uniform_t else 1
+        n_rows = (1 if uniform_t else 2 * B) + n_pass * n_u
+        ws = self._workspace(L, 2 * B + n_pass * B, n_rows, 0)
+        with torch.cuda.device(x.device):
+            _lib.check(L.scldm_dit_forward_cfg(h, x.data_ptr(), tt.data_ptr(), t_stride,
+                                               C.cast(ul, _lib.c_void_pp) if ul is not None else None, n_u, cell_row, B, n_pass,
+                                               masks, scales, out.data_ptr(), self._prec(), ws, _stream_ptr()),
+                       "scldm_dit_forward_cfg")
+        del keep
+        return out
+
+    # ------------------------------------------------------------------ fused sampler (transport.py:324-369 + models.py:801-812)
+    @torch.no_grad()
+    def sample_ode_cfg(self, z: torch.Tensor, condition: dict[str, torch.Tensor] | None, cfg_scale: dict[str, float] | None,
+                       num_steps: int, sampling_method: str = "euler") -> torch.Tensor:
+        """Integrate dz/dt = forward_with_cfg(z, t) over linspace(0, 1, num_steps) entirely on device.
+
+        `z` is the doubled state cat([z0, z0]) (2B,S,C); `condition` the doubled label dict; `num_steps` has the
+        reference meaning (grid POINTS: num_steps-1 Euler evaluations).  Returns the final state (what the
+        reference indexes with [-1], models.py:812).
+        """
+        if self.training:
+            raise NotImplementedError("sampling is an inference path; call .eval() first")
+        if num_steps < 2:
+            raise ValueError("num_steps must be >= 2 (grid points)")
+        L, h = self._native()
+        z = _require_cuda_f32("z", z).clone()
+        n = z.shape[0]
+        B = n // 2
+        if n != 2 * B or z.shape[1:] != (self.seq_len, self.n_embed_input):
+            raise ValueError(f"expected z (2B,{self.seq_len},{self.n_embed_input}), got {tuple(z.shape)}")
+        ul, n_u, cell_row, n_pass, masks, scales, keep = self._cfg_plan(condition, cfg_scale, B, dedup=True)
+        ws = self._workspace(L, 2 * B + n_pass * B, 1 + n_pass * n_u, 2 * B)
+        with torch.cuda.device(z.device):
+            _lib.check(L.scldm_sample_ode(h, z.data_ptr(), C.cast(ul, _lib.c_void_pp) if ul is not None else None, n_u, cell_row,
+                                          B, n_pass, masks, scales, num_steps - 1, _lib.METHODS[sampling_method.lower()],
+                                          self._prec(), ws, _stream_ptr()), "scldm_sample_ode")
+        del keep
+        return z
+
+    # ------------------------------------------------------------------ bench hook
+    def block_timing(self, enable: bool | None = None):
+        L, h = self._native()
+        if enable is not None:
+            L.scldm_dit_block_timing_enable(h, int(enable))
+            return None
+        n, ms = C.c_int(), C.c_double()
+        _lib.check(L.scldm_dit_block_timing(h, C.byref(n), C.byref(ms)), "scldm_dit_block_timing")
+        return n.value, ms.value

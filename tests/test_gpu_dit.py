@@ -1,0 +1,144 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI via the
+reference-shaped Python classes, against the golden vectors of the reference and against the CPU oracle.
+
+Tolerances (scale-relative max error, max|a-b| / max|b|):
+  fp32 path (exact-fp32 MFMA): 1e-4  - BASELINE.json north_star gate
+  bf16 path (bf16 operands, fp32 accumulate/LN/softmax/residual): 3e-2 (bf16 has 8 mantissa bits; 8 layers deep)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, load_golden, max_abs_rel
+from oracle.dit import DiTConfig, dit_forward, dit_forward_with_cfg
+from oracle.transport import sample_ode_fixed
+from oracle.weights import make_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL_FP32 = 1e-4
+TOL_BF16 = 3e-2
+
+
+def build(name, precision="fp32"):
+    from scldm_amd.nnets import DiT
+    g = load_golden(name)
+    kw = golden_json(g, "kwargs_json")
+    shapes = {k: tuple(v) for k, v in golden_json(g, "shapes_json").items()}
+    sd = make_state_dict(shapes, int(g["seed"]))
+    m = DiT(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    cfg = DiTConfig(n_embed=kw["n_embed"], n_embed_input=kw["n_embed_input"], n_layer=kw["n_layer"], n_head=kw["n_head"],
+                    seq_len=kw["seq_len"], multiple_of=kw["multiple_of"], layernorm_eps=kw["layernorm_eps"],
+                    class_vocab_sizes=kw["class_vocab_sizes"], condition_strategy=kw["condition_strategy"])
+    return g, m, cfg, sd
+
+
+def cu(a):
+    return torch.from_numpy(np.asarray(a)).cuda()
+
+
+@pytest.mark.parametrize("name", ["dit_base", "dit_joint"])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_forward_matches_reference_golden(name, precision, tol):
+    g, m, cfg, sd = build(name, precision)
+    cond = {k: cu(g[f"fwd_label_{k}"]) for k in golden_json(g, "fwd_classes")}
+    y = m(cu(g["fwd_x"]), cu(g["fwd_t"]), cond)
+    assert y.shape == g["fwd_out"].shape and torch.isfinite(y).all()
+    assert max_abs_rel(y.cpu(), g["fwd_out"]) < tol
+
+
+@pytest.mark.parametrize("name", ["dit_base", "dit_joint"])
+@pytest.mark.parametrize("tag", ["s1", "s2"])
+def test_forward_with_cfg_matches_reference_golden(name, tag):
+    g, m, cfg, sd = build(name)
+    cond = {k: cu(g[f"cfg_label_{k}"]) for k in cfg.class_vocab_sizes}
+    scales = golden_json(g, f"cfg_scales_{tag}")
+    x, t = cu(g["cfg_x"]), cu(g["cfg_t"])
+    y = m.forward_with_cfg(x, t, cond, scales)           # per-sample-t path
+    assert max_abs_rel(y.cpu(), g[f"cfg_out_{tag}"]) < TOL_FP32
+    t._scldm_uniform_t = True                              # scalar-t path with label de-duplication
+    y2 = m.forward_with_cfg(x, t, cond, scales)
+    assert max_abs_rel(y2.cpu(), g[f"cfg_out_{tag}"]) < TOL_FP32
+
+
+@pytest.mark.parametrize("n", [1, 3, 8, 13, 37])
+def test_ragged_batches_vs_oracle(n):
+    """Batch sizes that do not fill a 64/128-token tile (tile padding, odd sample pairing)."""
+    g, m, cfg, sd = build("dit_base")
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 16, 16)).astype(np.float32)
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    lab = rng.integers(0, 14, n).astype(np.int64)
+    ref = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.from_numpy(lab)})
+    y = m(cu(x), cu(t), {"clusters": cu(lab)})
+    assert max_abs_rel(y.cpu(), ref) < TOL_FP32
+
+
+def test_bf16_vs_oracle_medium_batch():
+    g, m, cfg, sd = build("dit_base", "bf16")
+    rng = np.random.default_rng(5)
+    n = 96
+    x = rng.standard_normal((n, 16, 16)).astype(np.float32)
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    lab = rng.integers(0, 14, n).astype(np.int64)
+    ref = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.from_numpy(lab)})
+    y = m(cu(x), cu(t), {"clusters": cu(lab)})
+    assert max_abs_rel(y.cpu(), ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("name,method,steps", [("dit_base", "euler", 5), ("dit_base", "heun", 4), ("dit_joint", "euler", 4)])
+def test_fused_sampler_vs_oracle(name, method, steps):
+    g, m, cfg, sd = build(name)
+    rng = np.random.default_rng(11)
+    B = 6
+    z0 = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    labs = {k: rng.integers(0, v, B).astype(np.int64) for k, v in cfg.class_vocab_sizes.items()}
+    scales = {k: 1.5 for k in cfg.class_vocab_sizes}
+    z2 = torch.from_numpy(np.concatenate([z0, z0]))
+    cond2 = {k: torch.from_numpy(np.concatenate([v, v])) for k, v in labs.items()}
+    ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales), steps, method)
+    out = m.sample_ode_cfg(z2.cuda(), {k: v.cuda() for k, v in cond2.items()}, scales, steps, method)
+    assert max_abs_rel(out.cpu(), ref) < TOL_FP32
+    # the generic reference-style call chain (Sampler -> lambda -> forward_with_cfg) gives the same trajectory end
+    from scldm_amd.transport import Sampler, create_transport
+    fn = Sampler(create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)).sample_ode(sampling_method=method, num_steps=steps)
+    condc = {k: v.cuda() for k, v in cond2.items()}
+    model_fn = lambda x, t, **kw: m.forward_with_cfg(x, t, **kw, cfg_scale=scales)
+    traj = fn(z2.cuda(), model_fn, **{"condition": condc})
+    assert traj.shape[0] == steps and max_abs_rel(traj[-1].cpu(), ref) < TOL_FP32
+    assert max_abs_rel(traj[-1].cpu(), out.cpu()) < 1e-5
+
+
+def test_bitwise_repeatability_and_batch_permutation_at_full_size():
+    """Size-independent properties at the benchmark batch (3 x 4096 sample-forwards): identical bytes on repeat,
+    and permuting the cells permutes the outputs exactly (cells are independent; cross-sample MFMA blocks are masked)."""
+    g, m, cfg, sd = build("dit_base", "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    n = 12288
+    x = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    t = torch.rand(n, device="cuda", generator=gen)
+    lab = torch.randint(0, 14, (n,), device="cuda", generator=gen)
+    y1 = m(x, t, {"clusters": lab})
+    y2 = m(x, t, {"clusters": lab})
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all()
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    y3 = m(x[perm], t[perm], {"clusters": lab[perm]})
+    assert torch.equal(y3, y1[perm])
+    # spot-check 16 random cells of the big batch against the oracle
+    idx = perm[:16].cpu()
+    ref = dit_forward(sd, cfg, x.cpu()[idx], t.cpu()[idx], {"clusters": lab.cpu()[idx]})
+    assert max_abs_rel(y1.cpu()[idx], ref) < TOL_BF16
+
+
+def test_error_paths():
+    from scldm_amd._lib import ScldmError
+    g, m, cfg, sd = build("dit_base")
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 16, 8, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(3, dtype=torch.long, device="cuda")})
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
