@@ -102,7 +102,7 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
     return dt, blocks
 
 
-def cpu_baseline(m, wl, budget_cells=128, evals=2):
+def cpu_baseline(m, wl, budget_cells=256, evals=3):
     """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on this
     box's host cores over a bounded sample: `budget_cells` cells x `evals` Euler evaluations with CFG."""
     from oracle.dit import DiTConfig, dit_forward_with_cfg
@@ -110,7 +110,7 @@ def cpu_baseline(m, wl, budget_cells=128, evals=2):
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     cfg = DiTConfig(class_vocab_sizes=wl["vocab"], condition_strategy=wl["strategy"])
     z2, cond2, scales = make_inputs(wl, budget_cells, "cpu", seed=99)
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)  # small GEMMs: more threads than this only adds contention (measured)
     torch.set_num_threads(cores)
     f = lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales)
     sample_ode_fixed(z2[:8].repeat(1, 1, 1), lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, {k: v[:8] for k, v in cond2.items()}, scales), 2, "euler")
@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--evals", type=int, default=0, help="override the number of CFG evaluations (profiling only; not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra-workload measurements")
     args = ap.parse_args()
@@ -152,6 +153,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
+    if args.evals:
+        wl["evals"] = args.evals
     m = make_model(wl, args.precision, device)
     dt, blocks = time_workload(m, wl, device, args.steps, args.warmup, dist_on, world, rank, time_blocks=True)
     ms_per_step = 1e3 * dt / args.steps
