@@ -136,6 +136,11 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
 void scldm_dit_block_timing_enable(scldm_dit* h, int enable);
 int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms);
 
+/* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
+ * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the
+ * production library returns SCLDM_ERR_STATE. */
+int scldm_dit_set_debug_buffer(scldm_dit* h, void* dev_buf);
+
 #ifdef __cplusplus
 }
 #endif

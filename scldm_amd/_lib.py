@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscldm_hip.so")
+LIB_PATH = os.environ.get("SCLDM_LIB", os.path.join(_HERE, "libscldm_hip.so"))  # SCLDM_LIB: debug-build override
 
 MAX_CLASSES = 8
 PREC_FP32, PREC_BF16 = 0, 1
@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
     L.scldm_dit_block_timing_enable.argtypes = [C.c_void_p, C.c_int]
     L.scldm_dit_block_timing_enable.restype = None
     L.scldm_dit_block_timing.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.scldm_dit_set_debug_buffer.argtypes = [C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -76,7 +77,7 @@ def lib() -> C.CDLL:
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
            "scldm_dit_mod_width", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
-           "scldm_dit_block_timing"]
+           "scldm_dit_block_timing", "scldm_dit_set_debug_buffer"]
 
 
 def check(rc: int, what: str) -> None:

@@ -9,7 +9,7 @@
 
 #include "../../include/scldm_hip.h"
 #include "dit_aux.hpp"
-#include "dit_block.hpp"
+#include "dit_forward.hpp"
 
 using namespace scldm;
 
@@ -36,29 +36,27 @@ static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 128-token tile
 
-struct LayerPack {
-  void* stream[2];  // [precision] packed weight stream of the layer (+ ring over-read slack)
-  float* b_qkv;
-  float* b_proj;
-};
 
 struct scldm_dit {
   scldm_dit_config cfg;
   int n_chunks;   // padded hidden / 128
   int mod_w;
   bool loaded;
-  std::vector<LayerPack> layers;
+  void* stream[2];   // [precision] packed weight streams, [layer][wave][unit] (+ ring over-read slack)
+  void* wfinal[2];   // [precision] packed final_layer.linear
+  float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)
   float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
   float* emb;                      // concatenated class tables
   int emb_row0[SCLDM_MAX_CLASSES];
   float *ada_t, *ada_b;            // (256, mod_w), (mod_w)
   float *in_wt, *in_b, *pos;       // (Din,256), (256), (16,256)
-  float *fin_w, *fin_b;            // (Din,256), (Din)
+  float* fin_b;                    // (Din)
   // timing hook
   bool timing;
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   int force_ntt;
+  unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
 };
 
 extern "C" const char* scldm_last_error(void) { return g_err; }
@@ -71,7 +69,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (cfg->n_embed != 256 || cfg->n_head != 8 || cfg->seq_len != 16)
     return fail(SCLDM_ERR_SHAPE, "fused DiT block supports n_embed=256, n_head=8, seq_len=16 (got %d,%d,%d)", cfg->n_embed,
                 cfg->n_head, cfg->seq_len);
-  if (cfg->n_embed_input < 1 || cfg->n_embed_input > 64) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be in [1,64]");
+  if (cfg->n_embed_input < 1 || cfg->n_embed_input > 32) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be in [1,32]");
   if (cfg->n_layer < 1 || cfg->hidden_dim < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / hidden_dim");
   if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
   scldm_dit* h = new scldm_dit();
@@ -82,22 +80,20 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->timing = false;
   h->ev_used = 0;
   h->force_ntt = 0;
+  h->dbg = nullptr;
   if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
-  h->layers.resize(cfg->n_layer);
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
   const int L = cfg->n_layer, din = cfg->n_embed_input, nc = h->n_chunks;
   hipError_t e = hipSuccess;
-  for (int i = 0; i < L && e == hipSuccess; ++i) {
-    LayerPack& lp = h->layers[i];
-    for (int p = 0; p < 2 && e == hipSuccess; ++p) {
-      const size_t es = esize(p);
-      const size_t elems = ((size_t)4 * units_per_wave(nc) + kMaxPF) * 1024;  // + slack for the ring's over-read
-      if ((e = alloc(&lp.stream[p], elems * es)) != hipSuccess) break;
-      if ((e = hipMemset(lp.stream[p], 0, elems * es)) != hipSuccess) break;
-    }
-    if (e == hipSuccess) e = alloc((void**)&lp.b_qkv, 768 * 4);
-    if (e == hipSuccess) e = alloc((void**)&lp.b_proj, 256 * 4);
+  for (int p = 0; p < 2 && e == hipSuccess; ++p) {
+    const size_t es = esize(p);
+    const size_t elems = ((size_t)4 * L * units_per_layer(nc) + kMaxPF) * 1024;  // + slack for the ring's over-read
+    if ((e = alloc(&h->stream[p], elems * es)) != hipSuccess) break;
+    if ((e = hipMemset(h->stream[p], 0, elems * es)) != hipSuccess) break;
+    if ((e = alloc(&h->wfinal[p], 16 * 512 * es)) != hipSuccess) break;
   }
+  if (e == hipSuccess) e = alloc((void**)&h->b_qkv, (size_t)L * 768 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->b_proj, (size_t)L * 256 * 4);
   int emb_rows = 0;
   for (int c = 0; c < cfg->n_classes; ++c) {
     h->emb_row0[c] = emb_rows;
@@ -113,7 +109,6 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->in_wt, (size_t)din * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
-  if (e == hipSuccess) e = alloc((void**)&h->fin_w, (size_t)din * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
   if (e != hipSuccess) {
     int rc = fail(SCLDM_ERR_HIP, "hipMalloc failed in scldm_dit_create: %s", hipGetErrorString(e));
@@ -126,14 +121,11 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
 
 extern "C" void scldm_dit_destroy(scldm_dit* h) {
   if (!h) return;
-  for (auto& lp : h->layers) {
-    for (int p = 0; p < 2; ++p) {
-      if (lp.stream[p]) (void)hipFree(lp.stream[p]);
-    }
-    if (lp.b_qkv) (void)hipFree(lp.b_qkv);
-    if (lp.b_proj) (void)hipFree(lp.b_proj);
+  for (int p = 0; p < 2; ++p) {
+    if (h->stream[p]) (void)hipFree(h->stream[p]);
+    if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
-  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_b, h->pos, h->fin_w, h->fin_b};
+  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_b, h->pos, h->fin_b, h->b_qkv, h->b_proj};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -149,14 +141,13 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, nc = h->n_chunks, mw = h->mod_w;
   const int T = 256;
   for (int i = 0; i < L; ++i) {
-    LayerPack& lp = h->layers[i];
-    const long long npk = (long long)4 * units_per_wave(nc) * 1024;
+    const long long npk = (long long)4 * units_per_layer(nc) * 1024;
     pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                          (float*)lp.stream[0], H, nc);
+                                                          (float*)h->stream[0], H, nc, i, L);
     pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                           (__bf16*)lp.stream[1], H, nc);
-    copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], lp.b_qkv, 768);
-    copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], lp.b_proj, 256);
+                                                           (__bf16*)h->stream[1], H, nc, i, L);
+    copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], h->b_qkv + (size_t)i * 768, 768);
+    copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], h->b_proj + (size_t)i * 256, 256);
     // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
     transpose_kernel<<<cdiv(1536 * 256, T), T, 0, st>>>(w->ada_w[i], h->ada_t, 1536, 256, mw, i * 1536);
     copy_kernel<<<cdiv(1536, T), T, 0, st>>>(w->ada_b[i], h->ada_b + i * 1536, 1536);
@@ -170,7 +161,8 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   transpose_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_wt, 256, din, 256, 0);
   copy_kernel<<<1, T, 0, st>>>(w->in_b, h->in_b, 256);
   copy_kernel<<<cdiv(16 * 256, T), T, 0, st>>>(w->pos_embed, h->pos, 16 * 256);
-  copy_kernel<<<cdiv(din * 256, T), T, 0, st>>>(w->fin_w, h->fin_w, din * 256);
+  pack_final_kernel<float><<<cdiv(16 * 512, T), T, 0, st>>>(w->fin_w, (float*)h->wfinal[0], din);
+  pack_final_kernel<__bf16><<<cdiv(16 * 512, T), T, 0, st>>>(w->fin_w, (__bf16*)h->wfinal[1], din);
   copy_kernel<<<1, T, 0, st>>>(w->fin_b, h->fin_b, din);
   for (int ci = 0; ci < c.n_classes; ++ci) {
     const int n = (c.class_vocab[ci] + 1) * 256;
@@ -183,7 +175,7 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
 
 // ------------------------------------------------------------------------------------------------
 struct Ws {
-  float* h;       // (n_fwd*16, 256)
+  float* h;       // (pad8(n_fwd)*16, 256) residual between layer launches
   float* v;       // (n_fwd, 16*din)
   float* mod;     // (n_rows, mod_w)
   float* silu;    // (n_rows, 256)
@@ -199,7 +191,7 @@ static Ws carve(const scldm_dit* h, void* base, int n_fwd, int n_rows, int n_sta
   size_t off = 0;
   const size_t e = (size_t)16 * h->cfg.n_embed_input;
   auto take = [&](size_t bytes) { char* r = p + off; off += align256(bytes); return r; };
-  w.h = (float*)take((size_t)pad8(n_fwd) * 16 * 256 * 4);  // whole 128-token tiles
+  w.h = (float*)take((size_t)pad8(n_fwd) * 16 * 256 * 4);
   w.v = (float*)take((size_t)n_fwd * e * 4);
   w.mod = (float*)take((size_t)n_rows * h->mod_w * 4);
   w.silu = (float*)take((size_t)(n_rows + 1) * 256 * 4);  // +1 spare row (device scalar t)
@@ -244,15 +236,15 @@ static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows,
 }
 
 template <typename OP, int NTT>
-static int launch_block_t(scldm_dit* h, const BlockArgs& a, hipStream_t st) {
-  using L = BlockLayout<OP, NTT>;
+static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
+  using L = FwdLayout<OP, NTT>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dit_block_kernel<OP, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)dit_forward_kernel<OP, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
     attr_set = true;
   }
   const int grid = cdiv((long long)a.n_fwd * 16, L::TM);
-  dit_block_kernel<OP, NTT><<<grid, 256, L::LDS_BYTES, st>>>(a);
+  dit_forward_kernel<OP, NTT><<<grid, 256, L::LDS_BYTES, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -260,59 +252,61 @@ static int launch_block_t(scldm_dit* h, const BlockArgs& a, hipStream_t st) {
 static int pick_ntt(const scldm_dit* h, int n_fwd, int prec) {
   if (prec == SCLDM_PREC_FP32) return 2;
   if (h->force_ntt == 2 || h->force_ntt == 4) return h->force_ntt;
-  // 128-token tiles once they fill the 256 CUs at least twice; 64-token tiles (2 workgroups / CU) below that
-  return ((long long)n_fwd * 16 >= 2LL * 256 * 128) ? 4 : 2;
+  return 2;  // 64-token tiles, two workgroups per CU (measured faster than 128-token tiles at every size so far)
 }
 
-static int launch_block(scldm_dit* h, const BlockArgs& a, int prec, hipStream_t st) {
-  const int ntt = pick_ntt(h, a.n_fwd, prec);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->timing && h->ev_used + 2 <= 40000) {
-    while (h->ev.size() < h->ev_used + 2) {
-      hipEvent_t ev;
-      HIP_TRY(hipEventCreate(&ev));
-      h->ev.push_back(ev);
-    }
-    e0 = h->ev[h->ev_used];
-    e1 = h->ev[h->ev_used + 1];
-    h->ev_used += 2;
-    HIP_TRY(hipEventRecord(e0, st));
-  }
-  int rc;
-  if (prec == SCLDM_PREC_FP32) rc = launch_block_t<OpF32, 2>(h, a, st);
-  else if (ntt == 4) rc = launch_block_t<OpBF16, 4>(h, a, st);
-  else rc = launch_block_t<OpBF16, 2>(h, a, st);
-  if (rc != SCLDM_OK) return rc;
-  if (e1) HIP_TRY(hipEventRecord(e1, st));
-  return SCLDM_OK;
-}
-
+// The DiT trunk: one fused launch per layer (input projection rides in the first, the final layer in the last).
 static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd, const float* mod, const int32_t* ridx,
                  float* hbuf, float* out, int prec, hipStream_t st) {
   const scldm_dit_config& c = h->cfg;
-  input_proj_kernel<<<pad8(n_fwd), 256, 0, st>>>(x, h->in_wt, h->in_b, h->pos, hbuf, c.n_embed_input, n_direct, rep, n_fwd);
-  LAUNCH_CHECK();
+  const size_t es = esize(prec);
+  const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks) * 1024;
+  const int ntt = pick_ntt(h, n_fwd, prec);
+  FwdArgs a;
+  a.z = x;
+  a.out = out;
+  a.x = hbuf;
+  a.mod = mod;
+  a.row_index = ridx;
+  a.w_final = h->wfinal[prec];
+  a.in_wt = h->in_wt;
+  a.in_b = h->in_b;
+  a.pos = h->pos;
+  a.fin_b = h->fin_b;
+  a.n_fwd = n_fwd;
+  a.n_direct = n_direct;
+  a.rep = rep;
+  a.din = c.n_embed_input;
+  a.n_layer = c.n_layer;
+  a.n_chunks = h->n_chunks;
+  a.mod_stride = h->mod_w;
+  a.eps = c.layernorm_eps;
+  a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
+  a.dbg = h->dbg;
   for (int i = 0; i < c.n_layer; ++i) {
-    const LayerPack& lp = h->layers[i];
-    BlockArgs a;
-    a.x = hbuf;
-    a.mod = mod;
-    a.row_index = ridx;
-    a.w_stream = lp.stream[prec];
-    a.b_qkv = lp.b_qkv; a.b_proj = lp.b_proj;
-    a.n_fwd = n_fwd;
-    a.mod_stride = h->mod_w;
-    a.mod_offset = i * kModBlock;
-    a.n_chunks = h->n_chunks;
-    a.eps = c.layernorm_eps;
-    a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
-    int rc = launch_block(h, a, prec, st);
+    a.layer = i;
+    a.w_stream = (const char*)h->stream[prec] + (size_t)i * layer_elems * es;
+    a.b_qkv = h->b_qkv + (size_t)i * 768;
+    a.b_proj = h->b_proj + (size_t)i * 256;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing && h->ev_used + 2 <= 40000) {
+      while (h->ev.size() < h->ev_used + 2) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        h->ev.push_back(ev);
+      }
+      e0 = h->ev[h->ev_used];
+      e1 = h->ev[h->ev_used + 1];
+      h->ev_used += 2;
+      HIP_TRY(hipEventRecord(e0, st));
+    }
+    int rc;
+    if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2>(a, st);
+    else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4>(a, st);
+    else rc = launch_fwd_t<OpBF16, 2>(a, st);
     if (rc != SCLDM_OK) return rc;
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
   }
-  const int n_tok = n_fwd * 16;
-  final_layer_kernel<<<cdiv(n_tok, 4), 256, 0, st>>>(hbuf, mod, ridx, h->mod_w, c.n_layer * kModBlock, h->fin_w, h->fin_b, out,
-                                                      n_tok, c.n_embed_input, c.layernorm_eps);
-  LAUNCH_CHECK();
   return SCLDM_OK;
 }
 
@@ -504,4 +498,17 @@ extern "C" int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* tot
   if (total_ms) *total_ms = tot;
   h->ev_used = 0;
   return SCLDM_OK;
+}
+
+// Debug hook: device buffer receiving per-(block, wave) s_memtime phase stamps of the LAST fused-block launch
+// (16 x u64 per wave).  Only -DSCLDM_PHASE_TIMING builds write it; production builds return SCLDM_ERR_STATE.
+extern "C" int scldm_dit_set_debug_buffer(scldm_dit* h, void* dev_buf) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+#ifdef SCLDM_PHASE_TIMING
+  h->dbg = (unsigned long long*)dev_buf;
+  return SCLDM_OK;
+#else
+  (void)dev_buf;
+  return fail(SCLDM_ERR_STATE, "phase timing is not compiled in (build with -DSCLDM_PHASE_TIMING)");
+#endif
 }

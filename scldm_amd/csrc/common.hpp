@@ -26,8 +26,16 @@ __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r 
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp each) - well inside the 1e-4 parity budget
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
-__device__ __forceinline__ float xor32_sum(float v) { return v + __shfl_xor(v, 32); }
-__device__ __forceinline__ float xor32_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+// Reductions across the two 32-lane halves of a wave with v_permlane32_swap (VALU, no LDS round trip):
+// swap(v, v) yields {v[l & 31]} and {v[(l & 31) + 32]} in every lane; sum / max are symmetric in the two.
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -44,6 +52,7 @@ struct OpBF16 {
   using Frag = bf16x8;
   using Quad = bf16x4;  // 4 consecutive elements (one accumulator register group)
   static constexpr bool kIsBF16 = true;
+  static constexpr bool kTwoPassLN = false;  // sum / sum-of-squares in one sweep (fp32 accumulation)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -65,6 +74,7 @@ struct OpF32 {
   using Frag = f32x8;
   using Quad = f32x4;
   static constexpr bool kIsBF16 = false;
+  static constexpr bool kTwoPassLN = true;   // parity path: mean first, then centred second moment
   // exact fp32: 8 x v_mfma_f32_32x32x2_f32 (each contracts k-groups 0 and 1 of one element slot)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
 #pragma unroll

@@ -2,13 +2,13 @@
 // + all-layer adaLN projection), input projection, final layer, CFG blend and ODE state update.
 #pragma once
 #include "common.hpp"
-#include "dit_block.hpp"
+#include "dit_forward.hpp"
 
 namespace scldm {
 
 // ------------------------------------------------------------------------------------------------
 // Weight packing: PyTorch (out, in) row-major fp32 -> one contiguous MFMA-fragment stream per wave
-// (layout documented at WStream in dit_block.hpp).  Element (unit gu, tile ft, lane l, j) lives at
+// (layout documented at WStream in dit_forward.hpp).  Element (unit gu, tile ft, lane l, j) lives at
 // ((gu*2 + ft)*64 + l)*8 + j; its k index inside the unit's k-step is (l>>5)*8 + j; its row is l&31.
 //   units 0-47 : c_attn rows p*256 + w*64 + ft*32 + r          (p = q,k,v)       attn.c_attn.weight (768,256)
 //   units 48-63: c_proj rows w*64 + ft*32 + r                                      attn.c_proj.weight (256,256)
@@ -19,12 +19,12 @@ namespace scldm {
 template <typename E>
 __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* __restrict__ Wproj, const float* __restrict__ W1,
                                   const float* __restrict__ W2, const float* __restrict__ Wcp, E* __restrict__ out, int H,
-                                  int n_chunks) {
-  const int UW = units_per_wave(n_chunks);
+                                  int n_chunks, int layer, int n_layer) {
+  const int UL = units_per_layer(n_chunks);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)4 * UW * 1024) return;
+  if (idx >= (long long)4 * UL * 1024) return;
   const int j = idx & 7, l = (idx >> 3) & 63, ft = (idx >> 9) & 1;
-  const int gu = (int)(idx >> 10), w = gu / UW, u = gu % UW;
+  const int gu = (int)(idx >> 10), w = gu / UL, u = gu % UL;
   const int r = l & 31, k8 = (l >> 5) * 8 + j;
   float val;
   if (u < 48) {
@@ -44,7 +44,18 @@ __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* _
       val = (hid < H) ? Wcp[(size_t)(w * 64 + ft * 32 + r) * H + hid] : 0.f;
     }
   }
-  out[idx] = (E)val;
+  (void)n_layer;
+  out[(((size_t)layer * 4 + w) * UL + u) * 1024 + (idx & 1023)] = (E)val;  // [layer][wave][unit]
+}
+
+// final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
+template <typename E>
+__global__ void pack_final_kernel(const float* __restrict__ W, E* __restrict__ out, int din) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 16 * 512) return;
+  const int j = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
+  const int row = l & 31, k = ks * 16 + (l >> 5) * 8 + j;
+  out[idx] = (E)((row < din) ? W[row * 256 + k] : 0.f);
 }
 
 // out[k*ldo + col0 + n] = W[n*K + k]  (transpose so that consecutive threads read consecutive floats)
@@ -138,66 +149,6 @@ __global__ __launch_bounds__(256) void adaln_all_kernel(const float* __restrict_
 #pragma unroll
   for (int r = 0; r < kAdaRU; ++r)
     if (u0 + r < rows) mod[(size_t)(u0 + r) * mod_w + n] = acc[r];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Input projection + positional embedding (nnets.py:290-291).  One workgroup per sample-forward.
-// Sample-forward s reads latent row (s < n_direct ? s : s - ((s - n_direct) / rep + 1) * rep ... ) -
-// expressed generally through src_row = s < n_direct ? s : n_direct - rep + (s - n_direct) % rep,
-// i.e. every extra (conditional) pass re-reads the LAST `rep` rows of the state (the guided half).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ z, const float* __restrict__ wt /*[din][256]*/,
-                                                         const float* __restrict__ b, const float* __restrict__ pos,
-                                                         float* __restrict__ h, int din, int n_direct, int rep, int n_fwd) {
-  __shared__ float xs[16 * 64];
-  const int s = blockIdx.x, n = threadIdx.x;
-  if (s >= n_fwd) {  // tile padding: finite (zero) rows so that 0 * pad never produces NaN inside shared MFMA tiles
-    for (int tok = 0; tok < 16; ++tok) h[((size_t)s * 16 + tok) * 256 + n] = 0.f;
-    return;
-  }
-  const int src = (s < n_direct) ? s : (n_direct - rep + (s - n_direct) % rep);
-  for (int i = n; i < 16 * din; i += 256) xs[i] = z[(size_t)src * 16 * din + i];
-  __syncthreads();
-  const float bn = b[n];
-  for (int tok = 0; tok < 16; ++tok) {
-    float acc = bn + pos[tok * 256 + n];
-    for (int k = 0; k < din; ++k) acc += wt[k * 256 + n] * xs[tok * din + k];
-    h[((size_t)s * 16 + tok) * 256 + n] = acc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Final layer (layers.py:397-401): LN (no affine) -> *(1+scale)+shift with (shift, scale) = chunks
-// (0, 1) of the final adaLN vector (conventional order) -> Linear 256 -> din.  One wave per token.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void final_layer_kernel(const float* __restrict__ h, const float* __restrict__ mod,
-                                                          const int32_t* __restrict__ row_index, int mod_stride, int fin_off,
-                                                          const float* __restrict__ w /*[din][256]*/, const float* __restrict__ b,
-                                                          float* __restrict__ out, int n_tok, int din, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= n_tok) return;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(h + (size_t)tok * 256 + lane * 4);
-  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256);
-  float d[4], ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    d[i] = v[i] - mean;
-    ss += d[i] * d[i];
-  }
-  const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * (1.0f / 256) + eps);
-  const float* mrow = mod + (size_t)row_index[tok >> 4] * mod_stride + fin_off;
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(mrow + lane * 4);
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(mrow + 256 + lane * 4);
-  float y[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) y[i] = d[i] * rstd * (1.0f + sc[i]) + sh[i];
-  for (int j = 0; j < din; ++j) {
-    const f32x4 wj = *reinterpret_cast<const f32x4*>(w + j * 256 + lane * 4);
-    float p = y[0] * wj[0] + y[1] * wj[1] + y[2] * wj[2] + y[3] * wj[3];
-    p = wave_sum(p);
-    if (lane == 0) out[(size_t)tok * din + j] = p + b[j];
-  }
 }
 
 // ------------------------------------------------------------------------------------------------

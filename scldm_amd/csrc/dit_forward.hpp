@@ -1,0 +1,668 @@
+// Fused adaLN-Zero DiT layer for gfx950: one launch = one transformer block over all sample-forwards
+// (the first launch also does the input projection, the last one the final layer).  Inside a layer the
+// fp32 residual lives in registers: it is read once and written once per layer.
+//
+// Why one launch per layer and not one persistent launch for the whole network: every workgroup streams
+// the layer's full 1.7 MB of weights; with all CUs of an XCD on the SAME layer that stream is served by the
+// 4 MB L2.  A whole-network persistent variant was measured (round 1): workgroups drift across layers, the
+// 13.6 MB weight set falls out of L2 and the GEMM phases slow down 1.8x.  Kernel boundaries are the cheapest
+// lockstep on this chip.
+//
+// Replaces the reference's (eager, ~230 launches per forward)
+//   DiT.forward trunk                     src/scldm/nnets.py:290-296
+//   Block.forward adaLN branch            src/scldm/layers.py:213-221  (+ modulate :91-94, F7 order)
+//   SelfAttention.forward                 src/scldm/layers.py:143-158
+//   MLP.forward (SwiGLU)                  src/scldm/layers.py:173-174
+//   FinalLayerDit.forward                 src/scldm/layers.py:397-401
+// Specialised to the reference's only DiT shape family: n_embed 256, 8 heads x 32, seq_len 16
+// (experiments/configs/model/ldm_base.yaml:16-25); hidden (684) is zero-padded to a multiple of 128.
+//
+// Work decomposition (MI355X-first, not a GEMM-library composition):
+//   * one workgroup = 4 waves (one per SIMD) owns a tile of TM = 32*NTT tokens (= 2*NTT samples); the
+//     residual x of the tile lives in VGPRs in MFMA accumulator layout for the whole layer (the first version
+//     re-read/re-wrote it five times per layer and spent 37 % of its time on that, in phase-locked bursts);
+//   * GEMMs are computed TRANSPOSED, Y^T[feature][token] = W[feature][k] * X^T[k][token]:
+//       A operand = weights, streamed L2 -> VGPR in a pre-packed per-wave fragment stream that runs
+//                   continuously through the layer (each weight byte is read by exactly one wave of the
+//                   workgroup -> no LDS staging; a register ring prefetches across phase boundaries),
+//       B operand = activations, shared by the four waves through LDS ([token][feature], +16 B row pad
+//                   => conflict-free ds_read_b128);
+//     wave w owns output features [64w, 64w+64) = heads 2w, 2w+1, for ALL tokens of the tile, so
+//     LayerNorm statistics are an in-lane sum + one xor-32 exchange + a 4-way LDS combine;
+//   * attention never leaves registers: Q^T and K^T tiles come out of the MFMA in a layout that is
+//     directly a valid A/B operand pair for S^T = K Q^T (any k permutation is legal if both sides
+//     share it); V is produced with swapped operands (V[token][d]) so that O^T = V^T P^T likewise
+//     needs no transpose; softmax over the 16 keys is 8 in-lane values + one xor-32 exchange.
+//     Two samples share each 32x32 MFMA tile; cross-sample score blocks are masked to exact zeros;
+//   * the SwiGLU hidden dimension is processed in chunks of 128 through a double-buffered LDS
+//     stage (w1/w2 rows are interleaved inside each 32-row weight tile so silu(a)*b is in-lane).
+#pragma once
+#include "common.hpp"
+
+namespace scldm {
+
+constexpr int kD = 256;        // n_embed
+constexpr int kHC = 128;       // hidden chunk per workgroup (4 waves x 32)
+constexpr int kModBlock = 6 * kD;
+constexpr int kDbgStamps = 32;
+
+// Phase stamps (s_memtime) for the debug build (first layer only); compiles to nothing otherwise.
+#ifdef SCLDM_PHASE_TIMING
+#define SCLDM_STAMP(i)                                                                                 \
+  do {                                                                                                 \
+    if (a.dbg && lane == 0)                                                                            \
+      a.dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter();       \
+  } while (0)
+#define SCLDM_STAMP_END(i)                                                                             \
+  do {                                                                                                 \
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define SCLDM_STAMP(i) do {} while (0)
+#define SCLDM_STAMP_END(i) do {} while (0)
+#endif
+
+struct FwdArgs {
+  const float* z;           // latents (n_src, 16, din) fp32 (read by the first layer)
+  float* out;               // (n_fwd, 16, din) fp32 (written by the last layer)
+  float* x;                 // (n_fwd padded to the tile, 16, 256) fp32 residual between layers
+  const float* mod;         // (rows, mod_stride) adaLN vectors: [layer][6][256] ... [final: shift, scale]
+  const int32_t* row_index; // (n_fwd) conditioning row of each sample-forward
+  const void* w_stream;     // packed weights of THIS layer, [wave][unit] (pack_layer_kernel)
+  const void* w_final;      // final_layer.linear packed as 16 fragments (rows >= din are zero)
+  const float* b_qkv;       // (768) of this layer
+  const float* b_proj;      // (256) of this layer
+  const float* in_wt;       // input_proj weight transposed (din, 256)
+  const float* in_b;        // (256)
+  const float* pos;         // (16, 256)
+  const float* fin_b;       // (din)
+  int n_fwd;                // number of sample-forwards (16 tokens each)
+  int n_direct, rep;        // sample-forward s reads latent s (s < n_direct) else n_direct - rep + (s - n_direct) % rep
+  int din;                  // latent channels (<= 32 handled by one output tile)
+  int layer, n_layer;       // this launch's layer index
+  int n_chunks;             // padded hidden / 128
+  int mod_stride;
+  float eps;
+  float attn_scale_log2e;   // log2(e) / sqrt(head_dim)
+  unsigned long long* dbg;  // phase stamps [block][wave][kDbgStamps]; only -DSCLDM_PHASE_TIMING builds write
+};
+
+template <typename OP, int NTT>
+struct FwdLayout {
+  using E = typename OP::E;
+  static constexpr int TM = 32 * NTT;
+  static constexpr int NS = 2 * NTT;            // samples per tile
+  static constexpr int PADE = 16 / sizeof(E);
+  static constexpr int XA_LD = kD + PADE;       // elements per activation row
+  static constexpr int HB_LD = kHC + PADE;      // elements per hidden-chunk row
+  static constexpr int XA_BYTES = TM * XA_LD * sizeof(E);   // LN output; later the attention output (AO aliases it)
+  static constexpr int HB_BYTES = TM * HB_LD * sizeof(E);   // one SwiGLU hidden chunk
+  static constexpr int RED_BYTES = 2 * 4 * TM * sizeof(float);
+  static constexpr int MOD_BYTES = NS * kModBlock * sizeof(float);  // the tile's six adaLN vectors per sample
+  static constexpr int LDS_BYTES = XA_BYTES + HB_BYTES + RED_BYTES + MOD_BYTES;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Weight stream.  Every wave consumes ONE contiguous sequence of "units" for the whole network
+// (unit = one k-step of 16 for the wave's two 32-row weight tiles = 2 fragments = 2 KiB bf16) per layer:
+//     Q (16 units) | K (16) | V (16) | proj (16) | for each hidden chunk: W12 (16) | c_proj (8)
+// A PF-deep register ring runs ahead of the MFMAs and persists across passes, so L2 latency is
+// hidden across phase boundaries too and nothing is fetched twice.  The ring over-reads PF units
+// past the wave's last unit (next wave's stream / allocation slack), which is never consumed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kUnitsFixed = 64;      // Q,K,V,proj
+constexpr int kUnitsPerChunk = 24;   // W12 (16) + c_proj (8)
+constexpr int kMaxPF = 8;
+__host__ __device__ constexpr int units_per_layer(int n_chunks) { return kUnitsFixed + n_chunks * kUnitsPerChunk; }
+
+template <typename OP, int NTT>
+struct Prefetch {  // k-steps of run-ahead: ~1k cycles of MFMA work per ring depth
+  static constexpr int PF = OP::kIsBF16 ? 4 : 2;
+};
+
+template <typename OP, int PF>
+struct WStream {
+  using Frag = typename OP::Frag;
+  const Frag* p;  // next unit to fetch (lane offset folded in)
+  Frag ring[PF][2];
+  __device__ __forceinline__ void init(const Frag* base) {
+    p = base;
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      ring[s][0] = p[0];
+      ring[s][1] = p[64];
+      p += 128;
+    }
+  }
+};
+
+// One GEMM pass: acc[ft][tt] (+)= W-tile(ft) * B-tile(tt) over KSTEPS*16 k-values; activations from LDS.
+// ZERO=true starts from zero accumulators (first k-step uses an inline-zero C operand: no register clearing).
+// SWAP=true computes the transposed tile (token rows, feature cols) - used for V.
+//
+// Schedule per k-step, pinned with sched_group_barrier (hipcc otherwise sinks every refill load to the end of
+// the unrolled body and waits for it two MFMAs later, and issues each ds_read right in front of its consumer):
+//     NTT ds_read_b128 (B fragments of the NEXT k-step)  |  2*NTT MFMAs (this k-step)  |  2 global loads
+// (refill of the ring slot just consumed = PF k-steps ahead).
+template <typename OP, int NTT, int KSTEPS, bool SWAP, bool ZERO, int PF>
+__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2][NTT], WStream<OP, PF>& ws,
+                                          const typename OP::E* __restrict__ bsm, int ldb, int lane) {
+  using Frag = typename OP::Frag;
+  static_assert(KSTEPS % PF == 0, "KSTEPS must be a multiple of the prefetch depth");
+  const int c32 = lane & 31, hh = lane >> 5;
+  const typename OP::E* bbase = bsm + c32 * ldb + hh * 8;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  Frag bcur[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) bcur[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb);
+  auto step = [&](int ks, int s, bool first) {
+    Frag bnext[NTT];
+    // B fragments of k-step ks+1 (after the last k-step this reads the row pad / next row: valid LDS, never used)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 1) * 16);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      if (SWAP) {
+        acc[0][tt] = OP::mma(bcur[tt], ws.ring[s][0], first ? zero : acc[0][tt]);
+        acc[1][tt] = OP::mma(bcur[tt], ws.ring[s][1], first ? zero : acc[1][tt]);
+      } else {
+        acc[0][tt] = OP::mma(ws.ring[s][0], bcur[tt], first ? zero : acc[0][tt]);
+        acc[1][tt] = OP::mma(ws.ring[s][1], bcur[tt], first ? zero : acc[1][tt]);
+      }
+    }
+    ws.ring[s][0] = ws.p[0];  // refill the slot just consumed: PF k-steps ahead
+    ws.ring[s][1] = ws.p[64];
+    ws.p += 128;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
+    if (OP::kIsBF16) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);      // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTT, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);        // VMEM read
+    }
+  };
+  // peeled first ring revolution (so that ZERO needs no accumulator clearing), then the rolled loop
+#pragma unroll
+  for (int s = 0; s < PF; ++s) step(s, s, ZERO && s == 0);
+#pragma unroll 1
+  for (int ks0 = PF; ks0 < KSTEPS; ks0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) step(ks0 + s, s, false);
+  }
+}
+
+// LayerNorm (no affine, biased variance, two-pass) over the 256 features of every token of the tile,
+// followed by y*(1+scale)+shift, written as OP::E into dst[token][feature].
+// v holds this wave's 64 features x TM tokens in accumulator layout.
+#ifdef SCLDM_PHASE_TIMING
+#define SCLDM_LN_STAMP(i)                                                                              \
+  do {                                                                                                 \
+    if (SB >= 0 && dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + SB + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define SCLDM_LN_STAMP(i) do {} while (0)
+#endif
+
+// LayerNorm (no affine, biased variance) over the 256 features of every token of the tile, followed by
+// y*(1+scale)+shift, written as OP::E into dst[token][feature].  v holds this wave's 64 features x TM tokens in
+// accumulator layout; scale/shift come from the LDS copy of the tile's adaLN vectors (msm[sample][6*256], vector
+// indices sc_v / sh_v).  Statistics: in-lane sums -> one permlane32 exchange -> 4-way combine through LDS.
+// `between` runs between the first statistics barrier and the last one (used to publish freshly staged LDS data).
+template <typename OP, int NTT, int SB = -1, typename Between>
+__device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], const float* msm, int sc_v, int sh_v,
+                                                  float eps, float* red, typename OP::E* dst, int ldd, int wave,
+                                                  int lane, unsigned long long* dbg, Between between) {
+  constexpr int TM = 32 * NTT;
+  const int c32 = lane & 31, hh = lane >> 5;
+  float* red_a = red;
+  float* red_b = red + 4 * TM;
+  float mean[NTT], rstd[NTT];
+  if (OP::kTwoPassLN) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += v[ft][tt][r];
+      s = xor32_sum(s);
+      if (hh == 0) red_a[wave * TM + tt * 32 + c32] = s;
+    }
+    SCLDM_LN_STAMP(0);
+    __syncthreads();
+    SCLDM_LN_STAMP(1);
+    between();
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int t = tt * 32 + c32;
+      mean[tt] = (red_a[t] + red_a[TM + t] + red_a[2 * TM + t] + red_a[3 * TM + t]) * (1.0f / kD);
+      float s = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = v[ft][tt][r] - mean[tt];
+          s += d * d;
+        }
+      s = xor32_sum(s);
+      if (hh == 0) red_b[wave * TM + t] = s;
+    }
+    SCLDM_LN_STAMP(2);
+    __syncthreads();
+    SCLDM_LN_STAMP(3);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int t = tt * 32 + c32;
+      const float var = (red_b[t] + red_b[TM + t] + red_b[2 * TM + t] + red_b[3 * TM + t]) * (1.0f / kD);
+      rstd[tt] = __builtin_amdgcn_rsqf(var + eps);
+    }
+  } else {
+    between();
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s += v[ft][tt][r];
+          ss += v[ft][tt][r] * v[ft][tt][r];
+        }
+      s = xor32_sum(s);
+      ss = xor32_sum(ss);
+      if (hh == 0) {
+        red_a[wave * TM + tt * 32 + c32] = s;
+        red_b[wave * TM + tt * 32 + c32] = ss;
+      }
+    }
+    SCLDM_LN_STAMP(0);
+    __syncthreads();
+    SCLDM_LN_STAMP(3);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int t = tt * 32 + c32;
+      mean[tt] = (red_a[t] + red_a[TM + t] + red_a[2 * TM + t] + red_a[3 * TM + t]) * (1.0f / kD);
+      const float ex2 = (red_b[t] + red_b[TM + t] + red_b[2 * TM + t] + red_b[3 * TM + t]) * (1.0f / kD);
+      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(ex2 - mean[tt] * mean[tt], 0.f) + eps);
+    }
+  }
+  const int sp = c32 >> 4;
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const float* mr = msm + (tt * 2 + sp) * kModBlock;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(mr + sc_v * kD + f);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(mr + sh_v * kD + f);
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+        *reinterpret_cast<typename OP::Quad*>(dst + (tt * 32 + c32) * ldd + f) = OP::pack4(y[0], y[1], y[2], y[3]);
+      }
+    }
+  }
+}
+
+template <typename OP, int NTT>
+__global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
+  using L = FwdLayout<OP, NTT>;
+  using E = typename OP::E;
+  using Frag = typename OP::Frag;
+  using Quad = typename OP::Quad;
+  constexpr int TM = L::TM;
+  constexpr int NS = L::NS;
+  constexpr int PF = Prefetch<OP, NTT>::PF;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  E* XA = reinterpret_cast<E*>(smem);
+  E* HB = reinterpret_cast<E*>(smem + L::XA_BYTES);
+  float* RED = reinterpret_cast<float*>(smem + L::XA_BYTES + L::HB_BYTES);
+  float* MOD = reinterpret_cast<float*>(smem + L::XA_BYTES + L::HB_BYTES + L::RED_BYTES);
+  E* AO = XA;  // the attention output reuses the LN1 buffer once every wave has finished its Q/K/V passes
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int tok0 = blockIdx.x * TM;
+  const int smp0 = blockIdx.x * NS;
+  const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
+  const int layer = a.layer;
+  auto nothing = [] {};
+
+  SCLDM_STAMP(0);
+  // the weight stream starts first: its first PF units fly while the prologue runs
+  WStream<OP, PF> ws;
+  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks) * 128 + lane);
+
+  // the tile's six adaLN vectors per sample: coalesced loads now, parked in LDS during LN1 (16 lanes share every
+  // value, so per-lane global loads would be 16x redundant and - measured - fully latency-exposed)
+  constexpr int kModLd = NS * kModBlock / 4 / 256;  // float4 per thread
+  f32x4 mstage[kModLd];
+#pragma unroll
+  for (int j = 0; j < kModLd; ++j) {
+    const int idx = tid + 256 * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    const int s = min(smp0 + sl, a.n_fwd - 1);
+    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
+  }
+
+  // per-token-tile bookkeeping; samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
+  bool live[NTT];
+  size_t xoff[NTT];  // the x buffer is padded to whole tiles: no predication on its loads/stores
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    xoff[tt] = (size_t)(tok0 + tt * 32 + c32) * kD + wave * 64 + hh * 4;
+    live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
+  }
+
+  float xr[2][NTT][16];  // the residual stream: features [64w, 64w+64) x TM tokens, accumulator layout (scalars:
+                         // it never feeds an MFMA, and whole-vector values would be copied around by the compiler)
+  if (layer == 0) {
+    // ---- input projection + positional embedding (nnets.py:290-291), exact fp32 on the VALU (K = din) ----
+    const int p16 = c32 & 15;  // token position inside its sample
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.in_b + f);
+        const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pos + p16 * kD + f);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = bb[i] + pp[i];
+      }
+    const float* zrow[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const int s = min((tok0 + tt * 32 + c32) >> 4, a.n_fwd - 1);
+      const int src = (s < a.n_direct) ? s : (a.n_direct - a.rep + (s - a.n_direct) % a.rep);
+      zrow[tt] = a.z + ((size_t)src * 16 + p16) * a.din;
+    }
+    for (int k = 0; k < a.din; ++k) {
+      float zk[NTT];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) zk[tt] = zrow[tt][k];
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.in_wt + k * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += w4[i] * zk[tt];
+        }
+    }
+  } else {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.x + xoff[tt] + ft * 32 + q * 8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = t4[i];
+        }
+  }
+
+  f32x16 acc[2][NTT];
+  const float* bq = a.b_qkv;
+  const float* bp = a.b_proj;
+
+  // ---- LN1 + modulate(a0 = scale, a1 = shift) -> XA (the staged adaLN vectors are published on the way) ----
+  ln_modulate_store<OP, NTT>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
+#pragma unroll
+    for (int j = 0; j < kModLd; ++j) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + 256 * j) * 4) = mstage[j];
+  });
+  __syncthreads();
+  SCLDM_STAMP(1);
+
+  // ---- attention for heads 2w, 2w+1, entirely in registers ----
+  //   Q pass, K pass -> S^T = K Q^T -> softmax -> P  (Q, K fragments die here: keeps the live MFMA
+  //   operand set inside the architectural VGPRs) -> V pass -> O^T = V^T P^T (kept in acc).
+  {
+    Frag Pf[2][NTT][2];
+    {
+      Frag QF[2][NTT][2], KF[2][NTT][2];
+      gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // Q^T (feature x token)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        float bias[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 0 * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bias[r];
+          QF[ft][tt][0] = OP::pack8(t);
+          QF[ft][tt][1] = OP::pack8(t + 8);
+        }
+      }
+      SCLDM_STAMP(2);
+      gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // K^T (feature x token)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+        float bias[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 1 * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
+        }
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          float t[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bias[r];
+          KF[ft][tt][0] = OP::pack8(t);
+          KF[ft][tt][1] = OP::pack8(t + 8);
+        }
+      }
+      SCLDM_STAMP(3);
+      // scores + softmax
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft) {
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          st = OP::mma(KF[ft][tt][0], QF[ft][tt][0], st);  // S^T[key][query], k = head dims
+          st = OP::mma(KF[ft][tt][1], QF[ft][tt][1], st);
+          float sv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // keys of the query's own sample (opaque copies keep this a v_cndmask,
+            float lo = st[i], hi = st[8 + i];  // not a dynamically indexed vector extract)
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            sv[i] = sp ? hi : lo;
+          }
+          float m = sv[0];
+#pragma unroll
+          for (int i = 1; i < 8; ++i) m = fmaxf(m, sv[i]);
+          m = xor32_max(m);
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            sv[i] = __builtin_amdgcn_exp2f((sv[i] - m) * a.attn_scale_log2e);
+            sum += sv[i];
+          }
+          sum = xor32_sum(sum);
+          const float inv = __builtin_amdgcn_rcpf(sum);
+          float p[16];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float pv = sv[i] * inv;
+            p[i] = sp ? 0.f : pv;       // cross-sample blocks of the shared 32x32 tile are exactly zero
+            p[8 + i] = sp ? pv : 0.f;
+          }
+          Pf[ft][tt][0] = OP::pack8(p);
+          Pf[ft][tt][1] = OP::pack8(p + 8);
+        }
+      }
+    }
+    SCLDM_STAMP(4);
+    // V (swapped operands: lane = feature, registers = tokens), then O^T = V^T P^T
+    gemm_pass<OP, NTT, 16, true, true, PF>(acc, ws, XA, L::XA_LD, lane);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+      const float bv = bq[2 * kD + wave * 64 + ft * 32 + c32];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bv;
+        const Frag v0 = OP::pack8(t), v1 = OP::pack8(t + 8);
+        f32x16 ot = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ot = OP::mma(v0, Pf[ft][tt][0], ot);  // O^T[d][query], k = keys
+        ot = OP::mma(v1, Pf[ft][tt][1], ot);
+        acc[ft][tt] = ot;
+      }
+    }
+  }
+  SCLDM_STAMP(5);
+  __syncthreads();  // every wave is done reading XA (Q/K/V passes): it may now be overwritten by the attention output
+#pragma unroll
+  for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<Quad*>(AO + (tt * 32 + c32) * L::XA_LD + wave * 64 + ft * 32 + q * 8 + hh * 4) =
+            OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]);
+  __syncthreads();  // AO complete
+  SCLDM_STAMP(6);
+
+  // ---- attention projection, gated residual (a2), LN2 + modulate(a3 = scale, a4 = shift) -> XA ----
+  gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane);
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + f);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(MOD + (tt * 2 + sp) * kModBlock + 2 * kD + f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * (acc[ft][tt][q * 4 + i] + b4[i]);
+      }
+  SCLDM_STAMP(7);
+  // (the statistics barrier inside also guarantees every wave has finished reading AO before XA is rewritten)
+  ln_modulate_store<OP, NTT, 16>(xr, MOD, 3, 4, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
+  SCLDM_STAMP(20);
+  __syncthreads();  // XA (MLP input) complete
+  SCLDM_STAMP(8);
+
+  // ---- SwiGLU MLP, hidden processed in chunks of 128 staged through HB ----
+  f32x16 accp[2][NTT];
+  for (int c = 0; c < a.n_chunks; ++c) {
+    gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);
+    // rows 0-15 of each weight tile are w1, rows 16-31 the matching w2 rows => registers r and r+8 pair up
+    Quad hq[2][NTT][2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float h[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h[i] = silu_f(acc[ft][tt][q * 4 + i]) * acc[ft][tt][8 + q * 4 + i];
+          hq[ft][tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
+        }
+    if (c > 0) __syncthreads();  // every wave has finished the previous chunk's c_proj pass: HB is free
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + wave * 32 + ft * 16 + q * 8 + hh * 4) = hq[ft][tt][q];
+    if (c == 0) SCLDM_STAMP(11);
+    __syncthreads();
+    if (c == 0) SCLDM_STAMP(12);
+    if (c == 0) gemm_pass<OP, NTT, 8, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
+    else gemm_pass<OP, NTT, 8, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
+    if (c == 0) SCLDM_STAMP(13);
+  }
+  SCLDM_STAMP(9);
+
+  // ---- gated residual (a5) ----
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(MOD + (tt * 2 + sp) * kModBlock + 5 * kD + f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * accp[ft][tt][q * 4 + i];
+      }
+  SCLDM_STAMP(10);
+
+  if (layer + 1 < a.n_layer) {  // hand the residual to the next layer's launch
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t4[i] = xr[ft][tt][q * 4 + i];
+          *reinterpret_cast<f32x4*>(a.x + xoff[tt] + ft * 32 + q * 8) = t4;
+        }
+  } else {
+    // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
+    constexpr int kFinLd = NS * 2 * kD / 4 / 256;  // float4 per thread for the tile's (shift, scale) vectors
+    f32x4 fstage[kFinLd];
+#pragma unroll
+    for (int j = 0; j < kFinLd; ++j) {
+      const int idx = tid + 256 * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
+      const int s = min(smp0 + sl, a.n_fwd - 1);
+      fstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + a.n_layer * kModBlock + w4 * 4);
+    }
+    __syncthreads();  // every wave has consumed its a5 gate: vector slots 0/1 of MOD can be replaced
+#pragma unroll
+    for (int j = 0; j < kFinLd; ++j) {
+      const int idx = tid + 256 * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
+      *reinterpret_cast<f32x4*>(MOD + sl * kModBlock + w4 * 4) = fstage[j];
+    }
+    ln_modulate_store<OP, NTT>(xr, MOD, 1, 0, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
+    __syncthreads();
+    // wave w projects token tile tt == w (mod 4); the 16 weight fragments (rows >= din zero) are tiny and L2-hot
+    const Frag* wf = reinterpret_cast<const Frag*>(a.w_final) + lane;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      if ((tt & 3) != wave) continue;  // wave-uniform
+      f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const Frag wfr = wf[ks * 64];
+        const Frag b = *reinterpret_cast<const Frag*>(XA + (tt * 32 + c32) * L::XA_LD + hh * 8 + ks * 16);
+        o = OP::mma(wfr, b, o);  // out^T[channel][token]
+      }
+      if (live[tt]) {
+        float* op = a.out + ((size_t)(tok0 + tt * 32 + c32)) * a.din;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = acc_row(r, hh);
+          if (ch < a.din) op[ch] = o[r] + a.fin_b[ch];
+        }
+      }
+    }
+  }
+  SCLDM_STAMP_END(14);
+}
+
+}  // namespace scldm
