@@ -65,7 +65,8 @@ constexpr int kDbgStamps = 32;
 struct FwdArgs {
   const float* z;           // latents (n_src, 16, din) fp32 (read by the first layer)
   float* out;               // (n_fwd, 16, din) fp32 (written by the last layer)
-  float* x;                 // (n_fwd padded to the tile, 16, 256) fp32 residual between layers
+  float* x;                 // fp32 residual between layers, private layout [tile][wave][reg-quad 8*NTT][lane][4]
+                            // (what each lane holds in registers, so every access is one coalesced 1 KiB)
   const float* mod;         // (rows, mod_stride) adaLN vectors: [layer][6][256] ... [final: shift, scale]
   const int32_t* row_index; // (n_fwd) conditioning row of each sample-forward
   const void* w_stream;     // packed weights of THIS layer, [wave][unit] (pack_layer_kernel)
@@ -352,12 +353,10 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
 
   // per-token-tile bookkeeping; samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
   bool live[NTT];
-  size_t xoff[NTT];  // the x buffer is padded to whole tiles: no predication on its loads/stores
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    xoff[tt] = (size_t)(tok0 + tt * 32 + c32) * kD + wave * 64 + hh * 4;
-    live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
-  }
+  for (int tt = 0; tt < NTT; ++tt) live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
+  // residual hand-off buffer: lane-linear, quad j = (tt*2 + ft)*4 + q  (padded to whole tiles: no predication)
+  float* xw = a.x + ((size_t)(blockIdx.x * 4 + wave) * (8 * NTT) * 64 + lane) * 4;
 
   float xr[2][NTT][16];  // the residual stream: features [64w, 64w+64) x TM tokens, accumulator layout (scalars:
                          // it never feeds an MFMA, and whole-vector values would be copied around by the compiler)
@@ -405,7 +404,7 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
       for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.x + xoff[tt] + ft * 32 + q * 8);
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(xw + ((tt * 2 + ft) * 4 + q) * 256);
 #pragma unroll
           for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = t4[i];
         }
@@ -620,7 +619,7 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
           f32x4 t4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) t4[i] = xr[ft][tt][q * 4 + i];
-          *reinterpret_cast<f32x4*>(a.x + xoff[tt] + ft * 32 + q * 8) = t4;
+          *reinterpret_cast<f32x4*>(xw + ((tt * 2 + ft) * 4 + q) * 256) = t4;
         }
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----

@@ -1,0 +1,701 @@
+// MCAB (multi-head cross-attention block) pooling / unpooling of the scLDM TransformerVAE on gfx950, fp32-exact.
+//
+// Replaces the reference's eager chains (all Python, flex_attention materialising (B,4,16,S) / (B,4,G,16) scores):
+//   InputTransformerVAE.forward (log1p)                 src/scldm/layers.py:28-31,111-118
+//   CrossAttention.forward                              src/scldm/layers.py:248-264
+//   CrossAttentionBlock.forward, non-adaLN branch       src/scldm/layers.py:325-330  (residual from q, not x)
+//   Encoder.forward / Decoder.forward                   src/scldm/nnets.py:137-144, 200-208
+//   Block.forward, non-adaLN branch (the 16-token trunks) src/scldm/layers.py:222-226
+//   NegativeBinomialTransformerLayer.forward (shared theta) src/scldm/stochastic_layers.py:102-116
+// Shapes are the reference's only VAE family (vae_base.yaml:8-19): n_embed 32, 16 inducing points, 16 latent
+// channels, trunk heads 8x4, cross heads 4x8, bias=False, affine LayerNorms, SwiGLU hidden 88 (padded to 96).
+//
+// Per-gene work (23 kFLOP per decoded gene, 6 kFLOP per encoded gene) runs as chains of fp32 MFMAs
+// (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains) on tiles of 32 genes that never leave the registers:
+// a 32x32 accumulator tile T[R][C] (lane = C, register = R) is directly a legal B operand (contracting R) or,
+// read as T^T, a legal A operand of the next MFMA, because the k order of an MFMA is free as long as both operands
+// use the same one.  Weights are pre-packed into matching A/B fragment order ("k = acc_row(step, lane>>5)").
+#pragma once
+#include "common.hpp"
+
+namespace scldm {
+
+constexpr int kE = 32;         // VAE n_embed
+constexpr int kNI = 16;        // inducing points / latent tokens
+constexpr int kHPad = 96;      // SwiGLU hidden 88 padded to 6 tiles of 16
+constexpr int kHTiles = kHPad / 16;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// ------------------------------------------------------------------------------------------------
+// Fragment packing (run once per weight load).  A "weight fragment" of step j holds, for lane l,
+// W[row = l & 31][k = kidx(j, l >> 5)]; fragments are stored 4 steps per lane as float4: ((j/4)*64 + l)*4 + (j&3).
+// ------------------------------------------------------------------------------------------------
+// plain matrix W (32 rows, ld) with k = acc_row(j, hh), j < 16  (K = 32)
+__global__ void pack_frag32_kernel(const float* __restrict__ W, int ld, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 16 * 64) return;
+  const int l = idx & 63, j = idx >> 6;
+  out[((j >> 2) * 64 + l) * 4 + (j & 3)] = W[(l & 31) * ld + acc_row(j, l >> 5)];
+}
+// SwiGLU up-projection, tile u (16 hidden): rows 0-15 = w1[16u + r], rows 16-31 = w2[16u + r]; hidden >= H -> 0
+__global__ void pack_frag_w12_kernel(const float* __restrict__ W1, const float* __restrict__ W2, int H, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kHTiles * 16 * 64) return;
+  const int l = idx & 63, j = (idx >> 6) & 15, u = idx >> 10;
+  const int r = l & 31, hid = 16 * u + (r & 15);
+  const float* src = (r < 16) ? W1 : W2;
+  out[(size_t)u * 1024 + ((j >> 2) * 64 + l) * 4 + (j & 3)] = (hid < H) ? src[hid * kE + acc_row(j, l >> 5)] : 0.f;
+}
+// SwiGLU down-projection Wc (32, H): tile u, step r < 8: k = hidden 16u + acc_row(r, hh) (< 16 for r < 8)
+__global__ void pack_frag_wc_kernel(const float* __restrict__ Wc, int H, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kHTiles * 8 * 64) return;
+  const int l = idx & 63, r = (idx >> 6) & 7, u = idx >> 9;
+  const int hid = 16 * u + acc_row(r, l >> 5);
+  out[(size_t)u * 512 + ((r >> 2) * 64 + l) * 4 + (r & 3)] = (hid < H) ? Wc[(l & 31) * H + hid] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 16-token trunk: n_layer non-adaLN Blocks (affine LN, 8 heads x 4, SwiGLU, no biases) on one cell's
+// (16, 32) state held in LDS.  One wave per cell; exact fp32 on the VALU (3.3 MFLOP per cell: never the bottleneck).
+// Packed per-layer weights (floats): ln1_w 32 | ln1_b 32 | attn (96,32) | proj (32,32) | ln2_w 32 | ln2_b 32 |
+//                                    w1 (H,32) | w2 (H,32) | c_proj (32,H)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int trunk_layer_floats(int H) { return 64 + 96 * 32 + 32 * 32 + 64 + 2 * H * 32 + 32 * H; }
+
+struct TrunkSmem {
+  float h[kNI][kE + 1];
+  float n[kNI][kE + 1];
+  float qkv[kNI][96 + 1];
+  float hid[kNI][kHPad + 1];
+};
+
+// LayerNorm of the 16 rows of src (width W <= 32) into dst; lane -> (token = l & 15, part = l >> 4)
+template <int W>
+__device__ __forceinline__ void trunk_ln(const float (*src)[kE + 1], float (*dst)[kE + 1], const float* w, const float* b, float eps, int lane) {
+  const int t = lane & 15, part = lane >> 4;
+  constexpr int PER = W / 4;
+  float v[PER], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { v[i] = src[t][part * PER + i]; s += v[i]; }
+  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+  const float mean = s * (1.0f / W);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
+  ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / W) + eps);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int k = part * PER + i;
+    float y = v[i] * rstd;
+    if (w) y = y * w[k] + b[k];
+    dst[t][k] = y;
+  }
+}
+
+// out[t][n] (+)= sum_k in[t][k] * W[n][k] for n in [n0, n0+64) restricted to n < N; lane owns row n0 + lane.
+template <int K, int LDI, int LDO, bool ACCUM>
+__device__ __forceinline__ void trunk_linear(const float (*in)[LDI], float (*out)[LDO], const float* W, int ldw, int N, int n0, int lane) {
+  const int n = n0 + lane;
+  if (n < N) {
+    float wr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[k] = W[(size_t)n * ldw + k];
+    for (int t = 0; t < kNI; ++t) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc += in[t][k] * wr[k];
+      if (ACCUM) out[t][n] += acc; else out[t][n] = acc;
+    }
+  }
+}
+
+__device__ __forceinline__ void trunk_blocks(TrunkSmem& sm, const float* wts, int n_layer, int H, float eps, int lane) {
+  for (int layer = 0; layer < n_layer; ++layer) {
+    const float* w = wts + (size_t)layer * trunk_layer_floats(H);
+    const float *ln1w = w, *ln1b = w + 32, *attn = w + 64, *proj = attn + 96 * 32, *ln2w = proj + 32 * 32, *ln2b = ln2w + 32;
+    const float *w1 = ln2b + 32, *w2 = w1 + H * 32, *cp = w2 + H * 32;
+    trunk_ln<kE>(sm.h, sm.n, ln1w, ln1b, eps, lane);
+    __syncthreads();
+    trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, attn, kE, 96, 0, lane);
+    trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, attn, kE, 96, 64, lane);
+    __syncthreads();
+    // attention: 8 heads x 16 queries = 128 (head, query) pairs, 2 per lane; q,k,v split order q|k|v (layers.py:147)
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int hq = lane + 64 * rep, hd = hq >> 4, qi = hq & 15;
+      float q[4], sc[16], m = -3.0e38f;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) q[d] = sm.qkv[qi][hd * 4 + d];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) s += q[d] * sm.qkv[j][32 + hd * 4 + d];
+        sc[j] = s * 0.5f;  // 1/sqrt(4)
+        m = fmaxf(m, sc[j]);
+      }
+      float sum = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float p = expf(sc[j] - m);
+        sum += p;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] += p * sm.qkv[j][64 + hd * 4 + d];
+      }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) sm.n[qi][hd * 4 + d] = o[d] * inv;  // n is free: reuse as the attention output
+    }
+    __syncthreads();
+    trunk_linear<kE, kE + 1, kE + 1, true>(sm.n, sm.h, proj, kE, kE, 0, lane);  // h += proj(att)
+    __syncthreads();
+    trunk_ln<kE>(sm.h, sm.n, ln2w, ln2b, eps, lane);
+    __syncthreads();
+    // SwiGLU: hid = silu(w1 n) * (w2 n); lane owns hidden rows lane, lane + 64
+    for (int j0 = 0; j0 < H; j0 += 64) {
+      const int j = j0 + lane;
+      if (j < H) {
+        float a1[kE], a2[kE];
+#pragma unroll
+        for (int k = 0; k < kE; ++k) { a1[k] = w1[j * kE + k]; a2[k] = w2[j * kE + k]; }
+        for (int t = 0; t < kNI; ++t) {
+          float u = 0.f, g = 0.f;
+#pragma unroll
+          for (int k = 0; k < kE; ++k) { u += sm.n[t][k] * a1[k]; g += sm.n[t][k] * a2[k]; }
+          sm.hid[t][j] = (u / (1.0f + expf(-u))) * g;
+        }
+      }
+    }
+    __syncthreads();
+    if (lane < kE) {
+      for (int t = 0; t < kNI; ++t) {
+        float acc = 0.f;
+        for (int k = 0; k < H; ++k) acc += sm.hid[t][k] * cp[lane * H + k];
+        sm.h[t][lane] += acc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder, per cell (one wave): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
+// packed as MFMA A-operand fragments for the per-gene kernel (48 fragments = 12 KiB per cell):
+//   K tile t (heads 2t, 2t+1), step jj < 8:  lane(row = hl*16 + key, hh): K[key][k] if head(k) == 2t + hl else 0,
+//                                             k = acc_row(8t + jj, hh)
+//   V tile t, step r < 16: lane(row = f, hh): V[key][f] if head(f) == 2t + hl else 0, (hl, key) = acc_row(r, hh) >> 4, & 15
+// ------------------------------------------------------------------------------------------------
+struct DecCellArgs {
+  const float* z;        // (B, 16, n_lat)
+  const float* lat_w;    // decoder_latent_input.1.weight (32, n_lat)
+  const float* trunk;    // packed trunk weights
+  const float* ca_ln1_w; const float* ca_ln1_b;  // decoder_cross_attention.ln_1
+  const float* ca_attn;  // decoder_cross_attention.attn.c_attn.weight (64, 32): k | v
+  float* kvfrag;         // (B, 48*64) floats
+  int n_lat, n_layer, H;
+  float eps;
+};
+__global__ __launch_bounds__(64) void dec_cell_kernel(const DecCellArgs a) {
+  __shared__ TrunkSmem sm;
+  const int lane = threadIdx.x, cell = blockIdx.x;
+  // LN (no affine) over the n_lat latent channels of each of the 16 tokens, then Linear n_lat -> 32 (no bias)
+  if (lane < kNI) {
+    const float* zr = a.z + ((size_t)cell * kNI + lane) * a.n_lat;
+    float s = 0.f;
+    for (int k = 0; k < a.n_lat; ++k) s += zr[k];
+    const float mean = s / a.n_lat;
+    float ss = 0.f;
+    for (int k = 0; k < a.n_lat; ++k) { const float d = zr[k] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(ss / a.n_lat + a.eps);
+    for (int k = 0; k < a.n_lat; ++k) sm.n[lane][k] = (zr[k] - mean) * rstd;
+  }
+  __syncthreads();
+  if (lane < kE) {
+    for (int t = 0; t < kNI; ++t) {
+      float acc = 0.f;
+      for (int k = 0; k < a.n_lat; ++k) acc += sm.n[t][k] * a.lat_w[lane * a.n_lat + k];
+      sm.h[t][lane] = acc;
+    }
+  }
+  __syncthreads();
+  trunk_blocks(sm, a.trunk, a.n_layer, a.H, a.eps, lane);
+  trunk_ln<kE>(sm.h, sm.n, a.ca_ln1_w, a.ca_ln1_b, a.eps, lane);
+  __syncthreads();
+  trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, a.ca_attn, kE, 64, 0, lane);  // qkv[:, 0:32] = K, [:, 32:64] = V
+  __syncthreads();
+  float* out = a.kvfrag + (size_t)cell * 48 * 64;
+  const int row = lane & 31, hh = lane >> 5;
+  for (int t = 0; t < 2; ++t)
+    for (int jj = 0; jj < 8; ++jj) {
+      const int hl = row >> 4, key = row & 15, k = acc_row(8 * t + jj, hh);
+      const int j = t * 8 + jj;
+      out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((k >> 3) == 2 * t + hl) ? sm.qkv[key][k] : 0.f;
+    }
+  for (int t = 0; t < 2; ++t)
+    for (int r = 0; r < 16; ++r) {
+      const int rr = acc_row(r, hh), hl = rr >> 4, key = rr & 15;
+      const int j = 16 + t * 16 + r;
+      out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((row >> 3) == 2 * t + hl) ? sm.qkv[key][32 + row] : 0.f;
+    }
+}
+
+// Per-gene query table (run once per weight load): Qtab[g] = c_attn_q(LN_1q(emb[g])) / sqrt(8)
+__global__ void dec_qtab_kernel(const float* __restrict__ emb, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                const float* __restrict__ wq, float* __restrict__ qtab, int rows, float eps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows) return;
+  float v[kE], s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kE; ++k) { v[k] = emb[(size_t)g * kE + k]; s += v[k]; }
+  const float mean = s * (1.0f / kE);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < kE; ++k) { v[k] -= mean; ss += v[k] * v[k]; }
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / kE) + eps);
+#pragma unroll
+  for (int k = 0; k < kE; ++k) v[k] = v[k] * rstd * lnw[k] + lnb[k];
+  for (int n = 0; n < kE; ++n) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < kE; ++k) acc += v[k] * wq[n * kE + k];
+    qtab[(size_t)g * kE + n] = acc * 0.35355339059327373f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder, per gene: MCAB unpooling + NB head logits.  Workgroup = 4 waves, each wave walks tiles of 32 genes of
+// ONE cell; everything between the gene-embedding gather and the logit is a register-resident MFMA chain.
+// ------------------------------------------------------------------------------------------------
+struct DecGeneArgs {
+  const int64_t* genes;   // (B, G)
+  const float* emb;       // input_layer.gene_embedding.weight (n_genes+1, 32)
+  const float* qtab;      // (n_genes+1, 32) pre-projected, pre-scaled queries
+  const float* theta_emb; // decoder_head.theta.weight (n_genes+1, 1)
+  const float* kvfrag;    // (B, 48*64)
+  const float* wfrag;     // packed c_proj (16 steps) | w12 (6*16) | wc (6*8) fragments = 160*64 floats
+  const float* ln2_w; const float* ln2_b;  // decoder_cross_attention.ln_2
+  const float* head_w; const float* head_b;  // decoder_head.params (1,32), (1)
+  float* logits;          // (B, G)  (aliases mu)
+  float* theta;           // (B, G)
+  float* part;            // (B, n_chunks, 2): running (max, sum exp) of logit / temperature per chunk
+  int G, n_chunks, tiles_per_wave;
+  float eps, inv_temp;
+};
+
+__global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
+  __shared__ f32x4 WF[40 * 64];   // 160 weight fragments, 4 steps per float4
+  __shared__ f32x4 KV[12 * 64];   // this cell's 48 K/V fragments
+  __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
+  __shared__ float RED[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int cell = blockIdx.y, chunk = blockIdx.x;
+  for (int i = tid; i < 40 * 64; i += 256) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
+  for (int i = tid; i < 12 * 64; i += 256) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
+  if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
+  __syncthreads();
+  const float hb = a.head_b[0];
+  float run_m = -3.0e38f, run_s = 0.f;
+  const int tile0 = (chunk * 4 + wave) * a.tiles_per_wave;
+  for (int ti = 0; ti < a.tiles_per_wave; ++ti) {
+    const int gi = (tile0 + ti) * 32 + c32;
+    if ((tile0 + ti) * 32 >= a.G) break;  // wave-uniform
+    const bool valid = gi < a.G;
+    const long long g = valid ? a.genes[(size_t)cell * a.G + gi] : 0;
+    // q^T and the raw embedding in accumulator order: register r <-> feature acc_row(r, hh)
+    float q[16], y[16];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.qtab + (size_t)g * kE + qd * 8 + hh * 4);
+      const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { q[qd * 4 + i] = t4[i]; y[qd * 4 + i] = e4[i]; }
+    }
+    // S^T[(head, key)][gene] = Kblk q^T  (block sparse: tile t only sees features 16t..16t+15)
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      st[t] = zero16();
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        const f32x4 kf = KV[(t * 2 + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[t] = mfma2(kf[i], q[8 * t + g4 * 4 + i], st[t]);
+      }
+    }
+    // softmax over the 16 keys of each head: 8 keys in-lane (registers 8hl..8hl+7) + 8 in the other half-wave
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        float m = st[t][8 * hl];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) m = fmaxf(m, st[t][8 * hl + i]);
+        m = xor32_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float p = __expf(st[t][8 * hl + i] - m);
+          st[t][8 * hl + i] = p;
+          sum += p;
+        }
+        sum = xor32_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[t][8 * hl + i] *= inv;
+      }
+    // O^T[f][gene] = Vblk^T P^T
+    f32x16 ot = zero16();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 vf = KV[(4 + t * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ot = mfma2(vf[i], st[t][g4 * 4 + i], ot);
+      }
+    // y = q_raw + c_proj(O)   (residual from the query, layers.py:327)
+    f32x16 yt = zero16();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 wf = WF[g4 * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) yt = mfma2(wf[i], ot[g4 * 4 + i], yt);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y[r] += yt[r]; s += y[r]; }
+    const float mean = xor32_sum(s) * (1.0f / kE);
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = y[r] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(xor32_sum(ss) * (1.0f / kE) + a.eps);
+    float yn[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = acc_row(r, hh);
+      yn[r] = (y[r] - mean) * rstd * VEC[f] + VEC[kE + f];
+    }
+    // SwiGLU: six tiles of 16 hidden units, each consumed by the down-projection as soon as it exists
+    f32x16 mo = zero16();
+#pragma unroll 1
+    for (int u = 0; u < kHTiles; ++u) {
+      f32x16 ht = zero16();
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 wf = WF[(4 + u * 4 + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ht = mfma2(wf[i], yn[g4 * 4 + i], ht);
+      }
+      float hv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) hv[r] = (ht[r] / (1.0f + __expf(-ht[r]))) * ht[r + 8];
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        const f32x4 wf = WF[(4 + kHTiles * 4 + u * 2 + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mo = mfma2(wf[i], hv[g4 * 4 + i], mo);
+      }
+    }
+    // NB head: logit = w . (y + mlp) + b
+    float lg = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lg += (y[r] + mo[r]) * VEC[2 * kE + acc_row(r, hh)];
+    lg = (xor32_sum(lg) + hb) * a.inv_temp;
+    if (valid && hh == 0) {
+      a.logits[(size_t)cell * a.G + gi] = lg;
+      a.theta[(size_t)cell * a.G + gi] = expf(a.theta_emb[g]);
+    }
+    if (valid) {  // online (max, sum exp) per lane; both half-waves carry the same value, count it once at the end
+      const float nm = fmaxf(run_m, lg);
+      run_s = run_s * __expf(run_m - nm) + __expf(lg - nm);
+      run_m = nm;
+    }
+  }
+  // reduce (max, sum) over the 32 gene lanes of the wave, then over the 4 waves
+  float m = run_m, sacc = run_s;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o), os = __shfl_xor(sacc, o);
+    const float nm = fmaxf(m, om);
+    sacc = sacc * __expf(m - nm) + os * __expf(om - nm);
+    m = nm;
+  }
+  if (lane == 0) { RED[wave][0] = m; RED[wave][1] = sacc; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = RED[0][0], S = RED[0][1];
+    for (int w = 1; w < 4; ++w) {
+      const float nm = fmaxf(M, RED[w][0]);
+      S = S * __expf(M - nm) + RED[w][1] * __expf(RED[w][0] - nm);
+      M = nm;
+    }
+    a.part[((size_t)cell * a.n_chunks + chunk) * 2 + 0] = M;
+    a.part[((size_t)cell * a.n_chunks + chunk) * 2 + 1] = S;
+  }
+}
+
+// mu = softmax_G(logit) * library_size  (stochastic_layers.py:115)
+__global__ __launch_bounds__(256) void dec_finalize_kernel(float* __restrict__ mu, const float* __restrict__ part,
+                                                           const float* __restrict__ library, int G, int n_chunks) {
+  __shared__ float MS[2];
+  const int cell = blockIdx.y;
+  if (threadIdx.x == 0) {
+    float M = -3.0e38f, S = 0.f;
+    for (int c = 0; c < n_chunks; ++c) {
+      const float m = part[((size_t)cell * n_chunks + c) * 2], s = part[((size_t)cell * n_chunks + c) * 2 + 1];
+      const float nm = fmaxf(M, m);
+      S = S * expf(M - nm) + s * expf(m - nm);
+      M = nm;
+    }
+    MS[0] = M;
+    MS[1] = library[cell] / S;
+  }
+  __syncthreads();
+  const float M = MS[0], scale = MS[1];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < G; i += gridDim.x * 256) {
+    float* p = mu + (size_t)cell * G + i;
+    *p = expf(*p - M) * scale;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder pooling, one workgroup (4 waves) per cell: 16 inducing-point queries x 4 heads attend over the S input
+// genes with an online softmax.  Per 32-gene tile:
+//   x = LN_1(emb[gene] * log1p(count))            (lane = gene; 16 features per half-wave)
+//   K^T = Wk x^T   (A = Wk fragments, B = x)      -> tile (lane = gene, reg = feature) = A operand of the scores
+//   V   = x Wv^T   (A = x, B = Wv fragments)      -> tile (lane = d, reg = gene)       = A operand of P V
+//   S_t[gene][(hl, q)] = K Qblk^T_t               -> lane = (head, query): running max / sum are per-lane scalars
+//   O^T_t[d][(hl, q)] += V^T P_t
+// ------------------------------------------------------------------------------------------------
+struct EncPoolArgs {
+  const float* counts;    // (B, S)
+  const int64_t* genes;   // (B, S)
+  const float* emb;       // (n_genes+1, 32)
+  const float* ln1_w; const float* ln1_b;   // encoder.ca_layer.ln_1
+  const float* kfrag;     // Wk (rows 0-31 of c_attn) fragments, 16 steps
+  const float* vfrag;     // Wv (rows 32-63 of c_attn) fragments, 16 steps
+  const float* qfrag;     // Qblk^T fragments: 2 tiles x 8 steps (built from the inducing points at weight load)
+  float* pooled;          // (B, 16, 32): softmax(QK^T/sqrt(8)) V, heads concatenated
+  int S;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
+  __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
+  __shared__ float VEC[2 * kE];
+  __shared__ float MRG[4][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int cell = blockIdx.x;
+  for (int i = tid; i < 4 * 64; i += 256) {
+    KF[i] = reinterpret_cast<const f32x4*>(a.kfrag)[i];
+    VF[i] = reinterpret_cast<const f32x4*>(a.vfrag)[i];
+    QF[i] = reinterpret_cast<const f32x4*>(a.qfrag)[i];
+  }
+  if (tid < kE) { VEC[tid] = a.ln1_w[tid]; VEC[kE + tid] = a.ln1_b[tid]; }
+  __syncthreads();
+  float m[2] = {-3.0e38f, -3.0e38f}, l[2] = {0.f, 0.f};
+  f32x16 O[2] = {zero16(), zero16()};
+  const int n_tiles = (a.S + 31) / 32;
+  for (int tile = wave; tile < n_tiles; tile += 4) {
+    const int gi = tile * 32 + c32;
+    const bool valid = gi < a.S;
+    const long long g = valid ? a.genes[(size_t)cell * a.S + gi] : 0;
+    const float lc = valid ? log1pf(a.counts[(size_t)cell * a.S + gi]) : 0.f;
+    float x[16], s = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[qd * 4 + i] = e4[i] * lc; s += x[qd * 4 + i]; }
+    }
+    const float mean = xor32_sum(s) * (1.0f / kE);
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { x[r] -= mean; ss += x[r] * x[r]; }
+    const float rstd = 1.0f / sqrtf(xor32_sum(ss) * (1.0f / kE) + a.eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int f = acc_row(r, hh); x[r] = x[r] * rstd * VEC[f] + VEC[kE + f]; }
+    f32x16 kt = zero16(), vt = zero16();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 kf = KF[g4 * 64 + lane], vf = VF[g4 * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kt = mfma2(kf[i], x[g4 * 4 + i], kt);   // K^T[feature][gene]
+        vt = mfma2(x[g4 * 4 + i], vf[i], vt);   // V[gene][d]
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 sc = zero16();
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        const f32x4 qf = QF[(t * 2 + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc = mfma2(kt[8 * t + g4 * 4 + i], qf[i], sc);  // S[gene][(hl, q)]
+      }
+      float tm = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (tile * 32 + acc_row(r, hh) >= a.S) sc[r] = -3.0e38f;  // tile padding
+        tm = fmaxf(tm, sc[r]);
+      }
+      tm = xor32_max(tm);
+      const float nm = fmaxf(m[t], tm), alpha = __expf(m[t] - nm);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - nm); ps += sc[r]; }
+      l[t] = l[t] * alpha + xor32_sum(ps);
+      m[t] = nm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[t] = mfma2(vt[r], sc[r], O[t]);  // O^T[d][(hl, q)] += V^T P
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    MRG[wave][t][lane][0] = m[t];
+    MRG[wave][t][lane][1] = l[t];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) MRG[wave][t][lane][2 + r] = O[t][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float M = MRG[0][t][lane][0];
+      for (int w = 1; w < 4; ++w) M = fmaxf(M, MRG[w][t][lane][0]);
+      float L = 0.f, o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        const float sc = __expf(MRG[w][t][lane][0] - M);
+        L += MRG[w][t][lane][1] * sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] += MRG[w][t][lane][2 + r] * sc;
+      }
+      // lane = column (hl, q) of tile t; rows d = acc_row(r, hh); only d in head 2t + hl carry this head's output
+      const int hl = c32 >> 4, qi = c32 & 15, head = 2 * t + hl;
+      const float inv = 1.0f / L;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = acc_row(r, hh);
+        if ((d >> 3) == head) a.pooled[((size_t)cell * kNI + qi) * kE + d] = o[r] * inv;
+      }
+    }
+  }
+}
+
+// Encoder tail, per cell (one wave): c_proj + inducing-point residual -> LN2 -> SwiGLU -> (+pos_embed) -> trunk ->
+// Linear 32 -> n_lat -> LN (no affine)  (layers.py:326-330, nnets.py:139-144)
+struct EncCellArgs {
+  const float* pooled;     // (B, 16, 32)
+  const float* ind;        // encoder.ca_layer.inducing_points (16, 32)
+  const float* ca_proj;    // encoder.ca_layer.attn.c_proj.weight (32, 32)
+  const float* ca_ln2_w; const float* ca_ln2_b;
+  const float* ca_w1; const float* ca_w2; const float* ca_cp;  // encoder.ca_layer.mlp
+  const float* pos;        // encoder.pos_embed (16, 32) or nullptr
+  const float* trunk;
+  const float* lat_w;      // encoder_latent_input.0.weight (n_lat, 32)
+  float* z;                // (B, 16, n_lat)
+  int n_lat, n_layer, H;
+  float eps;
+};
+__global__ __launch_bounds__(64) void enc_cell_kernel(const EncCellArgs a) {
+  __shared__ TrunkSmem sm;
+  const int lane = threadIdx.x, cell = blockIdx.x;
+  for (int i = lane; i < kNI * kE; i += 64) {
+    sm.n[i >> 5][i & 31] = a.pooled[(size_t)cell * kNI * kE + i];
+    sm.h[i >> 5][i & 31] = a.ind[i];
+  }
+  __syncthreads();
+  trunk_linear<kE, kE + 1, kE + 1, true>(sm.n, sm.h, a.ca_proj, kE, kE, 0, lane);  // h = inducing + c_proj(att)
+  __syncthreads();
+  trunk_ln<kE>(sm.h, sm.n, a.ca_ln2_w, a.ca_ln2_b, a.eps, lane);
+  __syncthreads();
+  for (int j0 = 0; j0 < a.H; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < a.H) {
+      float a1[kE], a2[kE];
+#pragma unroll
+      for (int k = 0; k < kE; ++k) { a1[k] = a.ca_w1[j * kE + k]; a2[k] = a.ca_w2[j * kE + k]; }
+      for (int t = 0; t < kNI; ++t) {
+        float u = 0.f, g = 0.f;
+#pragma unroll
+        for (int k = 0; k < kE; ++k) { u += sm.n[t][k] * a1[k]; g += sm.n[t][k] * a2[k]; }
+        sm.hid[t][j] = (u / (1.0f + expf(-u))) * g;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < kE) {
+    for (int t = 0; t < kNI; ++t) {
+      float acc = 0.f;
+      for (int k = 0; k < a.H; ++k) acc += sm.hid[t][k] * a.ca_cp[lane * a.H + k];
+      sm.h[t][lane] += acc + (a.pos ? a.pos[t * kE + lane] : 0.f);
+    }
+  }
+  __syncthreads();
+  trunk_blocks(sm, a.trunk, a.n_layer, a.H, a.eps, lane);
+  // latent head: Linear 32 -> n_lat (no bias), LN without affine over the n_lat channels
+  if (lane < a.n_lat) {
+    for (int t = 0; t < kNI; ++t) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < kE; ++k) acc += sm.h[t][k] * a.lat_w[lane * kE + k];
+      sm.n[t][lane] = acc;
+    }
+  }
+  __syncthreads();
+  if (lane < kNI) {
+    float s = 0.f;
+    for (int k = 0; k < a.n_lat; ++k) s += sm.n[lane][k];
+    const float mean = s / a.n_lat;
+    float ss = 0.f;
+    for (int k = 0; k < a.n_lat; ++k) { const float d = sm.n[lane][k] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(ss / a.n_lat + a.eps);
+    for (int k = 0; k < a.n_lat; ++k) a.z[((size_t)cell * kNI + lane) * a.n_lat + k] = (sm.n[lane][k] - mean) * rstd;
+  }
+}
+
+// Qblk^T fragments for the encoder scores (run once per weight load): tile t, step jj < 8:
+//   lane(col = hl*16 + q, hh): c_attn_q(LN_1q(inducing[q]))[k] / sqrt(8) if head(k) == 2t + hl else 0, k = acc_row(8t + jj, hh)
+__global__ __launch_bounds__(64) void enc_qfrag_kernel(const float* __restrict__ ind, const float* __restrict__ lnw,
+                                                       const float* __restrict__ lnb, const float* __restrict__ wq,
+                                                       float* __restrict__ out, float eps) {
+  __shared__ float qp[kNI][kE];
+  const int lane = threadIdx.x;
+  if (lane < kNI) {
+    float v[kE], s = 0.f;
+    for (int k = 0; k < kE; ++k) { v[k] = ind[lane * kE + k]; s += v[k]; }
+    const float mean = s * (1.0f / kE);
+    float ss = 0.f;
+    for (int k = 0; k < kE; ++k) { v[k] -= mean; ss += v[k] * v[k]; }
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / kE) + eps);
+    for (int k = 0; k < kE; ++k) v[k] = v[k] * rstd * lnw[k] + lnb[k];
+    for (int n = 0; n < kE; ++n) {
+      float acc = 0.f;
+      for (int k = 0; k < kE; ++k) acc += v[k] * wq[n * kE + k];
+      qp[lane][n] = acc * 0.35355339059327373f;
+    }
+  }
+  __syncthreads();
+  const int col = lane & 31, hh = lane >> 5, hl = col >> 4, qi = col & 15;
+  for (int t = 0; t < 2; ++t)
+    for (int jj = 0; jj < 8; ++jj) {
+      const int k = acc_row(8 * t + jj, hh), j = t * 8 + jj;
+      out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((k >> 3) == 2 * t + hl) ? qp[qi][k] : 0.f;
+    }
+}
+
+}  // namespace scldm
