@@ -136,6 +136,74 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
 void scldm_dit_block_timing_enable(scldm_dit* h, int enable);
 int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms);
 
+/* ------------------------------------------------------------------------------------------------
+ * TransformerVAE encode / decode (MCAB pooling / unpooling + negative-binomial head), fp32.
+ * Shape family of the reference (experiments/configs/model/vae_base.yaml:8-19,64-73): n_embed 32, 16 inducing
+ * points, trunk heads 8x4, cross heads 4x8, bias=False, shared gene embedding, shared theta, agg_func log1p.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct scldm_vae scldm_vae;
+
+typedef struct {
+  int n_genes;          /* vocabulary size; tables have n_genes+1 rows */
+  int n_embed;          /* 32 */
+  int n_inducing;       /* 16 */
+  int n_embed_latent;   /* <= 32 (16) */
+  int n_layer;          /* trunk Blocks per side */
+  int n_head;           /* 8 */
+  int n_head_cross;     /* 4 */
+  int hidden_dim;       /* SwiGLU hidden: 88 */
+  float layernorm_eps;
+  int positional_encoding; /* Encoder.pos_embed present (nnets.py:103-106) */
+  float nb_temperature; /* NegativeBinomialTransformerLayer.t (stochastic_layers.py:85) */
+} scldm_vae_config;
+
+/* One packed plain Block (state_dict prefix `encoder.encoder_layers.i.` / `decoder.decoder_layers.i.`). */
+typedef struct {
+  const float* ln1_w; const float* ln1_b; /* ln_1 (32) */
+  const float* attn_w;                    /* attn.c_attn.weight (96,32) */
+  const float* proj_w;                    /* attn.c_proj.weight (32,32) */
+  const float* ln2_w; const float* ln2_b;
+  const float* w1; const float* w2;       /* mlp.w1/w2.weight (H,32) */
+  const float* cproj;                     /* mlp.c_proj.weight (32,H) */
+} scldm_vae_block;
+
+/* Cross-attention block parameters (`encoder.ca_layer.` / `decoder.decoder_cross_attention.`). */
+typedef struct {
+  const float* ln1_w; const float* ln1_b;   /* ln_1 (applied to x) */
+  const float* ln1q_w; const float* ln1q_b; /* ln_1q (applied to the queries) */
+  const float* attn_kv;                     /* attn.c_attn.weight (64,32): k | v */
+  const float* attn_q;                      /* attn.c_attn_q.weight (32,32) */
+  const float* attn_proj;                   /* attn.c_proj.weight (32,32) */
+  const float* ln2_w; const float* ln2_b;
+  const float* w1; const float* w2; const float* cproj; /* mlp */
+} scldm_vae_cross;
+
+typedef struct {
+  const float* gene_embedding;     /* input_layer.gene_embedding.weight (n_genes+1, 32) */
+  const float* inducing_points;    /* encoder.ca_layer.inducing_points (16,32) */
+  const float* enc_pos_embed;      /* encoder.pos_embed (1,16,32) or NULL */
+  const float* enc_latent_w;       /* encoder.encoder_latent_input.0.weight (n_lat,32) */
+  const float* dec_latent_w;       /* decoder.decoder_latent_input.1.weight (32,n_lat) */
+  const float* theta;              /* decoder_head.theta.weight (n_genes+1,1) */
+  const float* head_w; const float* head_b; /* decoder_head.params (1,32),(1) */
+  scldm_vae_cross enc_cross, dec_cross;
+  const scldm_vae_block* enc_blocks; /* HOST array of n_layer entries */
+  const scldm_vae_block* dec_blocks;
+} scldm_vae_weights;
+
+int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out);
+void scldm_vae_destroy(scldm_vae* h);
+int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, void* stream);
+size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G);
+
+/* TransformerVAE.encode (vae.py:58-69): counts (B,S) fp32, genes (B,S) int64 -> z (B,16,n_lat). */
+int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, void* ws, void* stream);
+
+/* TransformerVAE.decode (vae.py:71-87) up to the distribution parameters: z (B,16,n_lat), genes (B,G) int64,
+ * library_size (B) -> mu (B,G) = softmax_G(logit / t) * library_size, theta (B,G) = exp(theta_emb[genes]). */
+int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
+                     float* theta, void* ws, void* stream);
+
 /* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
  * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the
  * production library returns SCLDM_ERR_STATE. */

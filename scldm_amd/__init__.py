@@ -7,5 +7,6 @@ No CPU fallback exists: using a network without the built library or without a G
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401  (ctypes binding; the library itself is loaded on first use)
-from .nnets import DiT  # noqa: F401
+from .nnets import Decoder, DiT, Encoder  # noqa: F401
+from .vae import TransformerVAE  # noqa: F401
 from .transport import Sampler, Transport, create_transport  # noqa: F401

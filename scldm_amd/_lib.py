@@ -33,6 +33,27 @@ class DitWeights(C.Structure):
                [(n, c_void_pp) for n in ("class_emb", "attn_w", "attn_b", "proj_w", "proj_b", "w1", "w2", "cproj", "ada_w", "ada_b")]
 
 
+class VaeConfig(C.Structure):
+    _fields_ = [("n_genes", C.c_int), ("n_embed", C.c_int), ("n_inducing", C.c_int), ("n_embed_latent", C.c_int),
+                ("n_layer", C.c_int), ("n_head", C.c_int), ("n_head_cross", C.c_int), ("hidden_dim", C.c_int),
+                ("layernorm_eps", C.c_float), ("positional_encoding", C.c_int), ("nb_temperature", C.c_float)]
+
+
+class VaeBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "attn_w", "proj_w", "ln2_w", "ln2_b", "w1", "w2", "cproj")]
+
+
+class VaeCross(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_w", "ln1_b", "ln1q_w", "ln1q_b", "attn_kv", "attn_q", "attn_proj", "ln2_w", "ln2_b",
+                                          "w1", "w2", "cproj")]
+
+
+class VaeWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("gene_embedding", "inducing_points", "enc_pos_embed", "enc_latent_w", "dec_latent_w",
+                                          "theta", "head_w", "head_b")] + \
+               [("enc_cross", VaeCross), ("dec_cross", VaeCross), ("enc_blocks", C.POINTER(VaeBlock)), ("dec_blocks", C.POINTER(VaeBlock))]
+
+
 class ScldmError(RuntimeError):
     pass
 
@@ -70,6 +91,15 @@ def lib() -> C.CDLL:
     L.scldm_dit_block_timing_enable.restype = None
     L.scldm_dit_block_timing.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.scldm_dit_set_debug_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    L.scldm_vae_create.argtypes = [C.POINTER(VaeConfig), C.POINTER(C.c_void_p)]
+    L.scldm_vae_destroy.argtypes = [C.c_void_p]
+    L.scldm_vae_destroy.restype = None
+    L.scldm_vae_load_weights.argtypes = [C.c_void_p, C.POINTER(VaeWeights), C.c_void_p]
+    L.scldm_vae_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.scldm_vae_workspace_bytes.restype = C.c_size_t
+    L.scldm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.scldm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -77,7 +107,8 @@ def lib() -> C.CDLL:
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
            "scldm_dit_mod_width", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
-           "scldm_dit_block_timing", "scldm_dit_set_debug_buffer"]
+           "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",
+           "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode"]
 
 
 def check(rc: int, what: str) -> None:

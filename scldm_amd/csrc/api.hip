@@ -7,35 +7,21 @@
 #include <cstring>
 #include <vector>
 
-#include "../../include/scldm_hip.h"
+#include "api_common.hpp"
 #include "dit_aux.hpp"
 #include "dit_forward.hpp"
 
 using namespace scldm;
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, ...) {
+int scldm_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
 }
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess) return fail(SCLDM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-#define LAUNCH_CHECK()                                                                             \
-  do {                                                                                             \
-    hipError_t e_ = hipGetLastError();                                                             \
-    if (e_ != hipSuccess) return fail(SCLDM_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
-static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 128-token tile
-
 
 struct scldm_dit {
   scldm_dit_config cfg;

@@ -1,0 +1,212 @@
+// C ABI of the TransformerVAE encode / decode path (see include/scldm_hip.h).
+#include <cstring>
+#include <vector>
+
+#include "api_common.hpp"
+#include "mcab.hpp"
+
+using namespace scldm;
+
+struct scldm_vae {
+  scldm_vae_config cfg;
+  bool loaded;
+  // owned device buffers
+  float* enc_trunk;   // n_layer * trunk_layer_floats(H)
+  float* dec_trunk;
+  float* frag_dec;    // c_proj 16 | w12 96 | wc 48 fragments (160*64 floats)
+  float* frag_enc_k;  // 16*64
+  float* frag_enc_v;  // 16*64
+  float* frag_enc_q;  // 16*64
+  float* qtab;        // (n_genes+1, 32)
+  float* small;       // copies of the small vectors / matrices (layout below)
+  // borrowed (caller-owned, must stay alive): the big tables
+  const float* emb;
+  const float* theta;
+};
+
+// offsets (floats) into `small`
+enum : int {
+  S_ENC_LN1W = 0, S_ENC_LN1B = 32, S_ENC_LN2W = 64, S_ENC_LN2B = 96, S_ENC_PROJ = 128,          // (32,32)
+  S_ENC_W1 = S_ENC_PROJ + 1024, S_ENC_W2 = S_ENC_W1 + 128 * 32, S_ENC_CP = S_ENC_W2 + 128 * 32,  // up to H=128
+  S_ENC_IND = S_ENC_CP + 32 * 128, S_ENC_POS = S_ENC_IND + 512, S_ENC_LAT = S_ENC_POS + 512,    // (n_lat<=32, 32)
+  S_DEC_LAT = S_ENC_LAT + 1024, S_DEC_LN1W = S_DEC_LAT + 1024, S_DEC_LN1B = S_DEC_LN1W + 32,
+  S_DEC_KV = S_DEC_LN1B + 32, S_DEC_LN2W = S_DEC_KV + 64 * 32, S_DEC_LN2B = S_DEC_LN2W + 32,
+  S_HEAD_W = S_DEC_LN2B + 32, S_HEAD_B = S_HEAD_W + 32, S_TOTAL = S_HEAD_B + 32
+};
+
+extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
+  if (!cfg || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (cfg->n_embed != 32 || cfg->n_inducing != 16 || cfg->n_head != 8 || cfg->n_head_cross != 4)
+    return fail(SCLDM_ERR_SHAPE, "MCAB kernels support n_embed=32, n_inducing=16, n_head=8, n_head_cross=4 (got %d,%d,%d,%d)",
+                cfg->n_embed, cfg->n_inducing, cfg->n_head, cfg->n_head_cross);
+  if (cfg->n_embed_latent < 1 || cfg->n_embed_latent > 32) return fail(SCLDM_ERR_SHAPE, "n_embed_latent must be in [1,32]");
+  if (cfg->hidden_dim < 1 || cfg->hidden_dim > kHPad) return fail(SCLDM_ERR_SHAPE, "hidden_dim must be in [1,%d]", kHPad);
+  if (cfg->n_layer < 0 || cfg->n_genes < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / n_genes");
+  scldm_vae* h = new scldm_vae();
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg;
+  const size_t tl = (size_t)(cfg->n_layer > 0 ? cfg->n_layer : 1) * trunk_layer_floats(cfg->hidden_dim) * 4;
+  hipError_t e = hipMalloc((void**)&h->enc_trunk, tl);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->dec_trunk, tl);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_dec, 160 * 64 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_k, 16 * 64 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_v, 16 * 64 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_q, 16 * 64 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->qtab, (size_t)(cfg->n_genes + 1) * 32 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->small, (size_t)S_TOTAL * 4);
+  if (e == hipSuccess) e = hipMemset(h->small, 0, (size_t)S_TOTAL * 4);
+  if (e != hipSuccess) {
+    int rc = fail(SCLDM_ERR_HIP, "hipMalloc failed in scldm_vae_create: %s", hipGetErrorString(e));
+    scldm_vae_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return SCLDM_OK;
+}
+
+extern "C" void scldm_vae_destroy(scldm_vae* h) {
+  if (!h) return;
+  float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_dec, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
+  for (float* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+static int copy_d2d(float* dst, const float* src, size_t n, hipStream_t st) {
+  HIP_TRY(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st));
+  return SCLDM_OK;
+}
+
+static int pack_trunk(float* dst, const scldm_vae_block* blocks, int n_layer, int H, hipStream_t st) {
+  for (int i = 0; i < n_layer; ++i) {
+    float* w = dst + (size_t)i * trunk_layer_floats(H);
+    const scldm_vae_block& b = blocks[i];
+    int rc;
+    if ((rc = copy_d2d(w, b.ln1_w, 32, st))) return rc;
+    if ((rc = copy_d2d(w + 32, b.ln1_b, 32, st))) return rc;
+    if ((rc = copy_d2d(w + 64, b.attn_w, 96 * 32, st))) return rc;
+    float* proj = w + 64 + 96 * 32;
+    if ((rc = copy_d2d(proj, b.proj_w, 32 * 32, st))) return rc;
+    if ((rc = copy_d2d(proj + 1024, b.ln2_w, 32, st))) return rc;
+    if ((rc = copy_d2d(proj + 1024 + 32, b.ln2_b, 32, st))) return rc;
+    float* w1 = proj + 1024 + 64;
+    if ((rc = copy_d2d(w1, b.w1, (size_t)H * 32, st))) return rc;
+    if ((rc = copy_d2d(w1 + (size_t)H * 32, b.w2, (size_t)H * 32, st))) return rc;
+    if ((rc = copy_d2d(w1 + (size_t)2 * H * 32, b.cproj, (size_t)32 * H, st))) return rc;
+  }
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, void* stream_) {
+  if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_vae_config& c = h->cfg;
+  const int H = c.hidden_dim, nl = c.n_embed_latent;
+  int rc;
+  if ((rc = pack_trunk(h->enc_trunk, w->enc_blocks, c.n_layer, H, st))) return rc;
+  if ((rc = pack_trunk(h->dec_trunk, w->dec_blocks, c.n_layer, H, st))) return rc;
+  float* s = h->small;
+  const scldm_vae_cross &ec = w->enc_cross, &dc = w->dec_cross;
+  if ((rc = copy_d2d(s + S_ENC_LN1W, ec.ln1_w, 32, st)) || (rc = copy_d2d(s + S_ENC_LN1B, ec.ln1_b, 32, st)) ||
+      (rc = copy_d2d(s + S_ENC_LN2W, ec.ln2_w, 32, st)) || (rc = copy_d2d(s + S_ENC_LN2B, ec.ln2_b, 32, st)) ||
+      (rc = copy_d2d(s + S_ENC_PROJ, ec.attn_proj, 1024, st)) || (rc = copy_d2d(s + S_ENC_W1, ec.w1, (size_t)H * 32, st)) ||
+      (rc = copy_d2d(s + S_ENC_W2, ec.w2, (size_t)H * 32, st)) || (rc = copy_d2d(s + S_ENC_CP, ec.cproj, (size_t)32 * H, st)) ||
+      (rc = copy_d2d(s + S_ENC_IND, w->inducing_points, 512, st)) ||
+      (rc = copy_d2d(s + S_ENC_LAT, w->enc_latent_w, (size_t)nl * 32, st)) ||
+      (rc = copy_d2d(s + S_DEC_LAT, w->dec_latent_w, (size_t)32 * nl, st)) ||
+      (rc = copy_d2d(s + S_DEC_LN1W, dc.ln1_w, 32, st)) || (rc = copy_d2d(s + S_DEC_LN1B, dc.ln1_b, 32, st)) ||
+      (rc = copy_d2d(s + S_DEC_KV, dc.attn_kv, 64 * 32, st)) || (rc = copy_d2d(s + S_DEC_LN2W, dc.ln2_w, 32, st)) ||
+      (rc = copy_d2d(s + S_DEC_LN2B, dc.ln2_b, 32, st)) || (rc = copy_d2d(s + S_HEAD_W, w->head_w, 32, st)) ||
+      (rc = copy_d2d(s + S_HEAD_B, w->head_b, 1, st)))
+    return rc;
+  if (c.positional_encoding) {
+    if (!w->enc_pos_embed) return fail(SCLDM_ERR_SHAPE, "positional_encoding set but enc_pos_embed is NULL");
+    if ((rc = copy_d2d(s + S_ENC_POS, w->enc_pos_embed, 512, st))) return rc;
+  }
+  // MFMA fragments
+  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec);                                  // 16 fragments
+  pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(dc.w1, dc.w2, H, h->frag_dec + 16 * 64);  // 96
+  pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(dc.cproj, H, h->frag_dec + (16 + 96) * 64); // 48
+  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_kv, 32, h->frag_enc_k);                                   // K rows 0-31
+  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_kv + 32 * 32, 32, h->frag_enc_v);                         // V rows 32-63
+  enc_qfrag_kernel<<<1, 64, 0, st>>>(w->inducing_points, ec.ln1q_w, ec.ln1q_b, ec.attn_q, h->frag_enc_q, c.layernorm_eps);
+  dec_qtab_kernel<<<cdiv(c.n_genes + 1, 128), 128, 0, st>>>(w->gene_embedding, dc.ln1q_w, dc.ln1q_b, dc.attn_q, h->qtab,
+                                                            c.n_genes + 1, c.layernorm_eps);
+  LAUNCH_CHECK();
+  h->emb = w->gene_embedding;
+  h->theta = w->theta;
+  h->loaded = true;
+  return SCLDM_OK;
+}
+
+static const int kDecTilesPerWave = 8;  // 4 waves x 8 tiles x 32 genes = 1024 genes per workgroup
+static inline int dec_chunks(int G) { return cdiv(G, 4 * kDecTilesPerWave * 32); }
+
+extern "C" size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G) {
+  if (!h) return 0;
+  size_t kv = align256((size_t)B * 48 * 64 * 4);
+  size_t part = align256((size_t)B * dec_chunks(G > 0 ? G : 1) * 2 * 4);
+  size_t pooled = align256((size_t)B * 16 * 32 * 4);
+  return kv + part + pooled;
+}
+
+static int vae_ready(const scldm_vae* h) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_vae_load_weights has not been called");
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, void* ws_,
+                                void* stream_) {
+  int rc = vae_ready(h);
+  if (rc) return rc;
+  if (B <= 0 || S <= 0 || !counts || !genes || !z || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_vae_config& c = h->cfg;
+  float* pooled = (float*)ws_;  // (B,16,32); encode and decode calls are stream-ordered, so they may share the workspace
+  EncPoolArgs p;
+  p.counts = counts; p.genes = genes; p.emb = h->emb;
+  p.ln1_w = h->small + S_ENC_LN1W; p.ln1_b = h->small + S_ENC_LN1B;
+  p.kfrag = h->frag_enc_k; p.vfrag = h->frag_enc_v; p.qfrag = h->frag_enc_q;
+  p.pooled = pooled; p.S = S; p.eps = c.layernorm_eps;
+  enc_pool_kernel<<<B, 256, 0, st>>>(p);
+  LAUNCH_CHECK();
+  EncCellArgs e;
+  e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.ca_proj = h->small + S_ENC_PROJ;
+  e.ca_ln2_w = h->small + S_ENC_LN2W; e.ca_ln2_b = h->small + S_ENC_LN2B;
+  e.ca_w1 = h->small + S_ENC_W1; e.ca_w2 = h->small + S_ENC_W2; e.ca_cp = h->small + S_ENC_CP;
+  e.pos = c.positional_encoding ? h->small + S_ENC_POS : nullptr;
+  e.trunk = h->enc_trunk; e.lat_w = h->small + S_ENC_LAT; e.z = z;
+  e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.H = c.hidden_dim; e.eps = c.layernorm_eps;
+  enc_cell_kernel<<<B, 64, 0, st>>>(e);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
+                                float* mu, float* theta, void* ws_, void* stream_) {
+  int rc = vae_ready(h);
+  if (rc) return rc;
+  if (B <= 0 || G <= 0 || !z || !genes || !library_size || !mu || !theta || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_vae_config& c = h->cfg;
+  float* kv = (float*)ws_;
+  float* part = (float*)((char*)ws_ + align256((size_t)B * 48 * 64 * 4));
+  DecCellArgs d;
+  d.z = z; d.lat_w = h->small + S_DEC_LAT; d.trunk = h->dec_trunk;
+  d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.ca_attn = h->small + S_DEC_KV;
+  d.kvfrag = kv; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.H = c.hidden_dim; d.eps = c.layernorm_eps;
+  dec_cell_kernel<<<B, 64, 0, st>>>(d);
+  LAUNCH_CHECK();
+  const int nch = dec_chunks(G);
+  DecGeneArgs g;
+  g.genes = genes; g.emb = h->emb; g.qtab = h->qtab; g.theta_emb = h->theta; g.kvfrag = kv; g.wfrag = h->frag_dec;
+  g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
+  g.logits = mu; g.theta = theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
+  g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
+  dec_gene_kernel<<<dim3(nch, B), 256, 0, st>>>(g);
+  LAUNCH_CHECK();
+  dec_finalize_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, G, nch);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .layers import Block, FinalLayerDit, TimestepEmbedder, sincos_pos_embed, swiglu_hidden
+from .layers import Block, CrossAttentionBlock, FinalLayerDit, TimestepEmbedder, sincos_pos_embed, swiglu_hidden
 
 
 def _stream_ptr() -> int:
@@ -28,6 +28,59 @@ def _require_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+class Encoder(nn.Module):
+    """MCAB pooling encoder - parameter tree of scldm.nnets.Encoder (nnets.py:81-135).  Its arithmetic runs inside
+    scldm_amd.vae.TransformerVAE.encode (scldm_vae_encode); calling it on its own is not supported."""
+
+    def __init__(self, n_layer: int, n_inducing_points: int, n_embed: int, n_embed_latent: int, n_head: int, n_head_cross: int,
+                 dropout: float, bias: bool, multiple_of: int, layernorm_eps: float, norm_layer: str,
+                 positional_encoding: bool = False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("the MCAB kernels expect bias=False (vae_base.yaml:15)")
+        self.latent_embedding = n_embed_latent
+        self.latent_dim = n_inducing_points
+        self.n_embed, self.n_head, self.n_head_cross, self.n_layer = n_embed, n_head, n_head_cross, n_layer
+        self.multiple_of, self.layernorm_eps = multiple_of, layernorm_eps
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_inducing_points, n_embed), requires_grad=False) if positional_encoding else None
+        self.ca_layer = CrossAttentionBlock(n_embed=n_embed, n_inducing_points=n_inducing_points, n_head=n_head_cross, dropout=dropout,
+                                            bias=bias, norm_layer=norm_layer, multiple_of=multiple_of, layernorm_eps=layernorm_eps)
+        self.encoder_layers = nn.ModuleList([
+            Block(n_embed=n_embed, n_head=n_head, dropout=dropout, bias=bias, norm_layer=norm_layer, multiple_of=multiple_of,
+                  layernorm_eps=layernorm_eps) for _ in range(n_layer)])
+        self.encoder_latent_input = nn.Sequential(nn.Linear(n_embed, n_embed_latent, bias=bias),
+                                                  nn.LayerNorm(n_embed_latent, eps=layernorm_eps, elementwise_affine=False))
+
+    def forward(self, x):  # pragma: no cover - guard only
+        raise RuntimeError("Encoder is fused into scldm_amd.vae.TransformerVAE.encode (gene-embedding gather included); "
+                           "call TransformerVAE.encode")
+
+
+class Decoder(nn.Module):
+    """MCAB unpooling decoder - parameter tree of scldm.nnets.Decoder (nnets.py:147-198), shared_embedding only."""
+
+    def __init__(self, n_genes: int, n_embed: int, n_embed_latent: int, n_head: int, n_head_cross: int, n_layer: int,
+                 n_inducing_points: int, dropout: float, bias: bool, multiple_of: int, layernorm_eps: float, norm_layer: str,
+                 shared_embedding: bool, use_adaln: bool = False):
+        super().__init__()
+        if bias or use_adaln or not shared_embedding:
+            raise NotImplementedError("the MCAB kernels cover the reference configuration: bias=False, use_adaln=False, "
+                                      "shared_embedding=True (vae_base.yaml:15,36-37)")
+        self.gene_embedding = nn.Identity()
+        self.n_genes = n_genes
+        self.decoder_latent_input = nn.Sequential(nn.LayerNorm(n_embed_latent, eps=layernorm_eps, elementwise_affine=False),
+                                                  nn.Linear(n_embed_latent, n_embed, bias=bias))
+        self.decoder_layers = nn.ModuleList([
+            Block(n_embed=n_embed, n_head=n_head, dropout=dropout, bias=bias, norm_layer=norm_layer, multiple_of=multiple_of,
+                  layernorm_eps=layernorm_eps, use_adaln=use_adaln) for _ in range(n_layer)])
+        self.decoder_cross_attention = CrossAttentionBlock(n_embed=n_embed, n_inducing_points=0, n_head=n_head_cross, dropout=dropout,
+                                                           bias=bias, norm_layer=norm_layer, multiple_of=multiple_of,
+                                                           layernorm_eps=layernorm_eps, use_adaln=use_adaln)
+
+    def forward(self, x, genes, condition=None):  # pragma: no cover - guard only
+        raise RuntimeError("Decoder is fused into scldm_amd.vae.TransformerVAE.decode; call TransformerVAE.decode")
 
 
 class DiT(nn.Module):

@@ -1,0 +1,49 @@
+"""Output head of the VAE with the reference's API (src/scldm/stochastic_layers.py:76-116), shared-theta variant."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+class NegativeBinomialTransformerLayer(nn.Module):
+    """Parameter container: `theta` Embedding(n_genes+1, 1) (initialised to ones) and `params` Linear(n_embed, 1).
+    mu = softmax_G(params(h) / t) * library_size and theta = exp(theta[genes]) are computed by scldm_vae_decode."""
+
+    def __init__(self, *, n_genes: int, shared_theta: bool = False, n_embed: int | None = None, norm_layer: str = "layernorm",
+                 layernorm_eps: float = 1e-8, eps_: float = 1e-6, t: float = 1.0):
+        super().__init__()
+        if not shared_theta:
+            raise NotImplementedError("only the shared-theta head (decoder_name negative_binomial_shared_theta, vae_base.yaml:62) is built")
+        self.shared_theta = shared_theta
+        self.theta = nn.Embedding(n_genes + 1, 1)
+        nn.init.ones_(self.theta.weight)
+        self.params = nn.Linear(n_embed, 1, bias=True)
+        self.eps_ = eps_
+        self.t = t
+
+    def forward(self, *a, **k):  # pragma: no cover - guard only
+        raise RuntimeError("NegativeBinomialTransformerLayer is fused into scldm_amd.vae.TransformerVAE.decode")
+
+
+class NegativeBinomial(torch.distributions.Distribution):
+    """Minimal stand-in for scvi.distributions.NegativeBinomial(mu=, theta=) as used by the reference
+    (vae.py:87; models.py:819 calls .sample()): holds mu / theta, samples with the Gamma-Poisson mixture."""
+
+    arg_constraints = {}
+
+    def __init__(self, mu: torch.Tensor, theta: torch.Tensor, validate_args=False):
+        self.mu, self.theta = mu, theta
+        super().__init__(batch_shape=mu.shape, validate_args=validate_args)
+
+    @property
+    def mean(self):
+        return self.mu
+
+    @torch.no_grad()
+    def sample(self, sample_shape=torch.Size()):
+        # counts ~ Poisson(Gamma(concentration=theta, rate=theta/mu))  (the parameterisation scvi-tools uses)
+        shape = self._extended_shape(sample_shape)
+        theta = self.theta.expand(shape)
+        mu = self.mu.expand(shape)
+        gamma = torch.distributions.Gamma(concentration=theta, rate=theta / torch.clamp(mu, min=1e-8)).sample()
+        return torch.poisson(torch.clamp(gamma, max=1e8))

@@ -1,0 +1,145 @@
+"""TransformerVAE with the reference's API (src/scldm/vae.py:15-87); encode / decode run on the MI355X MCAB kernels."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .layers import InputTransformerVAE, swiglu_hidden
+from .nnets import Decoder, Encoder, _require_cuda_f32, _stream_ptr
+from .stochastic_layers import NegativeBinomial, NegativeBinomialTransformerLayer
+
+
+class TransformerVAE(nn.Module):
+    def __init__(self, encoder: Encoder, decoder: Decoder, decoder_head: NegativeBinomialTransformerLayer,
+                 input_layer: InputTransformerVAE):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.decoder_head = decoder_head
+        self.input_layer = input_layer
+        self._handle = None
+        self._weights_key = None
+        self._ws = None
+        self._keep = None
+
+    # ------------------------------------------------------------------ native handle
+    def _native(self):
+        L = _lib.lib()
+        emb = self.input_layer.gene_embedding.weight
+        if emb.device.type != "cuda":
+            raise RuntimeError("TransformerVAE parameters must live on a CUDA (ROCm) device; there is no CPU path")
+        enc = self.encoder
+        if self._handle is None:
+            cfg = _lib.VaeConfig(n_genes=emb.shape[0] - 1, n_embed=emb.shape[1], n_inducing=enc.latent_dim,
+                                 n_embed_latent=enc.latent_embedding, n_layer=enc.n_layer, n_head=enc.n_head,
+                                 n_head_cross=enc.n_head_cross, hidden_dim=swiglu_hidden(enc.n_embed, enc.multiple_of),
+                                 layernorm_eps=enc.layernorm_eps, positional_encoding=int(enc.pos_embed is not None),
+                                 nb_temperature=float(self.decoder_head.t))
+            h = C.c_void_p()
+            with torch.cuda.device(emb.device):
+                _lib.check(L.scldm_vae_create(C.byref(cfg), C.byref(h)), "scldm_vae_create")
+            self._handle = h
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key != self._weights_key:
+            self._load_weights(L)
+            self._weights_key = key
+        return L, self._handle
+
+    @staticmethod
+    def _block(b):
+        dp = lambda t: t.data_ptr()
+        return _lib.VaeBlock(ln1_w=dp(b.ln_1.weight), ln1_b=dp(b.ln_1.bias), attn_w=dp(b.attn.c_attn.weight),
+                             proj_w=dp(b.attn.c_proj.weight), ln2_w=dp(b.ln_2.weight), ln2_b=dp(b.ln_2.bias), w1=dp(b.mlp.w1.weight),
+                             w2=dp(b.mlp.w2.weight), cproj=dp(b.mlp.c_proj.weight))
+
+    @staticmethod
+    def _cross(c):
+        dp = lambda t: t.data_ptr()
+        return _lib.VaeCross(ln1_w=dp(c.ln_1.weight), ln1_b=dp(c.ln_1.bias), ln1q_w=dp(c.ln_1q.weight), ln1q_b=dp(c.ln_1q.bias),
+                             attn_kv=dp(c.attn.c_attn.weight), attn_q=dp(c.attn.c_attn_q.weight), attn_proj=dp(c.attn.c_proj.weight),
+                             ln2_w=dp(c.ln_2.weight), ln2_b=dp(c.ln_2.bias), w1=dp(c.mlp.w1.weight), w2=dp(c.mlp.w2.weight),
+                             cproj=dp(c.mlp.c_proj.weight))
+
+    def _load_weights(self, L):
+        for p in self.parameters():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("TransformerVAE parameters must be contiguous fp32")
+        enc, dec = self.encoder, self.decoder
+        n = enc.n_layer
+        eb = (_lib.VaeBlock * max(n, 1))(*[self._block(b) for b in enc.encoder_layers])
+        db = (_lib.VaeBlock * max(n, 1))(*[self._block(b) for b in dec.decoder_layers])
+        dp = lambda t: t.data_ptr()
+        w = _lib.VaeWeights(gene_embedding=dp(self.input_layer.gene_embedding.weight), inducing_points=dp(enc.ca_layer.inducing_points),
+                            enc_pos_embed=dp(enc.pos_embed) if enc.pos_embed is not None else None,
+                            enc_latent_w=dp(enc.encoder_latent_input[0].weight), dec_latent_w=dp(dec.decoder_latent_input[1].weight),
+                            theta=dp(self.decoder_head.theta.weight), head_w=dp(self.decoder_head.params.weight),
+                            head_b=dp(self.decoder_head.params.bias), enc_cross=self._cross(enc.ca_layer),
+                            dec_cross=self._cross(dec.decoder_cross_attention), enc_blocks=eb, dec_blocks=db)
+        self._keep = (eb, db)
+        with torch.cuda.device(self.input_layer.gene_embedding.weight.device):
+            _lib.check(L.scldm_vae_load_weights(self._handle, C.byref(w), _stream_ptr()), "scldm_vae_load_weights")
+
+    def _workspace(self, L, B: int, G: int) -> int:
+        need = L.scldm_vae_workspace_bytes(self._handle, B, G)
+        dev = self.input_layer.gene_embedding.weight.device
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws.data_ptr()
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _lib.lib().scldm_vae_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference API (vae.py:29-87)
+    @torch.no_grad()
+    def encode(self, counts: torch.Tensor, genes: torch.Tensor, counts_subset: torch.Tensor | None = None,
+               genes_subset: torch.Tensor | None = None) -> torch.Tensor:
+        c = counts_subset if counts_subset is not None else counts
+        g = genes_subset if genes_subset is not None else genes
+        L, h = self._native()
+        c = _require_cuda_f32("counts", c)
+        if not g.is_cuda:
+            raise RuntimeError("genes must be a CUDA (ROCm) tensor")
+        g = g.to(torch.long).contiguous()
+        if c.dim() != 2 or g.shape != c.shape:
+            raise ValueError(f"counts and genes must both be (B,S); got {tuple(c.shape)} and {tuple(g.shape)}")
+        B, S = c.shape
+        z = torch.empty(B, self.encoder.latent_dim, self.encoder.latent_embedding, device=c.device, dtype=torch.float32)
+        ws = self._workspace(L, B, 1)
+        with torch.cuda.device(c.device):
+            _lib.check(L.scldm_vae_encode(h, c.data_ptr(), g.data_ptr(), B, S, z.data_ptr(), ws, _stream_ptr()), "scldm_vae_encode")
+        return z
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, genes: torch.Tensor, library_size: torch.Tensor,
+               condition: dict[str, torch.Tensor] | None = None) -> torch.distributions.Distribution:
+        L, h = self._native()
+        z = _require_cuda_f32("z", z)
+        if not genes.is_cuda:
+            raise RuntimeError("genes must be a CUDA (ROCm) tensor")
+        g = genes.to(torch.long).contiguous()
+        lib = _require_cuda_f32("library_size", library_size).reshape(-1)
+        B, G = g.shape
+        if z.shape != (B, self.encoder.latent_dim, self.encoder.latent_embedding) or lib.shape[0] != B:
+            raise ValueError(f"expected z (B,{self.encoder.latent_dim},{self.encoder.latent_embedding}) and library_size (B,1); got "
+                             f"{tuple(z.shape)}, {tuple(library_size.shape)} for genes {tuple(g.shape)}")
+        mu = torch.empty(B, G, device=z.device, dtype=torch.float32)
+        theta = torch.empty(B, G, device=z.device, dtype=torch.float32)
+        ws = self._workspace(L, B, G)
+        with torch.cuda.device(z.device):
+            _lib.check(L.scldm_vae_decode(h, z.data_ptr(), g.data_ptr(), lib.data_ptr(), B, G, mu.data_ptr(), theta.data_ptr(), ws,
+                                          _stream_ptr()), "scldm_vae_decode")
+        return NegativeBinomial(mu=mu, theta=theta)
+
+    @torch.no_grad()
+    def forward(self, counts, genes, library_size, counts_subset=None, genes_subset=None):
+        """(params, z) with params = {"mu", "theta"} (vae.py:29-56).  Inference only: VAE training is out of scope."""
+        z = self.encode(counts, genes, counts_subset, genes_subset)
+        nb = self.decode(z, genes, library_size)
+        return {"mu": nb.mu, "theta": nb.theta}, z

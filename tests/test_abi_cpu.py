@@ -101,3 +101,43 @@ def test_transport_face_and_training_losses_cpu():
     traj = fn(torch.ones(2, 3), lambda x, t: (seen.append(float(t[0])), -x)[1])
     assert seen == [0.0, 0.25, 0.5, 0.75] and traj.shape == (5, 2, 3)
     assert torch.equal(traj[-1], torch.full((2, 3), 0.31640625))
+
+
+def _build_vae(n_genes):
+    from scldm_amd.layers import InputTransformerVAE
+    from scldm_amd.nnets import Decoder, Encoder
+    from scldm_amd.stochastic_layers import NegativeBinomialTransformerLayer
+    from scldm_amd.vae import TransformerVAE
+    enc = Encoder(n_layer=8, n_inducing_points=16, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, dropout=0.0, bias=False,
+                  multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", positional_encoding=True)
+    dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, n_inducing_points=16,
+                  dropout=0.0, bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
+                  use_adaln=False)
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm", layernorm_eps=1e-8)
+    inp = InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p")
+    return TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=inp)
+
+
+def test_vae_state_dict_is_checkpoint_compatible():
+    g = load_golden("vae_small")
+    shapes = {k: tuple(v) for k, v in golden_json(g, "shapes_json").items()}
+    vae = _build_vae(int(g["n_genes"]))
+    ours = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
+    assert ours == shapes
+    vae.load_state_dict(make_state_dict(shapes, int(g["seed"])), strict=True)
+    # attributes the reference's LatentDiffusion reads (models.py:789; vae.py:43,46,79,82)
+    assert vae.encoder.latent_embedding == 16 and isinstance(vae.decoder.gene_embedding, torch.nn.Identity)
+    assert vae.decoder_head.__class__.__name__ == "NegativeBinomialTransformerLayer"
+    assert float(_build_vae(5).decoder_head.theta.weight.min()) == 1.0  # ones init (stochastic_layers.py:93)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        vae.encode(torch.zeros(1, 4), torch.zeros(1, 4, dtype=torch.long))
+
+
+def test_negative_binomial_holder_samples_cpu():
+    from scldm_amd.stochastic_layers import NegativeBinomial
+    torch.manual_seed(0)
+    mu = torch.full((4000, 3), 5.0)
+    nb = NegativeBinomial(mu=mu, theta=torch.full((4000, 3), 2.0))
+    x = nb.sample()
+    assert x.shape == mu.shape and (x >= 0).all() and (x == x.round()).all()
+    assert abs(float(x.mean()) - 5.0) < 0.3 and abs(float(x.var()) - (5.0 + 25.0 / 2.0)) < 2.5  # mean mu, var mu + mu^2/theta

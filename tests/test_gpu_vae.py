@@ -1,0 +1,91 @@
+"""GPU parity of the MCAB encode / decode kernels (fp32) against the reference's golden vectors and the oracle.
+Tolerance: 1e-4 scale-relative max error (BASELINE.json north_star gate)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_json, load_golden, max_abs_rel
+from oracle.vae import VAEConfig, decode, encode
+from oracle.weights import make_state_dict
+from test_abi_cpu import _build_vae
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def build(name):
+    g = load_golden(name)
+    shapes = {k: tuple(v) for k, v in golden_json(g, "shapes_json").items()}
+    sd = make_state_dict(shapes, int(g["seed"]))
+    vae = _build_vae(int(g["n_genes"]))
+    vae.load_state_dict(sd, strict=True)
+    return g, vae.cuda().eval(), sd, VAEConfig(n_genes=int(g["n_genes"]))
+
+
+def cu(a):
+    return torch.from_numpy(np.asarray(a)).cuda()
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_2000"])
+def test_encode_decode_match_reference_golden(name):
+    g, vae, sd, cfg = build(name)
+    z = vae.encode(cu(g["counts"]), cu(g["genes"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
+    assert z.shape == g["z"].shape and max_abs_rel(z.cpu(), g["z"]) < TOL
+    nb = vae.decode(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]))
+    assert max_abs_rel(nb.mu.cpu(), g["mu"]) < TOL and max_abs_rel(nb.theta.cpu(), g["theta"]) < 1e-5
+    nb2 = vae.decode(cu(g["zrand"]), cu(g["genes"]), cu(g["library_size"]))
+    assert max_abs_rel(nb2.mu.cpu(), g["mu_rand"]) < TOL
+    assert torch.allclose(nb.mu.sum(1).cpu(), torch.from_numpy(g["library_size"][:, 0]), rtol=1e-4)
+    params, z2 = vae(cu(g["counts"]), cu(g["genes"]), cu(g["library_size"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
+    assert torch.equal(z2, z) and set(params) == {"mu", "theta"}
+
+
+@pytest.mark.parametrize("B,S,G", [(1, 1, 1), (3, 31, 33), (2, 64, 1025), (5, 100, 4099)])
+def test_ragged_sizes_vs_oracle(B, S, G):
+    """Sizes that do not fill 32-gene tiles / 1024-gene chunks; S=1 and G=1 edge cases."""
+    g, vae, sd, cfg = build("vae_2000")
+    rng = np.random.default_rng(B * 1000 + S + G)
+    genes_s = rng.integers(0, 2000, (B, S)).astype(np.int64)
+    counts_s = rng.poisson(1.5, (B, S)).astype(np.float32)
+    genes = np.stack([rng.permutation(2001)[:G] if G <= 2001 else rng.integers(0, 2001, G) for _ in range(B)]).astype(np.int64)
+    lib = rng.uniform(100, 2000, (B, 1)).astype(np.float32)
+    zr = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    z_ref = encode(sd, cfg, torch.from_numpy(counts_s), torch.from_numpy(genes_s))
+    z = vae.encode(cu(counts_s), cu(genes_s))
+    assert max_abs_rel(z.cpu(), z_ref) < TOL
+    mu_ref, th_ref = decode(sd, cfg, torch.from_numpy(zr), torch.from_numpy(genes), torch.from_numpy(lib))
+    nb = vae.decode(cu(zr), cu(genes), cu(lib))
+    assert max_abs_rel(nb.mu.cpu(), mu_ref) < TOL and max_abs_rel(nb.theta.cpu(), th_ref) < 1e-5
+
+
+def test_full_size_properties_dentate():
+    """dentate_gyrus shape (G=17002, S=6147): mu rows sum to the library size, results are repeatable bit for bit,
+    permuting a cell's gene list permutes its mu, and a few cells agree with the oracle."""
+    G, S, B = 17002, 6147, 8
+    g, vae, sd, cfg = build("vae_2000")
+    from test_abi_cpu import _build_vae as bv
+    shapes = {k: tuple(v.shape) for k, v in bv(G).state_dict().items()}
+    sd = make_state_dict(shapes, 77)
+    vae = bv(G)
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.cuda().eval()
+    cfg = VAEConfig(n_genes=G)
+    rng = np.random.default_rng(3)
+    genes = np.tile(np.arange(G, dtype=np.int64), (B, 1))
+    counts = rng.poisson(0.7, (B, G)).astype(np.float32)
+    sub = np.stack([np.sort(rng.permutation(G)[:S]) for _ in range(B)])
+    lib = counts.sum(1, keepdims=True) + 1
+    z = vae.encode(cu(np.take_along_axis(counts, sub, 1)), cu(np.take_along_axis(genes, sub, 1)))
+    nb = vae.decode(z, cu(genes), cu(lib))
+    nb_again = vae.decode(z, cu(genes), cu(lib))
+    assert torch.equal(nb.mu, nb_again.mu)
+    assert torch.allclose(nb.mu.sum(1), cu(lib[:, 0]), rtol=2e-4)
+    perm = rng.permutation(G)
+    nb_p = vae.decode(z, cu(genes[:, perm]), cu(lib))
+    assert max_abs_rel(nb_p.mu.cpu(), nb.mu.cpu()[:, perm]) < 1e-5   # same values up to the softmax-sum order
+    z_ref = encode(sd, cfg, torch.from_numpy(np.take_along_axis(counts, sub, 1))[:2], torch.from_numpy(np.take_along_axis(genes, sub, 1))[:2])
+    assert max_abs_rel(z.cpu()[:2], z_ref) < TOL
+    mu_ref, _ = decode(sd, cfg, z.cpu()[:2], torch.from_numpy(genes[:2]), torch.from_numpy(lib[:2]))
+    assert max_abs_rel(nb.mu.cpu()[:2], mu_ref) < TOL
+    x = nb.sample()
+    assert x.shape == (B, G) and (x >= 0).all()
