@@ -71,8 +71,8 @@ def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world):
         out = m.sample_ode_cfg(z2, cond2, scales, wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1, wl["method"])
         if dist_on:
             import torch.distributed as dist
-            gathered = torch.empty((world,) + tuple(out.shape), device=out.device, dtype=out.dtype)
-            dist.all_gather_into_tensor(gathered, out)
+            gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
+            dist.all_gather_into_tensor(gathered, out)  # the single collective of the path: generated latents, 1 KB per cell
             out = gathered
     return out
 
@@ -100,6 +100,39 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     return dt, blocks
+
+
+def decode_inclusive(m, wl, device, n_genes=17002):
+    """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count)."""
+    from scldm_amd.layers import InputTransformerVAE
+    from scldm_amd.nnets import Decoder, Encoder
+    from scldm_amd.stochastic_layers import NegativeBinomialTransformerLayer
+    from scldm_amd.vae import TransformerVAE
+    kw = dict(n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, dropout=0.0, bias=False, multiple_of=4,
+              layernorm_eps=1e-8, norm_layer="layernorm")
+    vae = TransformerVAE(Encoder(n_inducing_points=16, positional_encoding=True, **kw),
+                         Decoder(n_genes=n_genes, n_inducing_points=16, shared_embedding=True, use_adaln=False, **kw),
+                         NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32),
+                         InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p"))
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in vae.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (1.0 if "embedding" in n or "inducing" in n else 0.05) + (1.0 if ".ln_" in n and n.endswith("weight") else 0.0))
+    vae = vae.to(device).eval()
+    B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
+    w2 = dict(wl); w2["B"] = B
+    z2, cond2, scales = make_inputs(w2, B, device, seed=7)
+    genes = torch.arange(n_genes, device=device).repeat(2 * B, 1)
+    lib = torch.full((2 * B, 1), 3000.0, device=device)
+    steps = w2["evals"] + 1 if w2["method"] == "euler" else w2["evals"] // 2 + 1
+    def once():
+        z = m.sample_ode_cfg(z2, cond2, scales, steps, w2["method"])
+        return vae.decode(z, genes, lib)
+    once(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); once(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    t1 = time.perf_counter(); vae.decode(z2, genes, lib); torch.cuda.synchronize(); dd = time.perf_counter() - t1
+    return {"cells_per_gpu": B, "n_genes": n_genes, "cells_per_s": B / dt, "decode_only_cells_per_s": 2 * B / dd,
+            "note": "sampling + MCAB decode of the 2B latents to (mu, theta); decode rate counts decoded rows"}
 
 
 def cpu_baseline(m, wl, budget_cells=256, evals=3):
@@ -197,6 +230,7 @@ def main():
                               "dit_fwd_mfma_frac": nf2 * FLOPS_PER_SAMPLE_FWD * w2["evals"] / d2 / PEAK[args.precision]})
                 del m2
             result["other_workloads"] = extra
+            result["with_vae_decode"] = decode_inclusive(m, wl, device)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
     if rank == 0:

@@ -89,3 +89,40 @@ def test_full_size_properties_dentate():
     assert max_abs_rel(nb.mu.cpu()[:2], mu_ref) < TOL
     x = nb.sample()
     assert x.shape == (B, G) and (x >= 0).all()
+
+
+def test_sample_cells_harness_matches_oracle_chain():
+    """S1: noise -> fused CFG Euler sampling -> decode, against oracle DiT + oracle transport + oracle decode."""
+    from oracle.dit import DiTConfig, dit_forward_with_cfg
+    from oracle.transport import sample_ode_fixed
+    from scldm_amd.nnets import DiT
+    from scldm_amd.sampling import sample_cells
+    g, vae, sd_v, cfg_v = build("vae_2000")
+    gd = load_golden("dit_base")
+    kw = golden_json(gd, "kwargs_json")
+    shapes = {k: tuple(v) for k, v in golden_json(gd, "shapes_json").items()}
+    sd_d = make_state_dict(shapes, int(gd["seed"]))
+    dit = DiT(**kw)
+    dit.load_state_dict(sd_d, strict=True)
+    dit = dit.cuda().eval()
+    cfg_d = DiTConfig(class_vocab_sizes=kw["class_vocab_sizes"], condition_strategy=kw["condition_strategy"])
+    rng = np.random.default_rng(9)
+    B, G = 3, 300
+    z0 = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    lab = rng.integers(0, 14, B).astype(np.int64)
+    genes = np.stack([rng.permutation(2000)[:G] for _ in range(B)]).astype(np.int64)
+    logsf = rng.normal(7.0, 0.3, B).astype(np.float32)
+    scales = {"clusters": 2.0}
+    nb, z = sample_cells(dit, vae, {"clusters": cu(lab)}, scales, B, cu(genes), cu(logsf), num_steps=4, sampling_method="euler",
+                         z0=cu(z0), draw_counts=False)
+    z2 = torch.from_numpy(np.concatenate([z0, z0]))
+    cond2 = {"clusters": torch.from_numpy(np.concatenate([lab, lab]))}
+    z_ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd_d, cfg_d, x, t, cond2, scales), 4, "euler")
+    lib = torch.exp(torch.from_numpy(np.concatenate([logsf, logsf]))).view(-1, 1)
+    mu_ref, th_ref = decode(sd_v, cfg_v, z_ref, torch.from_numpy(np.concatenate([genes, genes])), lib)
+    assert z.shape == (2 * B, 16, 16) and max_abs_rel(z.cpu(), z_ref) < TOL
+    assert max_abs_rel(nb.mu.cpu(), mu_ref) < 2e-4 and max_abs_rel(nb.theta.cpu(), th_ref) < 1e-5
+    with pytest.raises(ValueError):
+        sample_cells(dit, vae, {"clusters": cu(lab)}, scales, B + 1, cu(genes), cu(logsf))
+    with pytest.raises(AssertionError):
+        sample_cells(dit, vae, {"clusters": cu(lab)}, {"other": 1.0}, B, cu(genes), cu(logsf))
