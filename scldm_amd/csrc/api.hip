@@ -28,7 +28,7 @@ struct scldm_dit {
   int n_chunks;   // padded hidden / 128
   int mod_w;
   bool loaded;
-  void* stream[2];   // [precision] packed weight streams, [layer][wave][unit] (+ ring over-read slack)
+  void* stream[2][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack)
   void* wfinal[2];   // [precision] packed final_layer.linear
   float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)
   float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
@@ -41,7 +41,7 @@ struct scldm_dit {
   bool timing;
   std::vector<hipEvent_t> ev;
   size_t ev_used;
-  int force_ntt;
+  int force_ntt, force_ft;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
 };
 
@@ -68,14 +68,19 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->force_ntt = 0;
   h->dbg = nullptr;
   if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
+  h->force_ft = 0;
+  if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
   const int L = cfg->n_layer, din = cfg->n_embed_input, nc = h->n_chunks;
   hipError_t e = hipSuccess;
   for (int p = 0; p < 2 && e == hipSuccess; ++p) {
     const size_t es = esize(p);
     const size_t elems = ((size_t)4 * L * units_per_layer(nc) + kMaxPF) * 1024;  // + slack for the ring's over-read
-    if ((e = alloc(&h->stream[p], elems * es)) != hipSuccess) break;
-    if ((e = hipMemset(h->stream[p], 0, elems * es)) != hipSuccess) break;
+    for (int f = 0; f < 2 && e == hipSuccess; ++f) {
+      if ((e = alloc(&h->stream[p][f], elems * es)) != hipSuccess) break;
+      e = hipMemset(h->stream[p][f], 0, elems * es);
+    }
+    if (e != hipSuccess) break;
     if ((e = alloc(&h->wfinal[p], 16 * 512 * es)) != hipSuccess) break;
   }
   if (e == hipSuccess) e = alloc((void**)&h->b_qkv, (size_t)L * 768 * 4);
@@ -108,7 +113,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
 extern "C" void scldm_dit_destroy(scldm_dit* h) {
   if (!h) return;
   for (int p = 0; p < 2; ++p) {
-    if (h->stream[p]) (void)hipFree(h->stream[p]);
+    for (int f = 0; f < 2; ++f)
+      if (h->stream[p][f]) (void)hipFree(h->stream[p][f]);
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_b, h->pos, h->fin_b, h->b_qkv, h->b_proj};
@@ -128,10 +134,12 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   const int T = 256;
   for (int i = 0; i < L; ++i) {
     const long long npk = (long long)4 * units_per_layer(nc) * 1024;
-    pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                          (float*)h->stream[0], H, nc, i, L);
-    pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                           (__bf16*)h->stream[1], H, nc, i, L);
+    for (int ft = 1; ft <= 2; ++ft) {
+      pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
+                                                            (float*)h->stream[0][ft - 1], H, nc, i, ft);
+      pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
+                                                             (__bf16*)h->stream[1][ft - 1], H, nc, i, ft);
+    }
     copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], h->b_qkv + (size_t)i * 768, 768);
     copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], h->b_proj + (size_t)i * 256, 256);
     // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
@@ -221,24 +229,32 @@ static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows,
   return SCLDM_OK;
 }
 
-template <typename OP, int NTT>
+template <typename OP, int NTT, int FT>
 static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
-  using L = FwdLayout<OP, NTT>;
+  using L = FwdLayout<OP, NTT, FT>;
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)dit_forward_kernel<OP, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)dit_forward_kernel<OP, NTT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
     attr_set = true;
   }
   const int grid = cdiv((long long)a.n_fwd * 16, L::TM);
-  dit_forward_kernel<OP, NTT><<<grid, 256, L::LDS_BYTES, st>>>(a);
+  dit_forward_kernel<OP, NTT, FT><<<grid, L::NT, L::LDS_BYTES, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
 
-static int pick_ntt(const scldm_dit* h, int n_fwd, int prec) {
-  if (prec == SCLDM_PREC_FP32) return 2;
-  if (h->force_ntt == 2 || h->force_ntt == 4) return h->force_ntt;
-  return 2;  // 64-token tiles, two workgroups per CU (measured faster than 128-token tiles at every size so far)
+// Kernel shape: (token tiles of 32*NTT, FT feature tiles per wave => 8/FT waves per workgroup).
+//   fp32 : NTT=2, FT=2 (4 waves, one per SIMD, 512-register budget)
+//   bf16 : NTT=2, FT=2, two workgroups per CU by default (measured fastest in round 1: 396 us per launch at 12288
+//          sample-forwards, although 35 VGPRs spill); FT=1 (8 waves, no spills, 422 us with an 8-deep ring) and
+//          NTT=4 (576 us) remain selectable through SCLDM_FT / SCLDM_NTT for A/B runs.
+static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
+  *ntt = 2;
+  *ft = 2;
+  if (prec == SCLDM_PREC_BF16) {
+    if (h->force_ft == 1 || h->force_ft == 2) *ft = h->force_ft;
+    if (h->force_ntt == 2 || (h->force_ntt == 4 && *ft == 2)) *ntt = h->force_ntt;
+  }
 }
 
 // The DiT trunk: one fused launch per layer (input projection rides in the first, the final layer in the last).
@@ -247,7 +263,8 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   const scldm_dit_config& c = h->cfg;
   const size_t es = esize(prec);
   const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks) * 1024;
-  const int ntt = pick_ntt(h, n_fwd, prec);
+  int ntt, ft;
+  pick_shape(h, prec, &ntt, &ft);
   FwdArgs a;
   a.z = x;
   a.out = out;
@@ -271,7 +288,7 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.dbg = h->dbg;
   for (int i = 0; i < c.n_layer; ++i) {
     a.layer = i;
-    a.w_stream = (const char*)h->stream[prec] + (size_t)i * layer_elems * es;
+    a.w_stream = (const char*)h->stream[prec][ft - 1] + (size_t)i * layer_elems * es;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -287,9 +304,10 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
       HIP_TRY(hipEventRecord(e0, st));
     }
     int rc;
-    if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2>(a, st);
-    else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4>(a, st);
-    else rc = launch_fwd_t<OpBF16, 2>(a, st);
+    if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2, 2>(a, st);
+    else if (ft == 1) rc = launch_fwd_t<OpBF16, 2, 1>(a, st);
+    else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4, 2>(a, st);
+    else rc = launch_fwd_t<OpBF16, 2, 2>(a, st);
     if (rc != SCLDM_OK) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, st));
   }

@@ -9,7 +9,7 @@ namespace scldm {
 // ------------------------------------------------------------------------------------------------
 // Weight packing: PyTorch (out, in) row-major fp32 -> one contiguous MFMA-fragment stream per wave
 // (layout documented at WStream in dit_forward.hpp).  Element (unit gu, tile ft, lane l, j) lives at
-// ((gu*2 + ft)*64 + l)*8 + j; its k index inside the unit's k-step is (l>>5)*8 + j; its row is l&31.
+// ((gu*FT + ft)*64 + l)*8 + j; its k index inside the unit's k-step is (l>>5)*8 + j; its row is l&31.
 //   units 0-47 : c_attn rows p*256 + w*64 + ft*32 + r          (p = q,k,v)       attn.c_attn.weight (768,256)
 //   units 48-63: c_proj rows w*64 + ft*32 + r                                      attn.c_proj.weight (256,256)
 //   chunk c, units 0-15: tile rows 0-15 = w1[hid], rows 16-31 = w2[hid], hid = c*128 + w*32 + ft*16 + (r&15)
@@ -19,33 +19,34 @@ namespace scldm {
 template <typename E>
 __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* __restrict__ Wproj, const float* __restrict__ W1,
                                   const float* __restrict__ W2, const float* __restrict__ Wcp, E* __restrict__ out, int H,
-                                  int n_chunks, int layer, int n_layer) {
-  const int UL = units_per_layer(n_chunks);
+                                  int n_chunks, int layer, int FT) {
+  // FT = 32-row tiles per wave (2: four waves, 1: eight waves); a unit holds FT fragments of 512 elements
+  const int UL = units_per_layer(n_chunks), NW = 8 / FT, unit_elems = 512 * FT;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)4 * UL * 1024) return;
-  const int j = idx & 7, l = (idx >> 3) & 63, ft = (idx >> 9) & 1;
-  const int gu = (int)(idx >> 10), w = gu / UL, u = gu % UL;
+  if (idx >= (long long)NW * UL * unit_elems) return;
+  const int j = idx & 7, l = (idx >> 3) & 63, ft = (int)((idx >> 9) % FT);
+  const int gu = (int)(idx / unit_elems), w = gu / UL, u = gu % UL;
   const int r = l & 31, k8 = (l >> 5) * 8 + j;
+  const int frow = (w * FT + ft) * 32 + r;  // output feature row of this wave's tile
   float val;
   if (u < 48) {
     const int p = u >> 4, ks = u & 15;
-    val = Wqkv[(size_t)(p * 256 + w * 64 + ft * 32 + r) * 256 + ks * 16 + k8];
+    val = Wqkv[(size_t)(p * 256 + frow) * 256 + ks * 16 + k8];
   } else if (u < 64) {
     const int ks = u - 48;
-    val = Wproj[(size_t)(w * 64 + ft * 32 + r) * 256 + ks * 16 + k8];
+    val = Wproj[(size_t)frow * 256 + ks * 16 + k8];
   } else {
     const int v = u - 64, c = v / kUnitsPerChunk, vv = v % kUnitsPerChunk;
     if (vv < 16) {
-      const int hid = c * kHC + w * 32 + ft * 16 + (r & 15);
+      const int hid = c * kHC + (w * FT + ft) * 16 + (r & 15);
       const float* src = (r < 16) ? W1 : W2;
       val = (hid < H) ? src[(size_t)hid * 256 + vv * 16 + k8] : 0.f;
     } else {
       const int hid = c * kHC + (vv - 16) * 16 + k8;
-      val = (hid < H) ? Wcp[(size_t)(w * 64 + ft * 32 + r) * H + hid] : 0.f;
+      val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;
     }
   }
-  (void)n_layer;
-  out[(((size_t)layer * 4 + w) * UL + u) * 1024 + (idx & 1023)] = (E)val;  // [layer][wave][unit]
+  out[((size_t)layer * NW * UL) * unit_elems + idx] = (E)val;  // [layer][wave][unit][ft][lane][8]
 }
 
 // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)

@@ -18,7 +18,8 @@
 // (experiments/configs/model/ldm_base.yaml:16-25); hidden (684) is zero-padded to a multiple of 128.
 //
 // Work decomposition (MI355X-first, not a GEMM-library composition):
-//   * one workgroup = 4 waves (one per SIMD) owns a tile of TM = 32*NTT tokens (= 2*NTT samples); the
+//   * one workgroup = NW = 8/FT waves owns a tile of TM = 32*NTT tokens (= 2*NTT samples); wave w owns the FT
+//     32-row feature tiles [32*FT*w, 32*FT*(w+1)) (FT=2: 4 waves x 2 heads; FT=1: 8 waves x 1 head); the
 //     residual x of the tile lives in VGPRs in MFMA accumulator layout for the whole layer (the first version
 //     re-read/re-wrote it five times per layer and spent 37 % of its time on that, in phase-locked bursts);
 //   * GEMMs are computed TRANSPOSED, Y^T[feature][token] = W[feature][k] * X^T[k][token]:
@@ -27,8 +28,8 @@
 //                   workgroup -> no LDS staging; a register ring prefetches across phase boundaries),
 //       B operand = activations, shared by the four waves through LDS ([token][feature], +16 B row pad
 //                   => conflict-free ds_read_b128);
-//     wave w owns output features [64w, 64w+64) = heads 2w, 2w+1, for ALL tokens of the tile, so
-//     LayerNorm statistics are an in-lane sum + one xor-32 exchange + a 4-way LDS combine;
+//     every wave sees ALL tokens of the tile for its features, so LayerNorm statistics are an in-lane sum +
+//     one half-wave exchange + an NW-way LDS combine;
 //   * attention never leaves registers: Q^T and K^T tiles come out of the MFMA in a layout that is
 //     directly a valid A/B operand pair for S^T = K Q^T (any k permutation is legal if both sides
 //     share it); V is produced with swapped operands (V[token][d]) so that O^T = V^T P^T likewise
@@ -51,11 +52,11 @@ constexpr int kDbgStamps = 32;
 #define SCLDM_STAMP(i)                                                                                 \
   do {                                                                                                 \
     if (a.dbg && lane == 0)                                                                            \
-      a.dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter();       \
+      a.dbg[((size_t)blockIdx.x * 8 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter();       \
   } while (0)
 #define SCLDM_STAMP_END(i)                                                                             \
   do {                                                                                                 \
-    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter(); \
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 8 + wave) * kDbgStamps + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define SCLDM_STAMP(i) do {} while (0)
@@ -88,9 +89,11 @@ struct FwdArgs {
   unsigned long long* dbg;  // phase stamps [block][wave][kDbgStamps]; only -DSCLDM_PHASE_TIMING builds write
 };
 
-template <typename OP, int NTT>
+template <typename OP, int NTT, int FT>
 struct FwdLayout {
   using E = typename OP::E;
+  static constexpr int NW = 8 / FT;             // waves per workgroup (256 features / (32*FT) per wave)
+  static constexpr int NT = 64 * NW;            // threads
   static constexpr int TM = 32 * NTT;
   static constexpr int NS = 2 * NTT;            // samples per tile
   static constexpr int PADE = 16 / sizeof(E);
@@ -98,14 +101,14 @@ struct FwdLayout {
   static constexpr int HB_LD = kHC + PADE;      // elements per hidden-chunk row
   static constexpr int XA_BYTES = TM * XA_LD * sizeof(E);   // LN output; later the attention output (AO aliases it)
   static constexpr int HB_BYTES = TM * HB_LD * sizeof(E);   // one SwiGLU hidden chunk
-  static constexpr int RED_BYTES = 2 * 4 * TM * sizeof(float);
+  static constexpr int RED_BYTES = 2 * NW * TM * sizeof(float);
   static constexpr int MOD_BYTES = NS * kModBlock * sizeof(float);  // the tile's six adaLN vectors per sample
   static constexpr int LDS_BYTES = XA_BYTES + HB_BYTES + RED_BYTES + MOD_BYTES;
 };
 
 // ---------------------------------------------------------------------------------------------
 // Weight stream.  Every wave consumes ONE contiguous sequence of "units" for the whole network
-// (unit = one k-step of 16 for the wave's two 32-row weight tiles = 2 fragments = 2 KiB bf16) per layer:
+// (unit = one k-step of 16 for the wave's FT 32-row weight tiles = FT fragments of 1 KiB bf16) per layer:
 //     Q (16 units) | K (16) | V (16) | proj (16) | for each hidden chunk: W12 (16) | c_proj (8)
 // A PF-deep register ring runs ahead of the MFMAs and persists across passes, so L2 latency is
 // hidden across phase boundaries too and nothing is fetched twice.  The ring over-reads PF units
@@ -116,23 +119,27 @@ constexpr int kUnitsPerChunk = 24;   // W12 (16) + c_proj (8)
 constexpr int kMaxPF = 8;
 __host__ __device__ constexpr int units_per_layer(int n_chunks) { return kUnitsFixed + n_chunks * kUnitsPerChunk; }
 
-template <typename OP, int NTT>
-struct Prefetch {  // k-steps of run-ahead: ~1k cycles of MFMA work per ring depth
-  static constexpr int PF = OP::kIsBF16 ? 4 : 2;
+template <typename OP, int NTT, int FT>
+struct Prefetch {  // k-steps of run-ahead of the weight ring
+#ifdef SCLDM_PF
+  static constexpr int PF = OP::kIsBF16 ? SCLDM_PF : 2;
+#else
+  static constexpr int PF = OP::kIsBF16 ? (FT == 1 ? 4 : 2) : 2;
+#endif
 };
 
-template <typename OP, int PF>
+template <typename OP, int PF, int FT>
 struct WStream {
   using Frag = typename OP::Frag;
   const Frag* p;  // next unit to fetch (lane offset folded in)
-  Frag ring[PF][2];
+  Frag ring[PF][FT];
   __device__ __forceinline__ void init(const Frag* base) {
     p = base;
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-      ring[s][0] = p[0];
-      ring[s][1] = p[64];
-      p += 128;
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) ring[s][ft] = p[ft * 64];
+      p += 64 * FT;
     }
   }
 };
@@ -143,10 +150,10 @@ struct WStream {
 //
 // Schedule per k-step, pinned with sched_group_barrier (hipcc otherwise sinks every refill load to the end of
 // the unrolled body and waits for it two MFMAs later, and issues each ds_read right in front of its consumer):
-//     NTT ds_read_b128 (B fragments of the NEXT k-step)  |  2*NTT MFMAs (this k-step)  |  2 global loads
+//     NTT ds_read_b128 (B fragments of the NEXT k-step)  |  FT*NTT MFMAs (this k-step)  |  FT global loads
 // (refill of the ring slot just consumed = PF k-steps ahead).
-template <typename OP, int NTT, int KSTEPS, bool SWAP, bool ZERO, int PF>
-__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2][NTT], WStream<OP, PF>& ws,
+template <typename OP, int NTT, int FT, int KSTEPS, bool SWAP, bool ZERO, int PF>
+__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF, FT>& ws,
                                           const typename OP::E* __restrict__ bsm, int ldb, int lane) {
   using Frag = typename OP::Frag;
   static_assert(KSTEPS % PF == 0, "KSTEPS must be a multiple of the prefetch depth");
@@ -163,23 +170,21 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2][NTT], WStream<OP, PF>
     for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 1) * 16);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
-      if (SWAP) {
-        acc[0][tt] = OP::mma(bcur[tt], ws.ring[s][0], first ? zero : acc[0][tt]);
-        acc[1][tt] = OP::mma(bcur[tt], ws.ring[s][1], first ? zero : acc[1][tt]);
-      } else {
-        acc[0][tt] = OP::mma(ws.ring[s][0], bcur[tt], first ? zero : acc[0][tt]);
-        acc[1][tt] = OP::mma(ws.ring[s][1], bcur[tt], first ? zero : acc[1][tt]);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        if (SWAP) acc[ft][tt] = OP::mma(bcur[tt], ws.ring[s][ft], first ? zero : acc[ft][tt]);
+        else acc[ft][tt] = OP::mma(ws.ring[s][ft], bcur[tt], first ? zero : acc[ft][tt]);
       }
     }
-    ws.ring[s][0] = ws.p[0];  // refill the slot just consumed: PF k-steps ahead
-    ws.ring[s][1] = ws.p[64];
-    ws.p += 128;
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.p[ft * 64];  // refill the slot just consumed: PF k-steps ahead
+    ws.p += 64 * FT;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
     if (OP::kIsBF16) {
-      __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);      // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTT, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);        // VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);       // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, FT * NTT, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, FT, 0);        // VMEM read
     }
   };
   // peeled first ring revolution (so that ZERO needs no accumulator clearing), then the rolled loop
@@ -192,38 +197,36 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[2][NTT], WStream<OP, PF>
   }
 }
 
-// LayerNorm (no affine, biased variance, two-pass) over the 256 features of every token of the tile,
-// followed by y*(1+scale)+shift, written as OP::E into dst[token][feature].
-// v holds this wave's 64 features x TM tokens in accumulator layout.
 #ifdef SCLDM_PHASE_TIMING
 #define SCLDM_LN_STAMP(i)                                                                              \
   do {                                                                                                 \
-    if (SB >= 0 && dbg && lane == 0) dbg[((size_t)blockIdx.x * 4 + wave) * kDbgStamps + SB + (i)] = __builtin_readcyclecounter(); \
+    if (SB >= 0 && dbg && lane == 0) dbg[((size_t)blockIdx.x * 8 + wave) * kDbgStamps + SB + (i)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define SCLDM_LN_STAMP(i) do {} while (0)
 #endif
 
 // LayerNorm (no affine, biased variance) over the 256 features of every token of the tile, followed by
-// y*(1+scale)+shift, written as OP::E into dst[token][feature].  v holds this wave's 64 features x TM tokens in
+// y*(1+scale)+shift, written as OP::E into dst[token][feature].  v holds this wave's 32*FT features x TM tokens in
 // accumulator layout; scale/shift come from the LDS copy of the tile's adaLN vectors (msm[sample][6*256], vector
-// indices sc_v / sh_v).  Statistics: in-lane sums -> one permlane32 exchange -> 4-way combine through LDS.
-// `between` runs between the first statistics barrier and the last one (used to publish freshly staged LDS data).
-template <typename OP, int NTT, int SB = -1, typename Between>
-__device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], const float* msm, int sc_v, int sh_v,
+// indices sc_v / sh_v).  Statistics: in-lane sums -> one permlane32 exchange -> NW-way combine through LDS.
+// `between` runs before the last statistics barrier (used to publish freshly staged LDS data).
+template <typename OP, int NTT, int FT, int SB = -1, typename Between>
+__device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16], const float* msm, int sc_v, int sh_v,
                                                   float eps, float* red, typename OP::E* dst, int ldd, int wave,
                                                   int lane, unsigned long long* dbg, Between between) {
   constexpr int TM = 32 * NTT;
+  constexpr int NW = 8 / FT;
   const int c32 = lane & 31, hh = lane >> 5;
   float* red_a = red;
-  float* red_b = red + 4 * TM;
+  float* red_b = red + NW * TM;
   float mean[NTT], rstd[NTT];
   if (OP::kTwoPassLN) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float s = 0.f;
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += v[ft][tt][r];
       s = xor32_sum(s);
@@ -236,10 +239,13 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int t = tt * 32 + c32;
-      mean[tt] = (red_a[t] + red_a[TM + t] + red_a[2 * TM + t] + red_a[3 * TM + t]) * (1.0f / kD);
+      float m = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m += red_a[w * TM + t];
+      mean[tt] = m * (1.0f / kD);
       float s = 0.f;
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float d = v[ft][tt][r] - mean[tt];
@@ -254,8 +260,10 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int t = tt * 32 + c32;
-      const float var = (red_b[t] + red_b[TM + t] + red_b[2 * TM + t] + red_b[3 * TM + t]) * (1.0f / kD);
-      rstd[tt] = __builtin_amdgcn_rsqf(var + eps);
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) var += red_b[w * TM + t];
+      rstd[tt] = __builtin_amdgcn_rsqf(var * (1.0f / kD) + eps);
     }
   } else {
     between();
@@ -263,7 +271,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
     for (int tt = 0; tt < NTT; ++tt) {
       float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           s += v[ft][tt][r];
@@ -282,9 +290,14 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const int t = tt * 32 + c32;
-      mean[tt] = (red_a[t] + red_a[TM + t] + red_a[2 * TM + t] + red_a[3 * TM + t]) * (1.0f / kD);
-      const float ex2 = (red_b[t] + red_b[TM + t] + red_b[2 * TM + t] + red_b[3 * TM + t]) * (1.0f / kD);
-      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(ex2 - mean[tt] * mean[tt], 0.f) + eps);
+      float m = 0.f, e2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        m += red_a[w * TM + t];
+        e2 += red_b[w * TM + t];
+      }
+      mean[tt] = m * (1.0f / kD);
+      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(e2 * (1.0f / kD) - mean[tt] * mean[tt], 0.f) + eps);
     }
   }
   const int sp = c32 >> 4;
@@ -292,10 +305,10 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
   for (int tt = 0; tt < NTT; ++tt) {
     const float* mr = msm + (tt * 2 + sp) * kModBlock;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
+    for (int ft = 0; ft < FT; ++ft) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const int f = (wave * FT + ft) * 32 + q * 8 + hh * 4;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(mr + sc_v * kD + f);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(mr + sh_v * kD + f);
         float y[4];
@@ -308,15 +321,17 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[2][NTT][16], 
   }
 }
 
-template <typename OP, int NTT>
-__global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
-  using L = FwdLayout<OP, NTT>;
+template <typename OP, int NTT, int FT>
+__global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
+  using L = FwdLayout<OP, NTT, FT>;
   using E = typename OP::E;
   using Frag = typename OP::Frag;
   using Quad = typename OP::Quad;
   constexpr int TM = L::TM;
   constexpr int NS = L::NS;
-  constexpr int PF = Prefetch<OP, NTT>::PF;
+  constexpr int NW = L::NW;
+  constexpr int NT = L::NT;
+  constexpr int PF = Prefetch<OP, NTT, FT>::PF;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   E* XA = reinterpret_cast<E*>(smem);
@@ -333,41 +348,42 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
   const int smp0 = blockIdx.x * NS;
   const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
   const int layer = a.layer;
+  const int fbase = wave * FT * 32;  // first feature owned by this wave
   auto nothing = [] {};
 
   SCLDM_STAMP(0);
   // the weight stream starts first: its first PF units fly while the prologue runs
-  WStream<OP, PF> ws;
-  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks) * 128 + lane);
+  WStream<OP, PF, FT> ws;
+  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks) * 64 * FT + lane);
 
   // the tile's six adaLN vectors per sample: coalesced loads now, parked in LDS during LN1 (16 lanes share every
   // value, so per-lane global loads would be 16x redundant and - measured - fully latency-exposed)
-  constexpr int kModLd = NS * kModBlock / 4 / 256;  // float4 per thread
+  constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 per thread
   f32x4 mstage[kModLd];
 #pragma unroll
   for (int j = 0; j < kModLd; ++j) {
-    const int idx = tid + 256 * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
     const int s = min(smp0 + sl, a.n_fwd - 1);
     mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
   }
 
-  // per-token-tile bookkeeping; samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
+  // samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
   bool live[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
-  // residual hand-off buffer: lane-linear, quad j = (tt*2 + ft)*4 + q  (padded to whole tiles: no predication)
-  float* xw = a.x + ((size_t)(blockIdx.x * 4 + wave) * (8 * NTT) * 64 + lane) * 4;
+  // residual hand-off buffer: lane-linear, quad j = (tt*FT + ft)*4 + q  (padded to whole tiles: no predication)
+  float* xw = a.x + ((size_t)(blockIdx.x * NW + wave) * (4 * FT * NTT) * 64 + lane) * 4;
 
-  float xr[2][NTT][16];  // the residual stream: features [64w, 64w+64) x TM tokens, accumulator layout (scalars:
-                         // it never feeds an MFMA, and whole-vector values would be copied around by the compiler)
+  float xr[FT][NTT][16];  // the residual stream: this wave's features x TM tokens, accumulator layout (scalars:
+                          // it never feeds an MFMA, and whole-vector values would be copied around by the compiler)
   if (layer == 0) {
     // ---- input projection + positional embedding (nnets.py:290-291), exact fp32 on the VALU (K = din) ----
     const int p16 = c32 & 15;  // token position inside its sample
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const int f = fbase + ft * 32 + q * 8 + hh * 4;
         const f32x4 bb = *reinterpret_cast<const f32x4*>(a.in_b + f);
         const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pos + p16 * kD + f);
 #pragma unroll
@@ -387,10 +403,10 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) zk[tt] = zrow[tt][k];
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.in_wt + k * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.in_wt + k * kD + fbase + ft * 32 + q * 8 + hh * 4);
 #pragma unroll
           for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -401,41 +417,42 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(xw + ((tt * 2 + ft) * 4 + q) * 256);
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256);
 #pragma unroll
           for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = t4[i];
         }
   }
 
-  f32x16 acc[2][NTT];
+  f32x16 acc[FT][NTT];
   const float* bq = a.b_qkv;
   const float* bp = a.b_proj;
 
   // ---- LN1 + modulate(a0 = scale, a1 = shift) -> XA (the staged adaLN vectors are published on the way) ----
-  ln_modulate_store<OP, NTT>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
+  ln_modulate_store<OP, NTT, FT>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
 #pragma unroll
-    for (int j = 0; j < kModLd; ++j) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + 256 * j) * 4) = mstage[j];
+    for (int j = 0; j < kModLd; ++j)
+      if (tid + NT * j < NS * kModBlock / 4) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + NT * j) * 4) = mstage[j];
   });
   __syncthreads();
   SCLDM_STAMP(1);
 
-  // ---- attention for heads 2w, 2w+1, entirely in registers ----
+  // ---- attention for this wave's FT heads, entirely in registers ----
   //   Q pass, K pass -> S^T = K Q^T -> softmax -> P  (Q, K fragments die here: keeps the live MFMA
   //   operand set inside the architectural VGPRs) -> V pass -> O^T = V^T P^T (kept in acc).
   {
-    Frag Pf[2][NTT][2];
+    Frag Pf[FT][NTT][2];
     {
-      Frag QF[2][NTT][2], KF[2][NTT][2];
-      gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // Q^T (feature x token)
+      Frag QF[FT][NTT][2], KF[FT][NTT][2];
+      gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // Q^T (feature x token)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < FT; ++ft) {
         float bias[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 0 * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 0 * kD + fbase + ft * 32 + q * 8 + hh * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
         }
@@ -449,13 +466,13 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
         }
       }
       SCLDM_STAMP(2);
-      gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // K^T (feature x token)
+      gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // K^T (feature x token)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < FT; ++ft) {
         float bias[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 1 * kD + wave * 64 + ft * 32 + q * 8 + hh * 4);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 1 * kD + fbase + ft * 32 + q * 8 + hh * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
         }
@@ -471,7 +488,7 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
       SCLDM_STAMP(3);
       // scores + softmax
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < FT; ++ft) {
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
           f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -510,10 +527,10 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
     }
     SCLDM_STAMP(4);
     // V (swapped operands: lane = feature, registers = tokens), then O^T = V^T P^T
-    gemm_pass<OP, NTT, 16, true, true, PF>(acc, ws, XA, L::XA_LD, lane);
+    gemm_pass<OP, NTT, FT, 16, true, true, PF>(acc, ws, XA, L::XA_LD, lane);
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const float bv = bq[2 * kD + wave * 64 + ft * 32 + c32];
+    for (int ft = 0; ft < FT; ++ft) {
+      const float bv = bq[2 * kD + fbase + ft * 32 + c32];
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
         float t[16];
@@ -530,25 +547,25 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
   SCLDM_STAMP(5);
   __syncthreads();  // every wave is done reading XA (Q/K/V passes): it may now be overwritten by the attention output
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
+  for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<Quad*>(AO + (tt * 32 + c32) * L::XA_LD + wave * 64 + ft * 32 + q * 8 + hh * 4) =
+        *reinterpret_cast<Quad*>(AO + (tt * 32 + c32) * L::XA_LD + fbase + ft * 32 + q * 8 + hh * 4) =
             OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]);
   __syncthreads();  // AO complete
   SCLDM_STAMP(6);
 
   // ---- attention projection, gated residual (a2), LN2 + modulate(a3 = scale, a4 = shift) -> XA ----
-  gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane);
+  gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const int f = fbase + ft * 32 + q * 8 + hh * 4;
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + f);
         const f32x4 g = *reinterpret_cast<const f32x4*>(MOD + (tt * 2 + sp) * kModBlock + 2 * kD + f);
 #pragma unroll
@@ -556,19 +573,19 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
       }
   SCLDM_STAMP(7);
   // (the statistics barrier inside also guarantees every wave has finished reading AO before XA is rewritten)
-  ln_modulate_store<OP, NTT, 16>(xr, MOD, 3, 4, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
+  ln_modulate_store<OP, NTT, FT, 16>(xr, MOD, 3, 4, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
   SCLDM_STAMP(20);
   __syncthreads();  // XA (MLP input) complete
   SCLDM_STAMP(8);
 
-  // ---- SwiGLU MLP, hidden processed in chunks of 128 staged through HB ----
-  f32x16 accp[2][NTT];
+  // ---- SwiGLU MLP, hidden processed in chunks of 128 (NW waves x FT tiles x 16 hidden) staged through HB ----
+  f32x16 accp[FT][NTT];
   for (int c = 0; c < a.n_chunks; ++c) {
-    gemm_pass<OP, NTT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);
+    gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);
     // rows 0-15 of each weight tile are w1, rows 16-31 the matching w2 rows => registers r and r+8 pair up
-    Quad hq[2][NTT][2];
+    Quad hq[FT][NTT][2];
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -580,17 +597,17 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
         }
     if (c > 0) __syncthreads();  // every wave has finished the previous chunk's c_proj pass: HB is free
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + wave * 32 + ft * 16 + q * 8 + hh * 4) = hq[ft][tt][q];
+          *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + (wave * FT + ft) * 16 + q * 8 + hh * 4) = hq[ft][tt][q];
     if (c == 0) SCLDM_STAMP(11);
     __syncthreads();
     if (c == 0) SCLDM_STAMP(12);
-    if (c == 0) gemm_pass<OP, NTT, 8, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
-    else gemm_pass<OP, NTT, 8, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
+    if (c == 0) gemm_pass<OP, NTT, FT, 8, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
+    else gemm_pass<OP, NTT, FT, 8, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
     if (c == 0) SCLDM_STAMP(13);
   }
   SCLDM_STAMP(9);
@@ -599,10 +616,10 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int f = wave * 64 + ft * 32 + q * 8 + hh * 4;
+        const int f = fbase + ft * 32 + q * 8 + hh * 4;
         const f32x4 g = *reinterpret_cast<const f32x4*>(MOD + (tt * 2 + sp) * kModBlock + 5 * kD + f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * accp[ft][tt][q * 4 + i];
@@ -613,37 +630,37 @@ __global__ __launch_bounds__(256, (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_fo
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft)
+      for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 t4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) t4[i] = xr[ft][tt][q * 4 + i];
-          *reinterpret_cast<f32x4*>(xw + ((tt * 2 + ft) * 4 + q) * 256) = t4;
+          *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
         }
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
-    constexpr int kFinLd = NS * 2 * kD / 4 / 256;  // float4 per thread for the tile's (shift, scale) vectors
+    constexpr int kFinLd = (NS * 2 * kD / 4 + NT - 1) / NT;  // float4 per thread for the tile's (shift, scale) vectors
     f32x4 fstage[kFinLd];
 #pragma unroll
     for (int j = 0; j < kFinLd; ++j) {
-      const int idx = tid + 256 * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
+      const int idx = min(tid + NT * j, NS * 2 * kD / 4 - 1), sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
       const int s = min(smp0 + sl, a.n_fwd - 1);
       fstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + a.n_layer * kModBlock + w4 * 4);
     }
     __syncthreads();  // every wave has consumed its a5 gate: vector slots 0/1 of MOD can be replaced
 #pragma unroll
     for (int j = 0; j < kFinLd; ++j) {
-      const int idx = tid + 256 * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
-      *reinterpret_cast<f32x4*>(MOD + sl * kModBlock + w4 * 4) = fstage[j];
+      const int idx = tid + NT * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
+      if (idx < NS * 2 * kD / 4) *reinterpret_cast<f32x4*>(MOD + sl * kModBlock + w4 * 4) = fstage[j];
     }
-    ln_modulate_store<OP, NTT>(xr, MOD, 1, 0, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
+    ln_modulate_store<OP, NTT, FT>(xr, MOD, 1, 0, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
     __syncthreads();
-    // wave w projects token tile tt == w (mod 4); the 16 weight fragments (rows >= din zero) are tiny and L2-hot
+    // wave w projects token tile tt == w; the 16 weight fragments (rows >= din zero) are tiny and L2-hot
     const Frag* wf = reinterpret_cast<const Frag*>(a.w_final) + lane;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
-      if ((tt & 3) != wave) continue;  // wave-uniform
+      if (tt != wave) continue;  // wave-uniform (NTT <= NW)
       f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int ks = 0; ks < 16; ++ks) {

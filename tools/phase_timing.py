@@ -25,7 +25,7 @@ m = _random_dit(n_layer=n_layer).cuda()
 m.precision = prec
 L, h = m._native()
 n_blocks = (n_fwd * 16 + 63) // 64  # upper bound (NTT=2)
-buf = torch.zeros(n_blocks * 4 * 32, dtype=torch.int64, device="cuda")
+buf = torch.zeros(n_blocks * 8 * 32, dtype=torch.int64, device="cuda")
 _lib.check(L.scldm_dit_set_debug_buffer(h, buf.data_ptr()), "set_debug_buffer")
 x = torch.randn(n_fwd, 16, 16, device="cuda")
 t = torch.rand(n_fwd, device="cuda")
@@ -33,7 +33,7 @@ lab = torch.randint(0, 14, (n_fwd,), device="cuda")
 for _ in range(2):
     m(x, t, {"clusters": lab})
 torch.cuda.synchronize()
-st = buf.view(n_blocks * 4, 32).cpu()
+st = buf.view(n_blocks * 8, 32).cpu()
 st = st[st[:, 14] > 0]
 print(f"n_fwd={n_fwd} precision={prec} layers={n_layer} waves recorded={st.shape[0]}  (s_memtime ticks; phases are those of layer 0)")
 whole = (st[:, 14] - st[:, 0]).double()
@@ -48,7 +48,9 @@ span = (st[:, 14].max() - st[:, 0].min())
 print("launch span (first start -> last end):", int(span))
 
 # within-workgroup skew: spread (max - min over the 4 waves) of each stamp, averaged over workgroups
-full = buf.view(n_blocks, 4, 32).cpu()
+full = buf.view(n_blocks, 8, 32).cpu()
+nw = int((full[0, :, 14] > 0).sum())
+full = full[:, :nw]
 ok = (full[:, :, 14] > 0).all(dim=1)
 full = full[ok].double()
 print("within-workgroup spread (max-min over the 4 waves) per stamp:")
