@@ -37,6 +37,14 @@ __device__ __forceinline__ float xor32_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries an all-address-space release fence: with
+// global stores (or LDS-bound DMA) in flight it drains vmcnt(0) - and with it the weight-stream prefetch ring.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

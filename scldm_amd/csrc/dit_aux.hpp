@@ -38,9 +38,12 @@ __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* _
   } else {
     const int v = u - 64, c = v / kUnitsPerChunk, vv = v % kUnitsPerChunk;
     if (vv < 16) {
-      const int hid = c * kHC + (w * FT + ft) * 16 + (r & 15);
+      // FT=2: units 0-7 = tile 0, units 8-15 = tile 1, each unit = k-steps (2j, 2j+1) of that tile (gemm_pass_tile)
+      const int tile = (FT == 2) ? (vv >> 3) : ft;
+      const int ks = (FT == 2) ? (2 * (vv & 7) + ft) : vv;
+      const int hid = c * kHC + (w * FT + tile) * 16 + (r & 15);
       const float* src = (r < 16) ? W1 : W2;
-      val = (hid < H) ? src[(size_t)hid * 256 + vv * 16 + k8] : 0.f;
+      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] : 0.f;
     } else {
       const int hid = c * kHC + (vv - 16) * 16 + k8;
       val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;

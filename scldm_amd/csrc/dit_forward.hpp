@@ -110,6 +110,8 @@ struct FwdLayout {
 // Weight stream.  Every wave consumes ONE contiguous sequence of "units" for the whole network
 // (unit = one k-step of 16 for the wave's FT 32-row weight tiles = FT fragments of 1 KiB bf16) per layer:
 //     Q (16 units) | K (16) | V (16) | proj (16) | for each hidden chunk: W12 (16) | c_proj (8)
+// With FT=2 the W12 units of a chunk are ordered tile 0 (8 units of two consecutive k-steps) then tile 1, so that the
+// up-projection can be computed one 32-row tile at a time (half the accumulator registers).
 // A PF-deep register ring runs ahead of the MFMAs and persists across passes, so L2 latency is
 // hidden across phase boundaries too and nothing is fetched twice.  The ring over-reads PF units
 // past the wave's last unit (next wave's stream / allocation slack), which is never consumed.
@@ -124,7 +126,7 @@ struct Prefetch {  // k-steps of run-ahead of the weight ring
 #ifdef SCLDM_PF
   static constexpr int PF = OP::kIsBF16 ? SCLDM_PF : 2;
 #else
-  static constexpr int PF = OP::kIsBF16 ? (FT == 1 ? 4 : 2) : 2;
+  static constexpr int PF = OP::kIsBF16 ? 4 : 2;
 #endif
 };
 
@@ -197,6 +199,53 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
   }
 }
 
+// Up-projection pass for ONE 32-row weight tile over K = 256 (FT=2 only): the ring still moves units of two
+// fragments, here the two consecutive k-steps (2j, 2j+1) of the same tile.  Halves the accumulator footprint of the
+// SwiGLU phase (the residual + down-projection accumulators are live there); B fragments are read once per tile.
+template <typename OP, int NTT, int PF>
+__device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, PF, 2>& ws,
+                                               const typename OP::E* __restrict__ bsm, int ldb, int lane) {
+  using Frag = typename OP::Frag;
+  constexpr int UNITS = 8;
+  static_assert(UNITS % PF == 0, "8 units must be a multiple of the prefetch depth");
+  const int c32 = lane & 31, hh = lane >> 5;
+  const typename OP::E* bbase = bsm + c32 * ldb + hh * 8;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  Frag bcur[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) bcur[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb);
+  auto unit = [&](int u, int s, bool first) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int ks = 2 * u + half;
+      Frag bnext[NTT];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 1) * 16);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) acc[tt] = OP::mma(ws.ring[s][half], bcur[tt], (first && half == 0) ? zero : acc[tt]);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
+      if (half == 1) {
+        ws.ring[s][0] = ws.p[0];
+        ws.ring[s][1] = ws.p[64];
+        ws.p += 128;
+      }
+      if (OP::kIsBF16) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NTT, 0);
+        if (half == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < PF; ++s) unit(s, s, s == 0);
+#pragma unroll 1
+  for (int u0 = PF; u0 < UNITS; u0 += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) unit(u0 + s, s, false);
+  }
+}
+
 #ifdef SCLDM_PHASE_TIMING
 #define SCLDM_LN_STAMP(i)                                                                              \
   do {                                                                                                 \
@@ -233,7 +282,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
       if (hh == 0) red_a[wave * TM + tt * 32 + c32] = s;
     }
     SCLDM_LN_STAMP(0);
-    __syncthreads();
+    lds_barrier();
     SCLDM_LN_STAMP(1);
     between();
 #pragma unroll
@@ -255,7 +304,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
       if (hh == 0) red_b[wave * TM + t] = s;
     }
     SCLDM_LN_STAMP(2);
-    __syncthreads();
+    lds_barrier();
     SCLDM_LN_STAMP(3);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -285,7 +334,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
       }
     }
     SCLDM_LN_STAMP(0);
-    __syncthreads();
+    lds_barrier();
     SCLDM_LN_STAMP(3);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -374,8 +423,37 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   // residual hand-off buffer: lane-linear, quad j = (tt*FT + ft)*4 + q  (padded to whole tiles: no predication)
   float* xw = a.x + ((size_t)(blockIdx.x * NW + wave) * (4 * FT * NTT) * 64 + lane) * 4;
 
-  float xr[FT][NTT][16];  // the residual stream: this wave's features x TM tokens, accumulator layout (scalars:
-                          // it never feeds an MFMA, and whole-vector values would be copied around by the compiler)
+  // The residual stream (this wave's features x TM tokens, accumulator layout; scalars: it never feeds an MFMA and
+  // whole-vector values would be copied around by the compiler).  With FT=2 the allocator parks ~1/3 of it in scratch
+  // during attention / MLP.  Parking it explicitly in the hand-off buffer and re-reading it ahead of the preceding GEMM
+  // was measured SLOWER (451 vs 396 us): vmcnt retires in order, so every wait on a weight-ring load issued after
+  // the slow residual loads/stores also waits for them.
+  float xr[FT][NTT][16];
+  auto load_x = [&](float (&dst)[FT][NTT][16]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[ft][tt][q * 4 + i] = t4[i];
+        }
+  };
+  auto store_x = [&](const float (&src)[FT][NTT][16]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t4[i] = src[ft][tt][q * 4 + i];
+          *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
+        }
+  };
   if (layer == 0) {
     // ---- input projection + positional embedding (nnets.py:290-291), exact fp32 on the VALU (K = din) ----
     const int p16 = c32 & 15;  // token position inside its sample
@@ -414,16 +492,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
         }
     }
   } else {
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 t4 = *reinterpret_cast<const f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = t4[i];
-        }
+    load_x(xr);
   }
 
   f32x16 acc[FT][NTT];
@@ -436,7 +505,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     for (int j = 0; j < kModLd; ++j)
       if (tid + NT * j < NS * kModBlock / 4) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + NT * j) * 4) = mstage[j];
   });
-  __syncthreads();
+  lds_barrier();
   SCLDM_STAMP(1);
 
   // ---- attention for this wave's FT heads, entirely in registers ----
@@ -545,7 +614,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     }
   }
   SCLDM_STAMP(5);
-  __syncthreads();  // every wave is done reading XA (Q/K/V passes): it may now be overwritten by the attention output
+  lds_barrier();  // every wave is done reading XA (Q/K/V passes): it may now be overwritten by the attention output
 #pragma unroll
   for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
@@ -554,7 +623,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<Quad*>(AO + (tt * 32 + c32) * L::XA_LD + fbase + ft * 32 + q * 8 + hh * 4) =
             OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]);
-  __syncthreads();  // AO complete
+  lds_barrier();  // AO complete
   SCLDM_STAMP(6);
 
   // ---- attention projection, gated residual (a2), LN2 + modulate(a3 = scale, a4 = shift) -> XA ----
@@ -575,27 +644,44 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   // (the statistics barrier inside also guarantees every wave has finished reading AO before XA is rewritten)
   ln_modulate_store<OP, NTT, FT, 16>(xr, MOD, 3, 4, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
   SCLDM_STAMP(20);
-  __syncthreads();  // XA (MLP input) complete
+  lds_barrier();  // XA (MLP input) complete
   SCLDM_STAMP(8);
 
   // ---- SwiGLU MLP, hidden processed in chunks of 128 (NW waves x FT tiles x 16 hidden) staged through HB ----
   f32x16 accp[FT][NTT];
   for (int c = 0; c < a.n_chunks; ++c) {
-    gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);
     // rows 0-15 of each weight tile are w1, rows 16-31 the matching w2 rows => registers r and r+8 pair up
     Quad hq[FT][NTT][2];
+    if constexpr (FT == 2) {
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
+      for (int ft = 0; ft < 2; ++ft) {
+        f32x16 a1[NTT];
+        gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
+        for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float h[4];
+          for (int q = 0; q < 2; ++q) {
+            float h[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h[i] = silu_f(acc[ft][tt][q * 4 + i]) * acc[ft][tt][8 + q * 4 + i];
-          hq[ft][tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
-        }
-    if (c > 0) __syncthreads();  // every wave has finished the previous chunk's c_proj pass: HB is free
+            for (int i = 0; i < 4; ++i) h[i] = silu_f(a1[tt][q * 4 + i]) * a1[tt][8 + q * 4 + i];
+            hq[ft][tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
+          }
+      }
+    } else {
+      gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h[i] = silu_f(acc[ft][tt][q * 4 + i]) * acc[ft][tt][8 + q * 4 + i];
+            hq[ft][tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
+          }
+    }
+    if (c > 0) lds_barrier();  // every wave has finished the previous chunk's c_proj pass: HB is free
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
@@ -604,7 +690,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
         for (int q = 0; q < 2; ++q)
           *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + (wave * FT + ft) * 16 + q * 8 + hh * 4) = hq[ft][tt][q];
     if (c == 0) SCLDM_STAMP(11);
-    __syncthreads();
+    lds_barrier();
     if (c == 0) SCLDM_STAMP(12);
     if (c == 0) gemm_pass<OP, NTT, FT, 8, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
     else gemm_pass<OP, NTT, FT, 8, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
@@ -627,17 +713,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   SCLDM_STAMP(10);
 
   if (layer + 1 < a.n_layer) {  // hand the residual to the next layer's launch
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 t4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) t4[i] = xr[ft][tt][q * 4 + i];
-          *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
-        }
+    store_x(xr);
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
     constexpr int kFinLd = (NS * 2 * kD / 4 + NT - 1) / NT;  // float4 per thread for the tile's (shift, scale) vectors
@@ -648,14 +724,14 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       const int s = min(smp0 + sl, a.n_fwd - 1);
       fstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + a.n_layer * kModBlock + w4 * 4);
     }
-    __syncthreads();  // every wave has consumed its a5 gate: vector slots 0/1 of MOD can be replaced
+    lds_barrier();  // every wave has consumed its a5 gate: vector slots 0/1 of MOD can be replaced
 #pragma unroll
     for (int j = 0; j < kFinLd; ++j) {
       const int idx = tid + NT * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
       if (idx < NS * 2 * kD / 4) *reinterpret_cast<f32x4*>(MOD + sl * kModBlock + w4 * 4) = fstage[j];
     }
     ln_modulate_store<OP, NTT, FT>(xr, MOD, 1, 0, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
-    __syncthreads();
+    lds_barrier();
     // wave w projects token tile tt == w; the 16 weight fragments (rows >= din zero) are tiny and L2-hot
     const Frag* wf = reinterpret_cast<const Frag*>(a.w_final) + lane;
 #pragma unroll
