@@ -236,11 +236,18 @@ def main():
             result["with_vae_decode"] = decode_inclusive(m, wl, device)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
-    if rank == 0:
-        print(json.dumps(result))
     if dist_on:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        try:  # RCCL prints its banner through C stdio: flush that buffer first so the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)  # the one JSON line
 
 
 if __name__ == "__main__":
