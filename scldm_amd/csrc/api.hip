@@ -168,11 +168,13 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
 }
 
 // ------------------------------------------------------------------------------------------------
+static const int kMaxTembEvals = 4096;  // solves with more evaluations embed t step by step
 struct Ws {
   float* h;       // (pad8(n_fwd)*16, 256) residual between layer launches
   float* v;       // (n_fwd, 16*din)
   float* mod;     // (n_rows, mod_w)
   float* silu;    // (n_rows, 256)
+  float* temb;    // (256) timestep embedding shared by all rows of a scalar-t step
   int32_t* ridx;  // (n_fwd)
   float* dz;      // (n_state, e)
   float* k2;      // (n_state, e)
@@ -189,6 +191,7 @@ static Ws carve(const scldm_dit* h, void* base, int n_fwd, int n_rows, int n_sta
   w.v = (float*)take((size_t)n_fwd * e * 4);
   w.mod = (float*)take((size_t)n_rows * h->mod_w * 4);
   w.silu = (float*)take((size_t)(n_rows + 1) * 256 * 4);  // +1 spare row (device scalar t)
+  w.temb = (float*)take((size_t)kMaxTembEvals * 256 * 4);  // per-evaluation timestep embeddings of a whole solve
   w.ridx = (int32_t*)take((size_t)n_fwd * 4);
   w.dz = (float*)take((size_t)n_state * e * 4);
   w.k2 = (float*)take((size_t)n_state * e * 4);
@@ -223,7 +226,7 @@ static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t
   return SCLDM_OK;
 }
 static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st) {
-  dim3 grid(cdiv(h->mod_w, 256), cdiv(rows, kAdaRU));
+  dim3 grid(cdiv(h->mod_w, 64), cdiv(rows, kAdaRU));
   adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w);
   LAUNCH_CHECK();
   return SCLDM_OK;
@@ -377,14 +380,38 @@ __global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 
 static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
-                    float* dz, int prec, hipStream_t st) {
+                    float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr) {
   int rc;
-  // unconditional rows: every class null
-  if ((rc = launch_cond(h, t_dev, t_stride, nullptr, 0u, pl.uncond_rows, w.silu, st))) return rc;
-  for (int p = 0; p < pl.P; ++p) {
-    const float* tp = (t_stride == 0) ? t_dev : t_dev + pl.B;  // second half of t
-    if ((rc = launch_cond(h, tp, t_stride, pl.ulabels, pl.mask[p], pl.U, w.silu + (size_t)(pl.uncond_rows + p * pl.U) * 256, st)))
-      return rc;
+  if (t_stride == 0) {
+    // scalar t: one timestep-MLP evaluation per step, then all rows (unconditional + every pass) in one launch
+    const float* temb = temb_pre;
+    if (!temb) {
+      t_embed_kernel<<<1, 256, 0, st>>>(t_dev, h->w0t, h->b0, h->w2t, h->b2, w.temb);
+      temb = w.temb;
+    }
+    CondRowsArgs ca;
+    ca.temb = temb;
+    ca.emb = h->emb;
+    ca.n_classes = h->cfg.n_classes;
+    ca.U = pl.U > 0 ? pl.U : 1;
+    ca.rows = pl.n_rows;
+    for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
+      ca.emb_row0[c] = c < ca.n_classes ? h->emb_row0[c] : 0;
+      ca.null_tok[c] = c < ca.n_classes ? h->cfg.class_vocab[c] : 0;
+      ca.labels[c] = (c < ca.n_classes && pl.ulabels && pl.ulabels[c]) ? pl.ulabels[c] : nullptr;
+      ca.mask[c] = c < pl.P ? pl.mask[c] : 0u;
+    }
+    ca.silu_c = w.silu;
+    cond_rows_kernel<<<pl.n_rows, 256, 0, st>>>(ca);
+    LAUNCH_CHECK();
+  } else {
+    // per-sample t: unconditional rows (every class null), then one launch per conditional pass
+    if ((rc = launch_cond(h, t_dev, t_stride, nullptr, 0u, pl.uncond_rows, w.silu, st))) return rc;
+    for (int p = 0; p < pl.P; ++p) {
+      const float* tp = t_dev + pl.B;  // second half of t
+      if ((rc = launch_cond(h, tp, t_stride, pl.ulabels, pl.mask[p], pl.U, w.silu + (size_t)(pl.uncond_rows + p * pl.U) * 256, st)))
+        return rc;
+    }
   }
   if ((rc = launch_adaln(h, w.silu, w.mod, pl.n_rows, st))) return rc;
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;
@@ -464,17 +491,24 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
   const size_t n = (size_t)2 * B * 16 * h->cfg.n_embed_input;
   const int steps = n_steps + 1;
   float* tscal = w.silu + (size_t)pl.n_rows * 256;  // device scalar t: the spare row carve() reserves after the silu rows
+  const int n_evals = (method == SCLDM_METHOD_EULER) ? n_steps : 2 * n_steps;
+  const bool pre = n_evals <= kMaxTembEvals;
+  if (pre) {
+    t_embed_all_kernel<<<n_evals, 256, 0, st>>>(steps, method == SCLDM_METHOD_HEUN, h->w0t, h->b0, h->w2t, h->b2, w.temb);
+    LAUNCH_CHECK();
+  }
   for (int i = 0; i < n_steps; ++i) {
     const float t0 = linspace01(i, steps), t1 = linspace01(i + 1, steps);
     const float hs = t1 - t0;
-    set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t0);
-    if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st))) return rc;
+    if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t0);
     if (method == SCLDM_METHOD_EULER) {
+      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)i * 256 : nullptr))) return rc;
       axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, z, hs, n);
     } else {
+      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)(2 * i) * 256 : nullptr))) return rc;
       axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.ztmp, hs, n);
-      set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t1);
-      if ((rc = cfg_eval(h, pl, w.ztmp, tscal, 0, w, w.k2, precision, st))) return rc;
+      if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t1);
+      if ((rc = cfg_eval(h, pl, w.ztmp, tscal, 0, w, w.k2, precision, st, pre ? w.temb + (size_t)(2 * i + 1) * 256 : nullptr))) return rc;
       heun_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.k2, 0.5f * hs, n);
     }
     LAUNCH_CHECK();

@@ -315,7 +315,6 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
       rstd[tt] = __builtin_amdgcn_rsqf(var * (1.0f / kD) + eps);
     }
   } else {
-    between();
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float s = 0.f, ss = 0.f;
@@ -334,6 +333,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
       }
     }
     SCLDM_LN_STAMP(0);
+    between();  // after the statistics: whatever it publishes has had the whole sweep to arrive
     lds_barrier();
     SCLDM_LN_STAMP(3);
 #pragma unroll
@@ -404,17 +404,6 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   // the weight stream starts first: its first PF units fly while the prologue runs
   WStream<OP, PF, FT> ws;
   ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks) * 64 * FT + lane);
-
-  // the tile's six adaLN vectors per sample: coalesced loads now, parked in LDS during LN1 (16 lanes share every
-  // value, so per-lane global loads would be 16x redundant and - measured - fully latency-exposed)
-  constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 per thread
-  f32x4 mstage[kModLd];
-#pragma unroll
-  for (int j = 0; j < kModLd; ++j) {
-    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
-    const int s = min(smp0 + sl, a.n_fwd - 1);
-    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
-  }
 
   // samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
   bool live[NTT];
@@ -495,16 +484,31 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     load_x(xr);
   }
 
+  // the tile's six adaLN vectors per sample: coalesced loads (issued AFTER the residual loads: the row_index -> mod
+  // lookup is a dependent chain and would otherwise hold them back), parked in LDS during LN1 (16 lanes share every
+  // value, so per-lane global loads would be 16x redundant and - measured - fully latency-exposed)
+  constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 per thread
+  f32x4 mstage[kModLd];
+#pragma unroll
+  for (int j = 0; j < kModLd; ++j) {
+    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    const int s = min(smp0 + sl, a.n_fwd - 1);
+    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
+  }
+
+
   f32x16 acc[FT][NTT];
   const float* bq = a.b_qkv;
   const float* bp = a.b_proj;
 
   // ---- LN1 + modulate(a0 = scale, a1 = shift) -> XA (the staged adaLN vectors are published on the way) ----
-  ln_modulate_store<OP, NTT, FT>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
+  SCLDM_STAMP(21);
+  ln_modulate_store<OP, NTT, FT, 22>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
 #pragma unroll
     for (int j = 0; j < kModLd; ++j)
       if (tid + NT * j < NS * kModBlock / 4) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + NT * j) * 4) = mstage[j];
   });
+  SCLDM_STAMP(26);
   lds_barrier();
   SCLDM_STAMP(1);
 

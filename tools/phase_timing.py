@@ -44,6 +44,8 @@ for name, (a, b) in zip(NAMES, PAIRS):
     print(f"{name:24s} mean {d.mean():10.0f}  ({100 * d.mean() / tot.mean():5.1f}%)  min {d.min():8.0f} max {d.max():8.0f}")
 print("LN2 detail: proj-done->stats written", int((st[:, 16] - st[:, 7]).double().mean()), " stats barrier(s)+combine", int((st[:, 19] - st[:, 16]).double().mean()),
       " modulate+store", int((st[:, 20] - st[:, 19]).double().mean()), " final barrier", int((st[:, 8] - st[:, 20]).double().mean()))
+print("LN1 detail: start->prologue issued (x/mod/ring loads)", int((st[:, 21] - st[:, 0]).double().mean()), " ->stats written (incl. load wait + MOD publish)", int((st[:, 22] - st[:, 21]).double().mean()),
+      " barrier+combine", int((st[:, 25] - st[:, 22]).double().mean()), " modulate+store", int((st[:, 26] - st[:, 25]).double().mean()), " final barrier", int((st[:, 1] - st[:, 26]).double().mean()))
 span = (st[:, 14].max() - st[:, 0].min())
 print("launch span (first start -> last end):", int(span))
 
