@@ -25,7 +25,7 @@ static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 1
 
 struct scldm_dit {
   scldm_dit_config cfg;
-  int n_chunks;   // padded hidden / 128
+  int n_chunks[2], half[2];   // [FT-1]: full 128-unit SwiGLU chunks and the optional trailing 64-unit chunk (FT=2)
   int mod_w;
   bool loaded;
   void* stream[2][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack)
@@ -60,7 +60,13 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
   scldm_dit* h = new scldm_dit();
   h->cfg = *cfg;
-  h->n_chunks = (cfg->hidden_dim + kHC - 1) / kHC;
+  h->n_chunks[0] = (cfg->hidden_dim + kHC - 1) / kHC;  // FT=1: pad the hidden dimension to whole chunks
+  h->half[0] = 0;
+  {
+    const int hp = (cfg->hidden_dim + 63) / 64 * 64;     // FT=2: pad to 64, last chunk may be a half chunk
+    h->n_chunks[1] = hp / kHC;
+    h->half[1] = (hp % kHC) / 64;
+  }
   h->mod_w = cfg->n_layer * 6 * kD + 2 * kD;
   h->loaded = false;
   h->timing = false;
@@ -71,12 +77,12 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->force_ft = 0;
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
-  const int L = cfg->n_layer, din = cfg->n_embed_input, nc = h->n_chunks;
+  const int L = cfg->n_layer, din = cfg->n_embed_input;
   hipError_t e = hipSuccess;
   for (int p = 0; p < 2 && e == hipSuccess; ++p) {
     const size_t es = esize(p);
-    const size_t elems = ((size_t)4 * L * units_per_layer(nc) + kMaxPF) * 1024;  // + slack for the ring's over-read
     for (int f = 0; f < 2 && e == hipSuccess; ++f) {
+      const size_t elems = ((size_t)4 * L * units_per_layer(h->n_chunks[f], h->half[f]) + kMaxPF) * 1024;  // + ring over-read slack
       if ((e = alloc(&h->stream[p][f], elems * es)) != hipSuccess) break;
       e = hipMemset(h->stream[p][f], 0, elems * es);
     }
@@ -130,15 +136,16 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& c = h->cfg;
-  const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, nc = h->n_chunks, mw = h->mod_w;
+  const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, mw = h->mod_w;
   const int T = 256;
   for (int i = 0; i < L; ++i) {
-    const long long npk = (long long)4 * units_per_layer(nc) * 1024;
     for (int ft = 1; ft <= 2; ++ft) {
+      const int nc = h->n_chunks[ft - 1], hf = h->half[ft - 1];
+      const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
       pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                            (float*)h->stream[0][ft - 1], H, nc, i, ft);
+                                                            (float*)h->stream[0][ft - 1], H, nc, hf, i, ft);
       pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                             (__bf16*)h->stream[1][ft - 1], H, nc, i, ft);
+                                                             (__bf16*)h->stream[1][ft - 1], H, nc, hf, i, ft);
     }
     copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], h->b_qkv + (size_t)i * 768, 768);
     copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], h->b_proj + (size_t)i * 256, 256);
@@ -265,9 +272,9 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
                  float* hbuf, float* out, int prec, hipStream_t st) {
   const scldm_dit_config& c = h->cfg;
   const size_t es = esize(prec);
-  const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks) * 1024;
   int ntt, ft;
   pick_shape(h, prec, &ntt, &ft);
+  const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks[ft - 1], h->half[ft - 1]) * 1024;
   FwdArgs a;
   a.z = x;
   a.out = out;
@@ -284,7 +291,8 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.rep = rep;
   a.din = c.n_embed_input;
   a.n_layer = c.n_layer;
-  a.n_chunks = h->n_chunks;
+  a.n_chunks = h->n_chunks[ft - 1];
+  a.half_chunk = h->half[ft - 1];
   a.mod_stride = h->mod_w;
   a.eps = c.layernorm_eps;
   a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);

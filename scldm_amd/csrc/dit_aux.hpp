@@ -19,9 +19,9 @@ namespace scldm {
 template <typename E>
 __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* __restrict__ Wproj, const float* __restrict__ W1,
                                   const float* __restrict__ W2, const float* __restrict__ Wcp, E* __restrict__ out, int H,
-                                  int n_chunks, int layer, int FT) {
+                                  int n_chunks, int half, int layer, int FT) {
   // FT = 32-row tiles per wave (2: four waves, 1: eight waves); a unit holds FT fragments of 512 elements
-  const int UL = units_per_layer(n_chunks), NW = 8 / FT, unit_elems = 512 * FT;
+  const int UL = units_per_layer(n_chunks, half), NW = 8 / FT, unit_elems = 512 * FT;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)NW * UL * unit_elems) return;
   const int j = idx & 7, l = (idx >> 3) & 63, ft = (int)((idx >> 9) % FT);
@@ -35,6 +35,17 @@ __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* _
   } else if (u < 64) {
     const int ks = u - 48;
     val = Wproj[(size_t)frow * 256 + ks * 16 + k8];
+  } else if (u >= 64 + n_chunks * kUnitsPerChunk) {
+    // trailing half chunk (FT=2): 64 hidden units, wave w owns 16 of them in ONE tile; then a K=64 c_proj pass
+    const int vh = u - 64 - n_chunks * kUnitsPerChunk, hid0 = n_chunks * kHC;
+    if (vh < 8) {
+      const int ks = 2 * vh + ft, hid = hid0 + w * 16 + (r & 15);
+      const float* src = (r < 16) ? W1 : W2;
+      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] : 0.f;
+    } else {
+      const int hid = hid0 + (vh - 8) * 16 + k8;
+      val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;
+    }
   } else {
     const int v = u - 64, c = v / kUnitsPerChunk, vv = v % kUnitsPerChunk;
     if (vv < 16) {

@@ -38,6 +38,8 @@
 //   * the SwiGLU hidden dimension is processed in chunks of 128 through a double-buffered LDS
 //     stage (w1/w2 rows are interleaved inside each 32-row weight tile so silu(a)*b is in-lane).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace scldm {
@@ -82,7 +84,8 @@ struct FwdArgs {
   int n_direct, rep;        // sample-forward s reads latent s (s < n_direct) else n_direct - rep + (s - n_direct) % rep
   int din;                  // latent channels (<= 32 handled by one output tile)
   int layer, n_layer;       // this launch's layer index
-  int n_chunks;             // padded hidden / 128
+  int n_chunks;             // full SwiGLU chunks of 128 hidden units
+  int half_chunk;           // 1: a trailing chunk of 64 hidden units follows (FT=2 kernels; 684 -> 5*128 + 64 = 704)
   int mod_stride;
   float eps;
   float attn_scale_log2e;   // log2(e) / sqrt(head_dim)
@@ -119,7 +122,10 @@ struct FwdLayout {
 constexpr int kUnitsFixed = 64;      // Q,K,V,proj
 constexpr int kUnitsPerChunk = 24;   // W12 (16) + c_proj (8)
 constexpr int kMaxPF = 8;
-__host__ __device__ constexpr int units_per_layer(int n_chunks) { return kUnitsFixed + n_chunks * kUnitsPerChunk; }
+constexpr int kUnitsHalfChunk = 12;  // FT=2 only: one 32-row W12 tile (8 units) + a K=64 c_proj pass (4 units)
+__host__ __device__ constexpr int units_per_layer(int n_chunks, int half = 0) {
+  return kUnitsFixed + n_chunks * kUnitsPerChunk + half * kUnitsHalfChunk;
+}
 
 template <typename OP, int NTT, int FT>
 struct Prefetch {  // k-steps of run-ahead of the weight ring
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   SCLDM_STAMP(0);
   // the weight stream starts first: its first PF units fly while the prologue runs
   WStream<OP, PF, FT> ws;
-  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks) * 64 * FT + lane);
+  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
 
   // samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
   bool live[NTT];
@@ -653,12 +659,15 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
 
   // ---- SwiGLU MLP, hidden processed in chunks of 128 (NW waves x FT tiles x 16 hidden) staged through HB ----
   f32x16 accp[FT][NTT];
-  for (int c = 0; c < a.n_chunks; ++c) {
+  // one SwiGLU chunk; HALF (compile time) = the trailing 64-unit chunk: one W12 tile per wave, K = 64 down-projection
+  auto do_chunk = [&](auto half_tag, int c) {
+    constexpr bool HALF = decltype(half_tag)::value;
+    constexpr int TILES = (FT == 2 && HALF) ? 1 : FT;
     // rows 0-15 of each weight tile are w1, rows 16-31 the matching w2 rows => registers r and r+8 pair up
-    Quad hq[FT][NTT][2];
+    Quad hq[TILES][NTT][2];
     if constexpr (FT == 2) {
 #pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
+      for (int ft = 0; ft < TILES; ++ft) {
         f32x16 a1[NTT];
         gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);
 #pragma unroll
@@ -687,19 +696,24 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     }
     if (c > 0) lds_barrier();  // every wave has finished the previous chunk's c_proj pass: HB is free
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
+    for (int ft = 0; ft < TILES; ++ft) {
+      const int col0 = HALF ? wave * 16 : (wave * FT + ft) * 16;
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + (wave * FT + ft) * 16 + q * 8 + hh * 4) = hq[ft][tt][q];
+          *reinterpret_cast<Quad*>(HB + (tt * 32 + c32) * L::HB_LD + col0 + q * 8 + hh * 4) = hq[ft][tt][q];
+    }
     if (c == 0) SCLDM_STAMP(11);
     lds_barrier();
     if (c == 0) SCLDM_STAMP(12);
-    if (c == 0) gemm_pass<OP, NTT, FT, 8, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
-    else gemm_pass<OP, NTT, FT, 8, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
+    constexpr int KS = HALF ? 4 : 8;
+    if (c == 0) gemm_pass<OP, NTT, FT, KS, false, true, PF>(accp, ws, HB, L::HB_LD, lane);
+    else gemm_pass<OP, NTT, FT, KS, false, false, PF>(accp, ws, HB, L::HB_LD, lane);
     if (c == 0) SCLDM_STAMP(13);
-  }
+  };
+  for (int c = 0; c < a.n_chunks; ++c) do_chunk(std::false_type{}, c);
+  if (a.half_chunk) do_chunk(std::true_type{}, a.n_chunks);
   SCLDM_STAMP(9);
 
   // ---- gated residual (a5) ----
