@@ -215,8 +215,17 @@ def main():
         n_launch, tot_ms = blocks
         avg_s = tot_ms / n_launch / 1e3
         ach = n_fwd * FLOPS_PER_SAMPLE_BLOCK / avg_s / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": "dit_block_kernel", "achieved": ach, "peak": PEAK[args.precision] / 1e12,
-                              "unit": "TFLOP/s", "frac": ach / (PEAK[args.precision] / 1e12), "traffic": None,
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_dit_forward_kernel.json")
+        if args.precision == "bf16" and args.workload == "dentate_b4096_euler100" and not args.batch and os.path.exists(pmc):
+            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of this same workload
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; see the file's note)
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_dit_forward_kernel.json"
+        result["roofline"] = {"bound": "mfma", "kernel": "dit_forward_kernel", "achieved": ach, "peak": PEAK[args.precision] / 1e12,
+                              "unit": "TFLOP/s", "frac": ach / (PEAK[args.precision] / 1e12), "traffic": traffic,
+                              "traffic_source": traffic_src,
                               "launches": n_launch, "avg_launch_us": avg_s * 1e6,
                               "algorithmic_flops_per_launch": n_fwd * FLOPS_PER_SAMPLE_BLOCK}
     if rank == 0 and not dist_on:
