@@ -230,29 +230,39 @@ class DiT(nn.Module):
             pass
 
     # ------------------------------------------------------------------ label handling (nnets.py:380-456)
-    def _eval_label_ptrs(self, condition: dict[str, torch.Tensor], n: int):
-        """Device label pointers per class (sorted-name order) for an EVAL-mode forward; None -> null token."""
+    def _label_ptrs(self, condition: dict[str, torch.Tensor], n: int, force_drop_ids: bool):
+        """Device label pointers per class (sorted-name order); None -> the class uses its null token.
+
+        Eval: mutually_exclusive keeps the class drawn by torch.randint among the available ones (the reference draws it even
+        in eval, nnets.py:395), joint keeps every class (nnets.py:428-456).  Training / force_drop_ids additionally replaces
+        labels by the null token with probability cfg_dropout_prob (one mask per batch row, nnets.py:401-402,440-443)."""
         names = self._class_names
         available = [c for c in names if c in condition]
         if not available:
             raise ValueError("condition must contain at least one known class (reference raises StopIteration/KeyError here)")
         keep = []
+        dev = self.pos_embed.device
         if self.condition_strategy == "joint":
             missing = [c for c in names if c not in condition]
             if missing:
                 raise KeyError(missing[0])  # the reference indexes condition[class_name] for every class (nnets.py:449)
             chosen = set(names)
+            drop = self.training  # joint: dropout only in training mode (nnets.py:440-445)
         else:
-            # the reference draws the selected class with torch.randint even in eval (nnets.py:395)
             sel = int(torch.randint(0, len(available), ()).item()) if len(available) > 1 else 0
             chosen = {available[sel]}
+            drop = force_drop_ids
+        drop_mask = (torch.rand(n, device=dev) < self.cfg_dropout_prob) if drop else None
         ptrs = []
         for c in names:
             if c in chosen:
                 lab = condition[c]
                 if lab.shape[0] != n:
                     raise ValueError(f"Condition '{c}' length ({lab.shape[0]}) must match batch size ({n})")
-                lab = lab.to(device=self.pos_embed.device, dtype=torch.long).contiguous()
+                lab = lab.to(device=dev, dtype=torch.long)
+                if drop_mask is not None:
+                    lab = torch.where(drop_mask, torch.full_like(lab, self.class_vocab_sizes[c]), lab)
+                lab = lab.contiguous()
                 keep.append(lab)
                 ptrs.append(lab.data_ptr())
             else:
@@ -266,16 +276,16 @@ class DiT(nn.Module):
             force_drop_ids = self.training
         if not self.training:
             assert not force_drop_ids, "force_drop_ids must be False when not training"
-        if self.training or force_drop_ids:
-            raise NotImplementedError("training-mode forward (CFG label dropout + backward) is not built yet: "
-                                      "SURVEY.md section 8 row T1 / config 5 is a later round. Use .eval().")
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+            raise NotImplementedError("the fused HIP forward has no backward pass yet (SURVEY.md section 8 row T1 / config 5 is a later "
+                                      "round): call it under torch.no_grad() - training-mode label dropout itself is supported")
         L, h = self._native()
         x = _require_cuda_f32("x", x)
         t = _require_cuda_f32("t", t)
         n = x.shape[0]
         if x.shape[1:] != (self.seq_len, self.n_embed_input) or t.shape != (n,):
             raise ValueError(f"expected x (B,{self.seq_len},{self.n_embed_input}) and t (B,), got {tuple(x.shape)}, {tuple(t.shape)}")
-        labels, keep = self._eval_label_ptrs(condition, n)
+        labels, keep = self._label_ptrs(condition, n, force_drop_ids)
         out = torch.empty_like(x)
         ws = self._workspace(L, n, n, 0)
         with torch.cuda.device(x.device):

@@ -140,5 +140,29 @@ def test_error_paths():
     with pytest.raises(ValueError):
         m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(3, dtype=torch.long, device="cuda")})
     m.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError):  # no backward yet: training forward needs no_grad
         m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
+
+
+def test_training_mode_label_dropout_matches_oracle_mixture():
+    """Training-mode forward (force_drop_ids): every row equals the oracle output for its label OR for the null token,
+    and with cfg_dropout_prob=0.8 most rows are dropped (nnets.py:401-402)."""
+    g, m, cfg, sd = build("dit_base")
+    rng = np.random.default_rng(3)
+    n = 64
+    x = rng.standard_normal((n, 16, 16)).astype(np.float32)
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    lab = rng.integers(0, 14, n).astype(np.int64)
+    ref_lab = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.from_numpy(lab)})
+    ref_null = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.full((n,), 14, dtype=torch.long)})
+    m.train()
+    torch.manual_seed(0)
+    with torch.no_grad():
+        y = m(cu(x), cu(t), {"clusters": cu(lab)}).cpu()
+    m.eval()
+    scale = float(ref_lab.abs().max())
+    e_lab = (y - ref_lab).abs().amax(dim=(1, 2)) / scale
+    e_null = (y - ref_null).abs().amax(dim=(1, 2)) / scale
+    assert bool((torch.minimum(e_lab, e_null) < TOL_FP32).all())
+    dropped = int((e_null < e_lab).sum())
+    assert 35 <= dropped <= 62  # Binomial(64, 0.8)
