@@ -152,6 +152,62 @@ def gen_transport(m, kwargs, seed):
     print("transport loss", terms["loss"].numpy())
 
 
+TRAIN_CASES = {
+    # name: (kwargs, batch, seed) -- gradients of mean(training_losses) w.r.t. every parameter (SURVEY 8a row T1)
+    "train_tiny": (dict(n_embed=64, n_embed_input=16, n_layer=2, n_head=4, seq_len=16, class_vocab_sizes={"a": 5},
+                        condition_strategy="mutually_exclusive"), 3, 301),
+    "train_base2": (dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16,
+                         class_vocab_sizes={"cell_type": 18, "cytokine": 91}, condition_strategy="joint"), 5, 302),
+}
+GRAD_SAMPLE = 64  # strided entries kept per gradient tensor (plus its sum and L2 norm)
+
+
+def grad_digest(g: np.ndarray) -> np.ndarray:
+    """[sum, l2, GRAD_SAMPLE strided entries] -- small enough to commit, sensitive to any misplaced entry."""
+    f = g.reshape(-1).astype(np.float64)
+    stride = max(1, f.size // GRAD_SAMPLE)
+    smp = f[::stride][:GRAD_SAMPLE]
+    smp = np.pad(smp, (0, GRAD_SAMPLE - smp.size))
+    return np.concatenate([[f.sum(), np.sqrt((f * f).sum())], smp]).astype(np.float64)
+
+
+def gen_train(name, kwargs, B, seed):
+    """Transport.training_losses forward + autograd backward through the reference DiT (transport.py:110-150)."""
+    m, shapes = build_dit(kwargs, seed)
+    for p in m.parameters():
+        if p.dtype.is_floating_point:
+            p.grad = None
+    tr = create_transport(path_type="Linear", prediction="velocity", loss_weight="velocity", train_eps=1e-5, sample_eps=1e-5)
+    rng = np.random.default_rng(seed + 3000)
+    S, C = kwargs["seq_len"], kwargs["n_embed_input"]
+    x1 = rng.standard_normal((B, S, C)).astype(np.float32)
+    x0 = rng.standard_normal((B, S, C)).astype(np.float32)
+    t = rng.uniform(0, 1, (B,)).astype(np.float32)
+    labels = {k: rng.integers(0, v, (B,)).astype(np.int64) for k, v in kwargs["class_vocab_sizes"].items()}
+    # one class per cell replaced by its null token, as training-mode label dropout would do (nnets.py:300-334, index == vocab size)
+    k0 = sorted(labels)[0]
+    labels[k0][B // 2] = kwargs["class_vocab_sizes"][k0]
+    tr.sample = lambda x1_: (torch.from_numpy(t), torch.from_numpy(x0), x1_)
+    cond = {k: torch.from_numpy(v) for k, v in labels.items()}
+    terms = tr.training_losses(lambda xt, tt, **kw: m(xt, tt, kw["condition"], force_drop_ids=False),
+                               torch.from_numpy(x1), {"condition": cond})
+    terms["loss"].mean().backward()
+    out = {"kwargs_json": np.array(json.dumps({**kwargs, **COMMON})), "seed": np.array(seed), "x1": x1, "x0": x0, "t": t,
+           "shapes_json": np.array(json.dumps({k: list(v) for k, v in shapes.items()})),
+           "pred": terms["pred"].detach().numpy(), "loss": terms["loss"].detach().numpy()}
+    for k, v in labels.items():
+        out[f"label_{k}"] = v
+    frozen = []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            frozen.append(k)
+            continue
+        out[f"grad_{k}"] = grad_digest(p.grad.numpy())
+    out["frozen_json"] = np.array(json.dumps(frozen))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, "loss", terms["loss"].detach().numpy(), "frozen", frozen, "n grads", sum(k.startswith("grad_") for k in out))
+
+
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
 
 
@@ -195,5 +251,7 @@ if __name__ == "__main__":
     for name, (kw, B, seed) in DIT_CASES.items():
         models[name] = gen_dit(name, kw, B, seed)
     gen_transport(models["dit_tiny"], DIT_CASES["dit_tiny"][0], 101)
+    for name, (kw, B, seed) in TRAIN_CASES.items():
+        gen_train(name, kw, B, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
         gen_vae(name, kw["n_genes"], G, S, B, seed)
