@@ -7,5 +7,5 @@ OUT=${OUT:-scldm_amd/libscldm_hip.so}
 # v_pk_add_f32; with two waves per SIMD that packed code gave run-to-run different results on MI355X (bisected
 # in round 1: identical source, only this flag differs), and packed f32 VALU next to MFMAs is slower anyway.
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -fno-slp-vectorize \
-  ${SCLDM_HIPCC_FLAGS:-} -o "$OUT" scldm_amd/csrc/api.hip scldm_amd/csrc/vae_api.hip
+  ${SCLDM_HIPCC_FLAGS:-} -o "$OUT" scldm_amd/csrc/api.hip scldm_amd/csrc/vae_api.hip scldm_amd/csrc/train_api.hip
 echo "built $OUT"

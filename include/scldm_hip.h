@@ -137,6 +137,46 @@ void scldm_dit_block_timing_enable(scldm_dit* h, int enable);
 int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training path: DiT.forward with saved activations and its backward,
+ * exact-fp32 MFMA GEMMs.  The reference differentiates DiT.forward (nnets.py:273-297) with torch autograd
+ * inside Transport.training_losses (transport/transport.py:110-150); these two calls are the pair a
+ * torch.autograd.Function binds (scldm_amd/nnets.py).  Weights are read LIVE from the caller's parameter
+ * tensors (no packing, nothing to refresh after an optimiser step).  Labels are the ones the model sees:
+ * training-mode label dropout (nnets.py:300-334) is applied by the caller by substituting null tokens.
+ * ------------------------------------------------------------------------------------------------ */
+/* Writable mirror of scldm_dit_weights: every pointer receives d loss / d parameter in the parameter's own
+ * PyTorch layout (overwritten, not accumulated).  pos_embed may be NULL (frozen in the reference, nnets.py:248). */
+typedef struct {
+  float* pos_embed;
+  float* t_w0; float* t_b0;
+  float* t_w2; float* t_b2;
+  float* in_w; float* in_b;
+  float* fin_w; float* fin_b;
+  float* fin_ada_w; float* fin_ada_b;
+  float* const* class_emb;
+  float* const* attn_w; float* const* attn_b;
+  float* const* proj_w; float* const* proj_b;
+  float* const* w1; float* const* w2;
+  float* const* cproj;
+  float* const* ada_w; float* const* ada_b;
+} scldm_dit_grads;
+
+/* Bytes of the activation record written by train_forward and read by train_backward for n samples. */
+size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n);
+/* Scratch bytes for either call (gradient temporaries, split-K partials). */
+size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n);
+
+/* out (n,S,Din) = DiT.forward(x (n,S,Din), t (n), labels) keeping every intermediate the backward needs in `saved`. */
+int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
+                            const int64_t* const* labels, int n, float* out, void* saved, void* ws, void* stream);
+
+/* Given dout = d loss / d out (n,S,Din): all parameter gradients into `grads`, and d loss / d x into dx (n,S,Din)
+ * unless dx is NULL.  x, labels and `saved` must be those of the matching train_forward call. */
+int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* grads, const float* x,
+                             const int64_t* const* labels, const float* dout, int n, float* dx, void* saved, void* ws,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * TransformerVAE encode / decode (MCAB pooling / unpooling + negative-binomial head), fp32.
  * Shape family of the reference (experiments/configs/model/vae_base.yaml:8-19,64-73): n_embed 32, 16 inducing
  * points, trunk heads 8x4, cross heads 4x8, bias=False, shared gene embedding, shared theta, agg_func log1p.

@@ -1,0 +1,29 @@
+// The opaque handle behind `scldm_dit*` (shared by api.hip and train_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/scldm_hip.h"
+
+struct scldm_dit {
+  scldm_dit_config cfg;
+  int n_chunks[2], half[2];   // [FT-1]: full 128-unit SwiGLU chunks and the optional trailing 64-unit chunk (FT=2)
+  int mod_w;
+  bool loaded;
+  void* stream[2][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack)
+  void* wfinal[2];   // [precision] packed final_layer.linear
+  float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)
+  float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
+  float* emb;                      // concatenated class tables
+  int emb_row0[SCLDM_MAX_CLASSES];
+  float *ada_t, *ada_b;            // (256, mod_w), (mod_w)
+  float *in_wt, *in_b, *pos;       // (Din,256), (256), (16,256)
+  float* fin_b;                    // (Din)
+  // timing hook
+  bool timing;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used;
+  int force_ntt, force_ft;
+  unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
+};

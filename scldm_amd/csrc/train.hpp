@@ -1,0 +1,546 @@
+// Training path of the DiT: forward with saved activations and the hand-derived
+// backward, as plain (unfused) gfx950 kernels around one exact-fp32 MFMA GEMM.  First correct version: every
+// intermediate makes an HBM round trip; the fused inference kernel (dit_forward.hpp) is not used here.
+//
+// Reference arithmetic being differentiated: Block.forward adaLN branch (src/scldm/layers.py:208-221), modulate
+// (:91-94), SelfAttention (:143-158), MLP (:161-174), FinalLayerDit (:397-401), TimestepEmbedder (:351-364),
+// DiT.forward (src/scldm/nnets.py:273-297).  The reference gets its gradients from torch autograd.
+#pragma once
+#include "../../include/scldm_hip.h"
+#include "common.hpp"
+
+namespace scldm {
+namespace train {
+
+constexpr int kD = 256;    // n_embed
+constexpr int kS = 16;     // tokens per sample
+constexpr int kNH = 8;     // heads
+constexpr int kHD = 32;    // head dim
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]),  A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk].
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).  Tiles are staged through LDS k-major
+// ([k][m], m contiguous) so the MFMA operand reads (lane = row, two k per instruction) are bank-conflict free
+// whatever the source orientation; *_KC says the source is contiguous along k (sak/sbk == 1), otherwise it is
+// contiguous along m/n (sam/sbn == 1).  Split-K: blockIdx.z covers k range [z*kchunk, (z+1)*kchunk) and writes its
+// partial tile to C + z*M*ldc (the caller reduces deterministically with reduce_partials_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A; long sam, sak;
+  const float* B; long sbn, sbk;
+  float* C; long ldc;
+  const float* bias;
+  int M, N, K;
+  int kchunk;      // multiple of kBK; == K rounded up when there is no split
+  int accumulate;  // C += (only without split-K)
+};
+
+constexpr int kBK = 32;
+template <int WTM, int WTN>
+constexpr int gemm_smem_bytes() { return 2 * kBK * (64 * WTM + 4 + 64 * WTN + 4) * 4; }
+
+template <int BM, bool KC>
+struct TileLoader {
+  static constexpr int kVec = BM / 32;  // float4 loads per thread per tile
+  f32x4 v[kVec];
+  // Loads tile rows [m0, m0+BM) x k [k0, k0+kBK) (zero outside [0,M) x [0,kend)).
+  __device__ __forceinline__ void load(const float* __restrict__ P, long sm, long sk, int m0, int M, int k0, int kend) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (KC) {
+        const int m = m0 + (tid >> 3) + 32 * j, k = k0 + (tid & 7) * 4;
+        if (m < M) {
+          const float* p = P + (long)m * sm + k;
+          if (k + 3 < kend) r = *reinterpret_cast<const f32x4*>(p);
+          else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (k + i < kend) r[i] = p[i];
+          }
+        }
+      } else {
+        constexpr int kPerRow = BM / 4;            // float4 per k row
+        constexpr int kRowsPerPass = 256 / kPerRow;
+        const int m = m0 + (tid % kPerRow) * 4, k = k0 + tid / kPerRow + kRowsPerPass * j;
+        if (k < kend) {
+          const float* p = P + (long)k * sk + m;
+          if (m + 3 < M) r = *reinterpret_cast<const f32x4*>(p);
+          else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (m + i < M) r[i] = p[i];
+          }
+        }
+      }
+      v[j] = r;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S /* [kBK][BM+4] */) const {
+    constexpr int LD = BM + 4;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      if constexpr (KC) {
+        const int m = (tid >> 3) + 32 * j, k = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S[(k + i) * LD + m] = v[j][i];
+      } else {
+        constexpr int kPerRow = BM / 4;
+        constexpr int kRowsPerPass = 256 / kPerRow;
+        const int m = (tid % kPerRow) * 4, k = tid / kPerRow + kRowsPerPass * j;
+        *reinterpret_cast<f32x4*>(S + k * LD + m) = v[j];
+      }
+    }
+  }
+};
+
+template <int WTM, int WTN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
+  constexpr int BM = 64 * WTM, BN = 64 * WTN, LDA = BM + 4, LDB = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float gemm_smem[];   // As[2][kBK*LDA] | Bs[2][kBK*LDB]
+  auto As = [&](int b) { return gemm_smem + b * (kBK * LDA); };
+  auto Bs = [&](int b) { return gemm_smem + 2 * kBK * LDA + b * (kBK * LDB); };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  float* __restrict__ C = g.C + (long)blockIdx.z * g.M * g.ldc;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoader<BM, A_KC> la;
+  TileLoader<BN, B_KC> lb;
+  la.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend);
+  lb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend);
+  la.store(As(0));
+  lb.store(Bs(0));
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+    const bool more = k0 + kBK < kend;
+    if (more) {
+      la.load(g.A, g.sam, g.sak, m0, g.M, k0 + kBK, kend);
+      lb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + kBK, kend);
+    }
+    const float* __restrict__ as = As(buf) + (lane >> 5) * LDA + wm * 32 * WTM + (lane & 31);
+    const float* __restrict__ bs = Bs(buf) + (lane >> 5) * LDB + wn * 32 * WTN + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 2) {
+      float a[WTM], b[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) a[i] = as[kk * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) b[j] = bs[kk * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(As(buf ^ 1));
+      lb.store(Bs(buf ^ 1));
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int n = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * WTM + i * 32 + acc_row(r, lane >> 5);
+        if (m < g.M) {
+          float* p = C + (long)m * g.ldc + n;
+          float v = acc[i][j][r] + bv;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
+// C[m][n] (+)= bias[n] + sum_z P[z][m][n]   (P has leading dimension N, C has ldc)
+__global__ void reduce_partials_kernel(const float* __restrict__ P, int splits, int M, int N, float* __restrict__ C, long ldc,
+                                       const float* __restrict__ bias, int accumulate) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = bias ? bias[n] : 0.f;
+    for (int z = 0; z < splits; ++z) s += P[(long)z * total + i];
+    float* p = C + (long)m * ldc + n;
+    *p = accumulate ? *p + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Elementwise / per-token kernels
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// TimestepEmbedder.timestep_embedding (layers.py:351-361): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(1e4) k / 128)
+__global__ void t_freq_kernel(const float* __restrict__ t, int n, float* __restrict__ out) {
+  const int i = blockIdx.x, k = threadIdx.x & 127;
+  if (i >= n) return;
+  const float f = expf(-9.210340371976184f * (float)k / 128.0f);
+  const float a = t[i] * f;
+  out[(long)i * 256 + threadIdx.x] = threadIdx.x < 128 ? cosf(a) : sinf(a);
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v * sigmoid_f(v);
+  }
+}
+// dx = dy * silu'(x)
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i], s = sigmoid_f(v);
+    dx[i] = dy[i] * s * (1.0f + v * (1.0f - s));
+  }
+}
+
+// c[i] = temb[i] + sum_classes table_c[label_c[i] or null_c]     (nnets.py:283-288,380-456; labels already carry
+// the dropout decisions; labels[c] == NULL selects the null token for every row)
+struct EmbedArgs {
+  const float* table[SCLDM_MAX_CLASSES];
+  const int64_t* labels[SCLDM_MAX_CLASSES];
+  int vocab[SCLDM_MAX_CLASSES];
+  int n_classes;
+};
+__global__ void cond_sum_kernel(const float* __restrict__ temb, EmbedArgs e, int n, float* __restrict__ c) {
+  const int i = blockIdx.x, f = threadIdx.x;
+  if (i >= n) return;
+  float v = temb[(long)i * kD + f];
+  for (int k = 0; k < e.n_classes; ++k) {
+    long row = e.labels[k] ? (long)e.labels[k][i] : (long)e.vocab[k];
+    row = row < 0 ? 0 : (row > e.vocab[k] ? e.vocab[k] : row);
+    v += e.table[k][row * kD + f];
+  }
+  c[(long)i * kD + f] = v;
+}
+// d table_c[row] = sum over samples whose label is `row` of dc  (deterministic: one workgroup per table row)
+__global__ void embed_bwd_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels, int vocab, int n,
+                                 float* __restrict__ dtable) {
+  const int row = blockIdx.x, f = threadIdx.x;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) {
+    long l = labels ? (long)labels[i] : (long)vocab;
+    l = l < 0 ? 0 : (l > vocab ? vocab : l);
+    if (l == row) s += dc[(long)i * kD + f];
+  }
+  dtable[(long)row * kD + f] = s;
+}
+
+// x[t][f] += pos[t % 16][f]
+__global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long tokens) {
+  const long total = tokens * kD;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    x[i] += pos[i % (kS * kD)];
+}
+
+// h = LN(x) * (1 + scale[b]) + shift[b], LayerNorm without affine (nnets.py:257-258), one wave per token.
+// stats[t] = (mean, rstd).  mod row of sample b at mod + b*mod_stride; scale/shift at column offsets.
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mod, long mod_stride,
+                                                         int sc_off, int sh_off, float eps, long tokens, float* __restrict__ h,
+                                                         float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * kD + lane * 4);
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / kD);
+  const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+  const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / kD);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float* m = mod + (t / kS) * mod_stride;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(m + sc_off + lane * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(m + sh_off + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = d[i] * rstd * (1.0f + sc[i]) + sh[i];
+  *reinterpret_cast<f32x4*>(h + t * kD + lane * 4) = o;
+  if (lane == 0) {
+    stats[t * 2] = mean;
+    stats[t * 2 + 1] = rstd;
+  }
+}
+
+// Backward of ln_mod_fwd for one sample per workgroup (4 waves x 4 tokens):
+//   g = dh * (1 + scale);  dx (+)= rstd * (g - mean_f(g) - xhat * mean_f(g * xhat))
+//   dscale[b] = sum_t dh * xhat;  dshift[b] = sum_t dh      (written to dmod row b at the same column offsets)
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                         const float* __restrict__ stats, const float* __restrict__ mod,
+                                                         long mod_stride, int sc_off, int sh_off, float* __restrict__ dx,
+                                                         int accumulate_dx, float* __restrict__ dmod) {
+  __shared__ f32x4 red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long b = blockIdx.x;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + sc_off + lane * 4);
+  f32x4 dsc = {0.f, 0.f, 0.f, 0.f}, dsh = {0.f, 0.f, 0.f, 0.f};
+  for (int tt = 0; tt < 4; ++tt) {
+    const long t = b * kS + wave * 4 + tt;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * kD + lane * 4);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dh + t * kD + lane * 4);
+    const float mean = stats[t * 2], rstd = stats[t * 2 + 1];
+    f32x4 xh, g;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i] = (v[i] - mean) * rstd;
+      g[i] = d[i] * (1.0f + sc[i]);
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+      dsc[i] += d[i] * xh[i];
+      dsh[i] += d[i];
+    }
+    s1 = wave_sum(s1) * (1.0f / kD);
+    s2 = wave_sum(s2) * (1.0f / kD);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = rstd * (g[i] - s1 - xh[i] * s2);
+    float* p = dx + t * kD + lane * 4;
+    if (accumulate_dx) {
+      const f32x4 old = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] += old[i];
+    }
+    *reinterpret_cast<f32x4*>(p) = o;
+  }
+  red[0][wave][lane] = dsc;
+  red[1][wave][lane] = dsh;
+  __syncthreads();
+  if (wave < 2) {
+    f32x4 s = red[wave][0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const f32x4 o = red[wave][w][lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] += o[i];
+    }
+    *reinterpret_cast<f32x4*>(dmod + b * mod_stride + (wave == 0 ? sc_off : sh_off) + lane * 4) = s;
+  }
+}
+
+// x_out = x + gate[b] * y
+__global__ void gate_res_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mod,
+                                long mod_stride, int g_off, long tokens, float* __restrict__ out) {
+  const long total = tokens * (kD / 4);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i / (kD / 4);
+    const int f = (int)(i % (kD / 4)) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (t / kS) * mod_stride + g_off + f);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * kD + f), b = *reinterpret_cast<const f32x4*>(y + t * kD + f);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = a[k] + g[k] * b[k];
+    *reinterpret_cast<f32x4*>(out + t * kD + f) = o;
+  }
+}
+// dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (one workgroup per sample, thread = feature)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y,
+                                                       const float* __restrict__ mod, long mod_stride, int g_off,
+                                                       float* __restrict__ dy, float* __restrict__ dmod) {
+  const long b = blockIdx.x;
+  const int f = threadIdx.x;
+  const float g = mod[b * mod_stride + g_off + f];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < kS; ++t) {
+    const long i = (b * kS + t) * kD + f;
+    const float d = dx[i];
+    dy[i] = g * d;
+    s += d * y[i];
+  }
+  dmod[b * mod_stride + g_off + f] = s;
+}
+
+// hid = silu(a) * b   (MLP.forward, layers.py:172-174)
+__global__ void swiglu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ hid, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float v = a[i];
+    hid[i] = v * sigmoid_f(v) * b[i];
+  }
+}
+__global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const float* __restrict__ a, const float* __restrict__ b,
+                                  float* __restrict__ da, float* __restrict__ db, long count) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+    const float v = a[i], s = sigmoid_f(v), d = dhid[i];
+    da[i] = d * b[i] * s * (1.0f + v * (1.0f - s));
+    db[i] = d * v * s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Self-attention over the 16 tokens of one sample, one wave per (sample, head); qkv rows are [q | k | v] with head
+// h at columns h*32 (layers.py:147-151).  softmax(q k^T / sqrt(32)) v.  Nothing is saved: the backward recomputes P.
+// ---------------------------------------------------------------------------------------------------------------
+struct AttnTile {
+  float q[kS][kHD + 1], k[kS][kHD + 1], v[kS][kHD + 1], p[kS][kS + 1];
+};
+__device__ __forceinline__ void attn_load(AttnTile& s, const float* __restrict__ qkv, long sample, int head, int lane) {
+  // 3 x 16 x 32 floats; lane -> (token = lane / 4 [+16 never], 8 columns)
+  const int tok = lane >> 2, c0 = (lane & 3) * 8;
+  const float* base = qkv + (sample * kS + tok) * (3 * kD) + head * kHD + c0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    s.q[tok][c0 + i] = base[i];
+    s.k[tok][c0 + i] = base[kD + i];
+    s.v[tok][c0 + i] = base[2 * kD + i];
+  }
+}
+// lane -> (i = lane / 4, j in {j0..j0+3}, j0 = (lane & 3) * 4): returns this lane's 4 probabilities of row i
+__device__ __forceinline__ void attn_probs(const AttnTile& s, int lane, float* p4) {
+  const int i = lane >> 2, j0 = (lane & 3) * 4;
+  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  float mx = -INFINITY;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) acc += s.q[i][d] * s.k[j0 + jj][d];
+    p4[jj] = acc * scale;
+    mx = fmaxf(mx, p4[jj]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 1));
+  mx = fmaxf(mx, __shfl_xor(mx, 2));
+  float sum = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    p4[jj] = __expf(p4[jj] - mx);
+    sum += p4[jj];
+  }
+  sum += __shfl_xor(sum, 1);
+  sum += __shfl_xor(sum, 2);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) p4[jj] *= inv;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, float* __restrict__ ao) {
+  __shared__ AttnTile tiles[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long unit = blockIdx.x * 4L + wave;   // (sample, head)
+  if (unit >= n_samples * kNH) return;
+  const long sample = unit / kNH;
+  const int head = (int)(unit % kNH);
+  AttnTile& s = tiles[wave];
+  attn_load(s, qkv, sample, head, lane);
+  __builtin_amdgcn_wave_barrier();
+  float p4[4];
+  attn_probs(s, lane, p4);
+  const int i = lane >> 2, j0 = (lane & 3) * 4;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) s.p[i][j0 + jj] = p4[jj];
+  __builtin_amdgcn_wave_barrier();
+  const int d0 = (lane & 3) * 8;
+  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    const float pj = s.p[i][j];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] += pj * s.v[j][d0 + d];
+  }
+  float* out = ao + (sample * kS + i) * kD + head * kHD + d0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) out[d] = o[d];
+}
+
+// dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP));  dq = scale dS k;  dk = scale dS^T q;  dv = P^T dao
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao, long n_samples,
+                                                       float* __restrict__ dqkv) {
+  __shared__ AttnTile tiles[4];
+  __shared__ float dos[4][kS][kHD + 1];
+  __shared__ float dss[4][kS][kS + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long unit = blockIdx.x * 4L + wave;
+  if (unit >= n_samples * kNH) return;
+  const long sample = unit / kNH;
+  const int head = (int)(unit % kNH);
+  AttnTile& s = tiles[wave];
+  attn_load(s, qkv, sample, head, lane);
+  const int i = lane >> 2, c0 = (lane & 3) * 8, j0 = (lane & 3) * 4;
+  {
+    const float* src = dao + (sample * kS + i) * kD + head * kHD + c0;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dos[wave][i][c0 + d] = src[d];
+  }
+  __builtin_amdgcn_wave_barrier();
+  float p4[4], dp4[4];
+  attn_probs(s, lane, p4);
+  float dot = 0.f;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < kHD; ++d) acc += dos[wave][i][d] * s.v[j0 + jj][d];
+    dp4[jj] = acc;
+    dot += p4[jj] * acc;
+  }
+  dot += __shfl_xor(dot, 1);
+  dot += __shfl_xor(dot, 2);
+  const float scale = 0.17677669529663687f;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    s.p[i][j0 + jj] = p4[jj];
+    dss[wave][i][j0 + jj] = p4[jj] * (dp4[jj] - dot) * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // this lane now owns row `i` (as query row for dq, as key row for dk / dv) and 8 columns starting at c0
+  float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < kS; ++j) {
+    const float ds_ij = dss[wave][i][j], ds_ji = dss[wave][j][i], p_ji = s.p[j][i];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dq[d] += ds_ij * s.k[j][c0 + d];
+      dk[d] += ds_ji * s.q[j][c0 + d];
+      dv[d] += p_ji * dos[wave][j][c0 + d];
+    }
+  }
+  float* dst = dqkv + (sample * kS + i) * (3 * kD) + head * kHD + c0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    dst[d] = dq[d];
+    dst[kD + d] = dk[d];
+    dst[2 * kD + d] = dv[d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Column sums (bias gradients, pos_embed-style reductions): out[c] = sum_r X[r*ld + c], two deterministic stages.
+// Stage 1: grid (ceil(cols/64), splits), 256 threads = 64 columns x 4 row phases.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long rows, int cols, long ld,
+                                                             float* __restrict__ part /* [splits][cols] */) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float s = 0.f;
+  if (c < cols)
+    for (long r = r0 + ph; r < r1; r += 4) s += X[r * ld + c];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < cols) part[(long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int splits, int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += part[(long)z * cols + c];
+  out[c] = s;
+}
+
+}  // namespace train
+}  // namespace scldm

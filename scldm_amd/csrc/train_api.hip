@@ -1,0 +1,365 @@
+// C ABI of the training path (scldm_dit_train_*; see include/scldm_hip.h).  Host-side sequencing of the kernels in
+// train.hpp: forward with saved activations, then the backward in reverse order.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "api_common.hpp"
+#include "dit_handle.hpp"
+#include "train.hpp"
+
+using namespace scldm;
+using namespace scldm::train;
+
+namespace {
+
+// ---- activation record ---------------------------------------------------------------------------------------
+struct LayerSaved {
+  float *x_in, *st1, *h1, *qkv, *ao, *y1, *x_mid, *st2, *h2, *a, *b, *hid, *y2;
+};
+struct Saved {
+  float *freq, *th, *sth, *c, *sc, *mod;
+  std::vector<LayerSaved> layer;
+  float *x_last, *st_f, *h_f;
+  size_t bytes;
+};
+struct Scratch {
+  float *dx, *dh, *dy, *dao, *dqkv, *dhid, *da, *db, *dmod, *dsc, *dc, *dsth, *dth, *part, *temb;
+  size_t part_floats;
+  size_t bytes;
+};
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  float* take(size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += align256(floats * sizeof(float));
+    return p;
+  }
+};
+
+Saved carve_saved(const scldm_dit* h, int n, void* base) {
+  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim;
+  Carver c{reinterpret_cast<char*>(base)};
+  Saved s;
+  s.freq = c.take((size_t)n * 256);
+  s.th = c.take((size_t)n * kD);
+  s.sth = c.take((size_t)n * kD);
+  s.c = c.take((size_t)n * kD);
+  s.sc = c.take((size_t)n * kD);
+  s.mod = c.take((size_t)n * h->mod_w);
+  s.layer.resize(h->cfg.n_layer);
+  for (auto& l : s.layer) {
+    l.x_in = c.take(T * kD);
+    l.st1 = c.take(T * 2);
+    l.h1 = c.take(T * kD);
+    l.qkv = c.take(T * 3 * kD);
+    l.ao = c.take(T * kD);
+    l.y1 = c.take(T * kD);
+    l.x_mid = c.take(T * kD);
+    l.st2 = c.take(T * 2);
+    l.h2 = c.take(T * kD);
+    l.a = c.take(T * H);
+    l.b = c.take(T * H);
+    l.hid = c.take(T * H);
+    l.y2 = c.take(T * kD);
+  }
+  s.x_last = c.take(T * kD);
+  s.st_f = c.take(T * 2);
+  s.h_f = c.take(T * kD);
+  s.bytes = c.off;
+  return s;
+}
+
+constexpr int kMaxSplit = 32;
+Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
+  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim;
+  Carver c{reinterpret_cast<char*>(base)};
+  Scratch s;
+  s.dx = c.take(T * kD);
+  s.dh = c.take(T * kD);
+  s.dy = c.take(T * kD);
+  s.dao = c.take(T * kD);
+  s.dqkv = c.take(T * 3 * kD);
+  s.dhid = c.take(T * H);
+  s.da = c.take(T * H);
+  s.db = c.take(T * H);
+  s.dmod = c.take((size_t)n * h->mod_w);
+  s.dsc = c.take((size_t)n * kD);
+  s.dc = c.take((size_t)n * kD);
+  s.dsth = c.take((size_t)n * kD);
+  s.dth = c.take((size_t)n * kD);
+  s.temb = c.take((size_t)n * kD);
+  // split-K partials of the largest weight gradient (6D x D, or H x D) and column-sum partials
+  s.part_floats = (size_t)kMaxSplit * std::max<size_t>((size_t)6 * kD * kD, std::max<size_t>(H, 3 * kD) * kD);
+  s.part = c.take(s.part_floats);
+  s.bytes = c.off;
+  return s;
+}
+
+// ---- GEMM dispatch --------------------------------------------------------------------------------------------
+template <int WTM, int WTN, bool A_KC, bool B_KC>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int smem = gemm_smem_bytes<WTM, WTN>();
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)sgemm_kernel<WTM, WTN, A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid(cdiv(g.N, 64 * WTN), cdiv(g.M, 64 * WTM), splits);
+  hipLaunchKernelGGL((sgemm_kernel<WTM, WTN, A_KC, B_KC>), grid, dim3(256), smem, st, g);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+// C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); element strides as in train.hpp.  `part` = split-K scratch.
+int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
+         int N, int K, const float* bias, bool accumulate, float* part, size_t part_floats) {
+  if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
+  const bool a_kc = sak == 1, b_kc = sbk == 1;
+  if ((!a_kc && sam != 1) || (!b_kc && sbn != 1)) return fail(SCLDM_ERR_SHAPE, "gemm: operand needs a unit stride");
+  const bool big = (long)cdiv(M, 128) * cdiv(N, 128) >= 192;
+  const long tiles = big ? (long)cdiv(M, 128) * cdiv(N, 128) : (long)cdiv(M, 64) * cdiv(N, 64);
+  int splits = 1;
+  if (tiles < 256 && K >= 512) {
+    splits = (int)std::min<long>(std::min<long>(cdiv(512, tiles), K / 256), kMaxSplit);
+    while (splits > 1 && (size_t)splits * M * N > part_floats) --splits;
+  }
+  int kchunk = cdiv(cdiv(K, splits), kBK) * kBK;
+  splits = cdiv(K, kchunk);
+  GemmArgs g{A, sam, sak, B, sbn, sbk, C, ldc, bias, M, N, K, kchunk, accumulate ? 1 : 0};
+  if (splits > 1) {
+    g.C = part;
+    g.ldc = N;
+    g.bias = nullptr;
+    g.accumulate = 0;
+  }
+  int rc;
+#define SCLDM_GEMM_CASE(WT)                                                         \
+  (a_kc ? (b_kc ? launch_gemm<WT, WT, true, true>(g, splits, st) : launch_gemm<WT, WT, true, false>(g, splits, st)) \
+        : (b_kc ? launch_gemm<WT, WT, false, true>(g, splits, st) : launch_gemm<WT, WT, false, false>(g, splits, st)))
+  rc = big ? SCLDM_GEMM_CASE(2) : SCLDM_GEMM_CASE(1);
+#undef SCLDM_GEMM_CASE
+  if (rc != SCLDM_OK) return rc;
+  if (splits > 1) {
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, part,
+                       splits, M, N, C, ldc, bias, accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  return SCLDM_OK;
+}
+
+// y[rows, out] = x[rows, in] W[out, in]^T + b   (nn.Linear forward)
+int linear_fwd(hipStream_t st, const float* x, long ldx, const float* W, int rows, int out, int in, const float* b, float* y,
+               long ldy, Scratch& s) {
+  return gemm(st, x, ldx, 1, W, in, 1, y, ldy, rows, out, in, b, false, s.part, s.part_floats);
+}
+// dx[rows, in] (+)= dy[rows, out] W[out, in]
+int linear_dgrad(hipStream_t st, const float* dy, long lddy, const float* W, int rows, int out, int in, float* dx, long lddx,
+                 bool accumulate, Scratch& s) {
+  return gemm(st, dy, lddy, 1, W, 1, in, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats);
+}
+// dW[out, in] = dy[rows, out]^T x[rows, in]
+int linear_wgrad(hipStream_t st, const float* dy, long lddy, const float* x, long ldx, int rows, int out, int in, float* dW,
+                 Scratch& s) {
+  return gemm(st, dy, 1, lddy, x, 1, ldx, dW, in, out, in, rows, nullptr, false, s.part, s.part_floats);
+}
+// out[cols] = sum_r X[r, c]
+int colsum(hipStream_t st, const float* X, long rows, int cols, long ld, float* out, Scratch& s) {
+  int splits = (int)std::max<long>(1, std::min<long>(64, rows / 64));
+  while ((size_t)splits * cols > s.part_floats) --splits;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 64), splits), dim3(256), 0, st, X, rows, cols, ld, s.part);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, s.part, splits, cols, out);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+inline unsigned ew_grid(long count) { return (unsigned)std::max<long>(1, std::min<long>(cdiv(count, 256), 4096)); }
+
+int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, const void* saved, const void* ws) {
+  if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (n < 1) return fail(SCLDM_ERR_SHAPE, "n must be >= 1");
+  if (h->cfg.n_embed_input % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs n_embed_input %% 4 == 0 (got %d)", h->cfg.n_embed_input);
+  if (h->cfg.hidden_dim % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs hidden_dim %% 4 == 0 (got %d)", h->cfg.hidden_dim);
+  return SCLDM_OK;
+}
+
+#define TRY(expr)                   \
+  do {                              \
+    int rc_ = (expr);               \
+    if (rc_ != SCLDM_OK) return rc_; \
+  } while (0)
+
+}  // namespace
+
+extern "C" size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n) {
+  if (!h || n < 1) return 0;
+  return carve_saved(h, n, nullptr).bytes;
+}
+extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
+  if (!h || n < 1) return 0;
+  return carve_scratch(h, n, nullptr).bytes;
+}
+
+extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
+                                       const int64_t* const* labels, int n, float* out, void* saved_, void* ws, void* stream_) {
+  TRY(check_common(h, w, n, saved_, ws));
+  if (!x || !t || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_dit_config& cfg = h->cfg;
+  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, mw = h->mod_w;
+  const long T = (long)n * kS;
+  Saved s = carve_saved(h, n, saved_);
+  Scratch k = carve_scratch(h, n, ws);
+
+  // conditioning: c = t_embedder(t) + sum class embeddings; every adaLN vector (layers.py:351-364,206-216,395-398)
+  hipLaunchKernelGGL(t_freq_kernel, dim3(n), dim3(256), 0, st, t, n, s.freq);
+  LAUNCH_CHECK();
+  TRY(linear_fwd(st, s.freq, 256, w->t_w0, n, kD, 256, w->t_b0, s.th, kD, k));
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.th, s.sth, (long)n * kD);
+  LAUNCH_CHECK();
+  TRY(linear_fwd(st, s.sth, kD, w->t_w2, n, kD, kD, w->t_b2, k.temb, kD, k));
+  EmbedArgs e{};
+  e.n_classes = cfg.n_classes;
+  for (int c = 0; c < cfg.n_classes; ++c) {
+    e.table[c] = w->class_emb[c];
+    e.labels[c] = labels ? labels[c] : nullptr;
+    e.vocab[c] = cfg.class_vocab[c];
+  }
+  hipLaunchKernelGGL(cond_sum_kernel, dim3(n), dim3(kD), 0, st, k.temb, e, n, s.c);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
+  LAUNCH_CHECK();
+  for (int l = 0; l < L; ++l)
+    TRY(linear_fwd(st, s.sc, kD, w->ada_w[l], n, 6 * kD, kD, w->ada_b[l], s.mod + (long)l * 6 * kD, mw, k));
+  TRY(linear_fwd(st, s.sc, kD, w->fin_ada_w, n, 2 * kD, kD, w->fin_ada_b, s.mod + (long)L * 6 * kD, mw, k));
+
+  // x_0 = input_proj(x) + pos_embed (nnets.py:290)
+  float* x0 = L > 0 ? s.layer[0].x_in : s.x_last;
+  TRY(linear_fwd(st, x, din, w->in_w, (int)T, kD, din, w->in_b, x0, kD, k));
+  hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T);
+  LAUNCH_CHECK();
+
+  for (int l = 0; l < L; ++l) {
+    LayerSaved& a = s.layer[l];
+    const int o = l * 6 * kD;   // a0..a5 at o + i*256 (layers.py:214-216)
+    float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
+    hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T,
+                       a.h1, a.st1);
+    LAUNCH_CHECK();
+    TRY(linear_fwd(st, a.h1, kD, w->attn_w[l], (int)T, 3 * kD, kD, w->attn_b[l], a.qkv, 3 * kD, k));
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv((long)n * kNH, 4)), dim3(256), 0, st, a.qkv, (long)n, a.ao);
+    LAUNCH_CHECK();
+    TRY(linear_fwd(st, a.ao, kD, w->proj_w[l], (int)T, kD, kD, w->proj_b[l], a.y1, kD, k));
+    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, a.x_mid);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD,
+                       cfg.layernorm_eps, T, a.h2, a.st2);
+    LAUNCH_CHECK();
+    TRY(linear_fwd(st, a.h2, kD, w->w1[l], (int)T, H, kD, nullptr, a.a, H, k));
+    TRY(linear_fwd(st, a.h2, kD, w->w2[l], (int)T, H, kD, nullptr, a.b, H, k));
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H);
+    LAUNCH_CHECK();
+    TRY(linear_fwd(st, a.hid, H, w->cproj[l], (int)T, kD, H, nullptr, a.y2, kD, k));
+    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, x_next);
+    LAUNCH_CHECK();
+  }
+  // FinalLayerDit (layers.py:397-401): [shift | scale] = adaLN(c); LN(x) * (1 + scale) + shift; Linear
+  const int of = L * 6 * kD;
+  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T,
+                     s.h_f, s.st_f);
+  LAUNCH_CHECK();
+  TRY(linear_fwd(st, s.h_f, kD, w->fin_w, (int)T, din, kD, w->fin_b, out, din, k));
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* g, const float* x,
+                                        const int64_t* const* labels, const float* dout, int n, float* dx_out, void* saved_,
+                                        void* ws, void* stream_) {
+  TRY(check_common(h, w, n, saved_, ws));
+  if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");
+  hipStream_t st = (hipStream_t)stream_;
+  const scldm_dit_config& cfg = h->cfg;
+  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, mw = h->mod_w;
+  const long T = (long)n * kS;
+  Saved s = carve_saved(h, n, saved_);
+  Scratch k = carve_scratch(h, n, ws);
+
+  // ---- final layer ----
+  const int of = L * 6 * kD;
+  TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k));
+  TRY(colsum(st, dout, T, din, din, g->fin_b, k));
+  TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod);
+  LAUNCH_CHECK();
+
+  for (int l = L - 1; l >= 0; --l) {
+    LayerSaved& a = s.layer[l];
+    const int o = l * 6 * kD;
+    // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n), dim3(256), 0, st, k.dx, a.y2, s.mod, (long)mw, o + 5 * kD, k.dy, k.dmod);
+    LAUNCH_CHECK();
+    TRY(linear_wgrad(st, k.dy, kD, a.hid, H, (int)T, kD, H, g->cproj[l], k));
+    TRY(linear_dgrad(st, k.dy, kD, w->cproj[l], (int)T, kD, H, k.dhid, H, false, k));
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, k.da, k.db, T * H);
+    LAUNCH_CHECK();
+    TRY(linear_wgrad(st, k.da, H, a.h2, kD, (int)T, H, kD, g->w1[l], k));
+    TRY(linear_wgrad(st, k.db, H, a.h2, kD, (int)T, H, kD, g->w2[l], k));
+    TRY(linear_dgrad(st, k.da, H, w->w1[l], (int)T, H, kD, k.dh, kD, false, k));
+    TRY(linear_dgrad(st, k.db, H, w->w2[l], (int)T, H, kD, k.dh, kD, true, k));
+    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1,
+                       k.dmod);
+    LAUNCH_CHECK();
+    // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n), dim3(256), 0, st, k.dx, a.y1, s.mod, (long)mw, o + 2 * kD, k.dy, k.dmod);
+    LAUNCH_CHECK();
+    TRY(linear_wgrad(st, k.dy, kD, a.ao, kD, (int)T, kD, kD, g->proj_w[l], k));
+    TRY(colsum(st, k.dy, T, kD, kD, g->proj_b[l], k));
+    TRY(linear_dgrad(st, k.dy, kD, w->proj_w[l], (int)T, kD, kD, k.dao, kD, false, k));
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv((long)n * kNH, 4)), dim3(256), 0, st, a.qkv, k.dao, (long)n, k.dqkv);
+    LAUNCH_CHECK();
+    TRY(linear_wgrad(st, k.dqkv, 3 * kD, a.h1, kD, (int)T, 3 * kD, kD, g->attn_w[l], k));
+    TRY(colsum(st, k.dqkv, T, 3 * kD, 3 * kD, g->attn_b[l], k));
+    TRY(linear_dgrad(st, k.dqkv, 3 * kD, w->attn_w[l], (int)T, 3 * kD, kD, k.dh, kD, false, k));
+    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod);
+    LAUNCH_CHECK();
+  }
+
+  // ---- input projection + pos_embed ----
+  TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k));
+  TRY(colsum(st, k.dx, T, kD, kD, g->in_b, k));
+  if (g->pos_embed) TRY(colsum(st, k.dx, n, kS * kD, (long)kS * kD, g->pos_embed, k));
+  if (dx_out) TRY(linear_dgrad(st, k.dx, kD, w->in_w, (int)T, kD, din, dx_out, din, false, k));
+
+  // ---- adaLN Linears: mod_l = SiLU(c) W_l^T + b_l ----
+  for (int l = 0; l <= L; ++l) {
+    const int width = l < L ? 6 * kD : 2 * kD;
+    const float* dm = k.dmod + (long)l * 6 * kD;
+    float* gw = l < L ? g->ada_w[l] : g->fin_ada_w;
+    float* gb = l < L ? g->ada_b[l] : g->fin_ada_b;
+    const float* wl = l < L ? w->ada_w[l] : w->fin_ada_w;
+    TRY(linear_wgrad(st, dm, mw, s.sc, kD, n, width, kD, gw, k));
+    TRY(colsum(st, dm, n, width, mw, gb, k));
+    TRY(linear_dgrad(st, dm, mw, wl, n, width, kD, k.dsc, kD, l > 0, k));
+  }
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsc, s.c, k.dc, (long)n * kD);
+  LAUNCH_CHECK();
+
+  // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
+  for (int c = 0; c < cfg.n_classes; ++c) {
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cfg.class_vocab[c] + 1), dim3(kD), 0, st, k.dc, labels ? labels[c] : nullptr,
+                       cfg.class_vocab[c], n, g->class_emb[c]);
+    LAUNCH_CHECK();
+  }
+  TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k));
+  TRY(colsum(st, k.dc, n, kD, kD, g->t_b2, k));
+  TRY(linear_dgrad(st, k.dc, kD, w->t_w2, n, kD, kD, k.dsth, kD, false, k));
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
+  LAUNCH_CHECK();
+  TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k));
+  TRY(colsum(st, k.dth, n, kD, kD, g->t_b0, k));
+  return SCLDM_OK;
+}

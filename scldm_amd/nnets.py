@@ -83,6 +83,65 @@ class Decoder(nn.Module):
         raise RuntimeError("Decoder is fused into scldm_amd.vae.TransformerVAE.decode; call TransformerVAE.decode")
 
 
+class _DiTTrainFn(torch.autograd.Function):
+    """DiT.forward with a HIP backward: scldm_dit_train_forward / scldm_dit_train_backward (include/scldm_hip.h).
+    Replaces torch autograd over scldm.nnets.DiT.forward (nnets.py:273-297) inside Transport.training_losses."""
+
+    @staticmethod
+    def forward(ctx, module, x, t, labels, label_keep, *params):
+        L, h = module._native_handle()
+        module._check_params()
+        n = x.shape[0]
+        dev = x.device
+        x = x.detach().contiguous()
+        saved = torch.empty(L.scldm_dit_train_saved_bytes(h, n), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.scldm_dit_train_workspace_bytes(h, n), dtype=torch.uint8, device=dev)
+        w, keep = module._param_struct(lambda p: p.data_ptr())
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
+                                                 out.data_ptr(), saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
+                       "scldm_dit_train_forward")
+        del keep
+        ctx.module, ctx.saved, ctx.ws, ctx.x, ctx.n = module, saved, ws, x, n
+        ctx.labels, ctx.label_keep = labels, label_keep
+        ctx.param_versions = [p._version for p in params]
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        module, n = ctx.module, ctx.n
+        L, h = module._native_handle()
+        params = [p for _, p in module.named_parameters()]
+        if [p._version for p in params] != ctx.param_versions:
+            raise RuntimeError("DiT parameters were modified between forward and backward (the HIP backward reads them live)")
+        dout = dout.contiguous().float()
+        grads = {id(p): torch.empty_like(p) for p in params if p is not module.pos_embed}
+        w, keep_w = module._param_struct(lambda p: p.data_ptr())
+        need_pos = ctx.needs_input_grad[5 + [id(p) for p in params].index(id(module.pos_embed))]
+        gpos = torch.empty_like(module.pos_embed) if need_pos else None
+        g, keep_g = module._param_struct(lambda p: (gpos.data_ptr() if gpos is not None else None) if p is module.pos_embed
+                                         else grads[id(p)].data_ptr())
+        dx = torch.empty_like(ctx.x) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dout.device):
+            _lib.check(L.scldm_dit_train_backward(h, C.byref(w), C.byref(g), ctx.x.data_ptr(), C.cast(ctx.labels, _lib.c_void_pp),
+                                                  dout.data_ptr(), n, dx.data_ptr() if dx is not None else None,
+                                                  ctx.saved.data_ptr(), ctx.ws.data_ptr(), _stream_ptr()),
+                       "scldm_dit_train_backward")
+        del keep_w, keep_g
+        ctx.saved = ctx.ws = None
+        out = []
+        for i, p in enumerate(params):
+            if not ctx.needs_input_grad[5 + i]:
+                out.append(None)
+            elif p is module.pos_embed:
+                out.append(gpos)
+            else:
+                out.append(grads[id(p)])
+        return (None, dx, None, None, None, *out)
+
+
 class DiT(nn.Module):
     """Diffusion Transformer (adaLN-Zero) - drop-in for scldm.nnets.DiT.
 
@@ -160,7 +219,8 @@ class DiT(nn.Module):
     def _class_names(self) -> list[str]:
         return sorted(self.class_vocab_sizes.keys())
 
-    def _native(self):
+    def _native_handle(self):
+        """The C handle without touching the packed inference weights (the training path reads parameters live)."""
         L = _lib.lib()
         dev = self.pos_embed.device
         if dev.type != "cuda":
@@ -178,17 +238,19 @@ class DiT(nn.Module):
             with torch.cuda.device(dev):
                 _lib.check(L.scldm_dit_create(C.byref(cfg), C.byref(h)), "scldm_dit_create")
             self._handle = h
+        return L, self._handle
+
+    def _native(self):
+        L, _ = self._native_handle()
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if key != self._weights_key:
             self._load_weights(L)
             self._weights_key = key
         return L, self._handle
 
-    def _load_weights(self, L):
-        for p in self.parameters():
-            if p.dtype != torch.float32 or not p.is_contiguous():
-                raise RuntimeError("DiT parameters must be contiguous fp32 (master weights); bf16 copies are derived internally")
-        dp = lambda t: t.data_ptr()
+    def _param_struct(self, dp):
+        """scldm_dit_weights / scldm_dit_grads (same field order) filled with dp(parameter) -> device pointer or None.
+        Returns (struct, keepalive)."""
         blocks = list(self.blocks)
         keep = [
             _lib.ptr_array([dp(self.class_embeddings[n].weight) for n in self._class_names]),
@@ -207,8 +269,19 @@ class DiT(nn.Module):
             fin_ada_w=dp(self.final_layer.adaln_modulation[1].weight), fin_ada_b=dp(self.final_layer.adaln_modulation[1].bias),
             class_emb=cast(keep[0]), attn_w=cast(keep[1]), attn_b=cast(keep[2]), proj_w=cast(keep[3]), proj_b=cast(keep[4]),
             w1=cast(keep[5]), w2=cast(keep[6]), cproj=cast(keep[7]), ada_w=cast(keep[8]), ada_b=cast(keep[9]))
+        return w, keep
+
+    def _check_params(self):
+        for p in self.parameters():
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("DiT parameters must be contiguous fp32 (master weights); bf16 copies are derived internally")
+
+    def _load_weights(self, L):
+        self._check_params()
+        w, keep = self._param_struct(lambda t: t.data_ptr())
         with torch.cuda.device(self.pos_embed.device):
             _lib.check(L.scldm_dit_load_weights(self._handle, C.byref(w), _stream_ptr()), "scldm_dit_load_weights")
+        del keep
 
     def _workspace(self, L, n_fwd: int, n_rows: int, n_state: int) -> int:
         need = L.scldm_dit_workspace_bytes(self._handle, n_fwd, n_rows, n_state)
@@ -276,16 +349,17 @@ class DiT(nn.Module):
             force_drop_ids = self.training
         if not self.training:
             assert not force_drop_ids, "force_drop_ids must be False when not training"
-        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
-            raise NotImplementedError("the fused HIP forward has no backward pass yet (SURVEY.md section 8 row T1 / config 5 is a later "
-                                      "round): call it under torch.no_grad() - training-mode label dropout itself is supported")
-        L, h = self._native()
         x = _require_cuda_f32("x", x)
         t = _require_cuda_f32("t", t)
         n = x.shape[0]
         if x.shape[1:] != (self.seq_len, self.n_embed_input) or t.shape != (n,):
             raise ValueError(f"expected x (B,{self.seq_len},{self.n_embed_input}) and t (B,), got {tuple(x.shape)}, {tuple(t.shape)}")
         labels, keep = self._label_ptrs(condition, n, force_drop_ids)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # differentiable path (Transport.training_losses -> loss.backward()): forward with saved activations + HIP backward
+            params = [p for _, p in self.named_parameters()]
+            return _DiTTrainFn.apply(self, x, t, labels, keep, *params)
+        L, h = self._native()
         out = torch.empty_like(x)
         ws = self._workspace(L, n, n, 0)
         with torch.cuda.device(x.device):
