@@ -138,7 +138,9 @@ int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* total_ms);
 
 /* ------------------------------------------------------------------------------------------------
  * Training path: DiT.forward with saved activations and its backward,
- * exact-fp32 MFMA GEMMs.  The reference differentiates DiT.forward (nnets.py:273-297) with torch autograd
+ * GEMMs on MFMA with fp32 (exact, parity) or bf16 operands (SCLDM_PREC_*; fp32 accumulation, fp32 activations,
+ * LayerNorm / softmax / SiLU / residual in fp32 either way, as bf16-mixed autocast would keep them; the reference's
+ * trainer default is `precision: 32`, experiments/configs/training/default.yaml:6).  The reference differentiates DiT.forward (nnets.py:273-297) with torch autograd
  * inside Transport.training_losses (transport/transport.py:110-150); these two calls are the pair a
  * torch.autograd.Function binds (scldm_amd/nnets.py).  Weights are read LIVE from the caller's parameter
  * tensors (no packing, nothing to refresh after an optimiser step).  Labels are the ones the model sees:
@@ -168,13 +170,14 @@ size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n);
 
 /* out (n,S,Din) = DiT.forward(x (n,S,Din), t (n), labels) keeping every intermediate the backward needs in `saved`. */
 int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
-                            const int64_t* const* labels, int n, float* out, void* saved, void* ws, void* stream);
+                            const int64_t* const* labels, int n, float* out, int precision, void* saved, void* ws,
+                            void* stream);
 
 /* Given dout = d loss / d out (n,S,Din): all parameter gradients into `grads`, and d loss / d x into dx (n,S,Din)
  * unless dx is NULL.  x, labels and `saved` must be those of the matching train_forward call. */
 int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* grads, const float* x,
-                             const int64_t* const* labels, const float* dout, int n, float* dx, void* saved, void* ws,
-                             void* stream);
+                             const int64_t* const* labels, const float* dout, int n, float* dx, int precision, void* saved,
+                             void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * TransformerVAE encode / decode (MCAB pooling / unpooling + negative-binomial head), fp32.

@@ -97,9 +97,9 @@ def lib() -> C.CDLL:
     L.scldm_dit_train_workspace_bytes.restype = C.c_size_t
     # scldm_dit_grads has the field order of scldm_dit_weights, so DitWeights serves for both
     L.scldm_dit_train_forward.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p, C.c_void_p, c_void_pp, C.c_int, C.c_void_p,
-                                          C.c_void_p, C.c_void_p, C.c_void_p]
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scldm_dit_train_backward.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.POINTER(DitWeights), C.c_void_p, c_void_pp,
-                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+                                           C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scldm_vae_create.argtypes = [C.POINTER(VaeConfig), C.POINTER(C.c_void_p)]
     L.scldm_vae_destroy.argtypes = [C.c_void_p]
     L.scldm_vae_destroy.restype = None

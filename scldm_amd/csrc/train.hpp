@@ -170,6 +170,152 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16-operand variant (v_mfma_f32_32x32x16_bf16, fp32 accumulate): same contract and fp32 sources / outputs as
+// sgemm_kernel; operands are rounded to bf16 while they are staged into LDS.  LDS image is [m][k] with k contiguous
+// (row = kBK bf16 + 16 B pad = 80 B: the 32 rows of a ds_read_b128 fragment read hit 16 distinct 16-byte slots).
+// A source that is contiguous along m (the token-major activations of a weight-gradient GEMM) is transposed in
+// registers: each thread gathers 8 consecutive k for its m and writes one 16-byte row segment.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLDH = kBK + 8;   // bf16 elements per LDS row
+template <int WTM, int WTN>
+constexpr int hgemm_smem_bytes() { return 2 * (64 * WTM + 64 * WTN) * kLDH * 2; }
+
+template <int BM, bool KC>
+struct TileLoaderBF {
+  static constexpr int kFPT = BM / 64;   // KC: (row, 8-k group) items per thread; MC: rows (features) per thread, one 8-k group
+  float f[kFPT][8];                      // raw fp32 (converted in store(), so the loads stay in flight during the MFMAs)
+  __device__ __forceinline__ void load(const float* __restrict__ P, long sm, long sk, int m0, int M, int k0, int kend) {
+    const int tid = threadIdx.x;
+    const bool inside = m0 + BM <= M && k0 + kBK <= kend;   // workgroup-uniform: interior tiles skip every bounds test
+    if constexpr (KC) {
+#pragma unroll
+      for (int j = 0; j < kFPT; ++j) {
+        const int item = tid + 256 * j, m = m0 + (item >> 2), k = k0 + (item & 3) * 8;
+        const float* p = P + (long)m * sm + k;
+        if (inside || (m < M && k + 7 < kend)) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f[j][i] = lo[i]; f[j][4 + i] = hi[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[j][i] = (m < M && k + i < kend) ? p[i] : 0.f;
+        }
+      }
+    } else {
+      const int m = m0 + (tid & 63) * kFPT, k = k0 + (tid >> 6) * 8;
+      const float* p = P + (long)k * sk + m;
+      if (inside) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if constexpr (kFPT == 2) {
+            const auto v2 = *reinterpret_cast<const __attribute__((ext_vector_type(2))) float*>(p + (long)i * sk);
+            f[0][i] = v2[0];
+            f[1][i] = v2[1];
+          } else {
+            f[0][i] = p[(long)i * sk];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int e = 0; e < kFPT; ++e) f[e][i] = (k + i < kend && m + e < M) ? p[(long)i * sk + e] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S /* [BM][kLDH] */) const {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kFPT; ++j) {
+      bf16x8 v;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[j][i];
+      if constexpr (KC) {
+        const int item = tid + 256 * j;
+        *reinterpret_cast<bf16x8*>(S + (item >> 2) * kLDH + (item & 3) * 8) = v;
+      } else {
+        *reinterpret_cast<bf16x8*>(S + ((tid & 63) * kFPT + j) * kLDH + (tid >> 6) * 8) = v;
+      }
+    }
+  }
+};
+
+template <int WTM, int WTN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void hgemm_kernel(GemmArgs g) {
+  constexpr int BM = 64 * WTM, BN = 64 * WTN;
+  extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+  __bf16* const smem = reinterpret_cast<__bf16*>(gemm_smem);
+  auto As = [&](int b) { return smem + b * (BM * kLDH); };
+  auto Bs = [&](int b) { return smem + 2 * BM * kLDH + b * (BN * kLDH); };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  float* __restrict__ C = g.C + (long)blockIdx.z * g.M * g.ldc;
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TileLoaderBF<BM, A_KC> la;
+  TileLoaderBF<BN, B_KC> lb;
+  la.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend);
+  lb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend);
+  la.store(As(0));
+  lb.store(Bs(0));
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+    const bool more = k0 + kBK < kend;
+    if (more) {
+      la.load(g.A, g.sam, g.sak, m0, g.M, k0 + kBK, kend);
+      lb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + kBK, kend);
+    }
+    const __bf16* __restrict__ as = As(buf) + (wm * 32 * WTM + (lane & 31)) * kLDH + (lane >> 5) * 8;
+    const __bf16* __restrict__ bs = Bs(buf) + (wn * 32 * WTN + (lane & 31)) * kLDH + (lane >> 5) * 8;
+#pragma unroll
+    for (int kk = 0; kk < kBK; kk += 16) {
+      bf16x8 a[WTM], b[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kLDH + kk);
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * kLDH + kk);
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(As(buf ^ 1));
+      lb.store(Bs(buf ^ 1));
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int n = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 * WTM + i * 32 + acc_row(r, lane >> 5);
+        if (m < g.M) {
+          float* p = C + (long)m * g.ldc + n;
+          float v = acc[i][j][r] + bv;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 // C[m][n] (+)= bias[n] + sum_z P[z][m][n]   (P has leading dimension N, C has ldc)
 __global__ void reduce_partials_kernel(const float* __restrict__ P, int splits, int M, int N, float* __restrict__ C, long ldc,
                                        const float* __restrict__ bias, int accumulate) {
@@ -230,15 +376,37 @@ __global__ void cond_sum_kernel(const float* __restrict__ temb, EmbedArgs e, int
   }
   c[(long)i * kD + f] = v;
 }
-// d table_c[row] = sum over samples whose label is `row` of dc  (deterministic: one workgroup per table row)
-__global__ void embed_bwd_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels, int vocab, int n,
-                                 float* __restrict__ dtable) {
-  const int row = blockIdx.x, f = threadIdx.x;
+// d table_c[row] = sum over samples whose label is `row` of dc  (deterministic: one workgroup per table row; the
+// 256 threads test 256 labels at a time and exchange wave ballots through LDS, then walk the few matches in order)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels, int vocab,
+                                                        int n, float* __restrict__ dtable) {
+  __shared__ unsigned long long hit[4];
+  const int row = blockIdx.x, f = threadIdx.x, wave = threadIdx.x >> 6;
   float s = 0.f;
-  for (int i = 0; i < n; ++i) {
-    long l = labels ? (long)labels[i] : (long)vocab;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + f;
+    long l = vocab;
+    if (i < n && labels) l = (long)labels[i];
     l = l < 0 ? 0 : (l > vocab ? vocab : l);
-    if (l == row) s += dc[(long)i * kD + f];
+    const unsigned long long m = __ballot(i < n && l == row);
+    if ((f & 63) == 0) hit[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long mm = hit[w];
+      while (mm) {   // up to 8 matches per trip: the loads are independent, the adds keep sample order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
+          mm &= mm - 1;
+          v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * kD + f] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+      }
+    }
+    __syncthreads();
   }
   dtable[(long)row * kD + f] = s;
 }

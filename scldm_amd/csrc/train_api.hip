@@ -99,31 +99,35 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
 }
 
 // ---- GEMM dispatch --------------------------------------------------------------------------------------------
-template <int WTM, int WTN, bool A_KC, bool B_KC>
+template <bool BF, int WTM, int WTN, bool A_KC, bool B_KC>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
   static bool attr_set = false;
-  constexpr int smem = gemm_smem_bytes<WTM, WTN>();
+  constexpr int smem = BF ? hgemm_smem_bytes<WTM, WTN>() : gemm_smem_bytes<WTM, WTN>();
+  auto kern = BF ? hgemm_kernel<WTM, WTN, A_KC, B_KC> : sgemm_kernel<WTM, WTN, A_KC, B_KC>;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)sgemm_kernel<WTM, WTN, A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   dim3 grid(cdiv(g.N, 64 * WTN), cdiv(g.M, 64 * WTM), splits);
-  hipLaunchKernelGGL((sgemm_kernel<WTM, WTN, A_KC, B_KC>), grid, dim3(256), smem, st, g);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
 
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); element strides as in train.hpp.  `part` = split-K scratch.
+thread_local bool g_bf16 = false;   // operand precision of the GEMMs of the call in progress (SCLDM_PREC_*)
+
 int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
          int N, int K, const float* bias, bool accumulate, float* part, size_t part_floats) {
   if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
   const bool a_kc = sak == 1, b_kc = sbk == 1;
   if ((!a_kc && sam != 1) || (!b_kc && sbn != 1)) return fail(SCLDM_ERR_SHAPE, "gemm: operand needs a unit stride");
-  const bool big = (long)cdiv(M, 128) * cdiv(N, 128) >= 192;
+  // 128x128 tiles whenever both extents fill them (arithmetic intensity); split-K restores the workgroup count
+  const bool big = M >= 128 && N >= 128;
   const long tiles = big ? (long)cdiv(M, 128) * cdiv(N, 128) : (long)cdiv(M, 64) * cdiv(N, 64);
   int splits = 1;
-  if (tiles < 256 && K >= 512) {
-    splits = (int)std::min<long>(std::min<long>(cdiv(512, tiles), K / 256), kMaxSplit);
+  if (tiles < 384 && K >= 512) {
+    splits = (int)std::min<long>(std::min<long>(cdiv(768, tiles), K / 256), kMaxSplit);
     while (splits > 1 && (size_t)splits * M * N > part_floats) --splits;
   }
   int kchunk = cdiv(cdiv(K, splits), kBK) * kBK;
@@ -136,10 +140,11 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
     g.accumulate = 0;
   }
   int rc;
-#define SCLDM_GEMM_CASE(WT)                                                         \
-  (a_kc ? (b_kc ? launch_gemm<WT, WT, true, true>(g, splits, st) : launch_gemm<WT, WT, true, false>(g, splits, st)) \
-        : (b_kc ? launch_gemm<WT, WT, false, true>(g, splits, st) : launch_gemm<WT, WT, false, false>(g, splits, st)))
-  rc = big ? SCLDM_GEMM_CASE(2) : SCLDM_GEMM_CASE(1);
+#define SCLDM_GEMM_CASE(BF, WT)                                                                                             \
+  (a_kc ? (b_kc ? launch_gemm<BF, WT, WT, true, true>(g, splits, st) : launch_gemm<BF, WT, WT, true, false>(g, splits, st)) \
+        : (b_kc ? launch_gemm<BF, WT, WT, false, true>(g, splits, st) : launch_gemm<BF, WT, WT, false, false>(g, splits, st)))
+  if (g_bf16) rc = big ? SCLDM_GEMM_CASE(true, 2) : SCLDM_GEMM_CASE(true, 1);
+  else rc = big ? SCLDM_GEMM_CASE(false, 2) : SCLDM_GEMM_CASE(false, 1);
 #undef SCLDM_GEMM_CASE
   if (rc != SCLDM_OK) return rc;
   if (splits > 1) {
@@ -179,8 +184,10 @@ int colsum(hipStream_t st, const float* X, long rows, int cols, long ld, float* 
 
 inline unsigned ew_grid(long count) { return (unsigned)std::max<long>(1, std::min<long>(cdiv(count, 256), 4096)); }
 
-int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, const void* saved, const void* ws) {
+int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  g_bf16 = precision == SCLDM_PREC_BF16;
   if (n < 1) return fail(SCLDM_ERR_SHAPE, "n must be >= 1");
   if (h->cfg.n_embed_input % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs n_embed_input %% 4 == 0 (got %d)", h->cfg.n_embed_input);
   if (h->cfg.hidden_dim % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs hidden_dim %% 4 == 0 (got %d)", h->cfg.hidden_dim);
@@ -205,8 +212,9 @@ extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
 }
 
 extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
-                                       const int64_t* const* labels, int n, float* out, void* saved_, void* ws, void* stream_) {
-  TRY(check_common(h, w, n, saved_, ws));
+                                       const int64_t* const* labels, int n, float* out, int precision, void* saved_, void* ws,
+                                       void* stream_) {
+  TRY(check_common(h, w, n, precision, saved_, ws));
   if (!x || !t || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& cfg = h->cfg;
@@ -277,9 +285,9 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
 }
 
 extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* g, const float* x,
-                                        const int64_t* const* labels, const float* dout, int n, float* dx_out, void* saved_,
-                                        void* ws, void* stream_) {
-  TRY(check_common(h, w, n, saved_, ws));
+                                        const int64_t* const* labels, const float* dout, int n, float* dx_out, int precision,
+                                        void* saved_, void* ws, void* stream_) {
+  TRY(check_common(h, w, n, precision, saved_, ws));
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& cfg = h->cfg;

@@ -98,12 +98,13 @@ class _DiTTrainFn(torch.autograd.Function):
         ws = torch.empty(L.scldm_dit_train_workspace_bytes(h, n), dtype=torch.uint8, device=dev)
         w, keep = module._param_struct(lambda p: p.data_ptr())
         out = torch.empty_like(x)
+        prec = module._prec()
         with torch.cuda.device(dev):
             _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
-                                                 out.data_ptr(), saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
+                                                 out.data_ptr(), prec, saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
                        "scldm_dit_train_forward")
         del keep
-        ctx.module, ctx.saved, ctx.ws, ctx.x, ctx.n = module, saved, ws, x, n
+        ctx.module, ctx.saved, ctx.ws, ctx.x, ctx.n, ctx.prec = module, saved, ws, x, n, prec
         ctx.labels, ctx.label_keep = labels, label_keep
         ctx.param_versions = [p._version for p in params]
         return out
@@ -127,7 +128,7 @@ class _DiTTrainFn(torch.autograd.Function):
         with torch.cuda.device(dout.device):
             _lib.check(L.scldm_dit_train_backward(h, C.byref(w), C.byref(g), ctx.x.data_ptr(), C.cast(ctx.labels, _lib.c_void_pp),
                                                   dout.data_ptr(), n, dx.data_ptr() if dx is not None else None,
-                                                  ctx.saved.data_ptr(), ctx.ws.data_ptr(), _stream_ptr()),
+                                                  ctx.prec, ctx.saved.data_ptr(), ctx.ws.data_ptr(), _stream_ptr()),
                        "scldm_dit_train_backward")
         del keep_w, keep_g
         ctx.saved = ctx.ws = None
