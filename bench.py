@@ -32,6 +32,11 @@ WORKLOADS = {
     # configs[3]: 8192 cells over 8 GPUs = 1024 per GPU, joint conditioning
     "parse1m_b1024_euler100": dict(vocab={"cell_type": 18, "cytokine": 91}, strategy="joint", B=1024, evals=100, method="euler", scale=1.0),
 }
+TRAIN_WORKLOADS = {
+    # BASELINE.json configs[4] restated on the reference's own DiT shape (ldm_base.yaml; "DiT-L" is not a reference config):
+    # replogle labels (cell_line 4, gene 2024, joint), cfg_dropout_prob 0.8, per-GPU batch 1024, AdamW, data-parallel
+    "replogle_train_b1024": dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=1024),
+}
 FLOPS_PER_SAMPLE_FWD = 210_763_776
 FLOPS_PER_SAMPLE_BLOCK = 26_247_168 - 2 * 256 * 1536  # fused block kernel: everything of a block except the adaLN projection
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md:41-42
@@ -102,6 +107,37 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
     return dt, blocks
 
 
+def time_training(wl, precision, device, steps, warmup, dist_on, world):
+    """One step = Transport.training_losses forward + HIP backward + gradient all-reduce (N > 1) + fused AdamW on the per-GPU
+    batch of synthetic latents (standing in for frozen-VAE output).  Returns seconds for `steps` steps (max over ranks)."""
+    from scldm_amd.training import train_step
+    from scldm_amd.transport import create_transport
+    m = make_model(wl, precision, device).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(wl["B"], 16, 16, generator=g).to(device)
+    cond = {k: torch.randint(0, v, (wl["B"],), generator=g).to(device) for k, v in wl["vocab"].items()}
+    for _ in range(warmup):
+        train_step(m, tr, opt, x1, cond)
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_step(m, tr, opt, x1, cond)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, float(loss)
+
+
 def decode_inclusive(m, wl, device, n_genes=17002):
     """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count)."""
     from scldm_amd.layers import InputTransformerVAE
@@ -162,7 +198,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--evals", type=int, default=0, help="override the number of CFG evaluations (profiling only; not a valid bench line)")
@@ -186,6 +222,32 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
+    if args.workload in TRAIN_WORKLOADS:   # SURVEY 8a row T1 / BASELINE configs[4]: not the headline metric, its own line
+        wl = dict(TRAIN_WORKLOADS[args.workload])
+        if args.batch:
+            wl["B"] = args.batch
+        dt, loss = time_training(wl, args.precision, device, args.steps, max(args.warmup, 1), dist_on, world)
+        value = world * wl["B"] / (dt / args.steps)
+        result = {"metric": "training cells/sec (flow-matching step: forward + backward + gradient all-reduce + AdamW)", "value": value,
+                  "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * dt / args.steps,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                  "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": world * wl["B"],
+                             "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "AdamW (fused)",
+                             "parallelism": f"data-parallel x{world}, one flat-bucket all-reduce of gradients" if dist_on else "single GPU"},
+                  "train_tflops_per_gpu": 3 * FLOPS_PER_SAMPLE_FWD * wl["B"] / (dt / args.steps) / 1e12, "final_loss": loss}
+        if dist_on:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(result), flush=True)
+        return
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
@@ -243,6 +305,11 @@ def main():
                 del m2
             result["other_workloads"] = extra
             result["with_vae_decode"] = decode_inclusive(m, wl, device)
+            tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
+            torch.cuda.empty_cache()
+            dtt, _ = time_training(tw, args.precision, device, 5, 5, False, 1)
+            result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 5), "ms_per_step": 1e3 * dtt / 5,
+                                       "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 5) / 1e12, "dtype": args.precision}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
     if dist_on:

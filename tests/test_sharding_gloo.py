@@ -62,3 +62,46 @@ def test_shard_bounds_cover_and_balance():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, bucket_bytes, out_q):
+    from scldm_amd.training import allreduce_gradients, grad_buckets
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(7, 5), (3,), (64, 64), (1, 16, 8), (11,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    params[1].requires_grad_(False)                      # frozen (pos_embed-like): never touched
+    for i, p in enumerate(params):
+        if p.requires_grad and not (i == 4 and rank == 1):   # rank 1 has no gradient for the last one
+            g = torch.Generator().manual_seed(100 * rank + i)
+            p.grad = torch.randn(p.shape, generator=g)
+    calls = allreduce_gradients(params, bucket_bytes=bucket_bytes)
+    exp = []
+    for i, s in enumerate(shapes):
+        tot = torch.zeros(s)
+        for r in range(world):
+            if not (i == 4 and r == 1):
+                tot += torch.randn(s, generator=torch.Generator().manual_seed(100 * r + i))
+        exp.append(tot / world)
+    ok = all(torch.allclose(p.grad, e, atol=1e-6) for i, (p, e) in enumerate(zip(params, exp)) if i != 1) and params[1].grad is None
+    out_q.put((rank, ok, calls, len(grad_buckets(params, bucket_bytes))))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bucket_bytes", [(2, 256 << 20), (2, 4096), (3, 64)])
+def test_gradient_allreduce_buckets(world, bucket_bytes):
+    """The data-parallel training exchange (scldm_amd.training): flat-bucket all-reduce, mean over ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in results)
+    assert all(calls == nb for _, _, calls, nb in results)
+    assert results[0][3] == (1 if bucket_bytes > 1 << 20 else results[0][3]) and results[0][3] >= 1
