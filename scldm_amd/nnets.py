@@ -356,8 +356,10 @@ class DiT(nn.Module):
         if x.shape[1:] != (self.seq_len, self.n_embed_input) or t.shape != (n,):
             raise ValueError(f"expected x (B,{self.seq_len},{self.n_embed_input}) and t (B,), got {tuple(x.shape)}, {tuple(t.shape)}")
         labels, keep = self._label_ptrs(condition, n, force_drop_ids)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            # differentiable path (Transport.training_losses -> loss.backward()): forward with saved activations + HIP backward
+        if torch.is_grad_enabled() and (x.requires_grad or (self.training and any(p.requires_grad for p in self.parameters()))):
+            # differentiable path (Transport.training_losses -> loss.backward()): forward with saved activations + HIP backward.
+            # In eval mode the fused inference kernel runs unless the input itself requires grad: an eval-mode output is not
+            # differentiable w.r.t. the parameters (loss.backward() then fails loudly, it never returns silent zeros).
             params = [p for _, p in self.named_parameters()]
             return _DiTTrainFn.apply(self, x, t, labels, keep, *params)
         L, h = self._native()

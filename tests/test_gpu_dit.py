@@ -139,9 +139,11 @@ def test_error_paths():
         m(torch.zeros(2, 16, 8, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
     with pytest.raises(ValueError):
         m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(3, dtype=torch.long, device="cuda")})
+    y = m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
+    assert not y.requires_grad        # eval mode: fused inference kernel, output is not differentiable w.r.t. the parameters
     m.train()
-    with pytest.raises(NotImplementedError):  # no backward yet: training forward needs no_grad
-        m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
+    y = m(torch.zeros(2, 16, 16, device="cuda"), torch.zeros(2, device="cuda"), {"clusters": torch.zeros(2, dtype=torch.long, device="cuda")})
+    assert y.requires_grad and y.grad_fn is not None   # training mode: autograd-bound HIP backward (tests/test_gpu_train.py)
 
 
 def test_training_mode_label_dropout_matches_oracle_mixture():
