@@ -247,6 +247,18 @@ int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, in
 int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
                      float* theta, void* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Encoder input path: tokenize_cells(sample_genes="expressed"),
+ * reference src/scldm/datamodule.py:660-731.  counts: device (N,G) fp32; gene_idx: device int64 token ids,
+ * one shared row (gene_row_stride 0) or per cell (gene_row_stride G) - the reference tiles one row N times (:691).
+ * Outputs: genes_subset (N,S) int64 and counts_subset (N,S) fp32 - expressed genes (counts > 0) in gene order,
+ * padded with mask_idx / 0 (:709-716); num_expressed (N) int32; library_size (N) fp32 = row sums (:692).
+ * Rows with num_expressed > S keep their first S expressed genes; the caller raises like the reference (:706-707).
+ * ------------------------------------------------------------------------------------------------ */
+int scldm_tokenize_expressed(const float* counts, const int64_t* gene_idx, long gene_row_stride, int N, int G, int S,
+                             int64_t mask_idx, int64_t* genes_subset, float* counts_subset, int32_t* num_expressed,
+                             float* library_size, void* stream);
+
 /* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
  * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the
  * production library returns SCLDM_ERR_STATE. */

@@ -210,3 +210,19 @@ extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* gen
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
+
+// ---- encoder input path: tokenize_cells(sample_genes="expressed") --------------------------------------------------
+#include "tokenize.hpp"
+
+extern "C" int scldm_tokenize_expressed(const float* counts, const int64_t* gene_idx, long gene_row_stride, int N, int G, int S,
+                                        int64_t mask_idx, int64_t* genes_subset, float* counts_subset, int32_t* num_expressed,
+                                        float* library_size, void* stream_) {
+  if (!counts || !gene_idx || !genes_subset || !counts_subset || !num_expressed || !library_size) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (N < 0 || G < 1 || S < 1) return fail(SCLDM_ERR_SHAPE, "need N >= 0, G >= 1, genes_seq_len >= 1 (got %d, %d, %d)", N, G, S);
+  if (gene_row_stride != 0 && gene_row_stride != G) return fail(SCLDM_ERR_SHAPE, "gene_row_stride must be 0 (shared row) or G");
+  if (N == 0) return SCLDM_OK;
+  hipLaunchKernelGGL(tokenize_expressed_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream_, counts, gene_idx, gene_row_stride, G, S,
+                     mask_idx, genes_subset, counts_subset, num_expressed, library_size);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}

@@ -208,6 +208,68 @@ def gen_train(name, kwargs, B, seed):
     print(name, "loss", terms["loss"].detach().numpy(), "frozen", frozen, "n grads", sum(k.startswith("grad_") for k in out))
 
 
+def _import_reference_tokenizer():
+    """scldm.datamodule.tokenize_cells is pure NumPy, but its module imports the data stack (anndata, lightning,
+    cellarium-ml) at import time; give those import-time-only stand-ins (nothing of them is called by tokenize_cells) and
+    a StrEnum shim for Python 3.10 so scldm.constants imports for real."""
+    import enum
+    if not hasattr(enum, "StrEnum"):
+        class StrEnum(str, enum.Enum):
+            def __str__(self):
+                return str(self.value)
+        enum.StrEnum = StrEnum
+
+    class _Unused:
+        def __init__(self, *a, **k):
+            raise RuntimeError("import-time stand-in: must not be used")
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules.setdefault(name, m)
+    mod("anndata", AnnData=_Unused)
+    mod("pytorch_lightning", LightningDataModule=object)
+    mod("cellarium")
+    mod("cellarium.ml")
+    mod("cellarium.ml.data", DistributedAnnDataCollection=_Unused, IterableDistributedAnnDataCollectionDataset=_Unused)
+    mod("cellarium.ml.utilities")
+    mod("cellarium.ml.utilities.data", AnnDataField=_Unused, convert_to_tensor=lambda x: x)
+    mod("scldm._utils", get_tissue_adata_files=None, sort_h5ad_files=None)
+    mod("scldm.encoder", VocabularyEncoderSimplified=object)
+    from scldm.datamodule import tokenize_cells
+    return tokenize_cells
+
+
+TOKENIZE_CASES = {"tok_small": (5, 40, 12, 401), "tok_dentate": (3, 17002, 6147, 402)}   # name: (N, G, genes_seq_len, seed)
+
+
+def gen_tokenize(name, N, G, S, seed):
+    """tokenize_cells(sample_genes="expressed") (src/scldm/datamodule.py:660-731): expressed genes compacted to the front of
+    a genes_seq_len window, mask token / zero padding; plus library_size."""
+    tokenize_cells = _import_reference_tokenizer()
+    rng = np.random.default_rng(seed)
+    rate = min(0.25, 0.8 * S / G)
+    counts = (rng.poisson(0.9, (N, G)) * (rng.random((N, G)) < rate)).astype(np.float32)
+    counts[0, :] = 0                                   # a cell with nothing expressed
+    if name == "tok_small":
+        counts[1, :] = 0
+        counts[1, :S] = 3                              # exactly genes_seq_len expressed genes
+    gene_ids = rng.permutation(G + 1)[:G].astype(np.int64) + 1   # token ids 1..G+1 in arbitrary order; 0 = mask token
+
+    class Enc:                                         # the two members tokenize_cells uses (encoder.py:20,141-148)
+        mask_token_idx = 0
+
+        @staticmethod
+        def encode_genes(tokens):
+            return gene_ids
+
+    out = tokenize_cells(counts, [str(i) for i in range(G)], Enc, S, "expressed")
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), counts=counts, gene_ids=gene_ids, genes_seq_len=np.array(S),
+                        mask_idx=np.array(0), genes_subset=out["genes_subset"], counts_subset=out["counts_subset"],
+                        library_size=out["library_size"])
+    print(name, "expressed per cell", (counts > 0).sum(1), "lib", out["library_size"][:, 0])
+
+
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
 
 
@@ -253,5 +315,7 @@ if __name__ == "__main__":
     gen_transport(models["dit_tiny"], DIT_CASES["dit_tiny"][0], 101)
     for name, (kw, B, seed) in TRAIN_CASES.items():
         gen_train(name, kw, B, seed)
+    for name, (N, G, S, seed) in TOKENIZE_CASES.items():
+        gen_tokenize(name, N, G, S, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
         gen_vae(name, kw["n_genes"], G, S, B, seed)
