@@ -35,10 +35,16 @@ def sample_latents(dit, z0: torch.Tensor, condition: dict[str, torch.Tensor] | N
 
 
 @torch.no_grad()
-def sample_cells(dit, vae, condition, guidance_weight, batch_size: int, genes: torch.Tensor, size_factors: torch.Tensor,
-                 num_steps: int = 101, sampling_method: str = "euler", z0: torch.Tensor | None = None, draw_counts: bool = True):
-    """Reference `LatentDiffusion.sample` minus the size-factor draw (models.py:785 is caller-side):
-    returns (counts or NB distribution, latents) with 2*batch_size rows, unconditional first."""
+def sample_cells(dit, vae, condition, guidance_weight, batch_size: int, genes: torch.Tensor, size_factors: torch.Tensor | None,
+                 num_steps: int = 101, sampling_method: str = "euler", z0: torch.Tensor | None = None, draw_counts: bool = True,
+                 size_factor_sampler: "SizeFactorSampler | None" = None):
+    """Reference `LatentDiffusion.sample` (models.py:766-819): returns (counts or NB distribution, latents) with
+    2*batch_size rows, unconditional first.  Log size factors are either given or drawn on device by a
+    `SizeFactorSampler` (models.py:785 -> _sample_log_size_factors)."""
+    if size_factors is None:
+        if size_factor_sampler is None:
+            raise ValueError("pass size_factors or a size_factor_sampler")
+        size_factors = size_factor_sampler.sample(condition, batch_size)
     if len(genes) != batch_size:
         raise ValueError(f"genes batch dimension ({genes.shape[0]}) must match batch_size ({batch_size})")
     dev = dit.pos_embed.device
@@ -81,3 +87,102 @@ def sample_latents_sharded(sample_fn, z0: torch.Tensor, condition: dict[str, tor
         unc.append(out[r, 0, : rhi - rlo])
         gui.append(out[r, 1, : rhi - rlo])
     return torch.cat(unc + gui, dim=0)
+
+
+class SizeFactorSampler:
+    """Device-side `LatentDiffusion._sample_log_size_factors` (src/scldm/models.py:473-597).
+
+    The reference walks the batch in Python with one `.item()` host synchronisation and one `Normal(...).sample()` per cell.
+    Here the vocabulary encoder's statistics are flattened ONCE into dense device tables (mean, std, valid) - indexed by the
+    label for the independent path, by the mixed-radix code of the component labels for the joint path - and a batch is one
+    gather plus one `randn`: log_sf = mean[idx] + std[idx] * eps, zero where statistics are missing (the reference's
+    fall-back).  Key selection follows the reference: joint statistics when the strategy is "joint" and the joint key is in
+    both maps, else `size_factor_condition_key`, else the alphabetically first key common to the condition and both maps."""
+
+    def __init__(self, vocabulary_encoder, condition_strategy: str, device):
+        self.device = torch.device(device)
+        self.strategy = condition_strategy
+        enc = vocabulary_encoder
+        self.mu = getattr(enc, "mu_size_factor", None)
+        self.sd = getattr(enc, "sd_size_factor", None)
+        self.size_factor_condition_key = getattr(enc, "size_factor_condition_key", None)
+        self.joint_key = getattr(enc, "joint_key", None)
+        self.joint_components = getattr(enc, "joint_components", None)
+        self.joint_idx_2_classes = getattr(enc, "joint_idx_2_classes", None)
+        self._tables: dict = {}
+
+    # -- table builders (host, once per key) ------------------------------------------------------------------
+    def _dense(self, pairs, size):
+        tab = torch.zeros((3, size), dtype=torch.float32)
+        for idx, (mean, std) in pairs.items():
+            if mean is not None and std is not None and 0 <= idx < size:
+                tab[0, idx], tab[1, idx], tab[2, idx] = float(mean), float(std), 1.0
+        return tab.to(self.device)
+
+    def _independent_table(self, key):
+        if ("ind", key) not in self._tables:
+            mu, sd = self.mu[key], self.sd[key]
+            ids = [int(k) for k in set(mu) | set(sd)]
+            size = (max(ids) + 1) if ids else 1
+            self._tables[("ind", key)] = self._dense({int(k): (mu.get(k), sd.get(k)) for k in set(mu) | set(sd)}, size)
+        return self._tables[("ind", key)]
+
+    def _joint_table(self, keys):
+        tkey = ("joint", tuple(keys))
+        if tkey not in self._tables:
+            parts = [tuple(int(p) for p in k.split("_")) for k in self.joint_idx_2_classes]
+            parts = [p for p in parts if len(p) == len(keys)]
+            radix = [max((p[d] for p in parts), default=0) + 1 for d in range(len(keys))]
+            pairs = {}
+            mu, sd = self.mu[self.joint_key], self.sd[self.joint_key]
+            for k, cls in self.joint_idx_2_classes.items():
+                p = tuple(int(x) for x in k.split("_"))
+                if len(p) != len(keys):
+                    continue
+                code = 0
+                for d, v in enumerate(p):
+                    code = code * radix[d] + v
+                pairs[code] = (mu.get(cls), sd.get(cls))
+            size = 1
+            for r in radix:
+                size *= r
+            self._tables[tkey] = (self._dense(pairs, size), radix)
+        return self._tables[tkey]
+
+    # -- the call (device, no host synchronisation) -----------------------------------------------------------
+    @torch.no_grad()
+    def sample(self, condition: dict[str, torch.Tensor] | None, batch_size: int, generator: torch.Generator | None = None,
+               eps: torch.Tensor | None = None) -> torch.Tensor:
+        zeros = torch.zeros(batch_size, device=self.device)
+        if condition is None or self.mu is None or self.sd is None:
+            return zeros
+        use_joint = (self.strategy == "joint" and self.joint_idx_2_classes is not None and self.joint_key is not None
+                     and self.joint_key in self.mu and self.joint_key in self.sd)
+        if use_joint:
+            keys = [k for k in self.joint_components if k in condition] if self.joint_components is not None else list(condition.keys())
+            if any(len(condition[k]) != batch_size for k in keys):
+                return zeros
+            tab, radix = self._joint_table(keys)
+            code = torch.zeros(batch_size, dtype=torch.long, device=self.device)
+            inside = torch.ones(batch_size, dtype=torch.bool, device=self.device)
+            for d, k in enumerate(keys):
+                lab = condition[k].to(device=self.device, dtype=torch.long)
+                inside &= (lab >= 0) & (lab < radix[d])
+                code = code * radix[d] + lab.clamp(0, radix[d] - 1)
+        else:
+            sel = self.size_factor_condition_key
+            if not (sel and sel in condition and sel in self.mu and sel in self.sd):
+                inter = sorted(set(condition.keys()) & set(self.mu.keys()) & set(self.sd.keys()))
+                if not inter:
+                    return zeros
+                sel = inter[0]
+            if len(condition[sel]) != batch_size:
+                raise ValueError(f"Condition '{sel}' length ({len(condition[sel])}) must match batch size ({batch_size})")
+            tab = self._independent_table(sel)
+            lab = condition[sel].to(device=self.device, dtype=torch.long)
+            inside = (lab >= 0) & (lab < tab.shape[1])
+            code = lab.clamp(0, tab.shape[1] - 1)
+        if eps is None:
+            eps = torch.randn(batch_size, device=self.device, generator=generator)
+        valid = inside & (tab[2, code] > 0)
+        return torch.where(valid, tab[0, code] + tab[1, code] * eps, zeros)

@@ -270,6 +270,66 @@ def gen_tokenize(name, N, G, S, seed):
     print(name, "expressed per cell", (counts > 0).sum(1), "lib", out["library_size"][:, 0])
 
 
+SIZE_FACTOR_CASES = {
+    # name -> (condition_strategy, vocabulary-encoder attributes, condition labels).  Standard deviations are 1e-12 so the
+    # reference's Normal(loc, scale).sample() returns loc to fp32 precision: the fixture pins the LOOKUP logic (key choice, joint
+    # keys, missing statistics -> 0); the draw itself is checked statistically on the GPU.
+    "independent_key": ("mutually_exclusive",
+                        dict(size_factor_condition_key="cell_type",
+                             mu_size_factor={"cell_type": {0: 7.5, 1: 8.25, 3: 6.125}, "donor": {0: 1.0}},
+                             sd_size_factor={"cell_type": {0: 1e-12, 1: 1e-12, 3: 1e-12}, "donor": {0: 1e-12}}),
+                        {"cell_type": [0, 1, 2, 3, 1, 0], "donor": [0, 0, 0, 0, 0, 0]}),
+    "inferred_key": ("mutually_exclusive",
+                     dict(mu_size_factor={"zeta": {0: 3.0, 1: 4.0}, "beta": {0: 5.0, 1: 5.5, 2: 9.0}},
+                          sd_size_factor={"zeta": {0: 1e-12, 1: 1e-12}, "beta": {0: 1e-12, 1: 1e-12, 2: 1e-12}}),
+                     {"zeta": [0, 1, 1, 0], "beta": [2, 0, 1, 1]}),
+    "joint": ("joint",
+              dict(joint_key="ct_cyt", joint_components=["cell_type", "cytokine"],
+                   joint_idx_2_classes={"0_0": "A_x", "0_1": "A_y", "1_0": "B_x", "2_1": "C_y"},
+                   mu_size_factor={"ct_cyt": {"A_x": 6.5, "A_y": 7.0, "B_x": 8.0}},
+                   sd_size_factor={"ct_cyt": {"A_x": 1e-12, "A_y": 1e-12, "B_x": 1e-12, "C_y": 1e-12}}),
+              {"cell_type": [0, 0, 1, 1, 2, 0], "cytokine": [0, 1, 0, 1, 1, 0]}),
+    "no_stats": ("joint", dict(), {"cell_type": [0, 1], "cytokine": [1, 0]}),
+    "no_matching_key": ("mutually_exclusive", dict(mu_size_factor={"other": {0: 1.0}}, sd_size_factor={"other": {0: 1e-12}}),
+                        {"cell_type": [0, 1, 0]}),
+}
+
+
+def gen_size_factors():
+    """LatentDiffusion._sample_log_size_factors (src/scldm/models.py:473-597).  scldm.models cannot be imported here (lightning,
+    scvi, ema_pytorch, ...), so the METHOD is taken from the reference file with ast and executed as it stands against a duck-typed
+    `self` (trainer.datamodule.vocabulary_encoder, diffusion_model.condition_strategy, device) - nothing of it is copied."""
+    import ast
+    import logging
+    import textwrap
+    from types import SimpleNamespace
+    from typing import cast
+    from torch.distributions import Normal
+    path = os.path.join(REF, "models.py")
+    src = open(path).read()
+    fn_src = None
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.FunctionDef) and node.name == "_sample_log_size_factors":
+            fn_src = textwrap.dedent(ast.get_source_segment(src, node))
+    ns = {"torch": torch, "Normal": Normal, "cast": cast, "logger": logging.getLogger("golden")}
+    exec(compile(fn_src, path, "exec"), ns)
+    fn = ns["_sample_log_size_factors"]
+    out = {"cases_json": np.array(json.dumps({k: [v[0], v[1], v[2]] for k, v in SIZE_FACTOR_CASES.items()}))}
+    for name, (strategy, attrs, cond) in SIZE_FACTOR_CASES.items():
+        enc = SimpleNamespace(**attrs)
+        me = SimpleNamespace(trainer=SimpleNamespace(datamodule=SimpleNamespace(vocabulary_encoder=enc)),
+                             diffusion_model=SimpleNamespace(condition_strategy=strategy), device=torch.device("cpu"))
+        condition = {k: torch.tensor(v) for k, v in cond.items()}
+        B = len(next(iter(cond.values())))
+        res = fn(me, condition, B)
+        out[f"out_{name}"] = res.numpy()
+        print("size factors", name, res.numpy())
+    res = fn(SimpleNamespace(trainer=SimpleNamespace(datamodule=SimpleNamespace(vocabulary_encoder=SimpleNamespace())),
+                             diffusion_model=SimpleNamespace(condition_strategy="joint"), device=torch.device("cpu")), None, 4)
+    out["out_condition_none"] = res.numpy()
+    np.savez_compressed(os.path.join(HERE, "size_factors.npz"), **out)
+
+
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
 
 
@@ -317,5 +377,6 @@ if __name__ == "__main__":
         gen_train(name, kw, B, seed)
     for name, (N, G, S, seed) in TOKENIZE_CASES.items():
         gen_tokenize(name, N, G, S, seed)
+    gen_size_factors()
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
         gen_vae(name, kw["n_genes"], G, S, B, seed)
