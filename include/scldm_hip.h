@@ -259,6 +259,15 @@ int scldm_tokenize_expressed(const float* counts, const int64_t* gene_idx, long 
                              int64_t mask_idx, int64_t* genes_subset, float* counts_subset, int32_t* num_expressed,
                              float* library_size, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Output assembly: dense generated counts (N,G) fp32 -> CSR on device, replacing the
+ * per-batch scipy.sparse.csr_matrix(counts.cpu().numpy()) of src/scldm/_utils.py:192-197 (after models.py:742).
+ * Entries != 0 are kept in column order.  scldm_csr_count writes nnz per row; the caller forms
+ * indptr (N+1) int64 = exclusive scan of it; scldm_csr_fill writes indices (nnz) int32 and data (nnz) fp32.
+ * ------------------------------------------------------------------------------------------------ */
+int scldm_csr_count(const float* dense, int N, int G, int32_t* row_nnz, void* stream);
+int scldm_csr_fill(const float* dense, int N, int G, const int64_t* indptr, int32_t* indices, float* data, void* stream);
+
 /* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
  * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the
  * production library returns SCLDM_ERR_STATE. */

@@ -111,6 +111,8 @@ def lib() -> C.CDLL:
                                    C.c_void_p, C.c_void_p]
     L.scldm_tokenize_expressed.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.scldm_csr_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_csr_fill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -120,7 +122,7 @@ EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_d
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes",
            "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",
-           "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_tokenize_expressed"]
+           "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill"]
 
 
 def check(rc: int, what: str) -> None:

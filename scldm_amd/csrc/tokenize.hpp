@@ -83,4 +83,67 @@ __global__ __launch_bounds__(256) void tokenize_expressed_kernel(const float* __
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Output assembly: dense generated counts (N,G) -> CSR, replacing
+// scipy.sparse.csr_matrix(dense.cpu().numpy()) per batch (reference src/scldm/_utils.py:192-197 after models.py:742).
+// Same streaming compaction as the tokenizer; entries != 0 are kept in column order (what scipy keeps).
+// Pass 1 counts per row; the caller turns the counts into indptr (exclusive scan over N rows); pass 2 fills.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_count_kernel(const float* __restrict__ dense, int G, int32_t* __restrict__ row_nnz) {
+  __shared__ int part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* __restrict__ c = dense + blockIdx.x * (long)G;
+  int cnt = 0;
+  for (int j = tid; j < G; j += 256) cnt += c[j] != 0.f ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) part[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) row_nnz[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(const float* __restrict__ dense, int G, const int64_t* __restrict__ indptr,
+                                                       int32_t* __restrict__ indices, float* __restrict__ data) {
+  __shared__ int wave_tot[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long row = blockIdx.x;
+  const float* __restrict__ c = dense + row * (long)G;
+  int32_t* __restrict__ io = indices + indptr[row];
+  float* __restrict__ vo = data + indptr[row];
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int base = 0, buf = 0;
+  for (int j0 = 0; j0 < G; j0 += 256 * kTokPer, buf ^= 1) {
+    const int j = j0 + tid * kTokPer;
+    float v[kTokPer];
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < kTokPer; ++e) {
+      v[e] = j + e < G ? c[j + e] : 0.f;
+      cnt += v[e] != 0.f ? 1 : 0;
+    }
+    const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+    const int pre = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+    if (lane == 0) wave_tot[buf][wave] = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int t = wave_tot[buf][w];
+      before += w < wave ? t : 0;
+      tot += t;
+    }
+    int p = base + before + pre;
+#pragma unroll
+    for (int e = 0; e < kTokPer; ++e)
+      if (v[e] != 0.f) {
+        io[p] = j + e;
+        vo[p] = v[e];
+        ++p;
+      }
+    base += tot;
+  }
+}
+
 }  // namespace scldm

@@ -226,3 +226,19 @@ extern "C" int scldm_tokenize_expressed(const float* counts, const int64_t* gene
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
+
+// ---- output assembly: dense generated counts -> CSR ----------------------------------------------------------------
+extern "C" int scldm_csr_count(const float* dense, int N, int G, int32_t* row_nnz, void* stream_) {
+  if (!dense || !row_nnz) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (N < 1 || G < 1) return fail(SCLDM_ERR_SHAPE, "need N >= 1 and G >= 1 (got %d, %d)", N, G);
+  hipLaunchKernelGGL(csr_count_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream_, dense, G, row_nnz);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_csr_fill(const float* dense, int N, int G, const int64_t* indptr, int32_t* indices, float* data, void* stream_) {
+  if (!dense || !indptr || !indices || !data) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (N < 1 || G < 1) return fail(SCLDM_ERR_SHAPE, "need N >= 1 and G >= 1 (got %d, %d)", N, G);
+  hipLaunchKernelGGL(csr_fill_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream_, dense, G, indptr, indices, data);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}

@@ -48,3 +48,27 @@ def tokenize_cells_expressed(counts: torch.Tensor, gene_idx: torch.Tensor, genes
         raise ValueError("genes_seq_len is smaller than number of expressed genes")
     return {"genes": gene_idx if stride else gene_idx.unsqueeze(0).expand(N, G), "counts": counts, "genes_subset": genes_out,
             "counts_subset": counts_out, "library_size": lib, "num_expressed": nexp}
+
+
+def dense_to_csr(dense: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(N,G) fp32 CUDA -> (indptr (N+1) int64, indices (nnz) int32, data (nnz) fp32) on device: the arrays of
+    `scipy.sparse.csr_matrix(dense.cpu().numpy())` (reference _utils.py:192-197), so only nnz entries cross PCIe.
+    One host synchronisation (nnz sizes the outputs)."""
+    if dense.device.type != "cuda" or dense.dtype != torch.float32 or dense.dim() != 2:
+        raise ValueError("dense must be a 2-D float32 CUDA tensor; there is no CPU path")
+    N, G = dense.shape
+    dense = dense.contiguous()
+    indptr = torch.zeros(N + 1, dtype=torch.long, device=dense.device)
+    if N == 0 or G == 0:
+        return indptr, torch.empty(0, dtype=torch.int32, device=dense.device), torch.empty(0, dtype=torch.float32, device=dense.device)
+    L = _lib.lib()
+    nnz_row = torch.empty(N, dtype=torch.int32, device=dense.device)
+    st = torch.cuda.current_stream().cuda_stream
+    with torch.cuda.device(dense.device):
+        _lib.check(L.scldm_csr_count(dense.data_ptr(), N, G, nnz_row.data_ptr(), st), "scldm_csr_count")
+        indptr[1:] = torch.cumsum(nnz_row, 0, dtype=torch.long)
+        nnz = int(indptr[-1])
+        indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dense.device)
+        data = torch.empty(max(nnz, 1), dtype=torch.float32, device=dense.device)
+        _lib.check(L.scldm_csr_fill(dense.data_ptr(), N, G, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), st), "scldm_csr_fill")
+    return indptr, indices[:nnz], data[:nnz]

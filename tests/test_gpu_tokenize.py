@@ -82,3 +82,19 @@ def test_full_size_properties(G, S):
     dense.scatter_(1, torch.where(valid, cols, torch.zeros_like(cols)), torch.where(valid, out["counts_subset"], torch.zeros_like(out["counts_subset"])))
     dense[:, 0] = torch.where(counts[:, 0] > 0, counts[:, 0], torch.zeros_like(counts[:, 0]))   # slot 0 absorbed the padding writes
     assert torch.equal(dense, counts)
+
+
+@pytest.mark.parametrize("N,G,density", [(1, 1, 1.0), (5, 257, 0.3), (3, 1024, 0.0), (64, 2000, 0.12), (256, 17002, 0.15)])
+def test_dense_to_csr_matches_scipy(N, G, density):
+    """Output assembly: arrays identical to scipy.sparse.csr_matrix(dense) (the reference's call, _utils.py:192-197)."""
+    from scipy import sparse
+    from scldm_amd.datamodule import dense_to_csr
+    rng = np.random.default_rng(G)
+    dense = (rng.poisson(2.0, (N, G)) * (rng.random((N, G)) < density)).astype(np.float32)
+    ref = sparse.csr_matrix(dense)
+    indptr, indices, data = dense_to_csr(torch.from_numpy(dense).cuda())
+    assert np.array_equal(indptr.cpu().numpy(), ref.indptr.astype(np.int64))
+    assert np.array_equal(indices.cpu().numpy(), ref.indices) and indices.dtype == torch.int32
+    assert np.array_equal(data.cpu().numpy(), ref.data)
+    back = sparse.csr_matrix((data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(N, G)).toarray()
+    assert np.array_equal(back, dense)
