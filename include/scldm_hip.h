@@ -268,6 +268,19 @@ int scldm_tokenize_expressed(const float* counts, const int64_t* gene_idx, long 
 int scldm_csr_count(const float* dense, int N, int G, int32_t* row_nnz, void* stream);
 int scldm_csr_fill(const float* dense, int N, int G, const int64_t* indptr, int32_t* indices, float* data, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Generation-evaluation MMD: kernel matrices of src/scldm/evaluations.py:10-69 and the
+ * sums MMDLoss needs (:72-82), without the (Bx,By,D) broadcast tensors of the reference.
+ * x (nx,D), y (ny,D) device fp32.  sum_out: device double = sum_ij k(x_i, y_j).  kmat: device (nx,ny) fp32 or NULL.
+ * ------------------------------------------------------------------------------------------------ */
+#define SCLDM_MMD_RBF 0         /* exp(-scale * |x - y|^2), evaluations.py:10-21 */
+#define SCLDM_MMD_BRAYCURTIS 1  /* 1 - sum|x - y| / (sum|x + y| + 1e-8), :24-37 */
+#define SCLDM_MMD_TANIMOTO 2    /* sum xy / (sum(x + y - xy) + 1e-8), :40-53 */
+#define SCLDM_MMD_RUZICKA 3     /* sum min / (sum max + 1e-8), :56-69 */
+size_t scldm_mmd_workspace_bytes(int nx, int ny);
+int scldm_mmd_kernel_sum(const float* x, int nx, const float* y, int ny, int D, int kind, float scale, double* sum_out,
+                         float* kmat, void* ws, void* stream);
+
 /* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
  * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the
  * production library returns SCLDM_ERR_STATE. */

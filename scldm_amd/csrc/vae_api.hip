@@ -242,3 +242,31 @@ extern "C" int scldm_csr_fill(const float* dense, int N, int G, const int64_t* i
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
+
+// ---- generation-evaluation MMD kernels -------------------------------------------------------------------------------
+#include "mmd.hpp"
+
+extern "C" size_t scldm_mmd_workspace_bytes(int nx, int ny) {
+  if (nx < 1 || ny < 1) return 0;
+  return align256((size_t)cdiv(nx, kMmdTile) * cdiv(ny, kMmdTile) * sizeof(float));
+}
+
+extern "C" int scldm_mmd_kernel_sum(const float* x, int nx, const float* y, int ny, int D, int kind, float scale, double* sum_out,
+                                    float* kmat, void* ws, void* stream_) {
+  if (!x || !y || !sum_out || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (nx < 1 || ny < 1 || D < 1) return fail(SCLDM_ERR_SHAPE, "need nx, ny, D >= 1 (got %d, %d, %d)", nx, ny, D);
+  hipStream_t st = (hipStream_t)stream_;
+  dim3 grid(cdiv(ny, kMmdTile), cdiv(nx, kMmdTile));
+  float* partial = reinterpret_cast<float*>(ws);
+  switch (kind) {
+    case kMmdRbf: hipLaunchKernelGGL(mmd_tile_kernel<kMmdRbf>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    case kMmdBrayCurtis: hipLaunchKernelGGL(mmd_tile_kernel<kMmdBrayCurtis>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    case kMmdTanimoto: hipLaunchKernelGGL(mmd_tile_kernel<kMmdTanimoto>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    case kMmdRuzicka: hipLaunchKernelGGL(mmd_tile_kernel<kMmdRuzicka>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    default: return fail(SCLDM_ERR_SHAPE, "unknown MMD kernel kind %d", kind);
+  }
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(mmd_sum_kernel, dim3(1), dim3(256), 0, st, partial, (int)(grid.x * grid.y), sum_out);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}

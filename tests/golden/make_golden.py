@@ -330,6 +330,34 @@ def gen_size_factors():
     np.savez_compressed(os.path.join(HERE, "size_factors.npz"), **out)
 
 
+MMD_CASES = {"mmd_small": (5, 7, 33, 501), "mmd_counts": (48, 40, 700, 502)}   # name: (Bx, By, D, seed)
+
+
+def gen_mmd(name, Bx, By, D, seed):
+    """Kernel matrices and MMDLoss values of src/scldm/evaluations.py:10-82 (its `import ot` gets an import-time stand-in;
+    `wasserstein`, the only user of POT, is not exercised)."""
+    sys.modules.setdefault("ot", types.ModuleType("ot"))
+    from scldm.evaluations import BrayCurtisKernel, MMDLoss, RBFKernel, RuzickaKernel, TanimotoKernel
+    rng = np.random.default_rng(seed)
+    cx = (rng.poisson(1.5, (Bx, D)) * (rng.random((Bx, D)) < 0.3)).astype(np.float32)
+    cy = (rng.poisson(1.2, (By, D)) * (rng.random((By, D)) < 0.3)).astype(np.float32)
+    cx[0] = 0                                                        # an empty cell: denominators hit the 1e-8 guard
+    lx = np.log1p(cx / np.maximum(cx.sum(1, keepdims=True), 1) * 1e4).astype(np.float32)   # models.py:899-900 scaling
+    ly = np.log1p(cy / np.maximum(cy.sum(1, keepdims=True), 1) * 1e4).astype(np.float32)
+    zx = rng.standard_normal((Bx, D)).astype(np.float32) * 0.05      # signed data at a scale where the RBF kernel is not all ~0
+    zy = rng.standard_normal((By, D)).astype(np.float32) * 0.05 + 0.01
+    out = {"cx": cx, "cy": cy, "lx": lx, "ly": ly, "zx": zx, "zy": zy}
+    t = torch.from_numpy
+    for tag, kern, (a, b) in (("rbf", RBFKernel(), (zx, zy)), ("rbf_s", RBFKernel(scale=0.37), (zx, zy)),
+                              ("braycurtis", BrayCurtisKernel(), (lx, ly)), ("braycurtis_signed", BrayCurtisKernel(), (zx, zy)),
+                              ("tanimoto", TanimotoKernel(), (cx, cy)), ("ruzicka", RuzickaKernel(), (lx, ly)),
+                              ("ruzicka_signed", RuzickaKernel(), (zx, zy))):
+        out[f"k_{tag}"] = kern(t(a), t(b)).numpy()
+        out[f"mmd_{tag}"] = MMDLoss(kern)(t(a), t(b)).numpy()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, {k: float(v) for k, v in out.items() if k.startswith("mmd_")})
+
+
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
 
 
@@ -378,5 +406,7 @@ if __name__ == "__main__":
     for name, (N, G, S, seed) in TOKENIZE_CASES.items():
         gen_tokenize(name, N, G, S, seed)
     gen_size_factors()
+    for name, (Bx, By, D, seed) in MMD_CASES.items():
+        gen_mmd(name, Bx, By, D, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
         gen_vae(name, kw["n_genes"], G, S, B, seed)
