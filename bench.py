@@ -36,7 +36,19 @@ TRAIN_WORKLOADS = {
     # BASELINE.json configs[4] restated on the reference's own DiT shape (ldm_base.yaml; "DiT-L" is not a reference config):
     # replogle labels (cell_line 4, gene 2024, joint), cfg_dropout_prob 0.8, per-GPU batch 1024, AdamW, data-parallel
     "replogle_train_b1024": dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=1024),
+    # the same step on the DiT-L shape configs[4] names (1024 wide, 24 layers, 16 heads; not a reference config):
+    # outside the fused family, so it runs on the generic GEMM-based HIP path
+    "replogle_train_ditl_b256": dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=256,
+                                     shape=dict(n_embed=1024, n_layer=24, n_head=16)),
 }
+
+
+def dit_flops(n_embed=256, n_layer=8, n_embed_input=16, seq_len=16, multiple_of=4):
+    """Algorithmic FLOPs (2 x MAC, GEMMs + attention contractions) of one DiT sample-forward (BASELINE.md section 3 formula)."""
+    D, S = n_embed, seq_len
+    H = multiple_of * ((int(2 * (4 * D) / 3) + multiple_of - 1) // multiple_of)
+    block = 2 * D * 6 * D + S * (2 * D * 3 * D + 2 * D * D + 6 * D * H) + 2 * (2 * S * S * D)
+    return n_layer * block + 2 * 256 * D + 2 * D * D + S * 2 * n_embed_input * D + 2 * D * 2 * D + S * 2 * D * n_embed_input
 FLOPS_PER_SAMPLE_FWD = 210_763_776            # BASELINE.md section 3
 FLOPS_PER_SAMPLE_BLOCK = 26_247_168 - 2 * 256 * 1536  # fused block kernel: everything of a block except the adaLN projection
 PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md:41-42
@@ -44,9 +56,11 @@ PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}     # dense MFMA peaks, MI355X_MICROAR
 
 def make_model(wl, precision, device, seed=0):
     from scldm_amd.nnets import DiT
-    m = DiT(n_embed=256, n_embed_input=16, n_layer=8, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+    shape = dict(n_embed=256, n_layer=8, n_head=8)
+    shape.update(wl.get("shape", {}))
+    m = DiT(n_embed_input=16, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
             multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes=wl["vocab"], cfg_dropout_prob=0.8,
-            condition_strategy=wl["strategy"])
+            condition_strategy=wl["strategy"], **shape)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for p in m.parameters():  # random-init weights of the reference architecture (no checkpoints offline);
@@ -234,7 +248,10 @@ def main():
                   "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": world * wl["B"],
                              "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "AdamW (fused)",
                              "parallelism": f"data-parallel x{world}, one flat-bucket all-reduce of gradients" if dist_on else "single GPU"},
-                  "train_tflops_per_gpu": 3 * FLOPS_PER_SAMPLE_FWD * wl["B"] / (dt / args.steps) / 1e12, "final_loss": loss}
+                  "train_tflops_per_gpu": 3 * dit_flops(**{k: v for k, v in wl.get("shape", {}).items() if k != "n_head"}) * wl["B"]
+                  / (dt / args.steps) / 1e12, "final_loss": loss}
+        if "shape" in wl:
+            result["config"]["dit_shape"] = wl["shape"]
         if dist_on:
             import torch.distributed as dist
             dist.barrier()

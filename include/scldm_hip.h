@@ -45,10 +45,10 @@ typedef struct scldm_dit scldm_dit;
 /* Mirror of scldm.nnets.DiT.__init__ kwargs (reference src/scldm/nnets.py:219-234).
  * Classes are listed in SORTED NAME ORDER (the reference iterates sorted(class_vocab_sizes), :393,:404,:438). */
 typedef struct {
-  int n_embed;        /* 256 (only supported value this round) */
+  int n_embed;        /* 256 for the fused inference kernels; any multiple of 256 (<= 2048) on the generic scldm_dit_train_* path */
   int n_embed_input;  /* latent channels, <= 64 */
   int n_layer;
-  int n_head;         /* 8 (head_dim 32) */
+  int n_head;         /* 8 (head_dim 32) fused; head_dim 32 or 64 on the generic path */
   int seq_len;        /* 16 */
   int hidden_dim;     /* SwiGLU hidden (684 for n_embed 256, multiple_of 4), layers.py:165-167 */
   float layernorm_eps;
@@ -76,6 +76,8 @@ typedef struct {
 const char* scldm_last_error(void);
 int scldm_version(void);
 
+/* A handle for a shape outside the fused family (n_embed 256, n_head 8, seq_len 16, n_embed_input <= 32) is valid for
+ * scldm_dit_train_forward / _backward only; the fused entry points return SCLDM_ERR_SHAPE for it. */
 int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out);
 void scldm_dit_destroy(scldm_dit* h);
 

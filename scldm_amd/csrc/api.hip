@@ -32,14 +32,25 @@ static size_t esize(int prec) { return prec == SCLDM_PREC_BF16 ? 2 : 4; }
 
 extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (!cfg || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
-  if (cfg->n_embed != 256 || cfg->n_head != 8 || cfg->seq_len != 16)
-    return fail(SCLDM_ERR_SHAPE, "fused DiT block supports n_embed=256, n_head=8, seq_len=16 (got %d,%d,%d)", cfg->n_embed,
-                cfg->n_head, cfg->seq_len);
-  if (cfg->n_embed_input < 1 || cfg->n_embed_input > 32) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be in [1,32]");
+  if (cfg->n_embed < 1 || cfg->n_head < 1 || cfg->seq_len < 1) return fail(SCLDM_ERR_SHAPE, "bad n_embed / n_head / seq_len");
+  // The fused inference layer is specialised to the reference's DiT shape family; any other shape gets a handle that only
+  // serves the generic (GEMM-based) scldm_dit_train_* path, and the fused entry points report SCLDM_ERR_SHAPE.
+  const bool fused = cfg->n_embed == 256 && cfg->n_head == 8 && cfg->seq_len == 16 && cfg->n_embed_input <= 32;
+  if (cfg->n_embed_input < 1) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be >= 1");
   if (cfg->n_layer < 1 || cfg->hidden_dim < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / hidden_dim");
   if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
   scldm_dit* h = new scldm_dit();
   h->cfg = *cfg;
+  h->fused = fused;
+  if (!fused) {
+    h->mod_w = cfg->n_layer * 6 * cfg->n_embed + 2 * cfg->n_embed;
+    h->loaded = false;
+    h->timing = false;
+    h->ev_used = 0;
+    h->dbg = nullptr;
+    *out = h;
+    return SCLDM_OK;
+  }
   h->n_chunks[0] = (cfg->hidden_dim + kHC - 1) / kHC;  // FT=1: pad the hidden dimension to whole chunks
   h->half[0] = 0;
   {
@@ -114,6 +125,10 @@ extern "C" int scldm_dit_mod_width(const scldm_dit* h) { return h ? h->mod_w : 0
 
 extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream_) {
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (!h->fused)
+    return fail(SCLDM_ERR_SHAPE, "fused DiT layer supports n_embed=256, n_head=8, seq_len=16, n_embed_input<=32 (got %d,%d,%d,%d); "
+                "this shape is served by scldm_dit_train_forward / _backward only", h->cfg.n_embed, h->cfg.n_head, h->cfg.seq_len,
+                h->cfg.n_embed_input);
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& c = h->cfg;
   const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, mw = h->mod_w;

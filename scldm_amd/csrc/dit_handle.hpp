@@ -11,6 +11,7 @@ struct scldm_dit {
   int n_chunks[2], half[2];   // [FT-1]: full 128-unit SwiGLU chunks and the optional trailing 64-unit chunk (FT=2)
   int mod_w;
   bool loaded;
+  bool fused;   // shape served by the fused inference kernels (otherwise only the scldm_dit_train_* path)
   void* stream[2][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack)
   void* wfinal[2];   // [precision] packed final_layer.linear
   float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)

@@ -12,10 +12,7 @@
 namespace scldm {
 namespace train {
 
-constexpr int kD = 256;    // n_embed
-constexpr int kS = 16;     // tokens per sample
-constexpr int kNH = 8;     // heads
-constexpr int kHD = 32;    // head dim
+constexpr int kS = 16;     // tokens per sample (seq_len of every reference config)
 
 // ---------------------------------------------------------------------------------------------------------------
 // C[m][n] (+)= sum_k A(m,k) * B(n,k) (+ bias[n]),  A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk].
@@ -330,8 +327,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ P, int splits, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Elementwise / per-token kernels
+// Elementwise / per-token kernels.  Width D = n_embed is a runtime multiple of 256 (one float4 per lane per 256
+// features); 16 tokens per sample; heads of 32 or 64 features.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxNQ = 8;   // D <= 2048: float4 slots per lane of a token row (kernels are instantiated per D / 256)
+
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // TimestepEmbedder.timestep_embedding (layers.py:351-361): [cos(t f_k) | sin(t f_k)], f_k = exp(-ln(1e4) k / 128)
@@ -358,38 +358,38 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __res
 }
 
 // c[i] = temb[i] + sum_classes table_c[label_c[i] or null_c]     (nnets.py:283-288,380-456; labels already carry
-// the dropout decisions; labels[c] == NULL selects the null token for every row)
+// the dropout decisions; labels[c] == NULL selects the null token for every row).  grid (n, D/256).
 struct EmbedArgs {
   const float* table[SCLDM_MAX_CLASSES];
   const int64_t* labels[SCLDM_MAX_CLASSES];
   int vocab[SCLDM_MAX_CLASSES];
   int n_classes;
 };
-__global__ void cond_sum_kernel(const float* __restrict__ temb, EmbedArgs e, int n, float* __restrict__ c) {
-  const int i = blockIdx.x, f = threadIdx.x;
+__global__ void cond_sum_kernel(const float* __restrict__ temb, EmbedArgs e, int n, int D, float* __restrict__ c) {
+  const int i = blockIdx.x, f = blockIdx.y * 256 + threadIdx.x;
   if (i >= n) return;
-  float v = temb[(long)i * kD + f];
+  float v = temb[(long)i * D + f];
   for (int k = 0; k < e.n_classes; ++k) {
     long row = e.labels[k] ? (long)e.labels[k][i] : (long)e.vocab[k];
     row = row < 0 ? 0 : (row > e.vocab[k] ? e.vocab[k] : row);
-    v += e.table[k][row * kD + f];
+    v += e.table[k][row * D + f];
   }
-  c[(long)i * kD + f] = v;
+  c[(long)i * D + f] = v;
 }
-// d table_c[row] = sum over samples whose label is `row` of dc  (deterministic: one workgroup per table row; the
-// 256 threads test 256 labels at a time and exchange wave ballots through LDS, then walk the few matches in order)
+// d table_c[row] = sum over samples whose label is `row` of dc  (deterministic: one workgroup per (table row, 256-feature
+// slice); the 256 threads test 256 labels at a time and exchange wave ballots through LDS, then walk the matches in order)
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels, int vocab,
-                                                        int n, float* __restrict__ dtable) {
+                                                        int n, int D, float* __restrict__ dtable) {
   __shared__ unsigned long long hit[4];
-  const int row = blockIdx.x, f = threadIdx.x, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x, tid = threadIdx.x, f = blockIdx.y * 256 + tid, wave = tid >> 6;
   float s = 0.f;
   for (int i0 = 0; i0 < n; i0 += 256) {
-    const int i = i0 + f;
+    const int i = i0 + tid;
     long l = vocab;
     if (i < n && labels) l = (long)labels[i];
     l = l < 0 ? 0 : (l > vocab ? vocab : l);
     const unsigned long long m = __ballot(i < n && l == row);
-    if ((f & 63) == 0) hit[wave] = m;
+    if ((tid & 63) == 0) hit[wave] = m;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         for (int j = 0; j < 8; ++j) {
           const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
           mm &= mm - 1;
-          v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * kD + f] : 0.f;
+          v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * D + f] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[j];
@@ -408,36 +408,56 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     }
     __syncthreads();
   }
-  dtable[(long)row * kD + f] = s;
+  dtable[(long)row * D + f] = s;
 }
 
 // x[t][f] += pos[t % 16][f]
-__global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long tokens) {
-  const long total = tokens * kD;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    x[i] += pos[i % (kS * kD)];
+__global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long tokens, int D) {
+  const long total = tokens * D, period = (long)kS * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) x[i] += pos[i % period];
 }
 
 // h = LN(x) * (1 + scale[b]) + shift[b], LayerNorm without affine (nnets.py:257-258), one wave per token.
 // stats[t] = (mean, rstd).  mod row of sample b at mod + b*mod_stride; scale/shift at column offsets.
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mod, long mod_stride,
                                                          int sc_off, int sh_off, float eps, long tokens, float* __restrict__ h,
                                                          float* __restrict__ stats) {
+  constexpr int D = NQ * 256, nq = NQ, kMaxDQ = NQ;
   const int lane = threadIdx.x & 63;
   const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
   if (t >= tokens) return;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * kD + lane * 4);
-  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / kD);
-  const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
-  const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / kD);
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float* m = mod + (t / kS) * mod_stride;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(m + sc_off + lane * 4);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(m + sh_off + lane * 4);
-  f32x4 o;
+  f32x4 v[kMaxDQ];
+  float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = d[i] * rstd * (1.0f + sc[i]) + sh[i];
-  *reinterpret_cast<f32x4*>(h + t * kD + lane * 4) = o;
+  for (int q = 0; q < kMaxDQ; ++q)
+    if (q < nq) {
+      v[q] = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
+      sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+    }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < kMaxDQ; ++q)
+    if (q < nq) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[q][i] -= mean;
+        sq += v[q][i] * v[q][i];
+      }
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  const float* m = mod + (t / kS) * mod_stride;
+#pragma unroll
+  for (int q = 0; q < kMaxDQ; ++q)
+    if (q < nq) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(m + sc_off + q * 256 + lane * 4);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(m + sh_off + q * 256 + lane * 4);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = v[q][i] * rstd * (1.0f + sc[i]) + sh[i];
+      *reinterpret_cast<f32x4*>(h + t * D + q * 256 + lane * 4) = o;
+    }
   if (lane == 0) {
     stats[t * 2] = mean;
     stats[t * 2 + 1] = rstd;
@@ -447,85 +467,107 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
 // Backward of ln_mod_fwd for one sample per workgroup (4 waves x 4 tokens):
 //   g = dh * (1 + scale);  dx (+)= rstd * (g - mean_f(g) - xhat * mean_f(g * xhat))
 //   dscale[b] = sum_t dh * xhat;  dshift[b] = sum_t dh      (written to dmod row b at the same column offsets)
+template <int NQ>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ stats, const float* __restrict__ mod,
                                                          long mod_stride, int sc_off, int sh_off, float* __restrict__ dx,
                                                          int accumulate_dx, float* __restrict__ dmod) {
   __shared__ f32x4 red[2][4][64];
+  constexpr int D = NQ * 256, nq = NQ, kMaxDQ = NQ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long b = blockIdx.x;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + sc_off + lane * 4);
-  f32x4 dsc = {0.f, 0.f, 0.f, 0.f}, dsh = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc[kMaxDQ], dsc[kMaxDQ], dsh[kMaxDQ];
+#pragma unroll
+  for (int q = 0; q < kMaxDQ; ++q)
+    if (q < nq) {
+      sc[q] = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + sc_off + q * 256 + lane * 4);
+      dsc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dsh[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   for (int tt = 0; tt < 4; ++tt) {
     const long t = b * kS + wave * 4 + tt;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * kD + lane * 4);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dh + t * kD + lane * 4);
     const float mean = stats[t * 2], rstd = stats[t * 2 + 1];
-    f32x4 xh, g;
+    f32x4 xh[kMaxDQ], g[kMaxDQ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      xh[i] = (v[i] - mean) * rstd;
-      g[i] = d[i] * (1.0f + sc[i]);
-      s1 += g[i];
-      s2 += g[i] * xh[i];
-      dsc[i] += d[i] * xh[i];
-      dsh[i] += d[i];
-    }
-    s1 = wave_sum(s1) * (1.0f / kD);
-    s2 = wave_sum(s2) * (1.0f / kD);
-    f32x4 o;
+    for (int q = 0; q < kMaxDQ; ++q)
+      if (q < nq) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dh + t * D + q * 256 + lane * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = rstd * (g[i] - s1 - xh[i] * s2);
-    float* p = dx + t * kD + lane * 4;
-    if (accumulate_dx) {
-      const f32x4 old = *reinterpret_cast<const f32x4*>(p);
+        for (int i = 0; i < 4; ++i) {
+          xh[q][i] = (v[i] - mean) * rstd;
+          g[q][i] = d[i] * (1.0f + sc[q][i]);
+          s1 += g[q][i];
+          s2 += g[q][i] * xh[q][i];
+          dsc[q][i] += d[i] * xh[q][i];
+          dsh[q][i] += d[i];
+        }
+      }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] += old[i];
-    }
-    *reinterpret_cast<f32x4*>(p) = o;
+    for (int q = 0; q < kMaxDQ; ++q)
+      if (q < nq) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rstd * (g[q][i] - s1 - xh[q][i] * s2);
+        float* p = dx + t * D + q * 256 + lane * 4;
+        if (accumulate_dx) {
+          const f32x4 old = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] += old[i];
+        }
+        *reinterpret_cast<f32x4*>(p) = o;
+      }
   }
-  red[0][wave][lane] = dsc;
-  red[1][wave][lane] = dsh;
-  __syncthreads();
-  if (wave < 2) {
-    f32x4 s = red[wave][0][lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const f32x4 o = red[wave][w][lane];
+  for (int q = 0; q < kMaxDQ; ++q)
+    if (q < nq) {   // nq is workgroup-uniform: the barriers are reached by every thread
+      red[0][wave][lane] = dsc[q];
+      red[1][wave][lane] = dsh[q];
+      __syncthreads();
+      if (wave < 2) {
+        f32x4 s = red[wave][0][lane];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[i] += o[i];
+        for (int w = 1; w < 4; ++w) {
+          const f32x4 o = red[wave][w][lane];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s[i] += o[i];
+        }
+        *reinterpret_cast<f32x4*>(dmod + b * mod_stride + (wave == 0 ? sc_off : sh_off) + q * 256 + lane * 4) = s;
+      }
+      __syncthreads();
     }
-    *reinterpret_cast<f32x4*>(dmod + b * mod_stride + (wave == 0 ? sc_off : sh_off) + lane * 4) = s;
-  }
 }
 
 // x_out = x + gate[b] * y
 __global__ void gate_res_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mod,
-                                long mod_stride, int g_off, long tokens, float* __restrict__ out) {
-  const long total = tokens * (kD / 4);
+                                long mod_stride, int g_off, long tokens, int D, float* __restrict__ out) {
+  const int dq = D / 4;
+  const long total = tokens * dq;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = i / (kD / 4);
-    const int f = (int)(i % (kD / 4)) * 4;
+    const long t = i / dq;
+    const int f = (int)(i % dq) * 4;
     const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (t / kS) * mod_stride + g_off + f);
-    const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * kD + f), b = *reinterpret_cast<const f32x4*>(y + t * kD + f);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * D + f), b = *reinterpret_cast<const f32x4*>(y + t * D + f);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = a[k] + g[k] * b[k];
-    *reinterpret_cast<f32x4*>(out + t * kD + f) = o;
+    *reinterpret_cast<f32x4*>(out + t * D + f) = o;
   }
 }
-// dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (one workgroup per sample, thread = feature)
+// dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (grid (samples, D/256), thread = feature)
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y,
-                                                       const float* __restrict__ mod, long mod_stride, int g_off,
+                                                       const float* __restrict__ mod, long mod_stride, int g_off, int D,
                                                        float* __restrict__ dy, float* __restrict__ dmod) {
   const long b = blockIdx.x;
-  const int f = threadIdx.x;
+  const int f = blockIdx.y * 256 + threadIdx.x;
   const float g = mod[b * mod_stride + g_off + f];
   float s = 0.f;
 #pragma unroll
   for (int t = 0; t < kS; ++t) {
-    const long i = (b * kS + t) * kD + f;
+    const long i = (b * kS + t) * D + f;
     const float d = dx[i];
     dy[i] = g * d;
     s += d * y[i];
@@ -550,33 +592,37 @@ __global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Self-attention over the 16 tokens of one sample, one wave per (sample, head); qkv rows are [q | k | v] with head
-// h at columns h*32 (layers.py:147-151).  softmax(q k^T / sqrt(32)) v.  Nothing is saved: the backward recomputes P.
+// Self-attention over the 16 tokens of one sample, one wave per (sample, head); qkv rows are [q | k | v] (each D wide)
+// with head h at columns h*HD (layers.py:147-151).  softmax(q k^T / sqrt(HD)) v.  Nothing is saved: the backward
+// recomputes P.  HD = 32 or 64; lane -> (token = lane / 4, HD/4 consecutive columns).
 // ---------------------------------------------------------------------------------------------------------------
+template <int HD>
 struct AttnTile {
-  float q[kS][kHD + 1], k[kS][kHD + 1], v[kS][kHD + 1], p[kS][kS + 1];
+  float q[kS][HD + 1], k[kS][HD + 1], v[kS][HD + 1], p[kS][kS + 1];
 };
-__device__ __forceinline__ void attn_load(AttnTile& s, const float* __restrict__ qkv, long sample, int head, int lane) {
-  // 3 x 16 x 32 floats; lane -> (token = lane / 4 [+16 never], 8 columns)
-  const int tok = lane >> 2, c0 = (lane & 3) * 8;
-  const float* base = qkv + (sample * kS + tok) * (3 * kD) + head * kHD + c0;
+template <int HD>
+__device__ __forceinline__ void attn_load(AttnTile<HD>& s, const float* __restrict__ qkv, long sample, int head, int D, int lane) {
+  constexpr int CW = HD / 4;
+  const int tok = lane >> 2, c0 = (lane & 3) * CW;
+  const float* base = qkv + (sample * kS + tok) * (3L * D) + head * HD + c0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < CW; ++i) {
     s.q[tok][c0 + i] = base[i];
-    s.k[tok][c0 + i] = base[kD + i];
-    s.v[tok][c0 + i] = base[2 * kD + i];
+    s.k[tok][c0 + i] = base[D + i];
+    s.v[tok][c0 + i] = base[2 * D + i];
   }
 }
 // lane -> (i = lane / 4, j in {j0..j0+3}, j0 = (lane & 3) * 4): returns this lane's 4 probabilities of row i
-__device__ __forceinline__ void attn_probs(const AttnTile& s, int lane, float* p4) {
+template <int HD>
+__device__ __forceinline__ void attn_probs(const AttnTile<HD>& s, int lane, float* p4) {
   const int i = lane >> 2, j0 = (lane & 3) * 4;
-  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;  // 1/sqrt(HD)
   float mx = -INFINITY;
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < kHD; ++d) acc += s.q[i][d] * s.k[j0 + jj][d];
+    for (int d = 0; d < HD; ++d) acc += s.q[i][d] * s.k[j0 + jj][d];
     p4[jj] = acc * scale;
     mx = fmaxf(mx, p4[jj]);
   }
@@ -595,93 +641,102 @@ __device__ __forceinline__ void attn_probs(const AttnTile& s, int lane, float* p
   for (int jj = 0; jj < 4; ++jj) p4[jj] *= inv;
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, float* __restrict__ ao) {
-  __shared__ AttnTile tiles[4];
+template <int HD>
+__global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, int n_head, int D,
+                                                       float* __restrict__ ao) {
+  __shared__ AttnTile<HD> tiles[2];
+  constexpr int CW = HD / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long unit = blockIdx.x * 4L + wave;   // (sample, head)
-  if (unit >= n_samples * kNH) return;
-  const long sample = unit / kNH;
-  const int head = (int)(unit % kNH);
-  AttnTile& s = tiles[wave];
-  attn_load(s, qkv, sample, head, lane);
+  const long unit = blockIdx.x * 2L + wave;   // (sample, head)
+  if (unit >= n_samples * n_head) return;
+  const long sample = unit / n_head;
+  const int head = (int)(unit % n_head);
+  AttnTile<HD>& s = tiles[wave];
+  attn_load<HD>(s, qkv, sample, head, D, lane);
   __builtin_amdgcn_wave_barrier();
   float p4[4];
-  attn_probs(s, lane, p4);
+  attn_probs<HD>(s, lane, p4);
   const int i = lane >> 2, j0 = (lane & 3) * 4;
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) s.p[i][j0 + jj] = p4[jj];
   __builtin_amdgcn_wave_barrier();
-  const int d0 = (lane & 3) * 8;
-  float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int d0 = (lane & 3) * CW;
+  float o[CW];
+#pragma unroll
+  for (int d = 0; d < CW; ++d) o[d] = 0.f;
 #pragma unroll
   for (int j = 0; j < kS; ++j) {
     const float pj = s.p[i][j];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) o[d] += pj * s.v[j][d0 + d];
+    for (int d = 0; d < CW; ++d) o[d] += pj * s.v[j][d0 + d];
   }
-  float* out = ao + (sample * kS + i) * kD + head * kHD + d0;
+  float* out = ao + (sample * kS + i) * (long)D + head * HD + d0;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) out[d] = o[d];
+  for (int d = 0; d < CW; ++d) out[d] = o[d];
 }
 
 // dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP));  dq = scale dS k;  dk = scale dS^T q;  dv = P^T dao
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao, long n_samples,
-                                                       float* __restrict__ dqkv) {
-  __shared__ AttnTile tiles[4];
-  __shared__ float dos[4][kS][kHD + 1];
-  __shared__ float dss[4][kS][kS + 1];
+template <int HD>
+__global__ __launch_bounds__(128) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao, long n_samples,
+                                                       int n_head, int D, float* __restrict__ dqkv) {
+  __shared__ AttnTile<HD> tiles[2];
+  __shared__ float dos[2][kS][HD + 1];
+  __shared__ float dss[2][kS][kS + 1];
+  constexpr int CW = HD / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long unit = blockIdx.x * 4L + wave;
-  if (unit >= n_samples * kNH) return;
-  const long sample = unit / kNH;
-  const int head = (int)(unit % kNH);
-  AttnTile& s = tiles[wave];
-  attn_load(s, qkv, sample, head, lane);
-  const int i = lane >> 2, c0 = (lane & 3) * 8, j0 = (lane & 3) * 4;
+  const long unit = blockIdx.x * 2L + wave;
+  if (unit >= n_samples * n_head) return;
+  const long sample = unit / n_head;
+  const int head = (int)(unit % n_head);
+  AttnTile<HD>& s = tiles[wave];
+  attn_load<HD>(s, qkv, sample, head, D, lane);
+  const int i = lane >> 2, c0 = (lane & 3) * CW, j0 = (lane & 3) * 4;
   {
-    const float* src = dao + (sample * kS + i) * kD + head * kHD + c0;
+    const float* src = dao + (sample * kS + i) * (long)D + head * HD + c0;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) dos[wave][i][c0 + d] = src[d];
+    for (int d = 0; d < CW; ++d) dos[wave][i][c0 + d] = src[d];
   }
   __builtin_amdgcn_wave_barrier();
   float p4[4], dp4[4];
-  attn_probs(s, lane, p4);
+  attn_probs<HD>(s, lane, p4);
   float dot = 0.f;
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < kHD; ++d) acc += dos[wave][i][d] * s.v[j0 + jj][d];
+    for (int d = 0; d < HD; ++d) acc += dos[wave][i][d] * s.v[j0 + jj][d];
     dp4[jj] = acc;
     dot += p4[jj] * acc;
   }
   dot += __shfl_xor(dot, 1);
   dot += __shfl_xor(dot, 2);
-  const float scale = 0.17677669529663687f;
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.125f;
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     s.p[i][j0 + jj] = p4[jj];
     dss[wave][i][j0 + jj] = p4[jj] * (dp4[jj] - dot) * scale;
   }
   __builtin_amdgcn_wave_barrier();
-  // this lane now owns row `i` (as query row for dq, as key row for dk / dv) and 8 columns starting at c0
-  float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // this lane now owns row `i` (as query row for dq, as key row for dk / dv) and CW columns starting at c0
+  float dq[CW], dk[CW], dv[CW];
+#pragma unroll
+  for (int d = 0; d < CW; ++d) dq[d] = dk[d] = dv[d] = 0.f;
 #pragma unroll
   for (int j = 0; j < kS; ++j) {
     const float ds_ij = dss[wave][i][j], ds_ji = dss[wave][j][i], p_ji = s.p[j][i];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < CW; ++d) {
       dq[d] += ds_ij * s.k[j][c0 + d];
       dk[d] += ds_ji * s.q[j][c0 + d];
       dv[d] += p_ji * dos[wave][j][c0 + d];
     }
   }
-  float* dst = dqkv + (sample * kS + i) * (3 * kD) + head * kHD + c0;
+  float* dst = dqkv + (sample * kS + i) * (3L * D) + head * HD + c0;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
+  for (int d = 0; d < CW; ++d) {
     dst[d] = dq[d];
-    dst[kD + d] = dk[d];
-    dst[2 * kD + d] = dv[d];
+    dst[D + d] = dk[d];
+    dst[2 * D + d] = dv[d];
   }
 }
 

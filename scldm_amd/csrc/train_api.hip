@@ -40,7 +40,7 @@ struct Carver {
 };
 
 Saved carve_saved(const scldm_dit* h, int n, void* base) {
-  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim;
+  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim, kD = h->cfg.n_embed;
   Carver c{reinterpret_cast<char*>(base)};
   Saved s;
   s.freq = c.take((size_t)n * 256);
@@ -48,7 +48,7 @@ Saved carve_saved(const scldm_dit* h, int n, void* base) {
   s.sth = c.take((size_t)n * kD);
   s.c = c.take((size_t)n * kD);
   s.sc = c.take((size_t)n * kD);
-  s.mod = c.take((size_t)n * h->mod_w);
+  s.mod = c.take((size_t)n * ((size_t)h->cfg.n_layer * 6 * kD + 2 * kD));
   s.layer.resize(h->cfg.n_layer);
   for (auto& l : s.layer) {
     l.x_in = c.take(T * kD);
@@ -74,7 +74,7 @@ Saved carve_saved(const scldm_dit* h, int n, void* base) {
 
 constexpr int kMaxSplit = 32;
 Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
-  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim;
+  const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim, kD = h->cfg.n_embed;
   Carver c{reinterpret_cast<char*>(base)};
   Scratch s;
   s.dx = c.take(T * kD);
@@ -85,7 +85,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.dhid = c.take(T * H);
   s.da = c.take(T * H);
   s.db = c.take(T * H);
-  s.dmod = c.take((size_t)n * h->mod_w);
+  s.dmod = c.take((size_t)n * ((size_t)h->cfg.n_layer * 6 * kD + 2 * kD));
   s.dsc = c.take((size_t)n * kD);
   s.dc = c.take((size_t)n * kD);
   s.dsth = c.take((size_t)n * kD);
@@ -184,11 +184,60 @@ int colsum(hipStream_t st, const float* X, long rows, int cols, long ld, float* 
 
 inline unsigned ew_grid(long count) { return (unsigned)std::max<long>(1, std::min<long>(cdiv(count, 256), 4096)); }
 
+// ---- launches of the width-templated kernels -------------------------------------------------------------------
+#define SCLDM_NQ_SWITCH(nq, CALL)  \
+  switch (nq) {                    \
+    case 1: { CALL(1); break; }    \
+    case 2: { CALL(2); break; }    \
+    case 3: { CALL(3); break; }    \
+    case 4: { CALL(4); break; }    \
+    case 5: { CALL(5); break; }    \
+    case 6: { CALL(6); break; }    \
+    case 7: { CALL(7); break; }    \
+    default: { CALL(8); break; }   \
+  }
+
+int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int sc_off, int sh_off, float eps, long T, float* h,
+           float* stats) {
+#define CALL(NQ) hipLaunchKernelGGL(ln_mod_fwd_kernel<NQ>, dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats)
+  SCLDM_NQ_SWITCH(D / 256, CALL)
+#undef CALL
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const float* stats, const float* mod, long mw, int sc_off,
+           int sh_off, float* dx, int accumulate, float* dmod) {
+#define CALL(NQ) hipLaunchKernelGGL(ln_mod_bwd_kernel<NQ>, dim3(n), dim3(256), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
+  SCLDM_NQ_SWITCH(D / 256, CALL)
+#undef CALL
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+int attn_fwd(hipStream_t st, int D, int n_head, long n, const float* qkv, float* ao) {
+  const dim3 grid(cdiv(n * n_head, 2));
+  if (D / n_head == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, st, qkv, n, n_head, D, ao);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(128), 0, st, qkv, n, n_head, D, ao);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const float* dao, float* dqkv) {
+  const dim3 grid(cdiv(n * n_head, 2));
+  if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(128), 0, st, qkv, dao, n, n_head, D, dqkv);
+  else hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(128), 0, st, qkv, dao, n, n_head, D, dqkv);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
 int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
   g_bf16 = precision == SCLDM_PREC_BF16;
   if (n < 1) return fail(SCLDM_ERR_SHAPE, "n must be >= 1");
+  const scldm_dit_config& c = h->cfg;
+  const int hd = c.n_head > 0 ? c.n_embed / c.n_head : 0;
+  if (c.n_embed % 256 != 0 || c.n_embed > 256 * kMaxNQ || c.seq_len != kS || c.n_embed % c.n_head != 0 || (hd != 32 && hd != 64))
+    return fail(SCLDM_ERR_SHAPE, "training path supports n_embed %% 256 == 0 (<= %d), seq_len 16, head_dim 32 or 64 (got n_embed %d, n_head %d, seq_len %d)",
+                256 * kMaxNQ, c.n_embed, c.n_head, c.seq_len);
   if (h->cfg.n_embed_input % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs n_embed_input %% 4 == 0 (got %d)", h->cfg.n_embed_input);
   if (h->cfg.hidden_dim % 4 != 0) return fail(SCLDM_ERR_SHAPE, "training path needs hidden_dim %% 4 == 0 (got %d)", h->cfg.hidden_dim);
   return SCLDM_OK;
@@ -218,7 +267,8 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   if (!x || !t || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& cfg = h->cfg;
-  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, mw = h->mod_w;
+  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, kD = cfg.n_embed, kNH = cfg.n_head;
+  const int mw = L * 6 * kD + 2 * kD;
   const long T = (long)n * kS;
   Saved s = carve_saved(h, n, saved_);
   Scratch k = carve_scratch(h, n, ws);
@@ -237,7 +287,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     e.labels[c] = labels ? labels[c] : nullptr;
     e.vocab[c] = cfg.class_vocab[c];
   }
-  hipLaunchKernelGGL(cond_sum_kernel, dim3(n), dim3(kD), 0, st, k.temb, e, n, s.c);
+  hipLaunchKernelGGL(cond_sum_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.temb, e, n, kD, s.c);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
   LAUNCH_CHECK();
@@ -248,38 +298,31 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   // x_0 = input_proj(x) + pos_embed (nnets.py:290)
   float* x0 = L > 0 ? s.layer[0].x_in : s.x_last;
   TRY(linear_fwd(st, x, din, w->in_w, (int)T, kD, din, w->in_b, x0, kD, k));
-  hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T);
+  hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T, kD);
   LAUNCH_CHECK();
 
   for (int l = 0; l < L; ++l) {
     LayerSaved& a = s.layer[l];
-    const int o = l * 6 * kD;   // a0..a5 at o + i*256 (layers.py:214-216)
+    const int o = l * 6 * kD;   // a0..a5 at o + i*D (layers.py:214-216)
     float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
-    hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T,
-                       a.h1, a.st1);
-    LAUNCH_CHECK();
+    TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
     TRY(linear_fwd(st, a.h1, kD, w->attn_w[l], (int)T, 3 * kD, kD, w->attn_b[l], a.qkv, 3 * kD, k));
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv((long)n * kNH, 4)), dim3(256), 0, st, a.qkv, (long)n, a.ao);
-    LAUNCH_CHECK();
+    TRY(attn_fwd(st, kD, kNH, n, a.qkv, a.ao));
     TRY(linear_fwd(st, a.ao, kD, w->proj_w[l], (int)T, kD, kD, w->proj_b[l], a.y1, kD, k));
-    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, a.x_mid);
+    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD,
-                       cfg.layernorm_eps, T, a.h2, a.st2);
-    LAUNCH_CHECK();
+    TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
     TRY(linear_fwd(st, a.h2, kD, w->w1[l], (int)T, H, kD, nullptr, a.a, H, k));
     TRY(linear_fwd(st, a.h2, kD, w->w2[l], (int)T, H, kD, nullptr, a.b, H, k));
     hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H);
     LAUNCH_CHECK();
     TRY(linear_fwd(st, a.hid, H, w->cproj[l], (int)T, kD, H, nullptr, a.y2, kD, k));
-    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, x_next);
+    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
     LAUNCH_CHECK();
   }
   // FinalLayerDit (layers.py:397-401): [shift | scale] = adaLN(c); LN(x) * (1 + scale) + shift; Linear
   const int of = L * 6 * kD;
-  hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3(cdiv(T, 4)), dim3(256), 0, st, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T,
-                     s.h_f, s.st_f);
-  LAUNCH_CHECK();
+  TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
   TRY(linear_fwd(st, s.h_f, kD, w->fin_w, (int)T, din, kD, w->fin_b, out, din, k));
   return SCLDM_OK;
 }
@@ -291,7 +334,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& cfg = h->cfg;
-  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, mw = h->mod_w;
+  const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, kD = cfg.n_embed, kNH = cfg.n_head;
+  const int mw = L * 6 * kD + 2 * kD;
   const long T = (long)n * kS;
   Saved s = carve_saved(h, n, saved_);
   Scratch k = carve_scratch(h, n, ws);
@@ -301,14 +345,13 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k));
   TRY(colsum(st, dout, T, din, din, g->fin_b, k));
   TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
-  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod);
-  LAUNCH_CHECK();
+  TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
 
   for (int l = L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n), dim3(256), 0, st, k.dx, a.y2, s.mod, (long)mw, o + 5 * kD, k.dy, k.dmod);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dx, a.y2, s.mod, (long)mw, o + 5 * kD, kD, k.dy, k.dmod);
     LAUNCH_CHECK();
     TRY(linear_wgrad(st, k.dy, kD, a.hid, H, (int)T, kD, H, g->cproj[l], k));
     TRY(linear_dgrad(st, k.dy, kD, w->cproj[l], (int)T, kD, H, k.dhid, H, false, k));
@@ -318,22 +361,18 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(linear_wgrad(st, k.db, H, a.h2, kD, (int)T, H, kD, g->w2[l], k));
     TRY(linear_dgrad(st, k.da, H, w->w1[l], (int)T, H, kD, k.dh, kD, false, k));
     TRY(linear_dgrad(st, k.db, H, w->w2[l], (int)T, H, kD, k.dh, kD, true, k));
-    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1,
-                       k.dmod);
-    LAUNCH_CHECK();
+    TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n), dim3(256), 0, st, k.dx, a.y1, s.mod, (long)mw, o + 2 * kD, k.dy, k.dmod);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dx, a.y1, s.mod, (long)mw, o + 2 * kD, kD, k.dy, k.dmod);
     LAUNCH_CHECK();
     TRY(linear_wgrad(st, k.dy, kD, a.ao, kD, (int)T, kD, kD, g->proj_w[l], k));
     TRY(colsum(st, k.dy, T, kD, kD, g->proj_b[l], k));
     TRY(linear_dgrad(st, k.dy, kD, w->proj_w[l], (int)T, kD, kD, k.dao, kD, false, k));
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(cdiv((long)n * kNH, 4)), dim3(256), 0, st, a.qkv, k.dao, (long)n, k.dqkv);
-    LAUNCH_CHECK();
+    TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
     TRY(linear_wgrad(st, k.dqkv, 3 * kD, a.h1, kD, (int)T, 3 * kD, kD, g->attn_w[l], k));
     TRY(colsum(st, k.dqkv, T, 3 * kD, 3 * kD, g->attn_b[l], k));
     TRY(linear_dgrad(st, k.dqkv, 3 * kD, w->attn_w[l], (int)T, 3 * kD, kD, k.dh, kD, false, k));
-    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(n), dim3(256), 0, st, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod);
-    LAUNCH_CHECK();
+    TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
   }
 
   // ---- input projection + pos_embed ----
@@ -358,8 +397,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
   for (int c = 0; c < cfg.n_classes; ++c) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cfg.class_vocab[c] + 1), dim3(kD), 0, st, k.dc, labels ? labels[c] : nullptr,
-                       cfg.class_vocab[c], n, g->class_emb[c]);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cfg.class_vocab[c] + 1, kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
+                       cfg.class_vocab[c], n, kD, g->class_emb[c]);
     LAUNCH_CHECK();
   }
   TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k));

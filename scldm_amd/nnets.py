@@ -303,6 +303,59 @@ class DiT(nn.Module):
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ shapes outside the fused family
+    @property
+    def fused_shape(self) -> bool:
+        """True for the reference's DiT shape family (256 wide, 8 heads, 16 tokens), served by the fused layer kernel.
+        Other shapes (n_embed % 256 == 0, head_dim 32/64, e.g. a DiT-L) run on the generic GEMM-based HIP path: the
+        training kernels, also used for their inference."""
+        return self.n_embed == 256 and self.n_head == 8 and self.seq_len == 16 and self.n_embed_input <= 32
+
+    def _generic_forward(self, x: torch.Tensor, t: torch.Tensor, labels) -> torch.Tensor:
+        """DiT.forward through scldm_dit_train_forward without keeping the activation record (inference on non-fused shapes)."""
+        L, h = self._native_handle()
+        self._check_params()
+        n = x.shape[0]
+        saved = torch.empty(L.scldm_dit_train_saved_bytes(h, n), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(L.scldm_dit_train_workspace_bytes(h, n), dtype=torch.uint8, device=x.device)
+        w, keep = self._param_struct(lambda p: p.data_ptr())
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
+                                                 out.data_ptr(), self._prec(), saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
+                       "scldm_dit_train_forward")
+        del keep
+        return out
+
+    def _generic_forward_with_cfg(self, x, t, condition, cfg_scale):
+        """forward_with_cfg composed from forward passes exactly as the reference does (nnets.py:336-378)."""
+        n = x.shape[0]
+        B = n // 2
+        names = self._class_names
+        null = _lib.ptr_array([None] * len(names))
+        u = self._generic_forward(x, t, null)                                    # all-null conditioning, :352-356
+        if condition is None or cfg_scale is None:
+            return u
+        x2, t2, u2 = x[B:].contiguous(), t[B:].contiguous(), u[B:]
+        half = {k: v[B:].to(device=x.device, dtype=torch.long).contiguous() for k, v in condition.items()}
+
+        def cond_pass(keys):
+            ptrs = _lib.ptr_array([half[c].data_ptr() if c in keys else None for c in names])
+            return self._generic_forward(x2, t2, ptrs)
+
+        if self.condition_strategy == "joint":                                   # :364-369
+            for c in names:
+                if c not in half:
+                    raise KeyError(c)
+            g = u2 + (sum(cfg_scale.values()) / len(cfg_scale)) * (cond_pass(set(names)) - u2)
+        else:                                                                    # :372-376
+            g = u2.clone()
+            for c, s in cfg_scale.items():
+                if c not in half or c not in names:
+                    raise KeyError(c)
+                g = g + float(s) * (cond_pass({c}) - u2)
+        return torch.cat([u[:B], g], dim=0)
+
     # ------------------------------------------------------------------ label handling (nnets.py:380-456)
     def _label_ptrs(self, condition: dict[str, torch.Tensor], n: int, force_drop_ids: bool):
         """Device label pointers per class (sorted-name order); None -> the class uses its null token.
@@ -362,6 +415,8 @@ class DiT(nn.Module):
             # differentiable w.r.t. the parameters (loss.backward() then fails loudly, it never returns silent zeros).
             params = [p for _, p in self.named_parameters()]
             return _DiTTrainFn.apply(self, x, t, labels, keep, *params)
+        if not self.fused_shape:
+            return self._generic_forward(x, t, labels)
         L, h = self._native()
         out = torch.empty_like(x)
         ws = self._workspace(L, n, n, 0)
@@ -432,6 +487,12 @@ class DiT(nn.Module):
                          cfg_scale: dict[str, float] | None = None) -> torch.Tensor:
         if self.training:
             raise NotImplementedError("forward_with_cfg is an inference path; call .eval() first")
+        if not self.fused_shape:
+            xg, tg = _require_cuda_f32("x", x), _require_cuda_f32("t", t)
+            if xg.shape[0] % 2 or xg.shape[1:] != (self.seq_len, self.n_embed_input) or tg.shape != (xg.shape[0],):
+                raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(xg.shape)}, {tuple(tg.shape)}")
+            with torch.no_grad():
+                return self._generic_forward_with_cfg(xg, tg, condition, cfg_scale)
         L, h = self._native()
         uniform_t = getattr(t, "_scldm_uniform_t", False)  # set by scldm_amd.transport's ODE loop (scalar t broadcast)
         x = _require_cuda_f32("x", x)
@@ -467,6 +528,22 @@ class DiT(nn.Module):
             raise NotImplementedError("sampling is an inference path; call .eval() first")
         if num_steps < 2:
             raise ValueError("num_steps must be >= 2 (grid points)")
+        if not self.fused_shape:   # fixed-grid Euler / Heun over the generic forward_with_cfg (same grid as the fused loop)
+            z = _require_cuda_f32("z", z).clone()
+            method = sampling_method.lower()
+            if method not in _lib.METHODS:
+                raise KeyError(method)
+            hstep = 1.0 / (num_steps - 1)
+            for i in range(num_steps - 1):
+                t0 = torch.full((z.shape[0],), i * hstep, device=z.device)
+                k1 = self._generic_forward_with_cfg(z, t0, condition, cfg_scale)
+                if method == "euler":
+                    z = z + hstep * k1
+                else:
+                    t1 = torch.full((z.shape[0],), (i + 1) * hstep, device=z.device)
+                    k2 = self._generic_forward_with_cfg(z + hstep * k1, t1, condition, cfg_scale)
+                    z = z + (0.5 * hstep) * (k1 + k2)
+            return z
         L, h = self._native()
         z = _require_cuda_f32("z", z).clone()
         n = z.shape[0]
