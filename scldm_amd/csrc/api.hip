@@ -37,6 +37,13 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   // serves the generic (GEMM-based) scldm_dit_train_* path, and the fused entry points report SCLDM_ERR_SHAPE.
   const bool fused = cfg->n_embed == 256 && cfg->n_head == 8 && cfg->seq_len == 16 && cfg->n_embed_input <= 32;
   if (cfg->n_embed_input < 1) return fail(SCLDM_ERR_SHAPE, "n_embed_input must be >= 1");
+  if (!fused) {
+    const int hd = cfg->n_embed % cfg->n_head == 0 ? cfg->n_embed / cfg->n_head : 0;
+    if (cfg->n_embed % 256 != 0 || cfg->n_embed > 2048 || cfg->seq_len != 16 || (hd != 32 && hd != 64))
+      return fail(SCLDM_ERR_SHAPE, "unsupported DiT shape: fused kernels need n_embed=256, n_head=8, seq_len=16; the generic path needs "
+                  "n_embed %% 256 == 0 (<= 2048), seq_len=16, head_dim 32 or 64 (got n_embed=%d, n_head=%d, seq_len=%d)", cfg->n_embed,
+                  cfg->n_head, cfg->seq_len);
+  }
   if (cfg->n_layer < 1 || cfg->hidden_dim < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / hidden_dim");
   if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
   scldm_dit* h = new scldm_dit();

@@ -33,6 +33,13 @@ def test_create_rejects_unsupported_shapes_without_gpu():
     assert rc == -1 and b"n_embed=256" in L.scldm_last_error()
     with pytest.raises(_lib.ScldmError):
         _lib.check(rc, "scldm_dit_create")
+    # a wider shape gets a handle for the generic (training-kernel) path only: the fused entry points refuse it
+    cfg = _lib.DitConfig(n_embed=1024, n_embed_input=16, n_layer=24, n_head=16, seq_len=16, hidden_dim=2732, layernorm_eps=1e-8, n_classes=0)
+    assert L.scldm_dit_create(C.byref(cfg), C.byref(h)) == 0
+    assert L.scldm_dit_train_saved_bytes(h, 2) > 0 and L.scldm_dit_workspace_bytes(h, 2, 2, 0) >= 0
+    w = _lib.DitWeights()
+    assert L.scldm_dit_load_weights(h, C.byref(w), None) == -1 and b"fused DiT layer" in L.scldm_last_error()
+    L.scldm_dit_destroy(h)
 
 
 @pytest.mark.parametrize("name", ["dit_base", "dit_joint"])
