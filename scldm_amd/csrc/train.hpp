@@ -642,12 +642,15 @@ __device__ __forceinline__ void attn_probs(const AttnTile<HD>& s, int lane, floa
 }
 
 template <int HD>
-__global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, int n_head, int D,
-                                                       float* __restrict__ ao) {
-  __shared__ AttnTile<HD> tiles[2];
+constexpr int attn_waves() { return HD == 32 ? 4 : 2; }   // waves (= (sample, head) units) per workgroup: LDS-limited for HD 64
+
+template <int HD>
+__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, int n_head, int D,
+                                                                         float* __restrict__ ao) {
+  __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
   constexpr int CW = HD / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long unit = blockIdx.x * 2L + wave;   // (sample, head)
+  const long unit = blockIdx.x * (long)attn_waves<HD>() + wave;   // (sample, head)
   if (unit >= n_samples * n_head) return;
   const long sample = unit / n_head;
   const int head = (int)(unit % n_head);
@@ -677,14 +680,14 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__
 
 // dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP));  dq = scale dS k;  dk = scale dS^T q;  dv = P^T dao
 template <int HD>
-__global__ __launch_bounds__(128) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao, long n_samples,
-                                                       int n_head, int D, float* __restrict__ dqkv) {
-  __shared__ AttnTile<HD> tiles[2];
-  __shared__ float dos[2][kS][HD + 1];
-  __shared__ float dss[2][kS][kS + 1];
+__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao,
+                                                                         long n_samples, int n_head, int D, float* __restrict__ dqkv) {
+  __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
+  __shared__ float dos[attn_waves<HD>()][kS][HD + 1];
+  __shared__ float dss[attn_waves<HD>()][kS][kS + 1];
   constexpr int CW = HD / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long unit = blockIdx.x * 2L + wave;
+  const long unit = blockIdx.x * (long)attn_waves<HD>() + wave;
   if (unit >= n_samples * n_head) return;
   const long sample = unit / n_head;
   const int head = (int)(unit % n_head);

@@ -214,16 +214,14 @@ int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const 
   return SCLDM_OK;
 }
 int attn_fwd(hipStream_t st, int D, int n_head, long n, const float* qkv, float* ao) {
-  const dim3 grid(cdiv(n * n_head, 2));
-  if (D / n_head == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, st, qkv, n, n_head, D, ao);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(128), 0, st, qkv, n, n_head, D, ao);
+  if (D / n_head == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
+  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
 int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const float* dao, float* dqkv) {
-  const dim3 grid(cdiv(n * n_head, 2));
-  if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, grid, dim3(128), 0, st, qkv, dao, n, n_head, D, dqkv);
-  else hipLaunchKernelGGL(attn_bwd_kernel<64>, grid, dim3(128), 0, st, qkv, dao, n, n_head, D, dqkv);
+  if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
+  else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
