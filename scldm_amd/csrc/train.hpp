@@ -30,6 +30,8 @@ struct GemmArgs {
   int M, N, K;
   int kchunk;      // multiple of kBK; == K rounded up when there is no split
   int accumulate;  // C += (only without split-K)
+  float* rowsum;   // optional: rowsum[z*M + m] = sum_k A(m,k) over this split (bias gradient of a weight-gradient GEMM;
+                   // needs A contiguous along m); written by the workgroups of the first column of tiles
 };
 
 constexpr int kBK = 32;
@@ -74,6 +76,13 @@ struct TileLoader {
       v[j] = r;
     }
   }
+  // MC only: rs[i] += this tile's values of row (tid % (BM/4))*4 + i
+  __device__ __forceinline__ void add_rowsum(float (&rs)[4]) const {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rs[i] += v[j][i];
+  }
   __device__ __forceinline__ void store(float* __restrict__ S /* [kBK][BM+4] */) const {
     constexpr int LD = BM + 4;
     const int tid = threadIdx.x;
@@ -114,8 +123,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
 
   TileLoader<BM, A_KC> la;
   TileLoader<BN, B_KC> lb;
+  const bool want_rs = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;   // workgroup-uniform
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
   la.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend);
   lb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend);
+  if constexpr (!A_KC) if (want_rs) la.add_rowsum(rs);
   la.store(As(0));
   lb.store(Bs(0));
   __syncthreads();
@@ -141,11 +153,27 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
+      if constexpr (!A_KC) if (want_rs) la.add_rowsum(rs);
       la.store(As(buf ^ 1));
       lb.store(Bs(buf ^ 1));
     }
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (!A_KC) {
+    if (want_rs) {   // fold the per-thread row sums: threads sharing tid % (BM/4) hold the same four rows
+      constexpr int kPerRow = BM / 4, kGroups = 256 / kPerRow;
+      float* red = gemm_smem;   // the tiles are dead (the loop ended on a barrier)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[(threadIdx.x / kPerRow) * BM + (threadIdx.x % kPerRow) * 4 + i] = rs[i];
+      __syncthreads();
+      if (threadIdx.x < BM && m0 + threadIdx.x < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kGroups; ++q) t += red[q * BM + threadIdx.x];
+        g.rowsum[(long)blockIdx.z * g.M + m0 + threadIdx.x] = t;
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < WTM; ++i)
@@ -170,25 +198,28 @@ __global__ __launch_bounds__(256) void sgemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------------
 // bf16-operand variant (v_mfma_f32_32x32x16_bf16, fp32 accumulate): same contract and fp32 sources / outputs as
 // sgemm_kernel; operands are rounded to bf16 while they are staged into LDS.  LDS image is [m][k] with k contiguous
-// (row = kBK bf16 + 16 B pad = 80 B: the 32 rows of a ds_read_b128 fragment read hit 16 distinct 16-byte slots).
+// (row = kBKH bf16 + 16 B pad: the 32 rows of a ds_read_b128 fragment read hit 16 distinct 16-byte slots).
 // A source that is contiguous along m (the token-major activations of a weight-gradient GEMM) is transposed in
 // registers: each thread gathers 8 consecutive k for its m and writes one 16-byte row segment.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kLDH = kBK + 8;   // bf16 elements per LDS row
+constexpr int kBKH = 32;          // k per staged tile of the bf16 kernel (64 measured slower: 8.7 vs 8.4 ms per base-DiT step)
+constexpr int kKG = kBKH / 8;      // 8-element k groups per row
+constexpr int kLDH = kBKH + 8;     // bf16 elements per LDS row (144 B: fragment rows fall on distinct 16-byte slots)
 template <int WTM, int WTN>
 constexpr int hgemm_smem_bytes() { return 2 * (64 * WTM + 64 * WTN) * kLDH * 2; }
 
 template <int BM, bool KC>
 struct TileLoaderBF {
-  static constexpr int kFPT = BM / 64;   // KC: (row, 8-k group) items per thread; MC: rows (features) per thread, one 8-k group
-  float f[kFPT][8];                      // raw fp32 (converted in store(), so the loads stay in flight during the MFMAs)
+  static constexpr int kFPT = BM / 64;            // MC: rows (features) per thread
+  static constexpr int kSlots = BM * kKG / 256;   // 8-element row segments per thread (KC: items; MC: kFPT rows x kKG/4 k groups)
+  float f[kSlots][8];                             // raw fp32 (converted in store(), so the loads stay in flight during the MFMAs)
   __device__ __forceinline__ void load(const float* __restrict__ P, long sm, long sk, int m0, int M, int k0, int kend) {
     const int tid = threadIdx.x;
-    const bool inside = m0 + BM <= M && k0 + kBK <= kend;   // workgroup-uniform: interior tiles skip every bounds test
+    const bool inside = m0 + BM <= M && k0 + kBKH <= kend;   // workgroup-uniform: interior tiles skip every bounds test
     if constexpr (KC) {
 #pragma unroll
-      for (int j = 0; j < kFPT; ++j) {
-        const int item = tid + 256 * j, m = m0 + (item >> 2), k = k0 + (item & 3) * 8;
+      for (int j = 0; j < kSlots; ++j) {
+        const int item = tid + 256 * j, m = m0 + item / kKG, k = k0 + (item % kKG) * 8;
         const float* p = P + (long)m * sm + k;
         if (inside || (m < M && k + 7 < kend)) {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
@@ -200,39 +231,53 @@ struct TileLoaderBF {
         }
       }
     } else {
-      const int m = m0 + (tid & 63) * kFPT, k = k0 + (tid >> 6) * 8;
-      const float* p = P + (long)k * sk + m;
-      if (inside) {
+      const int m = m0 + (tid & 63) * kFPT;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if constexpr (kFPT == 2) {
-            const auto v2 = *reinterpret_cast<const __attribute__((ext_vector_type(2))) float*>(p + (long)i * sk);
-            f[0][i] = v2[0];
-            f[1][i] = v2[1];
-          } else {
-            f[0][i] = p[(long)i * sk];
+      for (int g = 0; g < kKG / 4; ++g) {
+        const int k = k0 + ((tid >> 6) + 4 * g) * 8;
+        const float* p = P + (long)k * sk + m;
+        if (inside) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if constexpr (kFPT == 2) {
+              const auto v2 = *reinterpret_cast<const __attribute__((ext_vector_type(2))) float*>(p + (long)i * sk);
+              f[g * kFPT][i] = v2[0];
+              f[g * kFPT + 1][i] = v2[1];
+            } else {
+              f[g][i] = p[(long)i * sk];
+            }
           }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < kFPT; ++e) f[g * kFPT + e][i] = (k + i < kend && m + e < M) ? p[(long)i * sk + e] : 0.f;
         }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int e = 0; e < kFPT; ++e) f[e][i] = (k + i < kend && m + e < M) ? p[(long)i * sk + e] : 0.f;
       }
     }
+  }
+  // MC only: rs[e] += this tile's values of row (tid & 63)*kFPT + e (fp32, before the bf16 rounding)
+  __device__ __forceinline__ void add_rowsum(float (&rs)[4]) const {
+#pragma unroll
+    for (int g = 0; g < kKG / 4; ++g)
+#pragma unroll
+      for (int e = 0; e < kFPT; ++e)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs[e] += f[g * kFPT + e][i];
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S /* [BM][kLDH] */) const {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < kFPT; ++j) {
+    for (int j = 0; j < kSlots; ++j) {
       bf16x8 v;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[j][i];
       if constexpr (KC) {
         const int item = tid + 256 * j;
-        *reinterpret_cast<bf16x8*>(S + (item >> 2) * kLDH + (item & 3) * 8) = v;
+        *reinterpret_cast<bf16x8*>(S + (item / kKG) * kLDH + (item % kKG) * 8) = v;
       } else {
-        *reinterpret_cast<bf16x8*>(S + ((tid & 63) * kFPT + j) * kLDH + (tid >> 6) * 8) = v;
+        const int g = j / kFPT, e = j % kFPT;
+        *reinterpret_cast<bf16x8*>(S + ((tid & 63) * kFPT + e) * kLDH + ((tid >> 6) + 4 * g) * 8) = v;
       }
     }
   }
@@ -260,22 +305,25 @@ __global__ __launch_bounds__(256) void hgemm_kernel(GemmArgs g) {
 
   TileLoaderBF<BM, A_KC> la;
   TileLoaderBF<BN, B_KC> lb;
+  const bool want_rs = !A_KC && g.rowsum != nullptr && blockIdx.x == 0;   // workgroup-uniform
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};
   la.load(g.A, g.sam, g.sak, m0, g.M, kbeg, kend);
   lb.load(g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend);
+  if constexpr (!A_KC) if (want_rs) la.add_rowsum(rs);
   la.store(As(0));
   lb.store(Bs(0));
   __syncthreads();
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
-    const bool more = k0 + kBK < kend;
+  for (int k0 = kbeg; k0 < kend; k0 += kBKH) {
+    const bool more = k0 + kBKH < kend;
     if (more) {
-      la.load(g.A, g.sam, g.sak, m0, g.M, k0 + kBK, kend);
-      lb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + kBK, kend);
+      la.load(g.A, g.sam, g.sak, m0, g.M, k0 + kBKH, kend);
+      lb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + kBKH, kend);
     }
     const __bf16* __restrict__ as = As(buf) + (wm * 32 * WTM + (lane & 31)) * kLDH + (lane >> 5) * 8;
     const __bf16* __restrict__ bs = Bs(buf) + (wn * 32 * WTN + (lane & 31)) * kLDH + (lane >> 5) * 8;
 #pragma unroll
-    for (int kk = 0; kk < kBK; kk += 16) {
+    for (int kk = 0; kk < kBKH; kk += 16) {
       bf16x8 a[WTM], b[WTN];
 #pragma unroll
       for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kLDH + kk);
@@ -287,11 +335,24 @@ __global__ __launch_bounds__(256) void hgemm_kernel(GemmArgs g) {
         for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
+      if constexpr (!A_KC) if (want_rs) la.add_rowsum(rs);
       la.store(As(buf ^ 1));
       lb.store(Bs(buf ^ 1));
     }
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (!A_KC) {
+    if (want_rs) {   // threads (tid & 63) of the four k-groups hold the same kFPT rows
+      constexpr int kFPT = BM / 64;
+      float* red = gemm_smem;
+#pragma unroll
+      for (int e = 0; e < kFPT; ++e) red[(threadIdx.x >> 6) * BM + (threadIdx.x & 63) * kFPT + e] = rs[e];
+      __syncthreads();
+      if (threadIdx.x < BM && m0 + threadIdx.x < g.M)
+        g.rowsum[(long)blockIdx.z * g.M + m0 + threadIdx.x] =
+            (red[threadIdx.x] + red[BM + threadIdx.x]) + (red[2 * BM + threadIdx.x] + red[3 * BM + threadIdx.x]);
+    }
   }
 #pragma unroll
   for (int i = 0; i < WTM; ++i)

@@ -92,7 +92,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.dth = c.take((size_t)n * kD);
   s.temb = c.take((size_t)n * kD);
   // split-K partials of the largest weight gradient (6D x D, or H x D) and column-sum partials
-  s.part_floats = (size_t)kMaxSplit * std::max<size_t>((size_t)6 * kD * kD, std::max<size_t>(H, 3 * kD) * kD);
+  s.part_floats = (size_t)kMaxSplit * (std::max<size_t>((size_t)6 * kD * kD, std::max<size_t>(H, 3 * kD) * kD) + 6 * kD);  // + row sums
   s.part = c.take(s.part_floats);
   s.bytes = c.off;
   return s;
@@ -118,7 +118,7 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
 thread_local bool g_bf16 = false;   // operand precision of the GEMMs of the call in progress (SCLDM_PREC_*)
 
 int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
-         int N, int K, const float* bias, bool accumulate, float* part, size_t part_floats) {
+         int N, int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
   const bool a_kc = sak == 1, b_kc = sbk == 1;
   if ((!a_kc && sam != 1) || (!b_kc && sbn != 1)) return fail(SCLDM_ERR_SHAPE, "gemm: operand needs a unit stride");
@@ -128,16 +128,19 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
   int splits = 1;
   if (tiles < 384 && K >= 512) {
     splits = (int)std::min<long>(std::min<long>(cdiv(768, tiles), K / 256), kMaxSplit);
-    while (splits > 1 && (size_t)splits * M * N > part_floats) --splits;
+    while (splits > 1 && (size_t)splits * M * (N + 1) > part_floats) --splits;
   }
-  int kchunk = cdiv(cdiv(K, splits), kBK) * kBK;
+  if (rowsum_out && a_kc) return fail(SCLDM_ERR_SHAPE, "gemm: row sums need the A operand contiguous along m");
+  const int bk = g_bf16 ? kBKH : kBK;
+  int kchunk = cdiv(cdiv(K, splits), bk) * bk;
   splits = cdiv(K, kchunk);
-  GemmArgs g{A, sam, sak, B, sbn, sbk, C, ldc, bias, M, N, K, kchunk, accumulate ? 1 : 0};
+  GemmArgs g{A, sam, sak, B, sbn, sbk, C, ldc, bias, M, N, K, kchunk, accumulate ? 1 : 0, rowsum_out};
   if (splits > 1) {
     g.C = part;
     g.ldc = N;
     g.bias = nullptr;
     g.accumulate = 0;
+    if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;   // [splits][M] behind the C partials
   }
   int rc;
 #define SCLDM_GEMM_CASE(BF, WT)                                                                                             \
@@ -152,6 +155,10 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, part,
                        splits, M, N, C, ldc, bias, accumulate ? 1 : 0);
     LAUNCH_CHECK();
+    if (rowsum_out) {
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, part + (size_t)splits * M * N, splits, M, rowsum_out);
+      LAUNCH_CHECK();
+    }
   }
   return SCLDM_OK;
 }
@@ -166,10 +173,10 @@ int linear_dgrad(hipStream_t st, const float* dy, long lddy, const float* W, int
                  bool accumulate, Scratch& s) {
   return gemm(st, dy, lddy, 1, W, 1, in, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats);
 }
-// dW[out, in] = dy[rows, out]^T x[rows, in]
+// dW[out, in] = dy[rows, out]^T x[rows, in];  optionally db[out] = sum_rows dy (row sums of the A operand, same pass)
 int linear_wgrad(hipStream_t st, const float* dy, long lddy, const float* x, long ldx, int rows, int out, int in, float* dW,
-                 Scratch& s) {
-  return gemm(st, dy, 1, lddy, x, 1, ldx, dW, in, out, in, rows, nullptr, false, s.part, s.part_floats);
+                 Scratch& s, float* db = nullptr) {
+  return gemm(st, dy, 1, lddy, x, 1, ldx, dW, in, out, in, rows, nullptr, false, s.part, s.part_floats, db);
 }
 // out[cols] = sum_r X[r, c]
 int colsum(hipStream_t st, const float* X, long rows, int cols, long ld, float* out, Scratch& s) {
@@ -340,8 +347,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
 
   // ---- final layer ----
   const int of = L * 6 * kD;
-  TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k));
-  TRY(colsum(st, dout, T, din, din, g->fin_b, k));
+  TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k, g->fin_b));
   TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
   TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
 
@@ -363,19 +369,16 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dx, a.y1, s.mod, (long)mw, o + 2 * kD, kD, k.dy, k.dmod);
     LAUNCH_CHECK();
-    TRY(linear_wgrad(st, k.dy, kD, a.ao, kD, (int)T, kD, kD, g->proj_w[l], k));
-    TRY(colsum(st, k.dy, T, kD, kD, g->proj_b[l], k));
+    TRY(linear_wgrad(st, k.dy, kD, a.ao, kD, (int)T, kD, kD, g->proj_w[l], k, g->proj_b[l]));
     TRY(linear_dgrad(st, k.dy, kD, w->proj_w[l], (int)T, kD, kD, k.dao, kD, false, k));
     TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
-    TRY(linear_wgrad(st, k.dqkv, 3 * kD, a.h1, kD, (int)T, 3 * kD, kD, g->attn_w[l], k));
-    TRY(colsum(st, k.dqkv, T, 3 * kD, 3 * kD, g->attn_b[l], k));
+    TRY(linear_wgrad(st, k.dqkv, 3 * kD, a.h1, kD, (int)T, 3 * kD, kD, g->attn_w[l], k, g->attn_b[l]));
     TRY(linear_dgrad(st, k.dqkv, 3 * kD, w->attn_w[l], (int)T, 3 * kD, kD, k.dh, kD, false, k));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
   }
 
   // ---- input projection + pos_embed ----
-  TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k));
-  TRY(colsum(st, k.dx, T, kD, kD, g->in_b, k));
+  TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k, g->in_b));
   if (g->pos_embed) TRY(colsum(st, k.dx, n, kS * kD, (long)kS * kD, g->pos_embed, k));
   if (dx_out) TRY(linear_dgrad(st, k.dx, kD, w->in_w, (int)T, kD, din, dx_out, din, false, k));
 
@@ -386,8 +389,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     float* gw = l < L ? g->ada_w[l] : g->fin_ada_w;
     float* gb = l < L ? g->ada_b[l] : g->fin_ada_b;
     const float* wl = l < L ? w->ada_w[l] : w->fin_ada_w;
-    TRY(linear_wgrad(st, dm, mw, s.sc, kD, n, width, kD, gw, k));
-    TRY(colsum(st, dm, n, width, mw, gb, k));
+    TRY(linear_wgrad(st, dm, mw, s.sc, kD, n, width, kD, gw, k, gb));
     TRY(linear_dgrad(st, dm, mw, wl, n, width, kD, k.dsc, kD, l > 0, k));
   }
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsc, s.c, k.dc, (long)n * kD);
@@ -399,12 +401,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
                        cfg.class_vocab[c], n, kD, g->class_emb[c]);
     LAUNCH_CHECK();
   }
-  TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k));
-  TRY(colsum(st, k.dc, n, kD, kD, g->t_b2, k));
+  TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k, g->t_b2));
   TRY(linear_dgrad(st, k.dc, kD, w->t_w2, n, kD, kD, k.dsth, kD, false, k));
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
   LAUNCH_CHECK();
-  TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k));
-  TRY(colsum(st, k.dth, n, kD, kD, g->t_b0, k));
+  TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
   return SCLDM_OK;
 }
