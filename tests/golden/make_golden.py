@@ -358,6 +358,20 @@ def gen_mmd(name, Bx, By, D, seed):
     print(name, {k: float(v) for k, v in out.items() if k.startswith("mmd_")})
 
 
+def gen_init():
+    """DiT.initialize_weights (src/scldm/nnets.py:458-492): the frozen sin|cos pos_embed exactly, and per-parameter statistics of a
+    fresh reference module (which tensors are exactly zero, std / abs-max of the random ones)."""
+    torch.manual_seed(1234)
+    kw = dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16, class_vocab_sizes={"clusters": 14},
+              condition_strategy="mutually_exclusive")
+    m = DiT(**kw, **COMMON)
+    stats = {k: [float(v.float().mean()), float(v.float().std()), float(v.abs().max())] for k, v in m.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "dit_init.npz"), pos_embed=m.pos_embed.detach().numpy(),
+                        kwargs_json=np.array(json.dumps({**kw, **COMMON})), stats_json=np.array(json.dumps(stats)),
+                        requires_grad_json=np.array(json.dumps({k: bool(p.requires_grad) for k, p in m.named_parameters()})))
+    print("init: zero tensors", [k for k, v in stats.items() if v[2] == 0.0])
+
+
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
 
 
@@ -406,6 +420,7 @@ if __name__ == "__main__":
     for name, (N, G, S, seed) in TOKENIZE_CASES.items():
         gen_tokenize(name, N, G, S, seed)
     gen_size_factors()
+    gen_init()
     for name, (Bx, By, D, seed) in MMD_CASES.items():
         gen_mmd(name, Bx, By, D, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():

@@ -148,3 +148,23 @@ def test_negative_binomial_holder_samples_cpu():
     x = nb.sample()
     assert x.shape == mu.shape and (x >= 0).all() and (x == x.round()).all()
     assert abs(float(x.mean()) - 5.0) < 0.3 and abs(float(x.var()) - (5.0 + 25.0 / 2.0)) < 2.5  # mean mu, var mu + mu^2/theta
+
+
+def test_fresh_dit_matches_reference_initialisation():
+    """A9 (nnets.py:458-492) against a fresh reference module (tests/golden/dit_init.npz): identical frozen pos_embed, the same
+    tensors exactly zero (adaLN-Zero, output layer, Linear biases), the same trainable flags, and matching spread of the random ones."""
+    from scldm_amd.nnets import DiT
+    g = load_golden("dit_init")
+    torch.manual_seed(99)
+    m = DiT(**golden_json(g, "kwargs_json"))
+    assert torch.allclose(m.pos_embed.detach(), torch.from_numpy(g["pos_embed"]), atol=1e-6)
+    stats = golden_json(g, "stats_json")
+    assert set(stats) == set(m.state_dict())
+    assert golden_json(g, "requires_grad_json") == {k: bool(p.requires_grad) for k, p in m.named_parameters()}
+    for k, v in m.state_dict().items():
+        mean, std, amax = stats[k]
+        if amax == 0.0:
+            assert float(v.abs().max()) == 0.0, k
+        elif k != "pos_embed":
+            assert abs(float(v.float().std()) - std) < 0.08 * std, k          # same distribution family and scale
+            assert float(v.abs().max()) < 1.6 * amax, k                       # xavier-uniform stays bounded, normal(0.02) tails
