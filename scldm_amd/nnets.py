@@ -517,7 +517,7 @@ class DiT(nn.Module):
     # ------------------------------------------------------------------ fused sampler (transport.py:324-369 + models.py:801-812)
     @torch.no_grad()
     def sample_ode_cfg(self, z: torch.Tensor, condition: dict[str, torch.Tensor] | None, cfg_scale: dict[str, float] | None,
-                       num_steps: int, sampling_method: str = "euler") -> torch.Tensor:
+                       num_steps: int, sampling_method: str = "euler", atol: float = 1e-5, rtol: float = 1e-5) -> torch.Tensor:
         """Integrate dz/dt = forward_with_cfg(z, t) over linspace(0, 1, num_steps) entirely on device.
 
         `z` is the doubled state cat([z0, z0]) (2B,S,C); `condition` the doubled label dict; `num_steps` has the
@@ -528,6 +528,10 @@ class DiT(nn.Module):
             raise NotImplementedError("sampling is an inference path; call .eval() first")
         if num_steps < 2:
             raise ValueError("num_steps must be >= 2 (grid points)")
+        if sampling_method.lower() == "dopri5":   # adaptive solve: host-driven steps over the fused forward_with_cfg
+            from .transport import Sampler, create_transport
+            fn = Sampler(create_transport()).sample_ode(sampling_method="dopri5", num_steps=2, atol=atol, rtol=rtol)
+            return fn(_require_cuda_f32("z", z), self.forward_with_cfg, condition=condition, cfg_scale=cfg_scale)[-1]
         if not self.fused_shape:   # fixed-grid Euler / Heun over the generic forward_with_cfg (same grid as the fused loop)
             z = _require_cuda_f32("z", z).clone()
             method = sampling_method.lower()

@@ -206,3 +206,25 @@ def test_fused_sampler_full_size_properties(vocab, strategy, B, method, steps, s
     ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, c2, scales), steps, method)
     got = torch.cat([out1[idx.cuda()], out1[(idx + B).cuda()]]).cpu()
     assert max_abs_rel(got, ref) < TOL_BF16
+
+
+def test_adaptive_dopri5_sampling_agrees_with_fine_heun():
+    """The reference's default sampler (sample_ode() -> dopri5, transport.py:324-332; parity unpinned, see oracle/transport.py):
+    adaptive solve over the fused forward_with_cfg agrees with a 400-evaluation fused Heun solve, both through
+    DiT.sample_ode_cfg and through the reference-style Sampler call (models.py:793-812)."""
+    from scldm_amd.transport import Sampler, create_transport
+    g, m, cfg, sd = build("dit_base")
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    B = 6
+    z0 = torch.randn(B, 16, 16, device="cuda", generator=gen)
+    z2 = torch.cat([z0, z0])
+    cond = {"clusters": torch.randint(0, 14, (B,), device="cuda", generator=gen).repeat(2)}
+    scales = {"clusters": 2.0}
+    ref = m.sample_ode_cfg(z2, cond, scales, 201, "heun")
+    out = m.sample_ode_cfg(z2, cond, scales, 2, "dopri5", atol=1e-6, rtol=1e-6)
+    assert max_abs_rel(out.cpu(), ref.cpu()) < 1e-3
+    fn = Sampler(create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)).sample_ode()      # the reference's default call
+    traj = fn(z2, m.forward_with_cfg, condition=cond, cfg_scale=scales)
+    assert traj.shape == (50, 2 * B, 16, 16) and torch.equal(traj[0], z2)
+    assert max_abs_rel(traj[-1].cpu(), ref.cpu()) < 1e-3
+    assert 20 < fn.last_stats["evaluations"] < 2000
