@@ -101,7 +101,9 @@ def test_transport_face_and_training_losses_cpu():
     with pytest.raises(NotImplementedError):
         create_transport(path_type="VP")
     with pytest.raises(NotImplementedError):
-        Sampler(tr).sample_ode(sampling_method="dopri5")
+        Sampler(tr).sample_ode(sampling_method="rk4")          # only euler / heun / dopri5 (the reference's own choices)
+    with pytest.raises(NotImplementedError):
+        Sampler(tr).sample_ode(reverse=True)
     # generic python ODE loop: KAT on f = -x, and grid semantics (N points -> N-1 evaluations)
     seen = []
     fn = Sampler(tr).sample_ode(sampling_method="euler", num_steps=5)
