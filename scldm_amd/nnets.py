@@ -514,6 +514,18 @@ class DiT(nn.Module):
         del keep
         return out
 
+    def forward_with_cfg_joint(self, x: torch.Tensor, t: torch.Tensor, condition: dict[str, torch.Tensor] | None = None,
+                               cfg_scale: dict[str, float] | None = None) -> torch.Tensor:
+        """Mirror of nnets.py:299-334 (no caller in the reference; kept for API completeness): unconditional pass on every
+        row, plus cfg_scale["cell_line"] times the conditional difference - composed from two `forward` calls as there."""
+        uncond = {c: torch.full((len(x),), v, device=x.device, dtype=torch.long) for c, v in self.class_vocab_sizes.items()}
+        with torch.no_grad():
+            u = self.forward(x, t, uncond, force_drop_ids=False)
+            g = u.clone()
+            if condition is not None and cfg_scale is not None:
+                g += cfg_scale["cell_line"] * (self.forward(x, t, condition, force_drop_ids=False) - u)
+        return g
+
     # ------------------------------------------------------------------ fused sampler (transport.py:324-369 + models.py:801-812)
     @torch.no_grad()
     def sample_ode_cfg(self, z: torch.Tensor, condition: dict[str, torch.Tensor] | None, cfg_scale: dict[str, float] | None,

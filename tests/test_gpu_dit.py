@@ -228,3 +228,22 @@ def test_adaptive_dopri5_sampling_agrees_with_fine_heun():
     assert traj.shape == (50, 2 * B, 16, 16) and torch.equal(traj[0], z2)
     assert max_abs_rel(traj[-1].cpu(), ref.cpu()) < 1e-3
     assert 20 < fn.last_stats["evaluations"] < 2000
+
+
+def test_forward_with_cfg_joint_mirror():
+    """nnets.py:299-334: u + s * (c - u) on every row, from two plain forwards (joint strategy, hard-coded 'cell_line' scale key)."""
+    from scldm_amd.nnets import DiT
+    kw = dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm", multiple_of=4,
+              layernorm_eps=1e-8, class_vocab_sizes={"cell_line": 4, "gene": 30}, cfg_dropout_prob=0.8, condition_strategy="joint")
+    m = DiT(**kw)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 55)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    cfg = DiTConfig(n_layer=2, class_vocab_sizes=kw["class_vocab_sizes"], condition_strategy="joint")
+    gen = torch.Generator().manual_seed(2)
+    x, t = torch.randn(5, 16, 16, generator=gen), torch.rand(5, generator=gen)
+    cond = {"cell_line": torch.randint(0, 4, (5,), generator=gen), "gene": torch.randint(0, 30, (5,), generator=gen)}
+    null = {"cell_line": torch.full((5,), 4), "gene": torch.full((5,), 30)}
+    u, c = dit_forward(sd, cfg, x, t, null), dit_forward(sd, cfg, x, t, cond)
+    out = m.forward_with_cfg_joint(x.cuda(), t.cuda(), {k: v.cuda() for k, v in cond.items()}, {"cell_line": 1.7})
+    assert max_abs_rel(out.cpu(), u + 1.7 * (c - u)) < TOL_FP32
