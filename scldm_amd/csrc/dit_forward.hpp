@@ -523,9 +523,23 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   }
 
 
+  // c_attn / c_proj biases: staged into LDS too (aliasing HB, which is free until the SwiGLU phase; LN2's barriers
+  // separate the last bias read from the first hidden-chunk write).  Read from global memory in the pass epilogues they
+  // cost 9 % of the kernel (383 -> 348 us in a no-bias timing proxy): vmcnt retires in order, so waiting for a bias
+  // load issued behind the weight ring's run-ahead refills drains the ring at every epilogue.
+  constexpr int kBiasLd = (4 * kD / 4 + NT - 1) / NT;  // float4 per thread for 3*kD + kD floats
+  f32x4 bstage[kBiasLd];
+#pragma unroll
+  for (int j = 0; j < kBiasLd; ++j) {
+    const int idx = min(tid + NT * j, 4 * kD / 4 - 1);
+    bstage[j] = idx < 3 * kD / 4 ? *reinterpret_cast<const f32x4*>(a.b_qkv + idx * 4)
+                                 : *reinterpret_cast<const f32x4*>(a.b_proj + (idx - 3 * kD / 4) * 4);
+  }
+  float* BIAS = reinterpret_cast<float*>(HB);
+
   f32x16 acc[FT][NTT];
-  const float* bq = a.b_qkv;
-  const float* bp = a.b_proj;
+  const float* bq = BIAS;
+  const float* bp = BIAS + 3 * kD;
 
   // ---- LN1 + modulate(a0 = scale, a1 = shift) -> XA (the staged adaLN vectors are published on the way) ----
   SCLDM_STAMP(21);
@@ -533,6 +547,9 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
 #pragma unroll
     for (int j = 0; j < kModLd; ++j)
       if (tid + NT * j < NS * kModBlock / 4) *reinterpret_cast<f32x4*>(MOD + (size_t)(tid + NT * j) * 4) = mstage[j];
+#pragma unroll
+    for (int j = 0; j < kBiasLd; ++j)
+      if (tid + NT * j < 4 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + (size_t)(tid + NT * j) * 4) = bstage[j];
   });
   SCLDM_STAMP(26);
   lds_barrier();
