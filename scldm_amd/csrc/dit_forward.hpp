@@ -560,86 +560,89 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   //   operand set inside the architectural VGPRs) -> V pass -> O^T = V^T P^T (kept in acc).
   {
     Frag Pf[FT][NTT][2];
-    {
+    // scores + softmax of one head: S^T = K Q^T (k = head dims), masked to the query's own sample, P packed as the next operand
+    auto scores = [&](const Frag (&QFh)[NTT][2], const Frag (&KFh)[NTT][2], Frag (&Ph)[NTT][2]) {
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        st = OP::mma(KFh[tt][0], QFh[tt][0], st);  // S^T[key][query]
+        st = OP::mma(KFh[tt][1], QFh[tt][1], st);
+        float sv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // keys of the query's own sample (opaque copies keep this a v_cndmask,
+          float lo = st[i], hi = st[8 + i];  // not a dynamically indexed vector extract)
+          asm volatile("" : "+v"(lo), "+v"(hi));
+          sv[i] = sp ? hi : lo;
+        }
+        float m = sv[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) m = fmaxf(m, sv[i]);
+        m = xor32_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sv[i] = __builtin_amdgcn_exp2f((sv[i] - m) * a.attn_scale_log2e);
+          sum += sv[i];
+        }
+        sum = xor32_sum(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float pv = sv[i] * inv;
+          p[i] = sp ? 0.f : pv;       // cross-sample blocks of the shared 32x32 tile are exactly zero
+          p[8 + i] = sp ? pv : 0.f;
+        }
+        Ph[tt][0] = OP::pack8(p);
+        Ph[tt][1] = OP::pack8(p + 8);
+      }
+    };
+    // accumulator tile (feature rows x token cols) + per-row bias -> the two k-halves of an MFMA operand
+    auto to_frags = [&](const f32x16 (&t_acc)[NTT], const float* brow, Frag (&F)[NTT][2]) {
+      float bias[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + q * 8 + hh * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
+      }
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = t_acc[tt][r] + bias[r];
+        F[tt][0] = OP::pack8(t);
+        F[tt][1] = OP::pack8(t + 8);
+      }
+    };
+    if constexpr (FT == 2) {
+      // one head at a time (stream order Q0 K0 Q1 K1): only one head's Q/K fragments and a 32-register accumulator are
+      // live next to the residual, instead of both heads' (64 + 64 registers) - the allocator no longer parks the
+      // residual in scratch here, and scratch traffic shares the in-order vmcnt queue with the weight ring
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) {
+        Frag QFh[NTT][2], KFh[NTT][2];
+        f32x16 a1[NTT];
+        gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);  // Q^T of head ft
+        to_frags(a1, bq + 0 * kD + fbase + ft * 32, QFh);
+        if (ft == 0) SCLDM_STAMP(2);
+        gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);  // K^T of head ft
+        to_frags(a1, bq + 1 * kD + fbase + ft * 32, KFh);
+        if (ft == 0) SCLDM_STAMP(3);
+        scores(QFh, KFh, Pf[ft]);
+      }
+    } else {
       Frag QF[FT][NTT][2], KF[FT][NTT][2];
       gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // Q^T (feature x token)
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        float bias[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 0 * kD + fbase + ft * 32 + q * 8 + hh * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
-        }
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-          float t[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bias[r];
-          QF[ft][tt][0] = OP::pack8(t);
-          QF[ft][tt][1] = OP::pack8(t + 8);
-        }
-      }
+      for (int ft = 0; ft < FT; ++ft) to_frags(acc[ft], bq + 0 * kD + fbase + ft * 32, QF[ft]);
       SCLDM_STAMP(2);
       gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // K^T (feature x token)
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-        float bias[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bq + 1 * kD + fbase + ft * 32 + q * 8 + hh * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bias[q * 4 + i] = b4[i];
-        }
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-          float t[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bias[r];
-          KF[ft][tt][0] = OP::pack8(t);
-          KF[ft][tt][1] = OP::pack8(t + 8);
-        }
-      }
+      for (int ft = 0; ft < FT; ++ft) to_frags(acc[ft], bq + 1 * kD + fbase + ft * 32, KF[ft]);
       SCLDM_STAMP(3);
-      // scores + softmax
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) {
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) {
-          f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          st = OP::mma(KF[ft][tt][0], QF[ft][tt][0], st);  // S^T[key][query], k = head dims
-          st = OP::mma(KF[ft][tt][1], QF[ft][tt][1], st);
-          float sv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {  // keys of the query's own sample (opaque copies keep this a v_cndmask,
-            float lo = st[i], hi = st[8 + i];  // not a dynamically indexed vector extract)
-            asm volatile("" : "+v"(lo), "+v"(hi));
-            sv[i] = sp ? hi : lo;
-          }
-          float m = sv[0];
-#pragma unroll
-          for (int i = 1; i < 8; ++i) m = fmaxf(m, sv[i]);
-          m = xor32_max(m);
-          float sum = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            sv[i] = __builtin_amdgcn_exp2f((sv[i] - m) * a.attn_scale_log2e);
-            sum += sv[i];
-          }
-          sum = xor32_sum(sum);
-          const float inv = __builtin_amdgcn_rcpf(sum);
-          float p[16];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float pv = sv[i] * inv;
-            p[i] = sp ? 0.f : pv;       // cross-sample blocks of the shared 32x32 tile are exactly zero
-            p[8 + i] = sp ? pv : 0.f;
-          }
-          Pf[ft][tt][0] = OP::pack8(p);
-          Pf[ft][tt][1] = OP::pack8(p + 8);
-        }
-      }
+      for (int ft = 0; ft < FT; ++ft) scores(QF[ft], KF[ft], Pf[ft]);
     }
     SCLDM_STAMP(4);
     // V (swapped operands: lane = feature, registers = tokens), then O^T = V^T P^T
