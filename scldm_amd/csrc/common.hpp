@@ -55,8 +55,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Operand-precision policies.  E = element type stored in LDS / packed weights,
 // Frag = one lane's 8 k-values.  `mma` accumulates a 32x32 tile over 16 k-values.
 // ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
 struct OpBF16 {
   using E = __bf16;
+  using ModE = _Float16;   // LDS copy of the adaLN vectors: fp16 (11-bit mantissa, far below the bf16 GEMM noise) halves its 24 KB
+  static __device__ __forceinline__ f32x4 load_mod4(const ModE* p) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  static __device__ __forceinline__ void store_mod4(ModE* p, const f32x4 v) {
+    *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  }
   using Frag = bf16x8;
   using Quad = bf16x4;  // 4 consecutive elements (one accumulator register group)
   static constexpr bool kIsBF16 = true;
@@ -79,6 +89,9 @@ struct OpBF16 {
 
 struct OpF32 {
   using E = float;
+  using ModE = float;
+  static __device__ __forceinline__ f32x4 load_mod4(const ModE* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store_mod4(ModE* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
   using Frag = f32x8;
   using Quad = f32x4;
   static constexpr bool kIsBF16 = false;
