@@ -61,7 +61,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->n_chunks[0] = (cfg->hidden_dim + kHC - 1) / kHC;  // FT=1: pad the hidden dimension to whole chunks
   h->half[0] = 0;
   {
-    const int hp = (cfg->hidden_dim + 63) / 64 * 64;     // FT=2: pad to 64, last chunk may be a half chunk
+    int hp = (cfg->hidden_dim + 63) / 64 * 64;     // FT=2: pad to 64, last chunk may be a half chunk
+    if (getenv("SCLDM_PAD128")) hp = (cfg->hidden_dim + 127) / 128 * 128;   // A/B switch: whole chunks only (needed for SCLDM_PF=8 builds)
     h->n_chunks[1] = hp / kHC;
     h->half[1] = (hp % kHC) / 64;
   }

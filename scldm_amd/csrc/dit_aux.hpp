@@ -30,10 +30,10 @@ __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* _
   const int frow = (w * FT + ft) * 32 + r;  // output feature row of this wave's tile
   float val;
   if (u < 32 && FT == 2) {
-    // Q / K passes run one 32-row tile (= one head) at a time: [Q tile 0 | K tile 0 | Q tile 1 | K tile 1], 8 units each,
-    // a unit = k-steps (2j, 2j+1) of that tile (gemm_pass_tile)
-    const int blk = u >> 3, tile = blk >> 1, p = blk & 1, ks = 2 * (u & 7) + ft;
-    val = Wqkv[(size_t)(p * 256 + (w * 2 + tile) * 32 + r) * 256 + ks * 16 + k8];
+    // Q and K of ONE head per pass: units 0-15 = head 0, 16-31 = head 1; inside a unit fragment 0 is the head's Q tile and
+    // fragment 1 its K tile of the same k-step (an ordinary two-tile gemm_pass whose "feature tiles" are Q_h and K_h)
+    const int head = u >> 4, ks = u & 15;
+    val = Wqkv[(size_t)(ft * 256 + (w * 2 + head) * 32 + r) * 256 + ks * 16 + k8];
   } else if (u < 48) {
     const int p = u >> 4, ks = u & 15;
     val = Wqkv[(size_t)(p * 256 + frow) * 256 + ks * 16 + k8];

@@ -179,7 +179,8 @@ template <typename OP, int NTT, int FT, int KSTEPS, bool SWAP, bool ZERO, int PF
 __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF, FT>& ws,
                                           const typename OP::E* __restrict__ bsm, int ldb, int lane) {
   using Frag = typename OP::Frag;
-  static_assert(KSTEPS % PF == 0, "KSTEPS must be a multiple of the prefetch depth");
+  // a pass shorter than the ring (the trailing half chunk's down-projection) is legal only as the LAST pass of the stream
+  static_assert(KSTEPS % PF == 0 || KSTEPS < PF, "KSTEPS must be a multiple of the prefetch depth (or a final short pass)");
   const int c32 = lane & 31, hh = lane >> 5;
   const typename OP::E* bbase = bsm + c32 * ldb + hh * 8;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -215,7 +216,7 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
   __builtin_amdgcn_s_setprio(SCLDM_SETPRIO);
 #endif
 #pragma unroll
-  for (int s = 0; s < PF; ++s) step(s, s, ZERO && s == 0);
+  for (int s = 0; s < (PF < KSTEPS ? PF : KSTEPS); ++s) step(s, s, ZERO && s == 0);
 #pragma unroll 1
   for (int ks0 = PF; ks0 < KSTEPS; ks0 += PF) {
 #pragma unroll
@@ -624,18 +625,17 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       }
     };
     if constexpr (FT == 2) {
-      // one head at a time (stream order Q0 K0 Q1 K1): only one head's Q/K fragments and a 32-register accumulator are
-      // live next to the residual, instead of both heads' (64 + 64 registers) - the allocator no longer parks the
-      // residual in scratch here, and scratch traffic shares the in-order vmcnt queue with the weight ring
+      // one head at a time: a two-tile pass whose tiles are the head's Q and K (the activation fragments are read from
+      // LDS once for both), then its scores.  Only one head's Q/K fragments are live next to the residual - with both
+      // heads' (the natural Q pass, K pass order) the allocator parked the residual in scratch, and scratch traffic shares
+      // the in-order vmcnt queue with the weight ring.
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) {
         Frag QFh[NTT][2], KFh[NTT][2];
-        f32x16 a1[NTT];
-        gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);  // Q^T of head ft
-        to_frags(a1, bq + 0 * kD + fbase + ft * 32, QFh);
+        gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // acc[0] = Q^T, acc[1] = K^T of head ft
+        to_frags(acc[0], bq + 0 * kD + fbase + ft * 32, QFh);
+        to_frags(acc[1], bq + 1 * kD + fbase + ft * 32, KFh);
         if (ft == 0) SCLDM_STAMP(2);
-        gemm_pass_tile<OP, NTT, PF>(a1, ws, XA, L::XA_LD, lane);  // K^T of head ft
-        to_frags(a1, bq + 1 * kD + fbase + ft * 32, KFh);
         if (ft == 0) SCLDM_STAMP(3);
         scores(QFh, KFh, Pf[ft]);
       }
