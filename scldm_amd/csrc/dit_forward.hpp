@@ -384,23 +384,27 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
     }
   }
   const int sp = c32 >> 4;
+  // 16 (scale, shift) quads per lane: the LDS reads of quad b+1 are issued before quad b is computed (hipcc otherwise emits
+  // read -> wait -> compute -> write per quad, ~130 stalled cycles each)
+  constexpr int NB = NTT * FT * 4;
+  auto quad_ptr = [&](int b, int vec) {
+    const int tt = b / (FT * 4), ft = (b / 4) % FT, q = b % 4;
+    return msm + (tt * 2 + sp) * kModBlock + vec * kD + (wave * FT + ft) * 32 + q * 8 + hh * 4;
+  };
+  f32x4 sc_n = OP::load_mod4(quad_ptr(0, sc_v)), sh_n = OP::load_mod4(quad_ptr(0, sh_v));
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    const typename OP::ModE* mr = msm + (tt * 2 + sp) * kModBlock;
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = (wave * FT + ft) * 32 + q * 8 + hh * 4;
-        const f32x4 sc = OP::load_mod4(mr + sc_v * kD + f);
-        const f32x4 sh = OP::load_mod4(mr + sh_v * kD + f);
-        float y[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
-        *reinterpret_cast<typename OP::Quad*>(dst + (tt * 32 + c32) * ldd + f) = OP::pack4(y[0], y[1], y[2], y[3]);
-      }
+  for (int b = 0; b < NB; ++b) {
+    const int tt = b / (FT * 4), ft = (b / 4) % FT, q = b % 4;
+    const f32x4 sc = sc_n, sh = sh_n;
+    if (b + 1 < NB) {
+      sc_n = OP::load_mod4(quad_ptr(b + 1, sc_v));
+      sh_n = OP::load_mod4(quad_ptr(b + 1, sh_v));
     }
+    const int f = (wave * FT + ft) * 32 + q * 8 + hh * 4;
+    float y[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+    *reinterpret_cast<typename OP::Quad*>(dst + (tt * 32 + c32) * ldd + f) = OP::pack4(y[0], y[1], y[2], y[3]);
   }
 }
 
