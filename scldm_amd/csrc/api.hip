@@ -103,6 +103,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->ada_t, (size_t)256 * h->mod_w * 4);
   if (e == hipSuccess) e = alloc((void**)&h->ada_b, (size_t)h->mod_w * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_wt, (size_t)din * 256 * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->in_w, (size_t)din * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
@@ -122,7 +123,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
       if (h->stream[p][f]) (void)hipFree(h->stream[p][f]);
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
-  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_b, h->pos, h->fin_b, h->b_qkv, h->b_proj};
+  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv, h->b_proj};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -163,6 +164,7 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   copy_kernel<<<1, T, 0, st>>>(w->t_b0, h->b0, 256);
   copy_kernel<<<1, T, 0, st>>>(w->t_b2, h->b2, 256);
   transpose_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_wt, 256, din, 256, 0);
+  copy_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_w, 256 * din);
   copy_kernel<<<1, T, 0, st>>>(w->in_b, h->in_b, 256);
   copy_kernel<<<cdiv(16 * 256, T), T, 0, st>>>(w->pos_embed, h->pos, 16 * 256);
   pack_final_kernel<float><<<cdiv(16 * 512, T), T, 0, st>>>(w->fin_w, (float*)h->wfinal[0], din);
@@ -286,6 +288,7 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.row_index = ridx;
   a.w_final = h->wfinal[prec];
   a.in_wt = h->in_wt;
+  a.in_w = h->in_w;
   a.in_b = h->in_b;
   a.pos = h->pos;
   a.fin_b = h->fin_b;

@@ -84,7 +84,8 @@ struct FwdArgs {
   const void* w_final;      // final_layer.linear packed as 16 fragments (rows >= din are zero)
   const float* b_qkv;       // (768) of this layer
   const float* b_proj;      // (256) of this layer
-  const float* in_wt;       // input_proj weight transposed (din, 256)
+  const float* in_wt;       // input_proj weight transposed (din, 256) (fp32 path)
+  const float* in_w;        // input_proj weight as stored (256, din) (bf16 path: MFMA operand rows)
   const float* in_b;        // (256)
   const float* pos;         // (16, 256)
   const float* fin_b;       // (din)
@@ -483,20 +484,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
         }
   };
   if (layer == 0) {
-    // ---- input projection + positional embedding (nnets.py:290-291), exact fp32 on the VALU (K = din) ----
+    // ---- input projection + positional embedding (nnets.py:290-291) ----
     const int p16 = c32 & 15;  // token position inside its sample
-#pragma unroll
-    for (int ft = 0; ft < FT; ++ft)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = fbase + ft * 32 + q * 8 + hh * 4;
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.in_b + f);
-        const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pos + p16 * kD + f);
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = bb[i] + pp[i];
-      }
     const float* zrow[NTT];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -504,20 +493,80 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       const int src = (s < a.n_direct) ? s : (a.n_direct - a.rep + (s - a.n_direct) % a.rep);
       zrow[tt] = a.z + ((size_t)src * 16 + p16) * a.din;
     }
-    for (int k = 0; k < a.din; ++k) {
-      float zk[NTT];
+    if constexpr (OP::kIsBF16) {
+      // bf16 path: K = din <= 32 is one or two MFMA k-steps.  Operands straight from global memory (this lane's 8 k-values
+      // of its weight row / its token's latent row), all loads issued together.  The former per-k VALU loop with its
+      // dependent global loads made the first layer's launch 114 us longer than the others (430 vs 316 us).
+      auto frag_of = [&](const float* row, int k0) {
+        float t[8];
+        if ((a.din & 7) == 0 && k0 + 8 <= a.din) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(row + k0), hi = *reinterpret_cast<const f32x4*>(row + k0 + 4);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) zk[tt] = zrow[tt][k];
+          for (int i = 0; i < 4; ++i) { t[i] = lo[i]; t[4 + i] = hi[i]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[i] = (k0 + i < a.din) ? row[k0 + i] : 0.f;
+        }
+        return OP::pack8(t);
+      };
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 pin[FT][NTT];
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) pin[ft][tt] = zero;
+      for (int ks = 0; ks * 16 < a.din; ++ks) {
+        Frag wf[FT], zf[NTT];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) wf[ft] = frag_of(a.in_w + (size_t)(fbase + ft * 32 + c32) * a.din, ks * 16 + hh * 8);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) zf[tt] = frag_of(zrow[tt], ks * 16 + hh * 8);
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt) pin[ft][tt] = OP::mma(wf[ft], zf[tt], pin[ft][tt]);
+      }
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.in_wt + k * kD + fbase + ft * 32 + q * 8 + hh * 4);
+          const int f = fbase + ft * 32 + q * 8 + hh * 4;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.in_b + f);
+          const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pos + p16 * kD + f);
 #pragma unroll
           for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += w4[i] * zk[tt];
+            for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = pin[ft][tt][q * 4 + i] + bb[i] + pp[i];
         }
+    } else {
+      // fp32 parity path: exact fp32 on the VALU (K = din)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = fbase + ft * 32 + q * 8 + hh * 4;
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(a.in_b + f);
+          const f32x4 pp = *reinterpret_cast<const f32x4*>(a.pos + p16 * kD + f);
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = bb[i] + pp[i];
+        }
+      for (int k = 0; k < a.din; ++k) {
+        float zk[NTT];
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) zk[tt] = zrow[tt][k];
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.in_wt + k * kD + fbase + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+            for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += w4[i] * zk[tt];
+          }
+      }
     }
   } else {
     load_x(xr);

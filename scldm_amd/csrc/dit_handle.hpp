@@ -20,6 +20,7 @@ struct scldm_dit {
   int emb_row0[SCLDM_MAX_CLASSES];
   float *ada_t, *ada_b;            // (256, mod_w), (mod_w)
   float *in_wt, *in_b, *pos;       // (Din,256), (256), (16,256)
+  float* in_w;                     // (256,Din) as stored
   float* fin_b;                    // (Din)
   // timing hook
   bool timing;
