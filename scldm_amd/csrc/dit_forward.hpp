@@ -441,7 +441,16 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   auto nothing = [] {};
 
   SCLDM_STAMP(0);
-  // the weight stream starts first: its first PF units fly while the prologue runs
+  // conditioning-row indices of the tile's samples FIRST: the adaLN-vector loads depend on them, and vmcnt retires in
+  // order - requested behind the residual tile (HBM) they could not be consumed before it arrived
+  constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 of adaLN vectors per thread
+  int mrow[kModLd];
+#pragma unroll
+  for (int j = 0; j < kModLd; ++j) {
+    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4);
+    mrow[j] = a.row_index[min(smp0 + sl, a.n_fwd - 1)];
+  }
+  // then the weight stream: its first PF units fly while the prologue runs
   WStream<OP, PF, FT> ws;
   ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
 
@@ -575,13 +584,11 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   // the tile's six adaLN vectors per sample: coalesced loads (issued AFTER the residual loads: the row_index -> mod
   // lookup is a dependent chain and would otherwise hold them back), parked in LDS during LN1 (16 lanes share every
   // value, so per-lane global loads would be 16x redundant and - measured - fully latency-exposed)
-  constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 per thread
   f32x4 mstage[kModLd];
 #pragma unroll
   for (int j = 0; j < kModLd; ++j) {
-    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
-    const int s = min(smp0 + sl, a.n_fwd - 1);
-    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
+    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), w4 = idx % (kModBlock / 4);
+    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)mrow[j] * a.mod_stride + layer * kModBlock + w4 * 4);
   }
 
 
@@ -861,8 +868,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     for (int tt = 0; tt < NTT; ++tt) {
       if (tt != wave) continue;  // wave-uniform (NTT <= NW)
       f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int ks = 0; ks < 16; ++ks) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {   // fully unrolled: the 16 L2-hot weight fragments are requested together (the residual registers are dead here)
         const Frag wfr = wf[ks * 64];
         const Frag b = *reinterpret_cast<const Frag*>(XA + (tt * 32 + c32) * L::XA_LD + hh * 8 + ks * 16);
         o = OP::mma(wfr, b, o);  // out^T[channel][token]
