@@ -302,9 +302,11 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.mod_stride = h->mod_w;
   a.eps = c.layernorm_eps;
   a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
-  a.dbg = h->dbg;
+  const char* dbg_layer_env = getenv("SCLDM_DBG_LAYER");   // debug builds: which layer's launch records the phase stamps
+  const int dbg_layer = dbg_layer_env ? atoi(dbg_layer_env) : c.n_layer / 2;
   for (int i = 0; i < c.n_layer; ++i) {
     a.layer = i;
+    a.dbg = (i == dbg_layer) ? h->dbg : nullptr;
     a.w_stream = (const char*)h->stream[prec][ft - 1] + (size_t)i * layer_elems * es;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;

@@ -15,7 +15,7 @@ from scldm_amd import _lib  # noqa: E402
 from __graft_entry__ import _random_dit  # noqa: E402
 
 NAMES = ["LN1", "Q pass", "K pass", "scores+softmax", "V pass+PV", "barrier(AO)", "proj+residual", "LN2",
-         "MLP (all chunks)", "gated residual", "| chunk0 W12+silu", "| chunk0 barrier", "| chunk0 c_proj", "LAYER 0 total"]
+         "MLP (all chunks)", "gated residual", "| chunk0 W12+silu", "| chunk0 barrier", "| chunk0 c_proj", "LAYER total"]
 PAIRS = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (8, 11), (11, 12), (12, 13), (0, 10)]
 
 n_fwd = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
@@ -35,9 +35,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 st = buf.view(n_blocks * 8, 32).cpu()
 st = st[st[:, 14] > 0]
-print(f"n_fwd={n_fwd} precision={prec} layers={n_layer} waves recorded={st.shape[0]}  (s_memtime ticks; phases are those of layer 0)")
+print(f"n_fwd={n_fwd} precision={prec} layers={n_layer} waves recorded={st.shape[0]}  (s_memtime ticks; phases are those of layer $SCLDM_DBG_LAYER, default the middle layer)")
 whole = (st[:, 14] - st[:, 0]).double()
-print(f"{'whole network per wave':24s} mean {whole.mean():10.0f}  min {whole.min():10.0f}  max {whole.max():10.0f}  per layer {whole.mean() / n_layer:9.0f}")
+print(f"{'start -> kernel end':24s} mean {whole.mean():10.0f}  min {whole.min():10.0f}  max {whole.max():10.0f}")
 tot = (st[:, 10] - st[:, 0]).double()
 for name, (a, b) in zip(NAMES, PAIRS):
     d = (st[:, b] - st[:, a]).double()
