@@ -1,6 +1,7 @@
 // C ABI of libscldm_hip.so (see include/scldm_hip.h).  gfx950 only; no torch dependency.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,11 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
+  for (int g = 0; g < 3; ++g) {
+    if (h->side[g]) (void)hipStreamDestroy(h->side[g]);
+    if (h->join_ev[g]) (void)hipEventDestroy(h->join_ev[g]);
+  }
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   delete h;
 }
 
@@ -252,7 +258,8 @@ static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
     HIP_TRY(hipFuncSetAttribute((const void*)dit_forward_kernel<OP, NTT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
     attr_set = true;
   }
-  const int grid = cdiv((long long)a.n_fwd * 16, L::TM);
+  const int tiles = cdiv((long long)a.n_fwd * 16, L::TM);
+  const int grid = a.grid_tiles > 0 ? a.grid_tiles : tiles;
   dit_forward_kernel<OP, NTT, FT><<<grid, L::NT, L::LDS_BYTES, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;
@@ -304,6 +311,28 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
   const char* dbg_layer_env = getenv("SCLDM_DBG_LAYER");   // debug builds: which layer's launch records the phase stamps
   const int dbg_layer = dbg_layer_env ? atoi(dbg_layer_env) : c.n_layer / 2;
+  // Tile groups: each layer is launched as G kernels over disjoint tile ranges, group g on its own stream, so that the
+  // round boundaries (burst of residual loads at the start, store drain and idle slots at the end) of one group fall
+  // inside the steady state of the others.
+  int G = 1;
+  if (const char* e = getenv("SCLDM_GROUPS")) G = std::min(4, std::max(1, atoi(e)));
+  const int tile_tok = 32 * ntt;
+  const int tiles_all = cdiv((long long)n_fwd * 16, tile_tok);
+  if (tiles_all < 512 * G) G = 1;
+  int gt0[5];
+  for (int g = 0; g <= G; ++g) gt0[g] = (int)((long long)tiles_all * g / G);
+  if (G > 1) {
+    for (int g = 1; g < G; ++g)
+      if (!h->side[g - 1]) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->side[g - 1], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->join_ev[g - 1], hipEventDisableTiming));
+      }
+    if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(h->fork_ev, st));
+    for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(h->side[g - 1], h->fork_ev, 0));
+  }
+  a.tile0 = 0;
+  a.grid_tiles = 0;
   for (int i = 0; i < c.n_layer; ++i) {
     a.layer = i;
     a.dbg = (i == dbg_layer) ? h->dbg : nullptr;
@@ -322,14 +351,26 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
       h->ev_used += 2;
       HIP_TRY(hipEventRecord(e0, st));
     }
-    int rc;
-    if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2, 2>(a, st);
-    else if (ft == 1) rc = launch_fwd_t<OpBF16, 2, 1>(a, st);
-    else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4, 2>(a, st);
-    else rc = launch_fwd_t<OpBF16, 2, 2>(a, st);
+    int rc = SCLDM_OK;
+    for (int g = 0; g < G && rc == SCLDM_OK; ++g) {
+      hipStream_t sg = g == 0 ? st : h->side[g - 1];
+      if (G > 1) {
+        a.tile0 = gt0[g];
+        a.grid_tiles = gt0[g + 1] - gt0[g];
+      }
+      if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2, 2>(a, sg);
+      else if (ft == 1) rc = launch_fwd_t<OpBF16, 2, 1>(a, sg);
+      else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4, 2>(a, sg);
+      else rc = launch_fwd_t<OpBF16, 2, 2>(a, sg);
+    }
     if (rc != SCLDM_OK) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, st));
   }
+  if (G > 1)
+    for (int g = 1; g < G; ++g) {
+      HIP_TRY(hipEventRecord(h->join_ev[g - 1], h->side[g - 1]));
+      HIP_TRY(hipStreamWaitEvent(st, h->join_ev[g - 1], 0));
+    }
   return SCLDM_OK;
 }
 

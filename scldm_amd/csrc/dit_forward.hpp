@@ -93,6 +93,8 @@ struct FwdArgs {
   int n_direct, rep;        // sample-forward s reads latent s (s < n_direct) else n_direct - rep + (s - n_direct) % rep
   int din;                  // latent channels (<= 32 handled by one output tile)
   int layer, n_layer;       // this launch's layer index
+  int tile0;                // first token tile of this launch (a layer may be launched as several tile groups)
+  int grid_tiles;           // tiles of this launch (0: all)
   int n_chunks;             // full SwiGLU chunks of 128 hidden units
   int half_chunk;           // 1: a trailing chunk of 64 hidden units follows (FT=2 kernels; 684 -> 5*128 + 64 = 704)
   int mod_stride;
@@ -433,8 +435,9 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c32 = lane & 31, hh = lane >> 5;
-  const int tok0 = blockIdx.x * TM;
-  const int smp0 = blockIdx.x * NS;
+  const int tile_id = blockIdx.x + a.tile0;
+  const int tok0 = tile_id * TM;
+  const int smp0 = tile_id * NS;
   const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
   const int layer = a.layer;
   const int fbase = wave * FT * 32;  // first feature owned by this wave
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
   // residual hand-off buffer: lane-linear, quad j = (tt*FT + ft)*4 + q  (padded to whole tiles: no predication)
-  float* xw = a.x + ((size_t)(blockIdx.x * NW + wave) * (4 * FT * NTT) * 64 + lane) * 4;
+  float* xw = a.x + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + lane) * 4;
 
   // The residual stream (this wave's features x TM tokens, accumulator layout; scalars: it never feeds an MFMA and
   // whole-vector values would be copied around by the compiler).  With FT=2 the allocator parks ~1/3 of it in scratch

@@ -26,6 +26,8 @@ struct scldm_dit {
   bool timing;
   std::vector<hipEvent_t> ev;
   size_t ev_used;
+  hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
+  hipEvent_t fork_ev, join_ev[3];
   int force_ntt, force_ft;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
 };
