@@ -293,7 +293,9 @@ def main():
     if blocks and blocks[0] > 0:
         n_launch, tot_ms = blocks
         avg_s = tot_ms / n_launch / 1e3
-        ach = n_fwd * FLOPS_PER_SAMPLE_BLOCK / avg_s / 1e12
+        lpl = m.layers_per_launch()                      # DiT layers one fused launch runs (2 unless SCLDM_LPL=1)
+        flops_launch = n_fwd * FLOPS_PER_SAMPLE_BLOCK * lpl
+        ach = flops_launch / avg_s / 1e12
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_dit_forward_kernel.json")
         if args.precision == "bf16" and args.workload == "dentate_b4096_euler100" and not args.batch and os.path.exists(pmc):
@@ -305,8 +307,8 @@ def main():
         result["roofline"] = {"bound": "mfma", "kernel": "dit_forward_kernel", "achieved": ach, "peak": PEAK[args.precision] / 1e12,
                               "unit": "TFLOP/s", "frac": ach / (PEAK[args.precision] / 1e12), "traffic": traffic,
                               "traffic_source": traffic_src,
-                              "launches": n_launch, "avg_launch_us": avg_s * 1e6,
-                              "algorithmic_flops_per_launch": n_fwd * FLOPS_PER_SAMPLE_BLOCK}
+                              "launches": n_launch, "avg_launch_us": avg_s * 1e6, "layers_per_launch": lpl,
+                              "algorithmic_flops_per_launch": flops_launch}
     if rank == 0 and not dist_on:
         if not args.no_extra:
             extra = []

@@ -133,6 +133,10 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
                      int n_pass, const uint32_t* pass_mask, const float* pass_scale, int n_steps, int method,
                      int precision, void* ws, void* stream);
 
+/* DiT layers one fused-kernel launch runs (2 by default: the residual stays in registers between the pair; 0 for a handle
+ * outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
+int scldm_dit_layers_per_launch(const scldm_dit* h);
+
 /* Timing hook for bench.py: when enabled, every fused-block launch is bracketed by HIP events on its
  * own stream; scldm_dit_block_timing drains them (synchronises) and returns launches and total ms. */
 void scldm_dit_block_timing_enable(scldm_dit* h, int enable);

@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
     L.scldm_dit_destroy.restype = None
     L.scldm_dit_load_weights.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p]
     L.scldm_dit_mod_width.argtypes = [C.c_void_p]
+    L.scldm_dit_layers_per_launch.argtypes = [C.c_void_p]
     L.scldm_dit_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.scldm_dit_workspace_bytes.restype = C.c_size_t
     L.scldm_dit_cond_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, c_void_pp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -122,7 +123,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
-           "scldm_dit_mod_width", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
+           "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes",
            "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",

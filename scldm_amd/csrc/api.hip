@@ -76,6 +76,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
   h->force_ft = 0;
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
+  h->lpl = 2;   // layers per fused launch (SCLDM_LPL=1: one layer per launch)
+  if (const char* e = getenv("SCLDM_LPL")) h->lpl = atoi(e) == 1 ? 1 : 2;
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
   const int L = cfg->n_layer, din = cfg->n_embed_input;
   hipError_t e = hipSuccess;
@@ -137,6 +139,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
 }
 
 extern "C" int scldm_dit_mod_width(const scldm_dit* h) { return h ? h->mod_w : 0; }
+extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h->fused) ? h->lpl : 0; }
 
 extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream_) {
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
@@ -333,9 +336,14 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   }
   a.tile0 = 0;
   a.grid_tiles = 0;
-  for (int i = 0; i < c.n_layer; ++i) {
+  // layers per launch (1 or 2): with 2 the residual stays in registers between the pair (half the hand-off traffic and
+  // half the launch boundaries); the weights of both layers are then live in each XCD's L2
+  const int lpl = h->lpl;
+  a.w_layer_elems = (long)layer_elems;
+  for (int i = 0; i < c.n_layer; i += lpl) {
     a.layer = i;
-    a.dbg = (i == dbg_layer) ? h->dbg : nullptr;
+    a.n_here = (i + lpl <= c.n_layer) ? lpl : c.n_layer - i;
+    a.dbg = (dbg_layer >= i && dbg_layer < i + a.n_here) ? h->dbg : nullptr;
     a.w_stream = (const char*)h->stream[prec][ft - 1] + (size_t)i * layer_elems * es;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;

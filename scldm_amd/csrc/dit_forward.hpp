@@ -92,7 +92,9 @@ struct FwdArgs {
   int n_fwd;                // number of sample-forwards (16 tokens each)
   int n_direct, rep;        // sample-forward s reads latent s (s < n_direct) else n_direct - rep + (s - n_direct) % rep
   int din;                  // latent channels (<= 32 handled by one output tile)
-  int layer, n_layer;       // this launch's layer index
+  int layer, n_layer;       // first layer of this launch, layers of the network
+  int n_here;               // consecutive layers this launch runs (1 or 2; the residual stays in registers between them)
+  long w_layer_elems;       // elements of the packed stream per layer (w_stream, b_qkv, b_proj point at `layer`)
   int tile0;                // first token tile of this launch (a layer may be launched as several tile groups)
   int grid_tiles;           // tiles of this launch (0: all)
   int n_chunks;             // full SwiGLU chunks of 128 hidden units
@@ -434,35 +436,22 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c32 = lane & 31, hh = lane >> 5;
   const int tile_id = blockIdx.x + a.tile0;
   const int tok0 = tile_id * TM;
   const int smp0 = tile_id * NS;
-  const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
-  const int layer = a.layer;
   const int fbase = wave * FT * 32;  // first feature owned by this wave
   auto nothing = [] {};
 
   SCLDM_STAMP(0);
-  // conditioning-row indices of the tile's samples FIRST: the adaLN-vector loads depend on them, and vmcnt retires in
-  // order - requested behind the residual tile (HBM) they could not be consumed before it arrived
   constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 of adaLN vectors per thread
-  int mrow[kModLd];
-#pragma unroll
-  for (int j = 0; j < kModLd; ++j) {
-    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4);
-    mrow[j] = a.row_index[min(smp0 + sl, a.n_fwd - 1)];
-  }
-  // then the weight stream: its first PF units fly while the prologue runs
+  // the weight stream starts first: its first PF units fly while the prologue runs
   WStream<OP, PF, FT> ws;
   ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
 
   // samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
-  bool live[NTT];
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) live[tt] = ((tok0 + tt * 32 + c32) >> 4) < a.n_fwd;
   // residual hand-off buffer: lane-linear, quad j = (tt*FT + ft)*4 + q  (padded to whole tiles: no predication)
-  float* xw = a.x + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + lane) * 4;
+  // (computed where it is used: kept in registers across the layer body it is one more value the allocator has to carry)
+  auto xw_ptr = [&]() { return a.x + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4; };
 
   // The residual stream (this wave's features x TM tokens, accumulator layout; scalars: it never feeds an MFMA and
   // whole-vector values would be copied around by the compiler).  With FT=2 the allocator parks ~1/3 of it in scratch
@@ -471,6 +460,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   // the slow residual loads/stores also waits for them.
   float xr[FT][NTT][16];
   auto load_x = [&](float (&dst)[FT][NTT][16]) {
+    const float* xw = xw_ptr();
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -483,6 +473,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
         }
   };
   auto store_x = [&](const float (&src)[FT][NTT][16]) {
+    float* xw = xw_ptr();
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -495,6 +486,20 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
           *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
         }
   };
+  // One or two consecutive layers per launch: the body below is instantiated once per layer slot (compile-time `li`), the
+  // residual `xr` stays in registers between the two and only the first slot reads / the last slot writes the hand-off
+  // buffer.  (A run-time loop over layers made the register allocator spill 170 VGPRs.)
+  auto layer_body = [&](auto li_tag) {
+  constexpr int li = decltype(li_tag)::value;
+  const int layer = a.layer + li;
+  // The second slot re-derives its per-lane indices from an opaque copy of the lane id: shared with the first slot, the
+  // common address arithmetic would stay live across the whole first layer (register pressure -> spills).
+  int lane_sh = threadIdx.x & 63;
+  if (li > 0) asm volatile("" : "+v"(lane_sh));
+  const int lane = lane_sh;
+  const int tid = wave * 64 + lane;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
   if (layer == 0) {
     // ---- input projection + positional embedding (nnets.py:290-291) ----
     const int p16 = c32 & 15;  // token position inside its sample
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
           }
       }
     }
-  } else {
+  } else if (li == 0) {
     load_x(xr);
   }
 
@@ -590,8 +595,9 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   f32x4 mstage[kModLd];
 #pragma unroll
   for (int j = 0; j < kModLd; ++j) {
-    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), w4 = idx % (kModBlock / 4);
-    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)mrow[j] * a.mod_stride + layer * kModBlock + w4 * 4);
+    const int idx = min(tid + NT * j, NS * kModBlock / 4 - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    const int s = min(smp0 + sl, a.n_fwd - 1);
+    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)a.row_index[s] * a.mod_stride + layer * kModBlock + w4 * 4);
   }
 
 
@@ -604,8 +610,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
 #pragma unroll
   for (int j = 0; j < kBiasLd; ++j) {
     const int idx = min(tid + NT * j, 4 * kD / 4 - 1);
-    bstage[j] = idx < 3 * kD / 4 ? *reinterpret_cast<const f32x4*>(a.b_qkv + idx * 4)
-                                 : *reinterpret_cast<const f32x4*>(a.b_proj + (idx - 3 * kD / 4) * 4);
+    bstage[j] = idx < 3 * kD / 4 ? *reinterpret_cast<const f32x4*>(a.b_qkv + li * 3 * kD + idx * 4)
+                                 : *reinterpret_cast<const f32x4*>(a.b_proj + li * kD + (idx - 3 * kD / 4) * 4);
   }
   float* BIAS = reinterpret_cast<float*>(HB);
 
@@ -845,8 +851,16 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       }
   SCLDM_STAMP(10);
 
-  if (layer + 1 < a.n_layer) {  // hand the residual to the next layer's launch
-    store_x(xr);
+  if (layer + 1 < a.n_layer) {
+    if (li + 1 >= a.n_here) {
+      store_x(xr);  // hand the residual to the next launch
+    } else {
+      // next layer in this launch: every wave is done with this layer's adaLN vectors, biases and hidden buffers before
+      // they are overwritten, and the weight ring restarts on the next layer's stream
+      lds_barrier();
+      ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)(li + 1) * (a.w_layer_elems / 8) +
+              (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
+    }
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
     constexpr int kFinLd = (NS * 2 * kD / 4 + NT - 1) / NT;  // float4 per thread for the tile's (shift, scale) vectors
@@ -877,7 +891,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
         const Frag b = *reinterpret_cast<const Frag*>(XA + (tt * 32 + c32) * L::XA_LD + hh * 8 + ks * 16);
         o = OP::mma(wfr, b, o);  // out^T[channel][token]
       }
-      if (live[tt]) {
+      if (((tok0 + tt * 32 + c32) >> 4) < a.n_fwd) {   // samples past n_fwd (tile padding) are never stored
         float* op = a.out + ((size_t)(tok0 + tt * 32 + c32)) * a.din;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -887,6 +901,9 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       }
     }
   }
+  };  // layer_body
+  layer_body(std::integral_constant<int, 0>{});
+  if (a.n_here > 1) layer_body(std::integral_constant<int, 1>{});
   SCLDM_STAMP_END(14);
 }
 

@@ -26,6 +26,7 @@ struct scldm_dit {
   bool timing;
   std::vector<hipEvent_t> ev;
   size_t ev_used;
+  int lpl;         // DiT layers per fused-kernel launch (1 or 2)
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
   hipEvent_t fork_ev, join_ev[3];
   int force_ntt, force_ft;

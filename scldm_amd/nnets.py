@@ -576,6 +576,10 @@ class DiT(nn.Module):
         return z
 
     # ------------------------------------------------------------------ bench hook
+    def layers_per_launch(self) -> int:
+        L, h = self._native()
+        return int(L.scldm_dit_layers_per_launch(h))
+
     def block_timing(self, enable: bool | None = None):
         L, h = self._native()
         if enable is not None:
