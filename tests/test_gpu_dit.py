@@ -247,3 +247,25 @@ def test_forward_with_cfg_joint_mirror():
     u, c = dit_forward(sd, cfg, x, t, null), dit_forward(sd, cfg, x, t, cond)
     out = m.forward_with_cfg_joint(x.cuda(), t.cuda(), {k: v.cuda() for k, v in cond.items()}, {"cell_line": 1.7})
     assert max_abs_rel(out.cpu(), u + 1.7 * (c - u)) < TOL_FP32
+
+
+@pytest.mark.parametrize("n_layer", [1, 3])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_odd_layer_counts(n_layer, precision, tol):
+    """The fused kernel runs two layers per launch: odd depths end with a one-layer launch (and depth 1 is input projection,
+    block and final layer in a single slot)."""
+    from scldm_amd.nnets import DiT
+    kw = dict(n_embed=256, n_embed_input=16, n_layer=n_layer, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+              multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes={"clusters": 14}, cfg_dropout_prob=0.8)
+    m = DiT(**kw)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 60 + n_layer)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.precision = precision
+    cfg = DiTConfig(n_layer=n_layer, class_vocab_sizes={"clusters": 14})
+    gen = torch.Generator().manual_seed(n_layer)
+    x, t = torch.randn(9, 16, 16, generator=gen), torch.rand(9, generator=gen)
+    lab = torch.randint(0, 14, (9,), generator=gen)
+    with torch.no_grad():
+        y = m(x.cuda(), t.cuda(), {"clusters": lab.cuda()})
+    assert max_abs_rel(y.cpu(), dit_forward(sd, cfg, x, t, {"clusters": lab})) < tol
