@@ -76,8 +76,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
   h->force_ft = 0;
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
-  h->lpl = 2;   // layers per fused launch (SCLDM_LPL=1: one layer per launch)
-  if (const char* e = getenv("SCLDM_LPL")) h->lpl = atoi(e) == 1 ? 1 : 2;
+  h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..4 for A/B runs)
+  if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
   const int L = cfg->n_layer, din = cfg->n_embed_input;
   hipError_t e = hipSuccess;
@@ -336,8 +336,8 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   }
   a.tile0 = 0;
   a.grid_tiles = 0;
-  // layers per launch (1 or 2): with 2 the residual stays in registers between the pair (half the hand-off traffic and
-  // half the launch boundaries); the weights of both layers are then live in each XCD's L2
+  // layers per launch: the residual stays in registers between the layers of a launch (fewer hand-off round trips and
+  // launch boundaries); the weights of that many layers are then live in each XCD's L2
   const int lpl = h->lpl;
   a.w_layer_elems = (long)layer_elems;
   for (int i = 0; i < c.n_layer; i += lpl) {
