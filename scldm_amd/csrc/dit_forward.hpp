@@ -839,6 +839,13 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
   if (a.half_chunk) do_chunk(std::true_type{}, a.n_chunks);
   SCLDM_STAMP(9);
 
+  // another layer follows in this launch: its weight ring starts now (the ring registers are free after the last pass),
+  // so the first units are in flight during the gated residual, the hand-over barrier and the next LayerNorm
+  const bool next_here = layer + 1 < a.n_layer && li + 1 < a.n_here;
+  if (next_here)
+    ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)(li + 1) * (a.w_layer_elems / 8) +
+            (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
+
   // ---- gated residual (a5) ----
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
@@ -858,10 +865,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       store_x(xr);  // hand the residual to the next launch
     } else {
       // next layer in this launch: every wave is done with this layer's adaLN vectors, biases and hidden buffers before
-      // they are overwritten, and the weight ring restarts on the next layer's stream
+      // they are overwritten (its weight ring was restarted above)
       lds_barrier();
-      ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)(li + 1) * (a.w_layer_elems / 8) +
-              (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
     }
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
