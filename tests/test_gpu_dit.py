@@ -269,3 +269,20 @@ def test_odd_layer_counts(n_layer, precision, tol):
     with torch.no_grad():
         y = m(x.cuda(), t.cuda(), {"clusters": lab.cuda()})
     assert max_abs_rel(y.cpu(), dit_forward(sd, cfg, x, t, {"clusters": lab})) < tol
+
+
+def test_tile_group_launches_are_bit_identical(monkeypatch):
+    """SCLDM_GROUPS=2 (each fused launch split into two tile groups on two streams) and SCLDM_LPL=1 (one layer per launch)
+    are scheduling choices only: same bits as the default."""
+    g, m, cfg, sd = build("dit_base", "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    n = 4100                                             # 1 025 tiles of 64 tokens: enough for two groups, ragged tail
+    x = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    t = torch.rand(n, device="cuda", generator=gen)
+    lab = torch.randint(0, 14, (n,), device="cuda", generator=gen)
+    with torch.no_grad():
+        ref = m(x, t, {"clusters": lab})
+        monkeypatch.setenv("SCLDM_GROUPS", "2")
+        y = m(x, t, {"clusters": lab})
+        torch.cuda.synchronize()
+    assert torch.equal(y, ref)
