@@ -169,6 +169,7 @@ def decode_inclusive(m, wl, device, n_genes=17002):
         for n, p in vae.named_parameters():
             p.copy_(torch.randn(p.shape, generator=g) * (1.0 if "embedding" in n or "inducing" in n else 0.05) + (1.0 if ".ln_" in n and n.endswith("weight") else 0.0))
     vae = vae.to(device).eval()
+    vae.precision = m.precision          # bf16 run: bf16-operand decode as well
     B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
     w2 = dict(wl); w2["B"] = B
     z2, cond2, scales = make_inputs(w2, B, device, seed=7)

@@ -250,8 +250,10 @@ int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, in
 
 /* TransformerVAE.decode (vae.py:71-87) up to the distribution parameters: z (B,16,n_lat), genes (B,G) int64,
  * library_size (B) -> mu (B,G) = softmax_G(logit / t) * library_size, theta (B,G) = exp(theta_emb[genes]). */
+/* precision: SCLDM_PREC_FP32 = exact-fp32 MFMA chain (parity path); SCLDM_PREC_BF16 = bf16 operands for the per-gene
+ * MCAB / SwiGLU contractions (fp32 accumulate, softmax, LayerNorm, logits), about 3x the decode rate. */
 int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
-                     float* theta, void* ws, void* stream);
+                     float* theta, int precision, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder input path: tokenize_cells(sample_genes="expressed"),

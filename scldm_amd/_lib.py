@@ -109,7 +109,7 @@ def lib() -> C.CDLL:
     L.scldm_vae_workspace_bytes.restype = C.c_size_t
     L.scldm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scldm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p]
+                                   C.c_int, C.c_void_p, C.c_void_p]
     L.scldm_tokenize_expressed.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scldm_csr_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

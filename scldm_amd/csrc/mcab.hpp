@@ -289,18 +289,53 @@ struct DecGeneArgs {
   float eps, inv_temp;
 };
 
+// BF = false: exact-fp32 chain (v_mfma_f32_32x32x2_f32, the parity path).  BF = true: the same chain with bf16 operands
+// (v_mfma_f32_32x32x16_bf16, fp32 accumulate; softmax / LayerNorm / SiLU / logits stay fp32): eight consecutive fp32 steps
+// contract exactly the 16 k-values of one bf16 MFMA in the same (step, half-wave) order, so the packed fragments are the
+// fp32 ones converted eight steps at a time and every activation operand is its accumulator registers 0-7 / 8-15.
+template <bool BF>
 __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
-  __shared__ f32x4 WF[40 * 64];   // 160 weight fragments, 4 steps per float4
-  __shared__ f32x4 KV[12 * 64];   // this cell's 48 K/V fragments
+  constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : 12 * 64, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
+  __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4
+  __shared__ f32x4 KV[kKV4];    // fp32: this cell's 48 K/V fragments
+  __shared__ bf16x8 WFh[kWF8];  // bf16: the same, 8 steps per 16-byte fragment
+  __shared__ bf16x8 KVh[kKV8];
   __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
   __shared__ float RED[4][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hh = lane >> 5;
   const int cell = blockIdx.y, chunk = blockIdx.x;
-  for (int i = tid; i < 40 * 64; i += 256) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
-  for (int i = tid; i < 12 * 64; i += 256) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
+  if constexpr (BF) {
+    auto cvt = [&](const float* src, bf16x8* dst, int nfrag8) {
+      for (int i = tid; i < nfrag8 * 64; i += 256) {
+        const int f = i >> 6, l = i & 63;
+        const f32x4 lo = reinterpret_cast<const f32x4*>(src)[(2 * f) * 64 + l], hi = reinterpret_cast<const f32x4*>(src)[(2 * f + 1) * 64 + l];
+        float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dst[i] = OpBF16::pack8(t);
+      }
+    };
+    cvt(a.wfrag, WFh, 20);
+    cvt(a.kvfrag + (size_t)cell * 48 * 64, KVh, 6);
+  } else {
+    for (int i = tid; i < 40 * 64; i += 256) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
+    for (int i = tid; i < 12 * 64; i += 256) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
+  }
   if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
   __syncthreads();
+  // acc += F[steps step0 .. step0+7] (A operand, from LDS) x x[0..7] (B operand, accumulator-order registers)
+  auto mm8 = [&](const f32x4* F4, const bf16x8* F8, int step0, const float* x, f32x16 acc) {
+    if constexpr (BF) {
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(F8[(step0 >> 3) * 64 + lane], OpBF16::pack8(x), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int g4 = 0; g4 < 2; ++g4) {
+        const f32x4 wf = F4[((step0 >> 2) + g4) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = mfma2(wf[i], x[g4 * 4 + i], acc);
+      }
+      return acc;
+    }
+  };
   const float hb = a.head_b[0];
   float run_m = -3.0e38f, run_s = 0.f;
   const int tile0 = (chunk * 4 + wave) * a.tiles_per_wave;
@@ -322,13 +357,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     f32x16 st[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      st[t] = zero16();
-#pragma unroll
-      for (int g4 = 0; g4 < 2; ++g4) {
-        const f32x4 kf = KV[(t * 2 + g4) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st[t] = mfma2(kf[i], q[8 * t + g4 * 4 + i], st[t]);
-      }
+      st[t] = mm8(KV, KVh, 8 * t, q + 8 * t, zero16());
     }
     // softmax over the 16 keys of each head: 8 keys in-lane (registers 8hl..8hl+7) + 8 in the other half-wave
 #pragma unroll
@@ -354,20 +383,21 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     // O^T[f][gene] = Vblk^T P^T
     f32x16 ot = zero16();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      float pr[16];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 vf = KV[(4 + t * 4 + g4) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ot = mfma2(vf[i], st[t][g4 * 4 + i], ot);
-      }
+      for (int r = 0; r < 16; ++r) pr[r] = st[t][r];
+      ot = mm8(KV, KVh, 16 + 16 * t, pr, ot);
+      ot = mm8(KV, KVh, 16 + 16 * t + 8, pr + 8, ot);
+    }
     // y = q_raw + c_proj(O)   (residual from the query, layers.py:327)
     f32x16 yt = zero16();
+    {
+      float ov[16];
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 wf = WF[g4 * 64 + lane];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) yt = mfma2(wf[i], ot[g4 * 4 + i], yt);
+      for (int r = 0; r < 16; ++r) ov[r] = ot[r];
+      yt = mm8(WF, WFh, 0, ov, yt);
+      yt = mm8(WF, WFh, 8, ov + 8, yt);
     }
     float s = 0.f;
 #pragma unroll
@@ -387,22 +417,12 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     f32x16 mo = zero16();
 #pragma unroll 1
     for (int u = 0; u < kHTiles; ++u) {
-      f32x16 ht = zero16();
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 wf = WF[(4 + u * 4 + g4) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ht = mfma2(wf[i], yn[g4 * 4 + i], ht);
-      }
+      f32x16 ht = mm8(WF, WFh, 16 + 16 * u, yn, zero16());
+      ht = mm8(WF, WFh, 16 + 16 * u + 8, yn + 8, ht);
       float hv[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) hv[r] = (ht[r] / (1.0f + __expf(-ht[r]))) * ht[r + 8];
-#pragma unroll
-      for (int g4 = 0; g4 < 2; ++g4) {
-        const f32x4 wf = WF[(4 + kHTiles * 4 + u * 2 + g4) * 64 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mo = mfma2(wf[i], hv[g4 * 4 + i], mo);
-      }
+      mo = mm8(WF, WFh, 16 + 16 * kHTiles + 8 * u, hv, mo);
     }
     // NB head: logit = w . (y + mlp) + b
     float lg = 0.f;

@@ -184,9 +184,10 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
 }
 
 extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
-                                float* mu, float* theta, void* ws_, void* stream_) {
+                                float* mu, float* theta, int precision, void* ws_, void* stream_) {
   int rc = vae_ready(h);
   if (rc) return rc;
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
   if (B <= 0 || G <= 0 || !z || !genes || !library_size || !mu || !theta || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_vae_config& c = h->cfg;
@@ -204,7 +205,8 @@ extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* gen
   g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
   g.logits = mu; g.theta = theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
   g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
-  dec_gene_kernel<<<dim3(nch, B), 256, 0, st>>>(g);
+  if (precision == SCLDM_PREC_BF16) dec_gene_kernel<true><<<dim3(nch, B), 256, 0, st>>>(g);
+  else dec_gene_kernel<false><<<dim3(nch, B), 256, 0, st>>>(g);
   LAUNCH_CHECK();
   dec_finalize_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, G, nch);
   LAUNCH_CHECK();

@@ -21,6 +21,7 @@ class TransformerVAE(nn.Module):
         self.decoder_head = decoder_head
         self.input_layer = input_layer
         self._handle = None
+        self.precision = "fp32"   # decode only: "bf16" = bf16 operands for the per-gene contractions (about 3x the decode rate)
         self._weights_key = None
         self._ws = None
         self._keep = None
@@ -133,8 +134,8 @@ class TransformerVAE(nn.Module):
         theta = torch.empty(B, G, device=z.device, dtype=torch.float32)
         ws = self._workspace(L, B, G)
         with torch.cuda.device(z.device):
-            _lib.check(L.scldm_vae_decode(h, z.data_ptr(), g.data_ptr(), lib.data_ptr(), B, G, mu.data_ptr(), theta.data_ptr(), ws,
-                                          _stream_ptr()), "scldm_vae_decode")
+            _lib.check(L.scldm_vae_decode(h, z.data_ptr(), g.data_ptr(), lib.data_ptr(), B, G, mu.data_ptr(), theta.data_ptr(),
+                                          _lib.PRECISIONS[self.precision], ws, _stream_ptr()), "scldm_vae_decode")
         return NegativeBinomial(mu=mu, theta=theta)
 
     @torch.no_grad()

@@ -126,3 +126,19 @@ def test_sample_cells_harness_matches_oracle_chain():
         sample_cells(dit, vae, {"clusters": cu(lab)}, scales, B + 1, cu(genes), cu(logsf))
     with pytest.raises(AssertionError):
         sample_cells(dit, vae, {"clusters": cu(lab)}, {"other": 1.0}, B, cu(genes), cu(logsf))
+
+
+def test_bf16_decode_close_to_fp32():
+    """decode with bf16 operands in the per-gene contractions (vae.precision = "bf16"): mu within bf16 noise of the fp32 path,
+    rows still sum to the library size, theta identical."""
+    g, vae, sd, cfg = build("vae_2000")
+    z = cu(g["z"])
+    genes, lib = cu(g["genes"]), cu(g["library_size"])
+    ref = vae.decode(z, genes, lib)
+    vae.precision = "bf16"
+    nb = vae.decode(z, genes, lib)
+    assert torch.equal(nb.theta, ref.theta)
+    assert max_abs_rel(nb.mu.cpu(), ref.mu.cpu()) < 3e-2
+    assert float(((nb.mu - ref.mu).norm() / ref.mu.norm())) < 1e-2
+    assert torch.allclose(nb.mu.sum(1, keepdim=True), lib.view(-1, 1), rtol=1e-4)
+    assert max_abs_rel(nb.mu.cpu(), g["mu"]) < 3e-2

@@ -29,4 +29,13 @@ for B in (256, 1024):
         for _ in range(5):
             nb = vae.decode(z, allg, lib)
         torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 5
+        vae.precision = "bf16"
+        for _ in range(2):
+            nb = vae.decode(z, allg, lib)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            nb = vae.decode(z, allg, lib)
+        torch.cuda.synchronize(); tdb = (time.perf_counter() - t0) / 5
+        vae.precision = "fp32"
+    print(f"B={B}: bf16-operand decode {tdb*1e3:.2f} ms = {B/tdb:.0f} cells/s")
     print(f"B={B}: encode (S={S}) {te*1e3:.2f} ms = {B/te:.0f} cells/s ({41.6e6*B/te/1e12:.1f} TFLOP/s); decode (G={G}) {td*1e3:.2f} ms = {B/td:.0f} cells/s ({396.4e6*B/td/1e12:.1f} TFLOP/s)")
