@@ -246,7 +246,8 @@ int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, void* strea
 size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G);
 
 /* TransformerVAE.encode (vae.py:58-69): counts (B,S) fp32, genes (B,S) int64 -> z (B,16,n_lat). */
-int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, void* ws, void* stream);
+int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision, void* ws,
+                     void* stream);
 
 /* TransformerVAE.decode (vae.py:71-87) up to the distribution parameters: z (B,16,n_lat), genes (B,G) int64,
  * library_size (B) -> mu (B,G) = softmax_G(logit / t) * library_size, theta (B,G) = exp(theta_emb[genes]). */

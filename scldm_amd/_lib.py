@@ -107,7 +107,7 @@ def lib() -> C.CDLL:
     L.scldm_vae_load_weights.argtypes = [C.c_void_p, C.POINTER(VaeWeights), C.c_void_p]
     L.scldm_vae_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.scldm_vae_workspace_bytes.restype = C.c_size_t
-    L.scldm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.scldm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.scldm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p]
     L.scldm_tokenize_expressed.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,

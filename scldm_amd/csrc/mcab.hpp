@@ -508,6 +508,9 @@ struct EncPoolArgs {
   float eps;
 };
 
+// BF: bf16 operands for the four contractions of a gene tile (see dec_gene_kernel); LayerNorm, the online softmax and the
+// output accumulators stay fp32.
+template <bool BF>
 __global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
   __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
   __shared__ float VEC[2 * kE];
@@ -544,24 +547,46 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
     const float rstd = 1.0f / sqrtf(xor32_sum(ss) * (1.0f / kE) + a.eps);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const int f = acc_row(r, hh); x[r] = x[r] * rstd * VEC[f] + VEC[kE + f]; }
+    // eight consecutive fp32 steps = the 16 k-values of one bf16 MFMA in the same order: fragment of steps [s0, s0+8)
+    auto frag8 = [&](const f32x4* F, int s0) {
+      const f32x4 lo = F[(s0 >> 2) * 64 + lane], hi = F[((s0 >> 2) + 1) * 64 + lane];
+      float t8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return OpBF16::pack8(t8);
+    };
     f32x16 kt = zero16(), vt = zero16();
+    if constexpr (BF) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 kf = KF[g4 * 64 + lane], vf = VF[g4 * 64 + lane];
+      for (int h8 = 0; h8 < 2; ++h8) {
+        const bf16x8 xf = OpBF16::pack8(x + 8 * h8);
+        kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8(KF, 8 * h8), xf, kt, 0, 0, 0);   // K^T[feature][gene]
+        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, frag8(VF, 8 * h8), vt, 0, 0, 0);   // V[gene][d]
+      }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kt = mfma2(kf[i], x[g4 * 4 + i], kt);   // K^T[feature][gene]
-        vt = mfma2(x[g4 * 4 + i], vf[i], vt);   // V[gene][d]
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 kf = KF[g4 * 64 + lane], vf = VF[g4 * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          kt = mfma2(kf[i], x[g4 * 4 + i], kt);   // K^T[feature][gene]
+          vt = mfma2(x[g4 * 4 + i], vf[i], vt);   // V[gene][d]
+        }
       }
     }
+    float ktv[16], vtv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ktv[r] = kt[r]; vtv[r] = vt[r]; }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x16 sc = zero16();
+      if constexpr (BF) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(ktv + 8 * t), frag8(QF, 8 * t), sc, 0, 0, 0);  // S[gene][(hl, q)]
+      } else {
 #pragma unroll
-      for (int g4 = 0; g4 < 2; ++g4) {
-        const f32x4 qf = QF[(t * 2 + g4) * 64 + lane];
+        for (int g4 = 0; g4 < 2; ++g4) {
+          const f32x4 qf = QF[(t * 2 + g4) * 64 + lane];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sc = mfma2(kt[8 * t + g4 * 4 + i], qf[i], sc);  // S[gene][(hl, q)]
+          for (int i = 0; i < 4; ++i) sc = mfma2(kt[8 * t + g4 * 4 + i], qf[i], sc);  // S[gene][(hl, q)]
+        }
       }
       float tm = -3.0e38f;
 #pragma unroll
@@ -578,8 +603,16 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
       m[t] = nm;
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+      if constexpr (BF) {
+        float pv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[t] = mfma2(vt[r], sc[r], O[t]);  // O^T[d][(hl, q)] += V^T P
+        for (int r = 0; r < 16; ++r) pv[r] = sc[r];
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(vtv), OpBF16::pack8(pv), O[t], 0, 0, 0);
+        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(vtv + 8), OpBF16::pack8(pv + 8), O[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t] = mfma2(vt[r], sc[r], O[t]);  // O^T[d][(hl, q)] += V^T P
+      }
     }
   }
 #pragma unroll

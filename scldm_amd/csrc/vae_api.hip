@@ -156,10 +156,11 @@ static int vae_ready(const scldm_vae* h) {
   return SCLDM_OK;
 }
 
-extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, void* ws_,
-                                void* stream_) {
+extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision,
+                                void* ws_, void* stream_) {
   int rc = vae_ready(h);
   if (rc) return rc;
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
   if (B <= 0 || S <= 0 || !counts || !genes || !z || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_vae_config& c = h->cfg;
@@ -169,7 +170,8 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
   p.ln1_w = h->small + S_ENC_LN1W; p.ln1_b = h->small + S_ENC_LN1B;
   p.kfrag = h->frag_enc_k; p.vfrag = h->frag_enc_v; p.qfrag = h->frag_enc_q;
   p.pooled = pooled; p.S = S; p.eps = c.layernorm_eps;
-  enc_pool_kernel<<<B, 256, 0, st>>>(p);
+  if (precision == SCLDM_PREC_BF16) enc_pool_kernel<true><<<B, 256, 0, st>>>(p);
+  else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
   LAUNCH_CHECK();
   EncCellArgs e;
   e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.ca_proj = h->small + S_ENC_PROJ;

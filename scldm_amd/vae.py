@@ -21,7 +21,7 @@ class TransformerVAE(nn.Module):
         self.decoder_head = decoder_head
         self.input_layer = input_layer
         self._handle = None
-        self.precision = "fp32"   # decode only: "bf16" = bf16 operands for the per-gene contractions (about 3x the decode rate)
+        self.precision = "fp32"   # "bf16" = bf16 operands for the per-gene contractions of encode / decode (fp32 everything else)
         self._weights_key = None
         self._ws = None
         self._keep = None
@@ -114,7 +114,8 @@ class TransformerVAE(nn.Module):
         z = torch.empty(B, self.encoder.latent_dim, self.encoder.latent_embedding, device=c.device, dtype=torch.float32)
         ws = self._workspace(L, B, 1)
         with torch.cuda.device(c.device):
-            _lib.check(L.scldm_vae_encode(h, c.data_ptr(), g.data_ptr(), B, S, z.data_ptr(), ws, _stream_ptr()), "scldm_vae_encode")
+            _lib.check(L.scldm_vae_encode(h, c.data_ptr(), g.data_ptr(), B, S, z.data_ptr(), _lib.PRECISIONS[self.precision], ws,
+                                          _stream_ptr()), "scldm_vae_encode")
         return z
 
     @torch.no_grad()

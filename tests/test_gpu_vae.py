@@ -142,3 +142,12 @@ def test_bf16_decode_close_to_fp32():
     assert float(((nb.mu - ref.mu).norm() / ref.mu.norm())) < 1e-2
     assert torch.allclose(nb.mu.sum(1, keepdim=True), lib.view(-1, 1), rtol=1e-4)
     assert max_abs_rel(nb.mu.cpu(), g["mu"]) < 3e-2
+
+
+def test_bf16_encode_close_to_fp32():
+    g, vae, sd, cfg = build("vae_2000")
+    counts, genes = cu(g["counts_subset"]), cu(g["genes_subset"])
+    ref = vae.encode(cu(g["counts"]), cu(g["genes"]), counts, genes)
+    vae.precision = "bf16"
+    z = vae.encode(cu(g["counts"]), cu(g["genes"]), counts, genes)
+    assert max_abs_rel(z.cpu(), ref.cpu()) < 3e-2 and max_abs_rel(z.cpu(), g["z"]) < 3e-2

@@ -31,6 +31,13 @@ for B in (256, 1024):
         torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 5
         vae.precision = "bf16"
         for _ in range(2):
+            zb = vae.encode(counts, genes, counts, genes)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            zb = vae.encode(counts, genes, counts, genes)
+        torch.cuda.synchronize(); teb = (time.perf_counter() - t0) / 5
+        print(f"B={B}: bf16-operand encode {teb*1e3:.2f} ms = {B/teb:.0f} cells/s")
+        for _ in range(2):
             nb = vae.decode(z, allg, lib)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(5):
