@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time MMDLoss (three fused kernel-mean terms) at a generation-evaluation size; VALU-bound: pair-feature updates per second."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from scldm_amd import evaluations as ev
 from oracle.evaluations import mmd as oracle_mmd

@@ -2,7 +2,7 @@
 """For a nondeterministically corrupted sample: which (t, label) reproduces the bad output?"""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import _random_dit
 from oracle.dit import DiTConfig, dit_forward

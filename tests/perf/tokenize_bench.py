@@ -2,7 +2,7 @@
 """HBM roofline of scldm_tokenize_expressed next to the NumPy restatement of the reference's tokenizer.
 Algorithmic bytes per cell: 4*G (counts in) + 12*S (int64 gene + fp32 count per window slot out) + 8 (num_expressed, library size)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from scldm_amd.datamodule import tokenize_cells_expressed

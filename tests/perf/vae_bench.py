@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of TransformerVAE.encode / decode (MCAB kernels, fp32-exact) at the dentate_gyrus sizes."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from test_abi_cpu import _build_vae
