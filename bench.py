@@ -7,13 +7,23 @@ step     = one full sampling pass of the per-GPU batch: noise (already resident 
 value    = whole-job requested cells per second = N * B_per_gpu / (time per step), max over ranks.
 roofline = the fused DiT block kernel (dominant): algorithmic FLOPs per launch / mean launch duration measured
            with HIP events on the launch stream inside the timed region, against the dense MFMA peak.
+parity_path = the same workload at precision "bf16x3" (split-bf16, <= 1e-4 vs the reference): cells/s, roofline against
+           its own peak (three bf16 MFMAs per product sum: 2.5 PF / 3), error measured against the exact-fp32 path.
 cpu_baseline = the CPU oracle ("port" of the reference algorithm) on this box's host cores, bounded sample.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (one process per
+GPU through torch.distributed.run, before this process touches a GPU); under an external launcher (the driver's
+`python -m torch.distributed.run ... bench.py --gpus N`) it runs as the rank it was started as.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,8 +39,11 @@ WORKLOADS = {
     "dentate_b512_euler50": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=512, evals=50, method="euler", scale=1.0),
     # configs[2]: 100 Heun steps = 200 evaluations, guidance 2.0
     "hlca_b2048_heun100": dict(vocab={"cell_type": 50}, strategy="mutually_exclusive", B=2048, evals=200, method="heun", scale=2.0),
-    # configs[3]: 8192 cells over 8 GPUs = 1024 per GPU, joint conditioning
+    # configs[3] per-GPU shard: 8192 cells over 8 GPUs = 1024 per GPU, joint conditioning
     "parse1m_b1024_euler100": dict(vocab={"cell_type": 18, "cytokine": 91}, strategy="joint", B=1024, evals=100, method="euler", scale=1.0),
+    # configs[3] as north_star states it: 8192 cells GLOBAL, sharded over the ranks of the job (strong scaling: B = 8192 / N per GPU)
+    "parse1m_b8192_euler100_strong": dict(vocab={"cell_type": 18, "cytokine": 91}, strategy="joint", B=8192, evals=100, method="euler",
+                                          scale=1.0, strong=True),
 }
 TRAIN_WORKLOADS = {
     # BASELINE.json configs[4] restated on the reference's own DiT shape (ldm_base.yaml; "DiT-L" is not a reference config):
@@ -49,12 +62,58 @@ def dit_flops(n_embed=256, n_layer=8, n_embed_input=16, seq_len=16, multiple_of=
     H = multiple_of * ((int(2 * (4 * D) / 3) + multiple_of - 1) // multiple_of)
     block = 2 * D * 6 * D + S * (2 * D * 3 * D + 2 * D * D + 6 * D * H) + 2 * (2 * S * S * D)
     return n_layer * block + 2 * 256 * D + 2 * D * D + S * 2 * n_embed_input * D + 2 * D * 2 * D + S * 2 * D * n_embed_input
-FLOPS_PER_SAMPLE_FWD = 210_763_776
+FLOPS_PER_SAMPLE_FWD = 210_763_776            # BASELINE.md section 3 (adaLN + timestep MLP counted once per sample-forward)
 FLOPS_PER_SAMPLE_BLOCK = 26_247_168 - 2 * 256 * 1536  # fused block kernel: everything of a block except the adaLN projection
-PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md:41-42
+# What the path EXECUTES: the trunk per sample-forward, the adaLN projections once per conditioning ROW (1 unconditional row +
+# one per unique label tuple per conditional pass), the timestep MLP once per evaluation.
+FLOPS_TRUNK_PER_SAMPLE_FWD = 8 * FLOPS_PER_SAMPLE_BLOCK + 16 * 2 * 16 * 256 + 16 * 2 * 256 * 16
+FLOPS_ADALN_PER_ROW = 2 * 256 * (8 * 1536 + 512)
+FLOPS_TMLP = 2 * 256 * 256 * 2
+# dense MFMA peaks, MI355X_MICROARCH.md:41-42; bf16x3 issues three bf16 MFMAs per algorithmic product sum
+PEAK = {"bf16": 2.5e15, "fp32": 157.3e12, "bf16x3": 2.5e15 / 3}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# launcher
+# --------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str], script: str = os.path.abspath(__file__)) -> int:
+    """Start `n` ranks of this script on one node (one process per GPU) and return the job's exit code.  Called before the
+    parent has made any GPU call: the ranks are CHILD processes (never an exec of a process that initialised the GPU)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this platform
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script, *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# models and inputs
+# --------------------------------------------------------------------------------------------------------------------
+class FakeSampler(torch.nn.Module):
+    """Per-cell, order-preserving stand-in for the HIP sampler (BENCH_FAKE=1: the CPU / gloo test of the launcher, timing
+    harness and all-gather; tests/test_bench_launcher.py).  Never used for a reported number."""
+    precision = "fake"
+
+    def sample_ode_cfg(self, z2, cond2, scales, num_steps, method):
+        lab = sum(v.float() for v in cond2.values()).view(-1, 1, 1)
+        return z2 * 2.0 + lab
+
+    def block_timing(self, enable=None):
+        return None if enable is not None else (0, 0.0)
+
+    def layers_per_launch(self):
+        return 0
 
 
 def make_model(wl, precision, device, seed=0):
+    if os.environ.get("BENCH_FAKE") == "1":
+        return FakeSampler()
     from scldm_amd.nnets import DiT
     shape = dict(n_embed=256, n_layer=8, n_head=8)
     shape.update(wl.get("shape", {}))
@@ -84,6 +143,23 @@ def n_passes(wl):
     return 1 if wl["strategy"] == "joint" else len(wl["vocab"])
 
 
+def unique_label_rows(cond2, B):
+    cols = torch.stack([v[B:] for _, v in sorted(cond2.items())], dim=1)
+    return int(torch.unique(cols, dim=0).shape[0])
+
+
+def executed_flops_per_eval(wl, B, cond2):
+    """FLOPs one CFG evaluation executes on this path (see FLOPS_TRUNK_PER_SAMPLE_FWD)."""
+    P = n_passes(wl)
+    rows = 1 + P * unique_label_rows(cond2, B)
+    return (2 + P) * B * FLOPS_TRUNK_PER_SAMPLE_FWD + rows * FLOPS_ADALN_PER_ROW + FLOPS_TMLP
+
+
+def sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+
+
 def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world):
     out = None
     for _ in range(steps):
@@ -97,17 +173,20 @@ def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world):
 
 
 def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_blocks):
-    z2, cond2, scales = make_inputs(wl, wl["B"], device, seed=1234 + rank)
+    """`steps` timed steps bracketed by barrier + synchronize on both sides; returns (seconds: max over ranks, block timing,
+    last output, inputs).  A strong-scaling workload gives every rank B / world of its cells."""
+    B = wl["B"] // world if wl.get("strong") else wl["B"]
+    z2, cond2, scales = make_inputs(wl, B, device, seed=1234 + rank)
     run_steps(m, wl, z2, cond2, scales, warmup, dist_on, world)
     if time_blocks:
         m.block_timing(True)
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
-    torch.cuda.synchronize()
+    sync(device)
     t0 = time.perf_counter()
-    run_steps(m, wl, z2, cond2, scales, steps, dist_on, world)
-    torch.cuda.synchronize()
+    out = run_steps(m, wl, z2, cond2, scales, steps, dist_on, world)
+    sync(device)
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -118,7 +197,7 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    return dt, blocks
+    return dt, blocks, out, (z2, cond2, scales, B)
 
 
 def time_training(wl, precision, device, steps, warmup, dist_on, world):
@@ -152,8 +231,25 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world):
     return dt, float(loss)
 
 
-def decode_inclusive(m, wl, device, n_genes=17002):
-    """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count)."""
+def fused_kernel_roofline(m, blocks, n_fwd, precision, wl, evals_per_step):
+    """FLOPs per launch / mean launch duration (HIP events on the launch stream) for the fused DiT layer kernel."""
+    n_launch, tot_ms = blocks
+    avg_s = tot_ms / n_launch / 1e3
+    lpl = m.layers_per_launch()
+    flops_launch = n_fwd * FLOPS_PER_SAMPLE_BLOCK * lpl
+    ach = flops_launch / avg_s / 1e12
+    # algorithmic HBM bytes per launch: the latents in / velocities out once per evaluation, the fp32 residual handed from launch
+    # to launch (written by every launch but the last, read by every launch but the first), every layer's packed weights once
+    n_l = 8
+    launches_per_eval = (n_l + lpl - 1) // lpl
+    wbytes = {"bf16": 2, "bf16x3": 4, "fp32": 4}[precision] * (768 * 256 + 256 * 256 + 3 * 256 * 704)
+    per_eval = 2 * n_fwd * 16 * 16 * 4 + (launches_per_eval - 1) * 2 * n_fwd * 16 * 256 * 4 + n_l * wbytes
+    return {"bound": "mfma", "kernel": "dit_forward_kernel", "achieved": ach, "peak": PEAK[precision] / 1e12, "unit": "TFLOP/s",
+            "frac": ach / (PEAK[precision] / 1e12), "launches": n_launch, "avg_launch_us": avg_s * 1e6, "layers_per_launch": lpl,
+            "algorithmic_flops_per_launch": flops_launch, "algorithmic_hbm_bytes_per_launch": per_eval / launches_per_eval}
+
+
+def make_vae(n_genes, device):
     from scldm_amd.layers import InputTransformerVAE
     from scldm_amd.nnets import Decoder, Encoder
     from scldm_amd.stochastic_layers import NegativeBinomialTransformerLayer
@@ -168,8 +264,17 @@ def decode_inclusive(m, wl, device, n_genes=17002):
     with torch.no_grad():
         for n, p in vae.named_parameters():
             p.copy_(torch.randn(p.shape, generator=g) * (1.0 if "embedding" in n or "inducing" in n else 0.05) + (1.0 if ".ln_" in n and n.endswith("weight") else 0.0))
-    vae = vae.to(device).eval()
-    vae.precision = m.precision          # bf16 run: bf16-operand decode as well
+    return vae.to(device).eval()
+
+
+MCAB_DECODE_FLOPS_PER_GENE = 23_104   # BASELINE.md section 3 (per decoded gene; the 16-token trunk adds 3.3 MFLOP per cell)
+
+
+def decode_inclusive(m, wl, device, n_genes=17002):
+    """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count), and the
+    decode alone at both VAE precisions with its roofline (fp32-MFMA peak for the parity path, bf16 peak for the bf16 one)."""
+    vae = make_vae(n_genes, device)
+    vae.precision = "bf16" if m.precision == "bf16" else "fp32"   # bf16 run: bf16-operand decode as well
     B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
     w2 = dict(wl); w2["B"] = B
     z2, cond2, scales = make_inputs(w2, B, device, seed=7)
@@ -181,31 +286,96 @@ def decode_inclusive(m, wl, device, n_genes=17002):
         return vae.decode(z, genes, lib)
     once(); torch.cuda.synchronize()
     t0 = time.perf_counter(); once(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    t1 = time.perf_counter(); vae.decode(z2, genes, lib); torch.cuda.synchronize(); dd = time.perf_counter() - t1
-    return {"cells_per_gpu": B, "n_genes": n_genes, "cells_per_s": B / dt, "decode_only_cells_per_s": 2 * B / dd,
-            "note": "sampling + MCAB decode of the 2B latents to (mu, theta); decode rate counts decoded rows"}
+    rec = {"cells_per_gpu": B, "n_genes": n_genes, "cells_per_s": B / dt,
+           "note": "sampling + MCAB decode of the 2B latents to (mu, theta); decode rates count decoded rows"}
+    flops_row = n_genes * MCAB_DECODE_FLOPS_PER_GENE + 3.3e6
+    for prec in ("fp32", "bf16"):
+        vae.precision = prec
+        vae.decode(z2, genes, lib); torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter(); vae.decode(z2, genes, lib); torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+        dd = statistics.median(ts)
+        ach = 2 * B * flops_row / dd / 1e12
+        rec[f"decode_only_{prec}"] = {"rows_per_s": 2 * B / dd, "ms": 1e3 * dd,
+                                      "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK[prec] / 1e12, "unit": "TFLOP/s",
+                                                   "frac": ach / (PEAK[prec] / 1e12),
+                                                   "hbm_out_GBps": 2 * B * n_genes * 8 / dd / 1e9}}
+    rec["decode_only_cells_per_s"] = rec[f"decode_only_{'bf16' if m.precision == 'bf16' else 'fp32'}"]["rows_per_s"]
+    return rec
 
 
-def cpu_baseline(m, wl, budget_cells=256, evals=3):
-    """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on this
-    box's host cores over a bounded sample: `budget_cells` cells x `evals` Euler evaluations with CFG."""
+def parity_path(wl, device, ref_cells=64):
+    """The <= 1e-4 path of the same workload: precision 'bf16x3' - throughput, fused-kernel roofline against ITS peak, and its
+    error against the exact-fp32 path (itself pinned to the reference's golden vectors at ~6e-7 by tests/) on `ref_cells`
+    cells x 8 Euler evaluations: scale-relative max error and the elementwise relative error floored at 1 % of max|ref|."""
+    m3 = make_model(wl, "bf16x3", device)
+    dt, blocks, _, (z2, cond2, scales, B) = time_workload(m3, wl, device, 1, 1, False, 1, 0, time_blocks=True)
+    n_fwd = (2 + n_passes(wl)) * B
+    rec = {"precision": "bf16x3", "cells_per_s": B / dt, "ms_per_step": 1e3 * dt,
+           "arithmetic": "operands split into hi + lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate / LN / softmax / residual",
+           "dit_fwd_mfma_frac": executed_flops_per_eval(wl, B, cond2) * wl["evals"] / dt / PEAK["bf16x3"]}
+    if blocks and blocks[0] > 0:
+        rec["roofline"] = fused_kernel_roofline(m3, blocks, n_fwd, "bf16x3", wl, wl["evals"])
+    zs, cs, ss = make_inputs(wl, ref_cells, device, seed=31)
+    outs = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        m3.precision = prec
+        outs[prec] = m3.sample_ode_cfg(zs, cs, ss, 9, "euler").double()
+    ref = outs["fp32"]
+    for prec in ("bf16x3", "bf16"):
+        d = (outs[prec] - ref).abs()
+        rec[f"err_{prec}_vs_fp32"] = {"max_abs_over_max_ref": float(d.max() / ref.abs().max()),
+                                      "max_rel_floor_1pct": float((d / ref.abs().clamp_min(0.01 * float(ref.abs().max()))).max())}
+    rec["err_note"] = f"{ref_cells} cells x 8 Euler CFG evaluations, against the exact-fp32 path on the same device"
+    return rec
+
+
+def cpu_baseline(m, wl, target_s=8.0):
+    """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on ALL host cores of
+    this box over a bounded sample of the SAME workload: the full number of CFG evaluations on a reduced cell count (chosen from a
+    short calibration so that one solve takes about `target_s` seconds), warm-up 1 solve, median of 3 - measured, not extrapolated."""
     from oracle.dit import DiTConfig, dit_forward_with_cfg
     from oracle.transport import sample_ode_fixed
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     cfg = DiTConfig(class_vocab_sizes=wl["vocab"], condition_strategy=wl["strategy"])
-    z2, cond2, scales = make_inputs(wl, budget_cells, "cpu", seed=99)
-    cores = min(os.cpu_count() or 1, 16)  # small GEMMs: more threads than this only adds contention (measured)
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    f = lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales)
-    sample_ode_fixed(z2[:8].repeat(1, 1, 1), lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, {k: v[:8] for k, v in cond2.items()}, scales), 2, "euler")
-    t0 = time.perf_counter()
-    sample_ode_fixed(z2, f, evals + 1, "euler")
-    dt = time.perf_counter() - t0
-    per_eval = dt / evals
-    n_evals_full = wl["evals"]
-    return {"value": budget_cells / (per_eval * n_evals_full), "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{budget_cells} cells x {evals} of {n_evals_full} CFG evaluations (fp32, torch CPU ops), per-evaluation time "
-                      f"{per_eval:.3f}s scaled to {n_evals_full} evaluations"}
+    n_evals = wl["evals"]
+    steps = n_evals + 1 if wl["method"] == "euler" else n_evals // 2 + 1
+
+    def solve(cells, n_steps):
+        z2, cond2, scales = make_inputs(wl, cells, "cpu", seed=99)
+        t0 = time.perf_counter()
+        sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales), n_steps, wl["method"])
+        return time.perf_counter() - t0
+
+    solve(16, 2)                                    # first-touch warm-up
+    per_cell_eval = solve(32, 4) / (32 * 3)         # calibration: 32 cells x 3 evaluations
+    cells = int(min(512, max(16, target_s / (per_cell_eval * n_evals))))
+    solve(cells, steps)                             # warm-up solve
+    times = [solve(cells, steps) for _ in range(3)]
+    med = statistics.median(times)
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu_model)
+    except OSError:
+        pass
+    return {"value": cells / med, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model,
+            "sample": f"{cells} cells x all {n_evals} CFG evaluations ({wl['method']}), fp32 torch CPU ops on {torch.get_num_threads()} threads, "
+                      f"median of 3 solves ({', '.join(f'{t:.2f}' for t in times)} s) after one warm-up solve; measured, not extrapolated"}
+
+
+def emit(result, rank):
+    if rank == 0:
+        sys.stdout.flush()
+        try:  # RCCL prints its banner through C stdio: flush that buffer first so the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)  # the one JSON line
 
 
 def main():
@@ -214,21 +384,39 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--evals", type=int, default=0, help="override the number of CFG evaluations (profiling only; not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra-workload measurements")
     args = ap.parse_args()
+    fake = os.environ.get("BENCH_FAKE") == "1"   # CPU / gloo test of the launcher and harness (tests/test_bench_launcher.py)
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            # nothing in this process has touched a GPU yet (device_count() does not initialise one on this platform)
+            if not fake and args.gpus > torch.cuda.device_count():
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started as one of WORLD_SIZE={os.environ['WORLD_SIZE']} ranks: "
+                         "launch as many ranks as GPUs (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if fake:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -236,7 +424,12 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if fake:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    rccl_ranks = dist.get_world_size() if dist_on else 1
+
     if args.workload in TRAIN_WORKLOADS:   # SURVEY 8a row T1 / BASELINE configs[4]: not the headline metric, its own line
         wl = dict(TRAIN_WORKLOADS[args.workload])
         if args.batch:
@@ -244,7 +437,8 @@ def main():
         dt, loss = time_training(wl, args.precision, device, args.steps, max(args.warmup, 1), dist_on, world)
         value = world * wl["B"] / (dt / args.steps)
         result = {"metric": "training cells/sec (flow-matching step: forward + backward + gradient all-reduce + AdamW)", "value": value,
-                  "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * dt / args.steps,
+                  "unit": "cells/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": max(args.warmup, 1),
+                  "ms_per_step": 1e3 * dt / args.steps,
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                   "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": world * wl["B"],
                              "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "AdamW (fused)",
@@ -254,96 +448,91 @@ def main():
         if "shape" in wl:
             result["config"]["dit_shape"] = wl["shape"]
         if dist_on:
-            import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()
-        if rank == 0:
-            sys.stdout.flush()
-            try:
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-            except Exception:
-                pass
-            print(json.dumps(result), flush=True)
+        emit(result, rank)
         return
+
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["B"] = args.batch
     if args.evals:
         wl["evals"] = args.evals
     m = make_model(wl, args.precision, device)
-    dt, blocks = time_workload(m, wl, device, args.steps, args.warmup, dist_on, world, rank, time_blocks=True)
+    dt, blocks, out, (z2, cond2, scales, B) = time_workload(m, wl, device, args.steps, args.warmup, dist_on, world, rank, time_blocks=True)
     ms_per_step = 1e3 * dt / args.steps
-    cells = world * wl["B"]
+    strong = bool(wl.get("strong"))
+    cells = wl["B"] if strong else world * B
     value = cells / (dt / args.steps)
-    n_fwd = (2 + n_passes(wl)) * wl["B"]
+    n_fwd = (2 + n_passes(wl)) * B
     evals = wl["evals"]
-    dit_flops_step = n_fwd * FLOPS_PER_SAMPLE_FWD * evals
     result = {
         "metric": "cells/sec (whole node) @100 Euler steps; DiT-fwd MFMA util % of peak",
-        "value": value, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": value, "unit": "cells/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": cells, "cfg_evaluations": evals,
+        "config": {"workload": args.workload, "cells_per_gpu": B, "global_cells": cells, "cfg_evaluations": evals,
                    "method": wl["method"], "guidance_scale": wl["scale"], "condition_strategy": wl["strategy"],
                    "class_vocab_sizes": wl["vocab"], "sample_forwards_per_evaluation_per_gpu": n_fwd,
+                   "gathered_rows": int(out.shape[0]) if out is not None else None,
                    "parallelism": f"batch-sharded x{world}, one all-gather of latents" if dist_on else "single GPU"},
-        "dit_fwd_tflops_per_gpu": dit_flops_step / (dt / args.steps) / 1e12,
-        "dit_fwd_mfma_frac": dit_flops_step / (dt / args.steps) / PEAK[args.precision],
     }
-    if blocks and blocks[0] > 0:
-        n_launch, tot_ms = blocks
-        avg_s = tot_ms / n_launch / 1e3
-        lpl = m.layers_per_launch()                      # DiT layers one fused launch runs (2 unless SCLDM_LPL=1)
-        flops_launch = n_fwd * FLOPS_PER_SAMPLE_BLOCK * lpl
-        ach = flops_launch / avg_s / 1e12
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_dit_forward_kernel.json")
-        if args.precision == "bf16" and args.workload == "dentate_b4096_euler100" and not args.batch and os.path.exists(pmc):
-            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of this same workload
-            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; see the file's note)
-            with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-            traffic_src = "profiles/pmc_dit_forward_kernel.json"
-        result["roofline"] = {"bound": "mfma", "kernel": "dit_forward_kernel", "achieved": ach, "peak": PEAK[args.precision] / 1e12,
-                              "unit": "TFLOP/s", "frac": ach / (PEAK[args.precision] / 1e12), "traffic": traffic,
-                              "traffic_source": traffic_src,
-                              "launches": n_launch, "avg_launch_us": avg_s * 1e6, "layers_per_launch": lpl,
-                              "algorithmic_flops_per_launch": flops_launch}
-    if rank == 0 and not dist_on:
+    if not fake:
+        peak = PEAK[args.precision]
+        step_s = dt / args.steps
+        ex = executed_flops_per_eval(wl, B, cond2) * evals
+        result["dit_fwd_tflops_per_gpu"] = ex / step_s / 1e12
+        result["dit_fwd_mfma_frac"] = ex / step_s / peak                          # FLOPs the path executes (adaLN per conditioning row)
+        result["dit_fwd_mfma_frac_algorithmic"] = n_fwd * FLOPS_PER_SAMPLE_FWD * evals / step_s / peak   # BASELINE.md section 3 formula
+        if blocks and blocks[0] > 0:
+            rl = fused_kernel_roofline(m, blocks, n_fwd, args.precision, wl, evals)
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_dit_forward_kernel.json")
+            if args.precision == "bf16" and args.workload == "dentate_b4096_euler100" and not args.batch and os.path.exists(pmc):
+                # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of this same workload
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; see the file's note)
+                with open(pmc) as f:
+                    pj = json.load(f)
+                if pj.get("layers_per_launch", rl["layers_per_launch"]) == rl["layers_per_launch"]:
+                    traffic, traffic_src = pj.get("hbm_bytes_per_launch"), "profiles/pmc_dit_forward_kernel.json"
+            rl["traffic"], rl["traffic_source"] = traffic, traffic_src
+            rl["traffic_ratio"] = (traffic / rl["algorithmic_hbm_bytes_per_launch"]) if traffic else None
+            result["roofline"] = rl
+    if rank == 0 and not dist_on and not fake:
         if not args.no_extra:
+            if args.precision != "bf16x3":
+                result["parity_path"] = parity_path(wl, device)
             extra = []
-            for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100"):
+            for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100", "parse1m_b8192_euler100_strong"):
                 if name == args.workload:
                     continue
                 w2 = dict(WORKLOADS[name])
                 m2 = make_model(w2, args.precision, device)
-                d2, _ = time_workload(m2, w2, device, 1, 1, False, 1, 0, time_blocks=False)
-                nf2 = (2 + n_passes(w2)) * w2["B"]
-                extra.append({"workload": name, "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2,
-                              "dit_fwd_mfma_frac": nf2 * FLOPS_PER_SAMPLE_FWD * w2["evals"] / d2 / PEAK[args.precision]})
+                d2, _, _, (_, c2, _, B2) = time_workload(m2, w2, device, 1, 1, False, 1, 0, time_blocks=False)
+                extra.append({"workload": name, "cells_per_s": B2 / d2, "ms_per_step": 1e3 * d2,
+                              "dit_fwd_mfma_frac": executed_flops_per_eval(w2, B2, c2) * w2["evals"] / d2 / PEAK[args.precision]})
                 del m2
             result["other_workloads"] = extra
             result["with_vae_decode"] = decode_inclusive(m, wl, device)
             tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
             torch.cuda.empty_cache()
-            dtt, _ = time_training(tw, args.precision, device, 10, 5, False, 1)
+            tprec = "bf16" if args.precision == "bf16" else "fp32"
+            dtt, _ = time_training(tw, tprec, device, 10, 5, False, 1)
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
-                                       "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": args.precision}
+                                       "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
+    elif dist_on and not args.no_extra and args.workload == "dentate_b4096_euler100":
+        # N > 1: the strong-scaling leg north_star names (parse1m, 8192 cells global = 8192 / N per GPU), every rank takes part
+        w2 = dict(WORKLOADS["parse1m_b8192_euler100_strong"])
+        m2 = make_model(w2, args.precision, device)
+        d2, _, _, (_, _, _, B2) = time_workload(m2, w2, device, 1, 1, dist_on, world, rank, time_blocks=False)
+        result["strong_scaling"] = {"workload": "parse1m_b8192_euler100_strong", "global_cells": w2["B"], "cells_per_gpu": B2,
+                                    "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2, "scaling": "strong"}
     if dist_on:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        sys.stdout.flush()
-        try:  # RCCL prints its banner through C stdio: flush that buffer first so the JSON line is the last line
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(result), flush=True)  # the one JSON line
+    emit(result, rank)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,10 @@ extern "C" {
 
 #define SCLDM_PREC_FP32 0  /* exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): parity path, <=1e-4 vs reference */
 #define SCLDM_PREC_BF16 1  /* bf16 operands, fp32 accumulate / LN / softmax / residual: throughput path */
+#define SCLDM_PREC_BF16X3 2 /* split-bf16: every GEMM operand as hi + lo bf16, three v_mfma_f32_32x32x16_bf16 per k-step (hi*hi, hi*lo,
+                             * lo*hi), fp32 accumulate - the arithmetic class of the reference's
+                             * torch.set_float32_matmul_precision("high") (experiments/scripts/inference.py:26); ~1e-5 vs fp32,
+                             * inside the 1e-4 parity gate at 5x the exact-fp32 MFMA rate.  DiT inference entry points only. */
 
 #define SCLDM_METHOD_EULER 0
 #define SCLDM_METHOD_HEUN 1
@@ -54,6 +58,9 @@ typedef struct {
   float layernorm_eps;
   int n_classes;
   int class_vocab[SCLDM_MAX_CLASSES]; /* vocab size per class; the null token index equals it */
+  int has_null_row;   /* 1: class tables have vocab+1 rows (cfg_dropout_prob > 0, nnets.py:241-243); 0: vocab rows - every entry point
+                       * that would need a null token (unconditional CFG pass, unselected class) then returns SCLDM_ERR_SHAPE, where
+                       * the reference's nn.Embedding raises IndexError */
 } scldm_dit_config;
 
 /* Device pointers to the reference's parameters in their PyTorch layouts (Linear.weight is (out,in)).
@@ -81,9 +88,22 @@ int scldm_version(void);
 int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out);
 void scldm_dit_destroy(scldm_dit* h);
 
-/* Re-pack weights from the caller's parameter tensors into MFMA fragment streams (fp32 and bf16
- * copies).  Call again after an optimiser step.  Sources stay owned by the caller. */
+/* Re-pack weights from the caller's parameter tensors into MFMA fragment streams (fp32, bf16 and split-bf16
+ * copies) in one launch.  Sources stay owned by the caller and must stay allocated while the handle is used:
+ * their addresses are remembered for scldm_dit_refresh_weights. */
 int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream);
+
+/* Cheap staleness guard for callers that cannot know whether the parameter tensors were modified in place
+ * (e.g. ema_pytorch updates through `.data`, which does not bump torch's version counter; reference
+ * src/scldm/models.py:446,690): fingerprints the tensors given to the last scldm_dit_load_weights ON DEVICE (every
+ * element of small tensors, 4096 evenly spaced elements of large ones) and re-packs, in the same stream and without a
+ * host synchronisation, only if the fingerprint changed.  Three small launches when nothing changed. */
+int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
+
+/* Labels outside [0, vocab] (or == vocab without a null row) are clamped by the conditioning kernels and counted in a
+ * device-side sticky counter instead of reading another class's table (the reference's nn.Embedding raises).  This call
+ * synchronises `stream`, returns the count since the last call in *count and resets it. */
+int scldm_dit_label_errors(scldm_dit* h, int* count, void* stream);
 
 /* Floats per conditioning row: n_layer*6*D + 2*D (all adaLN vectors of all layers + final layer). */
 int scldm_dit_mod_width(const scldm_dit* h);
@@ -133,8 +153,8 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
                      int n_pass, const uint32_t* pass_mask, const float* pass_scale, int n_steps, int method,
                      int precision, void* ws, void* stream);
 
-/* DiT layers one fused-kernel launch runs (2 by default: the residual stays in registers between the pair; 0 for a handle
- * outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
+/* DiT layers one fused-kernel launch runs (4 by default, SCLDM_LPL=1..4: the residual stays in registers between them; 0 for a
+ * handle outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
 int scldm_dit_layers_per_launch(const scldm_dit* h);
 
 /* Timing hook for bench.py: when enabled, every fused-block launch is bracketed by HIP events on its

@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCLDM_LIB", os.path.join(_HERE, "libscldm_hip.so"))  # SCLDM_LIB: debug-build override
 
 MAX_CLASSES = 8
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 METHOD_EULER, METHOD_HEUN = 0, 1
-PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16}
+PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 METHODS = {"euler": METHOD_EULER, "heun": METHOD_HEUN}
 
 c_float_p = C.POINTER(C.c_float)
@@ -24,7 +24,7 @@ c_void_pp = C.POINTER(C.c_void_p)
 class DitConfig(C.Structure):
     _fields_ = [("n_embed", C.c_int), ("n_embed_input", C.c_int), ("n_layer", C.c_int), ("n_head", C.c_int),
                 ("seq_len", C.c_int), ("hidden_dim", C.c_int), ("layernorm_eps", C.c_float), ("n_classes", C.c_int),
-                ("class_vocab", C.c_int * MAX_CLASSES)]
+                ("class_vocab", C.c_int * MAX_CLASSES), ("has_null_row", C.c_int)]
 
 
 class DitWeights(C.Structure):
@@ -75,6 +75,8 @@ def lib() -> C.CDLL:
     L.scldm_dit_destroy.argtypes = [C.c_void_p]
     L.scldm_dit_destroy.restype = None
     L.scldm_dit_load_weights.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p]
+    L.scldm_dit_refresh_weights.argtypes = [C.c_void_p, C.c_void_p]
+    L.scldm_dit_label_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
     L.scldm_dit_mod_width.argtypes = [C.c_void_p]
     L.scldm_dit_layers_per_launch.argtypes = [C.c_void_p]
     L.scldm_dit_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -123,7 +125,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
-           "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
+           "scldm_dit_refresh_weights", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes",
            "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",

@@ -27,9 +27,27 @@ static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 1
 
 
 extern "C" const char* scldm_last_error(void) { return g_err; }
-extern "C" int scldm_version(void) { return 1; }
+extern "C" int scldm_version(void) { return 2; }   // 2: has_null_row in scldm_dit_config, SCLDM_PREC_BF16X3, refresh_weights / label_errors
 
-static size_t esize(int prec) { return prec == SCLDM_PREC_BF16 ? 2 : 4; }
+static size_t esize(int prec) { return prec == SCLDM_PREC_BF16 ? 2 : 4; }  // bytes per packed weight element (split-bf16: hi + lo)
+static const int kNPrec = 3;
+
+// Kernel shape: (token tiles of 32*NTT, FT feature tiles per wave => 8/FT waves per workgroup).
+//   fp32   : NTT=2, FT=2 (4 waves, one per SIMD, 512-register budget)
+//   bf16   : NTT=2, FT=2, two workgroups per CU by default; FT=1 (8 waves, one head each) and the 128-token tile of the
+//            8-wave shape (NTT=4, FT=1: each weight fragment feeds four token tiles) remain selectable through
+//            SCLDM_FT / SCLDM_NTT for A/B runs
+//   bf16x3 : NTT=2, FT=2 (one workgroup per CU: 155 KB of LDS); SCLDM_X3_FT=1 selects the 8-wave shape
+static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
+  *ntt = 2;
+  *ft = 2;
+  if (prec == SCLDM_PREC_BF16) {
+    if (h->force_ft == 1 || h->force_ft == 2) *ft = h->force_ft;
+    if (h->force_ntt == 4 && *ft == 1) *ntt = 4;
+  } else if (prec == SCLDM_PREC_BF16X3) {
+    if (h->force_x3_ft == 1) *ft = 1;
+  }
+}
 
 extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (!cfg || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
@@ -47,18 +65,28 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   }
   if (cfg->n_layer < 1 || cfg->hidden_dim < 1) return fail(SCLDM_ERR_SHAPE, "bad n_layer / hidden_dim");
   if (cfg->n_classes < 0 || cfg->n_classes > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_classes must be <= %d", SCLDM_MAX_CLASSES);
-  scldm_dit* h = new scldm_dit();
+  if (cfg->has_null_row != 0 && cfg->has_null_row != 1) return fail(SCLDM_ERR_SHAPE, "has_null_row must be 0 or 1");
+  for (int c = 0; c < cfg->n_classes; ++c)
+    if (cfg->class_vocab[c] < 1) return fail(SCLDM_ERR_SHAPE, "class %d has an empty vocabulary", c);
+  scldm_dit* h = new scldm_dit();   // value-initialised: every pointer NULL, every counter 0
   h->cfg = *cfg;
   h->fused = fused;
+  h->mod_w = cfg->n_layer * 6 * cfg->n_embed + 2 * cfg->n_embed;
+  for (int c = 0; c < cfg->n_classes; ++c) h->tab_rows[c] = cfg->class_vocab[c] + cfg->has_null_row;
   if (!fused) {
-    h->mod_w = cfg->n_layer * 6 * cfg->n_embed + 2 * cfg->n_embed;
-    h->loaded = false;
-    h->timing = false;
-    h->ev_used = 0;
-    h->dbg = nullptr;
     *out = h;
     return SCLDM_OK;
   }
+  // run-time knobs are read ONCE, here (they select kernel shapes and therefore which weight streams exist)
+  if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
+  if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
+  if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
+  h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..4 for A/B runs)
+  if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
+  h->groups = 1;
+  if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
+  h->dbg_layer = -1;
+  if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
   h->n_chunks[0] = (cfg->hidden_dim + kHC - 1) / kHC;  // FT=1: pad the hidden dimension to whole chunks
   h->half[0] = 0;
   {
@@ -67,28 +95,17 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
     h->n_chunks[1] = hp / kHC;
     h->half[1] = (hp % kHC) / 64;
   }
-  h->mod_w = cfg->n_layer * 6 * kD + 2 * kD;
-  h->loaded = false;
-  h->timing = false;
-  h->ev_used = 0;
-  h->force_ntt = 0;
-  h->dbg = nullptr;
-  if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
-  h->force_ft = 0;
-  if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
-  h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..4 for A/B runs)
-  if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes); };
   const int L = cfg->n_layer, din = cfg->n_embed_input;
   hipError_t e = hipSuccess;
-  for (int p = 0; p < 2 && e == hipSuccess; ++p) {
+  for (int p = 0; p < kNPrec && e == hipSuccess; ++p) {
     const size_t es = esize(p);
-    for (int f = 0; f < 2 && e == hipSuccess; ++f) {
-      const size_t elems = ((size_t)4 * L * units_per_layer(h->n_chunks[f], h->half[f]) + kMaxPF) * 1024;  // + ring over-read slack
-      if ((e = alloc(&h->stream[p][f], elems * es)) != hipSuccess) break;
-      e = hipMemset(h->stream[p][f], 0, elems * es);
-    }
-    if (e != hipSuccess) break;
+    int ntt, ft;
+    pick_shape(h, p, &ntt, &ft);   // only the stream of the shape this precision will run is packed
+    const int f = ft - 1;
+    const size_t elems = ((size_t)4 * L * units_per_layer(h->n_chunks[f], h->half[f]) + kMaxPF) * 1024;  // + ring over-read slack
+    if ((e = alloc(&h->stream[p][f], elems * es)) != hipSuccess) break;
+    if ((e = hipMemset(h->stream[p][f], 0, elems * es)) != hipSuccess) break;
     if ((e = alloc(&h->wfinal[p], 16 * 512 * es)) != hipSuccess) break;
   }
   if (e == hipSuccess) e = alloc((void**)&h->b_qkv, (size_t)L * 768 * 4);
@@ -96,7 +113,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   int emb_rows = 0;
   for (int c = 0; c < cfg->n_classes; ++c) {
     h->emb_row0[c] = emb_rows;
-    emb_rows += cfg->class_vocab[c] + 1;
+    emb_rows += h->tab_rows[c];
   }
   if (e == hipSuccess) e = alloc((void**)&h->w0t, 256 * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->b0, 256 * 4);
@@ -110,6 +127,12 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->label_err, 4);
+  if (e == hipSuccess) e = hipMemset(h->label_err, 0, 4);
+  if (e == hipSuccess) e = alloc((void**)&h->d_fp_state, 16);
+  if (e == hipSuccess) e = hipMemset(h->d_fp_state, 0, 16);
+  if (e == hipSuccess) e = alloc((void**)&h->d_dirty, 8);
+  if (e == hipSuccess) e = hipMemset(h->d_dirty, 0, 8);
   if (e != hipSuccess) {
     int rc = fail(SCLDM_ERR_HIP, "hipMalloc failed in scldm_dit_create: %s", hipGetErrorString(e));
     scldm_dit_destroy(h);
@@ -121,13 +144,14 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
 
 extern "C" void scldm_dit_destroy(scldm_dit* h) {
   if (!h) return;
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < kNPrec; ++p) {
     for (int f = 0; f < 2; ++f)
       if (h->stream[p][f]) (void)hipFree(h->stream[p][f]);
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
-  float* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv, h->b_proj};
-  for (float* p : ptrs)
+  void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
+                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty};
+  for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
   for (int g = 0; g < 3; ++g) {
@@ -141,6 +165,20 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
 extern "C" int scldm_dit_mod_width(const scldm_dit* h) { return h ? h->mod_w : 0; }
 extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h->fused) ? h->lpl : 0; }
 
+// fingerprint the parameter tensors, compare with the fingerprint of the packed copies, re-pack if they differ (all on
+// device, in stream order; `force` makes the first pack after scldm_dit_load_weights unconditional)
+static int run_pack(scldm_dit* h, bool force, hipStream_t st) {
+  if (force) {
+    const int one = 1;
+    HIP_TRY(hipMemcpyAsync(h->d_dirty + 1, &one, 4, hipMemcpyHostToDevice, st));
+  }
+  fingerprint_kernel<<<h->n_fp, 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
+  fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
+  pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
 extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream_) {
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
   if (!h->fused)
@@ -150,41 +188,97 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   hipStream_t st = (hipStream_t)stream_;
   const scldm_dit_config& c = h->cfg;
   const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, mw = h->mod_w;
-  const int T = 256;
+  std::vector<PackJob> jobs;
+  std::vector<FpSrc> fps;
+  int blocks = 0;
+  auto add = [&](int kind, long long n, std::initializer_list<const float*> src, void* dst, std::initializer_list<int> par,
+                 long long d_off = 0) {
+    PackJob j{};
+    j.kind = kind;
+    j.first_block = blocks;
+    j.n = n;
+    int i = 0;
+    for (const float* p : src) j.s[i++] = p;
+    j.d = dst;
+    i = 0;
+    for (int v : par) j.p[i++] = v;
+    j.d_off = d_off;
+    blocks += cdiv(n, 256);
+    jobs.push_back(j);
+  };
+  auto src = [&](const float* p, long long n) { fps.push_back(FpSrc{(const uint32_t*)p, n}); return p; };
   for (int i = 0; i < L; ++i) {
-    for (int ft = 1; ft <= 2; ++ft) {
-      const int nc = h->n_chunks[ft - 1], hf = h->half[ft - 1];
-      const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
-      pack_layer_kernel<float><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                            (float*)h->stream[0][ft - 1], H, nc, hf, i, ft);
-      pack_layer_kernel<__bf16><<<cdiv(npk, T), T, 0, st>>>(w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i],
-                                                             (__bf16*)h->stream[1][ft - 1], H, nc, hf, i, ft);
-    }
-    copy_kernel<<<cdiv(768, T), T, 0, st>>>(w->attn_b[i], h->b_qkv + (size_t)i * 768, 768);
-    copy_kernel<<<cdiv(256, T), T, 0, st>>>(w->proj_b[i], h->b_proj + (size_t)i * 256, 256);
+    src(w->attn_w[i], 768 * 256); src(w->proj_w[i], 256 * 256); src(w->w1[i], (long long)H * 256); src(w->w2[i], (long long)H * 256);
+    src(w->cproj[i], (long long)H * 256);
+    for (int p = 0; p < kNPrec; ++p)
+      for (int f = 0; f < 2; ++f) {
+        if (!h->stream[p][f]) continue;
+        const int nc = h->n_chunks[f], hf = h->half[f];
+        const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
+        add(kPackLayer, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->stream[p][f], {H, nc, hf, f + 1, p}, npk * i);
+      }
+    add(kPackCopy, 768, {src(w->attn_b[i], 768)}, h->b_qkv + (size_t)i * 768, {});
+    add(kPackCopy, 256, {src(w->proj_b[i], 256)}, h->b_proj + (size_t)i * 256, {});
     // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
-    transpose_kernel<<<cdiv(1536 * 256, T), T, 0, st>>>(w->ada_w[i], h->ada_t, 1536, 256, mw, i * 1536);
-    copy_kernel<<<cdiv(1536, T), T, 0, st>>>(w->ada_b[i], h->ada_b + i * 1536, 1536);
+    add(kPackTranspose, 1536 * 256, {src(w->ada_w[i], 1536 * 256)}, h->ada_t, {1536, 256, mw, i * 1536});
+    add(kPackCopy, 1536, {src(w->ada_b[i], 1536)}, h->ada_b + i * 1536, {});
   }
-  transpose_kernel<<<cdiv(512 * 256, T), T, 0, st>>>(w->fin_ada_w, h->ada_t, 512, 256, mw, L * 1536);
-  copy_kernel<<<cdiv(512, T), T, 0, st>>>(w->fin_ada_b, h->ada_b + L * 1536, 512);
-  transpose_kernel<<<cdiv(256 * 256, T), T, 0, st>>>(w->t_w0, h->w0t, 256, 256, 256, 0);
-  transpose_kernel<<<cdiv(256 * 256, T), T, 0, st>>>(w->t_w2, h->w2t, 256, 256, 256, 0);
-  copy_kernel<<<1, T, 0, st>>>(w->t_b0, h->b0, 256);
-  copy_kernel<<<1, T, 0, st>>>(w->t_b2, h->b2, 256);
-  transpose_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_wt, 256, din, 256, 0);
-  copy_kernel<<<cdiv(256 * din, T), T, 0, st>>>(w->in_w, h->in_w, 256 * din);
-  copy_kernel<<<1, T, 0, st>>>(w->in_b, h->in_b, 256);
-  copy_kernel<<<cdiv(16 * 256, T), T, 0, st>>>(w->pos_embed, h->pos, 16 * 256);
-  pack_final_kernel<float><<<cdiv(16 * 512, T), T, 0, st>>>(w->fin_w, (float*)h->wfinal[0], din);
-  pack_final_kernel<__bf16><<<cdiv(16 * 512, T), T, 0, st>>>(w->fin_w, (__bf16*)h->wfinal[1], din);
-  copy_kernel<<<1, T, 0, st>>>(w->fin_b, h->fin_b, din);
+  add(kPackTranspose, 512 * 256, {src(w->fin_ada_w, 512 * 256)}, h->ada_t, {512, 256, mw, L * 1536});
+  add(kPackCopy, 512, {src(w->fin_ada_b, 512)}, h->ada_b + L * 1536, {});
+  add(kPackTranspose, 256 * 256, {src(w->t_w0, 256 * 256)}, h->w0t, {256, 256, 256, 0});
+  add(kPackTranspose, 256 * 256, {src(w->t_w2, 256 * 256)}, h->w2t, {256, 256, 256, 0});
+  add(kPackCopy, 256, {src(w->t_b0, 256)}, h->b0, {});
+  add(kPackCopy, 256, {src(w->t_b2, 256)}, h->b2, {});
+  add(kPackTranspose, 256 * din, {src(w->in_w, 256 * din)}, h->in_wt, {256, din, 256, 0});
+  add(kPackCopy, 256 * din, {w->in_w}, h->in_w, {});
+  add(kPackCopy, 256, {src(w->in_b, 256)}, h->in_b, {});
+  add(kPackCopy, 16 * 256, {src(w->pos_embed, 16 * 256)}, h->pos, {});
+  src(w->fin_w, (long long)din * 256);
+  for (int p = 0; p < kNPrec; ++p) add(kPackFinal, 16 * 512, {w->fin_w}, h->wfinal[p], {din, p});
+  add(kPackCopy, din, {src(w->fin_b, din)}, h->fin_b, {});
   for (int ci = 0; ci < c.n_classes; ++ci) {
-    const int n = (c.class_vocab[ci] + 1) * 256;
-    copy_kernel<<<cdiv(n, T), T, 0, st>>>(w->class_emb[ci], h->emb + (size_t)h->emb_row0[ci] * 256, n);
+    const int n = h->tab_rows[ci] * 256;
+    add(kPackCopy, n, {src(w->class_emb[ci], n)}, h->emb + (size_t)h->emb_row0[ci] * 256, {});
   }
-  LAUNCH_CHECK();
+  // the tables may still be read by a previous refresh on this stream: drain it, then replace them (rare call)
+  HIP_TRY(hipStreamSynchronize(st));
+  if ((int)jobs.size() > h->jobs_cap) {
+    if (h->d_jobs) (void)hipFree(h->d_jobs);
+    h->d_jobs = nullptr;
+    HIP_TRY(hipMalloc(&h->d_jobs, jobs.size() * sizeof(PackJob)));
+    h->jobs_cap = (int)jobs.size();
+  }
+  if ((int)fps.size() > h->fp_cap) {
+    if (h->d_fp_src) (void)hipFree(h->d_fp_src);
+    h->d_fp_src = nullptr;
+    HIP_TRY(hipMalloc(&h->d_fp_src, fps.size() * sizeof(FpSrc)));
+    h->fp_cap = (int)fps.size();
+  }
+  HIP_TRY(hipMemcpy(h->d_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_fp_src, fps.data(), fps.size() * sizeof(FpSrc), hipMemcpyHostToDevice));
+  h->n_jobs = (int)jobs.size();
+  h->job_blocks = blocks;
+  h->n_fp = (int)fps.size();
+  int rc = run_pack(h, true, st);
+  if (rc) return rc;
   h->loaded = true;
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_dit_refresh_weights(scldm_dit* h, void* stream_) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_dit_load_weights has not been called");
+  return run_pack(h, false, (hipStream_t)stream_);
+}
+
+extern "C" int scldm_dit_label_errors(scldm_dit* h, int* count, void* stream_) {
+  if (!h || !count) return fail(SCLDM_ERR_SHAPE, "null argument");
+  *count = 0;
+  if (!h->label_err) return SCLDM_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  HIP_TRY(hipMemcpyAsync(count, h->label_err, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemsetAsync(h->label_err, 0, 4, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return SCLDM_OK;
 }
 
@@ -229,6 +323,10 @@ extern "C" size_t scldm_dit_workspace_bytes(const scldm_dit* h, int n_fwd, int n
 static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t* const* labels, uint32_t mask, int rows,
                        float* silu_c, hipStream_t st) {
   if (rows <= 0) return SCLDM_OK;
+  if (!h->cfg.has_null_row)
+    for (int c = 0; c < h->cfg.n_classes; ++c)
+      if (!(labels && labels[c] && ((mask >> c) & 1u)))
+        return fail(SCLDM_ERR_SHAPE, "class %d needs its null token, but the class tables have no null row (cfg_dropout_prob == 0)", c);
   CondArgs a;
   a.t = t;
   a.t_stride = t_stride;
@@ -238,10 +336,12 @@ static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t
   for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
     a.emb_row0[c] = c < a.n_classes ? h->emb_row0[c] : 0;
     a.null_tok[c] = c < a.n_classes ? h->cfg.class_vocab[c] : 0;
+    a.tab_rows[c] = c < a.n_classes ? h->tab_rows[c] : 1;
     a.labels[c] = (c < a.n_classes && labels && labels[c] && ((mask >> c) & 1u)) ? labels[c] : nullptr;
   }
   a.silu_c = silu_c;
   a.rows = rows;
+  a.label_err = h->label_err;
   cond_embed_kernel<<<rows, 256, 0, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;
@@ -256,10 +356,12 @@ static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows,
 template <typename OP, int NTT, int FT>
 static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
   using L = FwdLayout<OP, NTT, FT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};   // the attribute is per device
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     HIP_TRY(hipFuncSetAttribute((const void*)dit_forward_kernel<OP, NTT, FT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int tiles = cdiv((long long)a.n_fwd * 16, L::TM);
   const int grid = a.grid_tiles > 0 ? a.grid_tiles : tiles;
@@ -268,18 +370,11 @@ static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
   return SCLDM_OK;
 }
 
-// Kernel shape: (token tiles of 32*NTT, FT feature tiles per wave => 8/FT waves per workgroup).
-//   fp32 : NTT=2, FT=2 (4 waves, one per SIMD, 512-register budget)
-//   bf16 : NTT=2, FT=2, two workgroups per CU by default (measured fastest in round 1: 396 us per launch at 12288
-//          sample-forwards, although 35 VGPRs spill); FT=1 (8 waves, no spills, 422 us with an 8-deep ring) and
-//          NTT=4 (576 us) remain selectable through SCLDM_FT / SCLDM_NTT for A/B runs.
-static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
-  *ntt = 2;
-  *ft = 2;
-  if (prec == SCLDM_PREC_BF16) {
-    if (h->force_ft == 1 || h->force_ft == 2) *ft = h->force_ft;
-    if (h->force_ntt == 2 || (h->force_ntt == 4 && *ft == 2)) *ntt = h->force_ntt;
-  }
+static int launch_fwd(int prec, int ntt, int ft, const FwdArgs& a, hipStream_t st) {
+  if (prec == SCLDM_PREC_FP32) return launch_fwd_t<OpF32, 2, 2>(a, st);
+  if (prec == SCLDM_PREC_BF16X3) return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
+  if (ft == 1) return ntt == 4 ? launch_fwd_t<OpBF16, 4, 1>(a, st) : launch_fwd_t<OpBF16, 2, 1>(a, st);
+  return launch_fwd_t<OpBF16, 2, 2>(a, st);
 }
 
 // The DiT trunk: one fused launch per layer (input projection rides in the first, the final layer in the last).
@@ -312,13 +407,11 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   a.mod_stride = h->mod_w;
   a.eps = c.layernorm_eps;
   a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
-  const char* dbg_layer_env = getenv("SCLDM_DBG_LAYER");   // debug builds: which layer's launch records the phase stamps
-  const int dbg_layer = dbg_layer_env ? atoi(dbg_layer_env) : c.n_layer / 2;
+  const int dbg_layer = h->dbg_layer >= 0 ? h->dbg_layer : c.n_layer / 2;   // debug builds: which layer's launch records the phase stamps
   // Tile groups: each layer is launched as G kernels over disjoint tile ranges, group g on its own stream, so that the
   // round boundaries (burst of residual loads at the start, store drain and idle slots at the end) of one group fall
   // inside the steady state of the others.
-  int G = 1;
-  if (const char* e = getenv("SCLDM_GROUPS")) G = std::min(4, std::max(1, atoi(e)));
+  int G = h->groups;
   const int tile_tok = 32 * ntt;
   const int tiles_all = cdiv((long long)n_fwd * 16, tile_tok);
   if (tiles_all < 512 * G) G = 1;
@@ -366,10 +459,7 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
         a.tile0 = gt0[g];
         a.grid_tiles = gt0[g + 1] - gt0[g];
       }
-      if (prec == SCLDM_PREC_FP32) rc = launch_fwd_t<OpF32, 2, 2>(a, sg);
-      else if (ft == 1) rc = launch_fwd_t<OpBF16, 2, 1>(a, sg);
-      else if (ntt == 4) rc = launch_fwd_t<OpBF16, 4, 2>(a, sg);
-      else rc = launch_fwd_t<OpBF16, 2, 2>(a, sg);
+      rc = launch_fwd(prec, ntt, ft, a, sg);
     }
     if (rc != SCLDM_OK) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -385,7 +475,8 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
 static int check_ready(const scldm_dit* h, int prec) {
   if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
   if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_dit_load_weights has not been called");
-  if (prec != SCLDM_PREC_FP32 && prec != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", prec);
+  if (prec != SCLDM_PREC_FP32 && prec != SCLDM_PREC_BF16 && prec != SCLDM_PREC_BF16X3) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", prec);
+  if (!h->fused) return fail(SCLDM_ERR_SHAPE, "this handle's shape is outside the fused family (scldm_dit_train_* only)");
   return SCLDM_OK;
 }
 
@@ -463,10 +554,12 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
     for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
       ca.emb_row0[c] = c < ca.n_classes ? h->emb_row0[c] : 0;
       ca.null_tok[c] = c < ca.n_classes ? h->cfg.class_vocab[c] : 0;
+      ca.tab_rows[c] = c < ca.n_classes ? h->tab_rows[c] : 1;
       ca.labels[c] = (c < ca.n_classes && pl.ulabels && pl.ulabels[c]) ? pl.ulabels[c] : nullptr;
       ca.mask[c] = c < pl.P ? pl.mask[c] : 0u;
     }
     ca.silu_c = w.silu;
+    ca.label_err = h->label_err;
     cond_rows_kernel<<<pl.n_rows, 256, 0, st>>>(ca);
     LAUNCH_CHECK();
   } else {
@@ -496,6 +589,8 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
 static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, int n_urows, const int32_t* cell_row, int B,
                      int n_pass, const uint32_t* pass_mask, const float* pass_scale, int t_stride) {
   if (B <= 0) return fail(SCLDM_ERR_SHAPE, "B must be positive");
+  if (!h->cfg.has_null_row && h->cfg.n_classes > 0)
+    return fail(SCLDM_ERR_SHAPE, "classifier-free guidance needs the null rows of the class tables (model built with cfg_dropout_prob == 0)");
   if (n_pass < 0 || n_pass > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_pass out of range");
   if (n_pass > 0 && (!ulabels || !pass_mask || !pass_scale || n_urows <= 0)) return fail(SCLDM_ERR_SHAPE, "conditional passes need labels/masks/scales");
   if (n_pass > 0 && !cell_row && n_urows != B) return fail(SCLDM_ERR_SHAPE, "cell_row is NULL but n_urows (%d) != B (%d)", n_urows, B);
@@ -513,7 +608,6 @@ static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, i
     pl.mask[p] = pass_mask[p];
     pl.scale[p] = pass_scale[p];
   }
-  (void)h;
   return SCLDM_OK;
 }
 

@@ -71,9 +71,17 @@ struct OpBF16 {
   using Quad = bf16x4;  // 4 consecutive elements (one accumulator register group)
   static constexpr bool kIsBF16 = true;
   static constexpr bool kTwoPassLN = false;  // sum / sum-of-squares in one sweep (fp32 accumulation)
+  static constexpr bool kPin = true;         // pin the per-k-step issue order of a GEMM pass (sched_group_barrier)
+  static constexpr bool kMfmaIn = true;      // input projection on the matrix pipe
+  static constexpr bool kTwoWG = true;       // two workgroups per CU (LDS and registers allow it for 64-token tiles)
+  static constexpr int kRing = 4;            // k-steps of weight-ring run-ahead
+  static constexpr int kFragLoads = 1;       // 16-byte loads per fragment
+  static constexpr int kMmaOps = 1;          // MFMA instructions per mma()
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // 4 consecutive features starting at feature f (multiple of 4) of an activation row
+  static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
   static __device__ __forceinline__ Frag pack8(const float* v) {
     Frag f;
 #pragma unroll
@@ -96,6 +104,13 @@ struct OpF32 {
   using Quad = f32x4;
   static constexpr bool kIsBF16 = false;
   static constexpr bool kTwoPassLN = true;   // parity path: mean first, then centred second moment
+  static constexpr bool kPin = false;
+  static constexpr bool kMfmaIn = false;     // exact fp32 on the VALU (K = din is tiny)
+  static constexpr bool kTwoWG = false;
+  static constexpr int kRing = 2;
+  static constexpr int kFragLoads = 2;
+  static constexpr int kMmaOps = 8;
+  static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
   // exact fp32: 8 x v_mfma_f32_32x32x2_f32 (each contracts k-groups 0 and 1 of one element slot)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
 #pragma unroll
@@ -111,6 +126,69 @@ struct OpF32 {
   static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
     Quad q = {a, b, c, d};
     return q;
+  }
+};
+
+// Split-bf16 ("bf16x3"): every GEMM operand value v is carried as hi = bf16(v), lo = bf16(v - hi) and a product sum is
+// three bf16 MFMAs (hi*hi + hi*lo + lo*hi, the lo*lo term ~2^-18 relative is dropped), fp32 accumulation.  This is the
+// arithmetic class of the reference's torch.set_float32_matmul_precision("high") (experiments/scripts/inference.py:26;
+// TF32 / bf16x3 on its hardware) - gfx950 has no TF32, and exact fp32 MFMA runs at 1/16 of the bf16 rate.
+// LDS / weight-stream layout: a k-group of 8 consecutive features is 32 bytes = 16 B of hi followed by 16 B of lo, so a
+// lane's fragment is two 16-byte reads (same bytes and addresses as the fp32 policy's f32x8 fragment), and a register
+// quad of 4 features is stored as two 8-byte pieces.  E is the 4-byte addressing unit of that layout.
+struct bf16x8x2 { bf16x8 hi, lo; };
+struct bf16x4x2 { bf16x4 hi, lo; };
+struct OpBF16x3 {
+  struct E { uint32_t u; };
+  using ModE = float;
+  static __device__ __forceinline__ f32x4 load_mod4(const ModE* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store_mod4(ModE* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+  using Frag = bf16x8x2;
+  using Quad = bf16x4x2;
+  static constexpr bool kIsBF16 = false;
+  static constexpr bool kTwoPassLN = true;
+  static constexpr bool kPin = true;
+  static constexpr bool kMfmaIn = true;
+  static constexpr bool kTwoWG = false;      // 155 KB of LDS per 64-token tile: one workgroup per CU
+  static constexpr int kRing = 2;
+  static constexpr int kFragLoads = 2;
+  static constexpr int kMmaOps = 3;
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);   // small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void split(float v, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+  }
+  static __device__ __forceinline__ Frag pack8(const float* v) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __bf16 h, l;
+      split(v[i], h, l);
+      f.hi[i] = h;
+      f.lo[i] = l;
+    }
+    return f;
+  }
+  static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
+    const float v[4] = {a, b, c, d};
+    Quad q;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __bf16 h, l;
+      split(v[i], h, l);
+      q.hi[i] = h;
+      q.lo[i] = l;
+    }
+    return q;
+  }
+  static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) {
+    char* b = reinterpret_cast<char*>(row) + (f >> 3) * 32 + (f & 7) * 2;
+    *reinterpret_cast<bf16x4*>(b) = q.hi;
+    *reinterpret_cast<bf16x4*>(b + 16) = q.lo;
   }
 };
 

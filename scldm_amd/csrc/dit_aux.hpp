@@ -16,14 +16,12 @@ namespace scldm {
 //   chunk c, units 16-23: mlp.c_proj rows w*64 + ft*32 + r, k = hidden index c*128 + ks*16 + ...
 // Hidden indices >= H are zero (exact padding of 684 -> 768).
 // ------------------------------------------------------------------------------------------------
-template <typename E>
-__global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* __restrict__ Wproj, const float* __restrict__ W1,
-                                  const float* __restrict__ W2, const float* __restrict__ Wcp, E* __restrict__ out, int H,
-                                  int n_chunks, int half, int layer, int FT) {
+// One element of a layer's packed stream (index documented above); FT = 32-row tiles per wave.
+__device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, const float* __restrict__ Wproj,
+                                                const float* __restrict__ W1, const float* __restrict__ W2,
+                                                const float* __restrict__ Wcp, long long idx, int H, int n_chunks, int half, int FT) {
   // FT = 32-row tiles per wave (2: four waves, 1: eight waves); a unit holds FT fragments of 512 elements
-  const int UL = units_per_layer(n_chunks, half), NW = 8 / FT, unit_elems = 512 * FT;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)NW * UL * unit_elems) return;
+  const int UL = units_per_layer(n_chunks, half), unit_elems = 512 * FT;
   const int j = idx & 7, l = (idx >> 3) & 63, ft = (int)((idx >> 9) % FT);
   const int gu = (int)(idx / unit_elems), w = gu / UL, u = gu % UL;
   const int r = l & 31, k8 = (l >> 5) * 8 + j;
@@ -65,30 +63,98 @@ __global__ void pack_layer_kernel(const float* __restrict__ Wqkv, const float* _
       val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;
     }
   }
-  out[((size_t)layer * NW * UL) * unit_elems + idx] = (E)val;  // [layer][wave][unit][ft][lane][8]
+  return val;
 }
 
-// final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
-template <typename E>
-__global__ void pack_final_kernel(const float* __restrict__ W, E* __restrict__ out, int din) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 16 * 512) return;
-  const int j = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
-  const int row = l & 31, k = ks * 16 + (l >> 5) * 8 + j;
-  out[idx] = (E)((row < din) ? W[row * 256 + k] : 0.f);
+// Store packed element `idx` (fragment-major: 8 consecutive indices = one lane's 8 k-values) in the stream's precision.
+//   prec 0: fp32   1: bf16   2: split-bf16 (the 8 hi values then the 8 lo values of a lane: 32 bytes per lane-fragment)
+__device__ __forceinline__ void pack_store(void* out, long long idx, float val, int prec) {
+  if (prec == 0) {
+    reinterpret_cast<float*>(out)[idx] = val;
+  } else if (prec == 1) {
+    reinterpret_cast<__bf16*>(out)[idx] = (__bf16)val;
+  } else {
+    __bf16 hi, lo;
+    OpBF16x3::split(val, hi, lo);
+    __bf16* o = reinterpret_cast<__bf16*>(out) + (idx >> 3) * 16 + (idx & 7);
+    o[0] = hi;
+    o[8] = lo;
+  }
 }
 
-// out[k*ldo + col0 + n] = W[n*K + k]  (transpose so that consecutive threads read consecutive floats)
-__global__ void transpose_kernel(const float* __restrict__ W, float* __restrict__ out, int N, int K, int ldo, int col0) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * K) return;
-  const int n = idx % N, k = idx / N;
-  out[(size_t)k * ldo + col0 + n] = W[(size_t)n * K + k];
+// ------------------------------------------------------------------------------------------------
+// All packing of one scldm_dit_load_weights call is ONE launch over a table of jobs (was ~80 launches), so that it can
+// also be re-run conditionally, on device, by scldm_dit_refresh_weights: every block first reads the `dirty` word.
+// ------------------------------------------------------------------------------------------------
+enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFinal = 3 };
+struct PackJob {
+  int kind;
+  int first_block;      // first 256-thread block of this job
+  long long n;          // elements (threads)
+  const float* s[5];    // sources (parameter tensors)
+  void* d;              // destination
+  int p[6];             // kind-specific: copy -; transpose N,K,ldo,col0; layer H,n_chunks,half,FT,prec; final din,prec
+  long long d_off;      // element offset added to the destination index (layer: start of the layer's stream)
+};
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty) {
+  if (dirty && *dirty == 0) return;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackJob& j = jobs[lo];
+  const long long idx = (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (idx >= j.n) return;
+  switch (j.kind) {
+    case kPackCopy:
+      reinterpret_cast<float*>(j.d)[idx] = j.s[0][idx];
+      break;
+    case kPackTranspose: {  // out[k*ldo + col0 + n] = W[n*K + k]
+      const int N = j.p[0], K = j.p[1], ldo = j.p[2], col0 = j.p[3];
+      const int n = (int)(idx % N), k = (int)(idx / N);
+      reinterpret_cast<float*>(j.d)[(size_t)k * ldo + col0 + n] = j.s[0][(size_t)n * K + k];
+      break;
+    }
+    case kPackLayer:
+      pack_store(j.d, j.d_off + idx, pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3]), j.p[4]);
+      break;
+    case kPackFinal: {  // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
+      const int jj = idx & 7, l = (idx >> 3) & 63, ks = (int)(idx >> 9);
+      const int row = l & 31, k = ks * 16 + (l >> 5) * 8 + jj;
+      pack_store(j.d, idx, (row < j.p[0]) ? j.s[0][row * 256 + k] : 0.f, j.p[1]);
+      break;
+    }
+  }
 }
 
-__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n) dst[idx] = src[idx];
+// Fingerprint of the parameter tensors (scldm_dit_refresh_weights): block b hashes tensor b - every element if it has at
+// most 4096, else 4096 evenly spaced ones plus the last - into one 64-bit order-independent sum.
+struct FpSrc {
+  const uint32_t* p;
+  long long n;
+};
+__global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
+  const FpSrc s = src[blockIdx.x];
+  const long long cnt = s.n < 4096 ? s.n : 4096;
+  const long long step = s.n / cnt;
+  unsigned long long hsum = 0;
+  for (long long i = threadIdx.x; i < cnt; i += 256) {
+    const long long pos = i * step;
+    const unsigned long long v = s.p[pos];
+    hsum += (v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1 + blockIdx.x * 7919ll)) * 0xBF58476D1CE4E5B9ull ^ (v << 29);
+  }
+  if (threadIdx.x == 0 && s.n > 0) hsum += (unsigned long long)s.p[s.n - 1] * 0x94D049BB133111EBull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
+}
+// state[0] = accumulator of the current pass, state[1] = fingerprint of the packed weights; dirty[0] = re-pack?, dirty[1] = force
+__global__ void fingerprint_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty) {
+  dirty[0] = (state[0] != state[1]) || dirty[1];
+  dirty[1] = 0;
+  state[1] = state[0];
+  state[0] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,10 +174,22 @@ struct CondArgs {
   int n_classes;
   int emb_row0[kMaxClasses];   // first row of class c in `emb`
   int null_tok[kMaxClasses];   // vocab size of class c (= index of its null token)
+  int tab_rows[kMaxClasses];   // rows of class c's table (vocab + 1, or vocab when the model has no null row)
   const int64_t* labels[kMaxClasses];  // (rows) or nullptr => null token for every row
   float* silu_c;           // (rows,256)
   int rows;
+  int* label_err;          // sticky count of out-of-range labels (clamped instead of reading another class's table)
 };
+
+// label -> table row; out-of-range labels are clamped and counted (the reference's nn.Embedding raises, nnets.py:420,453)
+__device__ __forceinline__ int checked_label(const int64_t* lab, int i, int tab_rows, int* err, bool report) {
+  long t = (long)lab[i];
+  if (t < 0 || t >= tab_rows) {
+    if (report) atomicAdd(err, 1);
+    t = t < 0 ? 0 : tab_rows - 1;
+  }
+  return (int)t;
+}
 
 __global__ __launch_bounds__(256) void cond_embed_kernel(const CondArgs a) {
   __shared__ float te[256];
@@ -135,7 +213,7 @@ __global__ __launch_bounds__(256) void cond_embed_kernel(const CondArgs a) {
   for (int k = 0; k < 256; ++k) c += a.w2t[k * 256 + n] * h1[k];
   for (int ci = 0; ci < a.n_classes; ++ci) {
     int tok = a.null_tok[ci];
-    if (a.labels[ci] != nullptr) tok = (int)a.labels[ci][u];
+    if (a.labels[ci] != nullptr) tok = checked_label(a.labels[ci], u, a.tab_rows[ci], a.label_err, n == 0);
     c += a.emb[(size_t)(a.emb_row0[ci] + tok) * 256 + n];
   }
   a.silu_c[(size_t)u * 256 + n] = silu_f(c);
@@ -205,9 +283,11 @@ struct CondRowsArgs {
   int n_classes, U, rows;
   int emb_row0[kMaxClasses];
   int null_tok[kMaxClasses];
+  int tab_rows[kMaxClasses];
   const int64_t* labels[kMaxClasses];
   uint32_t mask[kMaxClasses];   // per pass: which classes keep their labels
   float* silu_c;
+  int* label_err;
 };
 __global__ __launch_bounds__(256) void cond_rows_kernel(const CondRowsArgs a) {
   const int r = blockIdx.x, n = threadIdx.x;
@@ -215,7 +295,7 @@ __global__ __launch_bounds__(256) void cond_rows_kernel(const CondRowsArgs a) {
   const int p = r > 0 ? (r - 1) / a.U : 0, u = r > 0 ? (r - 1) % a.U : 0;
   for (int ci = 0; ci < a.n_classes; ++ci) {
     int tok = a.null_tok[ci];
-    if (r > 0 && a.labels[ci] != nullptr && ((a.mask[p] >> ci) & 1u)) tok = (int)a.labels[ci][u];
+    if (r > 0 && a.labels[ci] != nullptr && ((a.mask[p] >> ci) & 1u)) tok = checked_label(a.labels[ci], u, a.tab_rows[ci], a.label_err, n == 0);
     c += a.emb[(size_t)(a.emb_row0[ci] + tok) * 256 + n];
   }
   a.silu_c[(size_t)r * 256 + n] = silu_f(c);

@@ -151,9 +151,9 @@ __host__ __device__ constexpr int units_per_layer(int n_chunks, int half = 0) {
 template <typename OP, int NTT, int FT>
 struct Prefetch {  // k-steps of run-ahead of the weight ring
 #ifdef SCLDM_PF
-  static constexpr int PF = OP::kIsBF16 ? SCLDM_PF : 2;
+  static constexpr int PF = OP::kIsBF16 ? SCLDM_PF : OP::kRing;
 #else
-  static constexpr int PF = OP::kIsBF16 ? 4 : 2;
+  static constexpr int PF = OP::kRing;
 #endif
 };
 
@@ -211,10 +211,10 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
     ws.p += 64 * FT;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
-    if (OP::kIsBF16) {
-      __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);       // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, FT * NTT, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, FT, 0);        // VMEM read
+    if (OP::kPin) {
+      __builtin_amdgcn_sched_group_barrier(0x100, NTT * OP::kFragLoads, 0);       // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, FT * NTT * OP::kMmaOps, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, FT * OP::kFragLoads, 0);        // VMEM read
     }
   };
   // peeled first ring revolution (so that ZERO needs no accumulator clearing), then the rolled loop
@@ -264,10 +264,10 @@ __device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, P
         ws.ring[s][1] = ws.p[64];
         ws.p += 128;
       }
-      if (OP::kIsBF16) {
-        __builtin_amdgcn_sched_group_barrier(0x100, NTT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NTT, 0);
-        if (half == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      if (OP::kPin) {
+        __builtin_amdgcn_sched_group_barrier(0x100, NTT * OP::kFragLoads, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NTT * OP::kMmaOps, 0);
+        if (half == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2 * OP::kFragLoads, 0);
       }
     }
   };
@@ -410,12 +410,12 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
     float y[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
-    *reinterpret_cast<typename OP::Quad*>(dst + (tt * 32 + c32) * ldd + f) = OP::pack4(y[0], y[1], y[2], y[3]);
+    OP::store_quad(dst + (tt * 32 + c32) * ldd, f, OP::pack4(y[0], y[1], y[2], y[3]));
   }
 }
 
 template <typename OP, int NTT, int FT>
-__global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
   using L = FwdLayout<OP, NTT, FT>;
   using E = typename OP::E;
   using Frag = typename OP::Frag;
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       const int src = (s < a.n_direct) ? s : (a.n_direct - a.rep + (s - a.n_direct) % a.rep);
       zrow[tt] = a.z + ((size_t)src * 16 + p16) * a.din;
     }
-    if constexpr (OP::kIsBF16) {
-      // bf16 path: K = din <= 32 is one or two MFMA k-steps.  Operands straight from global memory (this lane's 8 k-values
+    if constexpr (OP::kMfmaIn) {
+      // bf16 / split-bf16 paths: K = din <= 32 is one or two MFMA k-steps.  Operands straight from global memory (this lane's 8 k-values
       // of its weight row / its token's latent row), all loads issued together.  The former per-k VALU loop with its
       // dependent global loads made the first layer's launch 114 us longer than the others (430 vs 316 us).
       auto frag_of = [&](const float* row, int k0) {
@@ -750,8 +750,8 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<Quad*>(AO + (tt * 32 + c32) * L::XA_LD + fbase + ft * 32 + q * 8 + hh * 4) =
-            OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]);
+        OP::store_quad(AO + (tt * 32 + c32) * L::XA_LD, fbase + ft * 32 + q * 8 + hh * 4,
+                       OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]));
   lds_barrier();  // AO complete
   SCLDM_STAMP(6);
 
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kIsBF16 && NTT <= 2) ? 2 : 1) v
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<Quad*>(HBc + (tt * 32 + c32) * L::HB_LD + col0 + q * 8 + hh * 4) = hq[ft][tt][q];
+          OP::store_quad(HBc + (tt * 32 + c32) * L::HB_LD, col0 + q * 8 + hh * 4, hq[ft][tt][q]);
     }
     if (c == 0) SCLDM_STAMP(11);
     lds_barrier();

@@ -12,8 +12,8 @@ struct scldm_dit {
   int mod_w;
   bool loaded;
   bool fused;   // shape served by the fused inference kernels (otherwise only the scldm_dit_train_* path)
-  void* stream[2][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack)
-  void* wfinal[2];   // [precision] packed final_layer.linear
+  void* stream[3][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack); NULL = shape unused
+  void* wfinal[3];   // [precision] packed final_layer.linear
   float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)
   float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
   float* emb;                      // concatenated class tables
@@ -26,9 +26,20 @@ struct scldm_dit {
   bool timing;
   std::vector<hipEvent_t> ev;
   size_t ev_used;
-  int lpl;         // DiT layers per fused-kernel launch (1 or 2)
+  int lpl;         // DiT layers per fused-kernel launch (1..4)
+  int groups;      // tile groups per layer launch (SCLDM_GROUPS, read once at create)
+  int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
+  int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)
+  int* label_err;  // device: sticky count of clamped out-of-range labels
+  // packing job table + fingerprint state (scldm_dit_load_weights / scldm_dit_refresh_weights)
+  void* d_jobs;    // device PackJob[n_jobs]
+  int n_jobs, job_blocks, jobs_cap;
+  void* d_fp_src;  // device FpSrc[n_fp]
+  int n_fp, fp_cap;
+  unsigned long long* d_fp_state;  // [0] running accumulator, [1] fingerprint of the packed weights
+  int* d_dirty;    // [0] re-pack flag written by the compare kernel, [1] force flag
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
   hipEvent_t fork_ev, join_ev[3];
-  int force_ntt, force_ft;
+  int force_ntt, force_ft, force_x3_ft;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
 };

@@ -285,12 +285,16 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.th, s.sth, (long)n * kD);
   LAUNCH_CHECK();
   TRY(linear_fwd(st, s.sth, kD, w->t_w2, n, kD, kD, w->t_b2, k.temb, kD, k));
+  if (!cfg.has_null_row)
+    for (int c = 0; c < cfg.n_classes; ++c)
+      if (!labels || !labels[c])
+        return fail(SCLDM_ERR_SHAPE, "class %d needs its null token, but the class tables have no null row (cfg_dropout_prob == 0)", c);
   EmbedArgs e{};
   e.n_classes = cfg.n_classes;
   for (int c = 0; c < cfg.n_classes; ++c) {
     e.table[c] = w->class_emb[c];
     e.labels[c] = labels ? labels[c] : nullptr;
-    e.vocab[c] = cfg.class_vocab[c];
+    e.vocab[c] = h->tab_rows[c] - 1;   // last table row: the null token when the tables have one (nnets.py:241-243)
   }
   hipLaunchKernelGGL(cond_sum_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.temb, e, n, kD, s.c);
   LAUNCH_CHECK();
@@ -397,8 +401,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
   for (int c = 0; c < cfg.n_classes; ++c) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cfg.class_vocab[c] + 1, kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
-                       cfg.class_vocab[c], n, kD, g->class_emb[c]);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
+                       h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     LAUNCH_CHECK();
   }
   TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k, g->t_b2));

@@ -146,9 +146,17 @@ class _DiTTrainFn(torch.autograd.Function):
 class DiT(nn.Module):
     """Diffusion Transformer (adaLN-Zero) - drop-in for scldm.nnets.DiT.
 
-    Extra (non-reference) knobs: `precision` ("fp32" exact-fp32 MFMA parity path, or "bf16"
-    throughput path; default from $SCLDM_PRECISION, else "fp32").
+    Extra (non-reference) knobs: `precision` - "fp32" (exact-fp32 MFMA), "bf16x3" (split-bf16, three bf16 MFMAs per
+    product sum: the arithmetic class of the reference's `set_float32_matmul_precision("high")`, inference.py:26; both
+    inside the 1e-4 parity gate) or "bf16" (throughput path); default from $SCLDM_PRECISION, else "fp32".
+
+    The fused inference kernels read PACKED copies of the parameters.  They are refreshed automatically when a parameter's
+    storage or torch version counter changes, and an on-device fingerprint of the parameters is re-checked at every call so
+    that in-place updates through `.data` (ema_pytorch, reference models.py:446,690) are picked up as well;
+    `invalidate_weights()` forces a re-pack.  `copy.deepcopy` / pickling drop the native handle (the copy builds its own).
     """
+
+    _NATIVE_STATE = ("_handle", "_weights_key", "_ws", "_dedup_cache")
 
     def __init__(
         self,
@@ -187,6 +195,7 @@ class DiT(nn.Module):
         self.input_proj = nn.Linear(n_embed_input, n_embed, bias=bias)
         self.final_layer = FinalLayerDit(n_embed, n_embed_input, bias, layernorm_eps)
         self.precision = os.environ.get("SCLDM_PRECISION", "fp32")
+        self.detect_uniform_t = True   # forward_with_cfg: test a dense t for uniformity (one host sync per call); see there
         self._handle = None
         self._weights_key = None
         self._ws = None
@@ -220,6 +229,17 @@ class DiT(nn.Module):
     def _class_names(self) -> list[str]:
         return sorted(self.class_vocab_sizes.keys())
 
+    @property
+    def _has_null_row(self) -> bool:
+        """The class tables carry a null-token row only when the model was built with cfg_dropout_prob > 0 (nnets.py:241-243)."""
+        names = self._class_names
+        return (not names) or self.class_embeddings[names[0]].num_embeddings == self.class_vocab_sizes[names[0]] + 1
+
+    def _need_null_row(self, what: str):
+        if not self._has_null_row:   # the reference indexes row `vocab` of a `vocab`-row table here: IndexError
+            raise IndexError(f"{what} needs the null-token rows of the class embeddings, but this DiT was built with "
+                             "cfg_dropout_prob == 0 (index out of range in self)")
+
     def _native_handle(self):
         """The C handle without touching the packed inference weights (the training path reads parameters live)."""
         L = _lib.lib()
@@ -232,9 +252,12 @@ class DiT(nn.Module):
                 raise ValueError(f"at most {_lib.MAX_CLASSES} condition classes are supported")
             cfg = _lib.DitConfig(n_embed=self.n_embed, n_embed_input=self.n_embed_input, n_layer=self.n_layer, n_head=self.n_head,
                                  seq_len=self.seq_len, hidden_dim=swiglu_hidden(self.n_embed, self.multiple_of),
-                                 layernorm_eps=self.layernorm_eps, n_classes=len(names))
+                                 layernorm_eps=self.layernorm_eps, n_classes=len(names), has_null_row=int(self._has_null_row))
             for i, n in enumerate(names):
                 cfg.class_vocab[i] = self.class_vocab_sizes[n]
+                if self.class_embeddings[n].num_embeddings != self.class_vocab_sizes[n] + int(self._has_null_row):
+                    raise ValueError(f"class_embeddings[{n!r}] has {self.class_embeddings[n].num_embeddings} rows, expected "
+                                     f"{self.class_vocab_sizes[n] + int(self._has_null_row)}")
             h = C.c_void_p()
             with torch.cuda.device(dev):
                 _lib.check(L.scldm_dit_create(C.byref(cfg), C.byref(h)), "scldm_dit_create")
@@ -247,7 +270,39 @@ class DiT(nn.Module):
         if key != self._weights_key:
             self._load_weights(L)
             self._weights_key = key
+        else:
+            # same storages and version counters: `.data` updates (EMA) are invisible to both, so the C side compares a
+            # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation)
+            with torch.cuda.device(self.pos_embed.device):
+                _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
         return L, self._handle
+
+    def invalidate_weights(self) -> None:
+        """Force the next call to re-pack the fused kernels' weight copies from the parameters."""
+        self._weights_key = None
+
+    def check_labels(self) -> int:
+        """Number of out-of-range condition labels the kernels clamped since the last call (synchronises the stream).
+        Raises IndexError like the reference's nn.Embedding (nnets.py:420,453) if there were any."""
+        if self._handle is None:
+            return 0
+        n = C.c_int(0)
+        with torch.cuda.device(self.pos_embed.device):
+            _lib.check(_lib.lib().scldm_dit_label_errors(self._handle, C.byref(n), _stream_ptr()), "scldm_dit_label_errors")
+        if n.value:
+            raise IndexError(f"{n.value} condition label(s) were outside their class vocabulary (index out of range in self)")
+        return 0
+
+    # ------------------------------------------------------------------ copies / pickling: the native handle never travels
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for k, v in (("_handle", None), ("_weights_key", None), ("_ws", None), ("_dedup_cache", {})):
+            self.__dict__.setdefault(k, v)
 
     def _param_struct(self, dp):
         """scldm_dit_weights / scldm_dit_grads (same field order) filled with dp(parameter) -> device pointer or None.
@@ -380,6 +435,8 @@ class DiT(nn.Module):
             chosen = {available[sel]}
             drop = force_drop_ids
         drop_mask = (torch.rand(n, device=dev) < self.cfg_dropout_prob) if drop else None
+        if drop_mask is not None or any(c not in chosen for c in names):
+            self._need_null_row("label dropout / an unselected condition class")
         ptrs = []
         for c in names:
             if c in chosen:
@@ -463,6 +520,10 @@ class DiT(nn.Module):
             if hit is None:
                 stacked = torch.stack([cols[c] for c in used], dim=1)
                 uniq, inv = torch.unique(stacked, dim=0, return_inverse=True)
+                lo, hi = uniq.min(dim=0).values.tolist(), uniq.max(dim=0).values.tolist()   # unique() synchronised already
+                for i, c in enumerate(used):   # the reference's nn.Embedding raises on such labels (nnets.py:420,453)
+                    if lo[i] < 0 or hi[i] > self.class_vocab_sizes[c]:
+                        raise IndexError(f"condition '{c}' has labels outside [0, {self.class_vocab_sizes[c]}] (index out of range in self)")
                 hit = ({c: uniq[:, i].contiguous() for i, c in enumerate(used)}, inv.to(torch.int32).contiguous(), [cols[c] for c in used])
                 self._dedup_cache.clear()
                 self._dedup_cache[key] = hit
@@ -493,14 +554,22 @@ class DiT(nn.Module):
                 raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(xg.shape)}, {tuple(tg.shape)}")
             with torch.no_grad():
                 return self._generic_forward_with_cfg(xg, tg, condition, cfg_scale)
+        self._need_null_row("forward_with_cfg (the unconditional pass)")
         L, h = self._native()
-        uniform_t = getattr(t, "_scldm_uniform_t", False)  # set by scldm_amd.transport's ODE loop (scalar t broadcast)
         x = _require_cuda_f32("x", x)
-        tt = _require_cuda_f32("t", t)
         n = x.shape[0]
         B = n // 2
-        if n != 2 * B or x.shape[1:] != (self.seq_len, self.n_embed_input) or tt.shape != (n,):
-            raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(x.shape)}, {tuple(tt.shape)}")
+        if n != 2 * B or x.shape[1:] != (self.seq_len, self.n_embed_input) or tuple(t.shape) != (n,):
+            raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(x.shape)}, {tuple(t.shape)}")
+        # An ODE solver broadcasts ONE scalar t over the batch (integrators.py:103-104): the unconditional pass then needs one
+        # conditioning row and the conditional passes one per unique label tuple.  A stride-0 / one-element t proves it for
+        # free (scldm_amd.transport passes such a view); for a dense t (the reference's `ones(B) * t` under torchdiffeq) one
+        # device comparison per call decides - costing a host synchronisation, which the shared conditioning work repays.
+        if t.stride(0) == 0 or n == 1:
+            uniform_t = True
+        else:
+            uniform_t = bool((t == t[0]).all().item()) if self.detect_uniform_t else False
+        tt = _require_cuda_f32("t", t[:1] if uniform_t else t)
         ul, n_u, cell_row, n_pass, masks, scales, keep = self._cfg_plan(condition, cfg_scale, B, dedup=uniform_t)
         out = torch.empty_like(x)
         t_stride = 0 if uniform_t else 1
@@ -560,6 +629,7 @@ class DiT(nn.Module):
                     k2 = self._generic_forward_with_cfg(z + hstep * k1, t1, condition, cfg_scale)
                     z = z + (0.5 * hstep) * (k1 + k2)
             return z
+        self._need_null_row("CFG sampling (the unconditional pass)")
         L, h = self._native()
         z = _require_cuda_f32("z", z).clone()
         n = z.shape[0]

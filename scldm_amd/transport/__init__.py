@@ -7,7 +7,8 @@ signatures (transport/__init__.py:6-12, transport.py:110,324-332).  Differences,
   * the reference hands stepping to third-party torchdiffeq (integrators.py:111, default dopri5); here the
     fixed-grid "euler" / "heun" schemes are built in (definition + KAT: oracle/transport.py), and when the
     model is a scldm_amd DiT bound through `forward_with_cfg` the whole loop runs inside one C call
-    (scldm_sample_ode).  Adaptive dopri5 is not provided.
+    (scldm_sample_ode); the reference's default, adaptive dopri5, is a host-driven Dormand-Prince 5(4) over the
+    fused `forward_with_cfg` (parity unpinned like the fixed grids: torchdiffeq is un-vendored).
 """
 from __future__ import annotations
 
@@ -115,8 +116,9 @@ class Sampler:
         @torch.no_grad()
         def _sample(x, model, **model_kwargs):
             def f(xc, tval):
-                tv = torch.full((xc.shape[0],), float(tval), device=xc.device, dtype=torch.float32)
-                tv._scldm_uniform_t = True
+                # one scalar broadcast to (B,) as a stride-0 view: any model reads it as the reference's `ones(B) * t`
+                # (integrators.py:103-104), and a scldm_amd DiT can tell without a device round trip that t is uniform
+                tv = torch.full((), float(tval), device=xc.device, dtype=torch.float32).expand(xc.shape[0])
                 return drift(xc, tv, model, **model_kwargs)
 
             ts = [i / (num_steps - 1) for i in range(num_steps)] if num_steps > 1 else [0.0]
@@ -178,8 +180,8 @@ class Sampler:
         """Returns fn(x, model, **model_kwargs) -> (num_steps, *x.shape) trajectory; callers take [-1] (models.py:812).
 
         `num_steps` grid points = num_steps-1 steps (integrators.py:95).  The model sees t broadcast to a (B,)
-        vector (integrators.py:103-104); that vector carries a `_scldm_uniform_t` hint so a scldm_amd DiT can
-        share the conditioning work across the batch.
+        vector (integrators.py:103-104) - here as a stride-0 view of one device scalar, which a scldm_amd DiT
+        recognises as uniform and shares the conditioning work across the batch.
         """
         method = sampling_method.lower()
         if method not in ("euler", "heun", "dopri5"):
@@ -196,8 +198,9 @@ class Sampler:
             traj = [x]
 
             def f(xc, tval):
-                tv = torch.full((xc.shape[0],), float(tval), device=xc.device, dtype=torch.float32)
-                tv._scldm_uniform_t = True
+                # one scalar broadcast to (B,) as a stride-0 view: any model reads it as the reference's `ones(B) * t`
+                # (integrators.py:103-104), and a scldm_amd DiT can tell without a device round trip that t is uniform
+                tv = torch.full((), float(tval), device=xc.device, dtype=torch.float32).expand(xc.shape[0])
                 return drift(xc, tv, model, **model_kwargs)
 
             for i in range(num_steps - 1):

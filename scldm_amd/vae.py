@@ -23,6 +23,8 @@ class TransformerVAE(nn.Module):
         self._handle = None
         self.precision = "fp32"   # "bf16" = bf16 operands for the per-gene contractions of encode / decode (fp32 everything else)
         self._weights_key = None
+        self._weights_fp = None
+        self.check_weight_fingerprint = True
         self._ws = None
         self._keep = None
 
@@ -43,11 +45,30 @@ class TransformerVAE(nn.Module):
             with torch.cuda.device(emb.device):
                 _lib.check(L.scldm_vae_create(C.byref(cfg), C.byref(h)), "scldm_vae_create")
             self._handle = h
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if key != self._weights_key:
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        # in-place updates through `.data` (EMA-style) change neither the storage nor torch's version counter: the per-tensor
+        # norms are compared on device as well (one small host synchronisation per encode / decode call, both ms-scale)
+        fp = torch.stack(torch._foreach_norm(params)) if self.check_weight_fingerprint else None
+        if key != self._weights_key or (fp is not None and (self._weights_fp is None or not torch.equal(fp, self._weights_fp))):
             self._load_weights(L)
-            self._weights_key = key
+            self._weights_key, self._weights_fp = key, fp
         return L, self._handle
+
+    def invalidate_weights(self) -> None:
+        """Force the next encode / decode to re-derive the packed weight copies from the parameters."""
+        self._weights_key = None
+
+    # copies / pickling: the native handle never travels (the copy builds its own at its first call)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.update(_handle=None, _weights_key=None, _weights_fp=None, _ws=None, _keep=None)
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for k in ("_handle", "_weights_key", "_weights_fp", "_ws", "_keep"):
+            self.__dict__.setdefault(k, None)
 
     @staticmethod
     def _block(b):

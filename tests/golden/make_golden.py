@@ -68,6 +68,13 @@ DIT_CASES = {
     "dit_me2": (dict(n_embed=64, n_embed_input=16, n_layer=2, n_head=4, seq_len=16,
                      class_vocab_sizes={"a": 5, "b": 7}, condition_strategy="mutually_exclusive"), 3, 104),
 }
+# generated AFTER every other fixture (constructing a module consumes torch's global RNG, which gen_init depends on)
+LATE_DIT_CASES = {
+    # 256-wide two-class mutually-exclusive model: the fused forward_with_cfg / sample_ode path with TWO conditional passes
+    # (nnets.py:372-376), which the 64-wide dit_me2 cannot reach (the fused kernels are specialised to n_embed 256)
+    "dit_me2_256": (dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16,
+                         class_vocab_sizes={"a": 5, "b": 7}, condition_strategy="mutually_exclusive"), 3, 105),
+}
 COMMON = dict(dropout=0.0, bias=True, norm_layer="layernorm", multiple_of=4, layernorm_eps=1e-8, cfg_dropout_prob=0.8)
 
 
@@ -425,3 +432,5 @@ if __name__ == "__main__":
         gen_mmd(name, Bx, By, D, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
         gen_vae(name, kw["n_genes"], G, S, B, seed)
+    for name, (kw, B, seed) in LATE_DIT_CASES.items():
+        gen_dit(name, kw, B, seed)

@@ -1,15 +1,17 @@
 """GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI via the
 reference-shaped Python classes, against the golden vectors of the reference and against the CPU oracle.
 
-Tolerances (scale-relative max error, max|a-b| / max|b|):
-  fp32 path (exact-fp32 MFMA): 1e-4  - BASELINE.json north_star gate
-  bf16 path (bf16 operands, fp32 accumulate/LN/softmax/residual): 3e-2 (bf16 has 8 mantissa bits; 8 layers deep)
+Tolerances (conftest.check_err: scale-relative max error max|a-b| / max|b| asserted against the tolerance, the elementwise
+relative error floored at 1 % of max|b| printed beside it and asserted against 10 x the tolerance):
+  fp32 path   (exact-fp32 MFMA): 1e-4  - BASELINE.json north_star gate
+  bf16x3 path (split-bf16, three bf16 MFMAs per product sum - the reference's "high" matmul precision class): 1e-4, same gate
+  bf16 path   (bf16 operands, fp32 accumulate/LN/softmax/residual): 3e-2 (bf16 has 8 mantissa bits; 8 layers deep)
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_json, load_golden, max_abs_rel
+from conftest import check_err, golden_json, load_golden, max_abs_rel
 from oracle.dit import DiTConfig, dit_forward, dit_forward_with_cfg
 from oracle.transport import sample_ode_fixed
 from oracle.weights import make_state_dict
@@ -17,6 +19,7 @@ from oracle.weights import make_state_dict
 pytestmark = pytest.mark.gpu
 TOL_FP32 = 1e-4
 TOL_BF16 = 3e-2
+PARITY = [("fp32", TOL_FP32), ("bf16x3", TOL_FP32)]
 
 
 def build(name, precision="fp32"):
@@ -39,41 +42,60 @@ def cu(a):
     return torch.from_numpy(np.asarray(a)).cuda()
 
 
-@pytest.mark.parametrize("name", ["dit_base", "dit_joint"])
-@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("name", ["dit_base", "dit_joint", "dit_me2_256"])
+@pytest.mark.parametrize("precision,tol", PARITY + [("bf16", TOL_BF16)])
 def test_forward_matches_reference_golden(name, precision, tol):
     g, m, cfg, sd = build(name, precision)
     cond = {k: cu(g[f"fwd_label_{k}"]) for k in golden_json(g, "fwd_classes")}
     y = m(cu(g["fwd_x"]), cu(g["fwd_t"]), cond)
     assert y.shape == g["fwd_out"].shape and torch.isfinite(y).all()
-    assert max_abs_rel(y.cpu(), g["fwd_out"]) < tol
+    check_err(y.cpu(), g["fwd_out"], tol, f"forward {name} [{precision}] vs reference golden")
 
 
-@pytest.mark.parametrize("name", ["dit_base", "dit_joint"])
+@pytest.mark.parametrize("name", ["dit_base", "dit_joint", "dit_me2_256"])
 @pytest.mark.parametrize("tag", ["s1", "s2"])
-def test_forward_with_cfg_matches_reference_golden(name, tag):
-    g, m, cfg, sd = build(name)
+@pytest.mark.parametrize("precision,tol", PARITY)
+def test_forward_with_cfg_matches_reference_golden(name, tag, precision, tol):
+    """dit_me2_256: two mutually-exclusive classes = TWO conditional passes through the fused kernel with distinct scales
+    (nnets.py:372-376; VERDICT r1 weak #3).  The golden t is the scalar broadcast an ODE solver passes (integrators.py:103-104)."""
+    g, m, cfg, sd = build(name, precision)
     cond = {k: cu(g[f"cfg_label_{k}"]) for k in cfg.class_vocab_sizes}
     scales = golden_json(g, f"cfg_scales_{tag}")
     x, t = cu(g["cfg_x"]), cu(g["cfg_t"])
-    y = m.forward_with_cfg(x, t, cond, scales)           # per-sample-t path
-    assert max_abs_rel(y.cpu(), g[f"cfg_out_{tag}"]) < TOL_FP32
-    t._scldm_uniform_t = True                              # scalar-t path with label de-duplication
+    m.detect_uniform_t = False
+    y = m.forward_with_cfg(x, t, cond, scales)           # per-sample-t path: one conditioning row per sample-forward
+    check_err(y.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] per-sample t")
+    m.detect_uniform_t = True                              # dense uniform t: detected on device -> shared rows + label de-duplication
     y2 = m.forward_with_cfg(x, t, cond, scales)
-    assert max_abs_rel(y2.cpu(), g[f"cfg_out_{tag}"]) < TOL_FP32
+    check_err(y2.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] dense uniform t")
+    y3 = m.forward_with_cfg(x, t[:1].expand(t.shape[0]), cond, scales)   # stride-0 view (what scldm_amd.transport passes): no sync
+    assert torch.equal(y3, y2)
+
+
+def test_forward_with_cfg_nonuniform_dense_t_takes_the_per_sample_path():
+    g, m, cfg, sd = build("dit_base")
+    cond = {"clusters": cu(g["cfg_label_clusters"])}
+    scales = {"clusters": 2.0}
+    x = cu(g["cfg_x"])
+    n = x.shape[0]
+    t = torch.linspace(0.1, 0.9, n, device="cuda")
+    y = m.forward_with_cfg(x, t, cond, scales)
+    ref = dit_forward_with_cfg(sd, cfg, x.cpu(), t.cpu(), {k: v.cpu() for k, v in cond.items()}, scales)
+    check_err(y.cpu(), ref, TOL_FP32, "forward_with_cfg with a genuinely per-sample t")
 
 
 @pytest.mark.parametrize("n", [1, 3, 8, 13, 37])
-def test_ragged_batches_vs_oracle(n):
+@pytest.mark.parametrize("precision,tol", PARITY)
+def test_ragged_batches_vs_oracle(n, precision, tol):
     """Batch sizes that do not fill a 64/128-token tile (tile padding, odd sample pairing)."""
-    g, m, cfg, sd = build("dit_base")
+    g, m, cfg, sd = build("dit_base", precision)
     rng = np.random.default_rng(n)
     x = rng.standard_normal((n, 16, 16)).astype(np.float32)
     t = rng.uniform(0, 1, n).astype(np.float32)
     lab = rng.integers(0, 14, n).astype(np.int64)
     ref = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.from_numpy(lab)})
     y = m(cu(x), cu(t), {"clusters": cu(lab)})
-    assert max_abs_rel(y.cpu(), ref) < TOL_FP32
+    check_err(y.cpu(), ref, tol, f"ragged n={n} [{precision}] vs oracle")
 
 
 def test_bf16_vs_oracle_medium_batch():
@@ -88,26 +110,28 @@ def test_bf16_vs_oracle_medium_batch():
     assert max_abs_rel(y.cpu(), ref) < TOL_BF16
 
 
-@pytest.mark.parametrize("name,method,steps", [("dit_base", "euler", 5), ("dit_base", "heun", 4), ("dit_joint", "euler", 4)])
-def test_fused_sampler_vs_oracle(name, method, steps):
-    g, m, cfg, sd = build(name)
+@pytest.mark.parametrize("name,method,steps", [("dit_base", "euler", 5), ("dit_base", "heun", 4), ("dit_joint", "euler", 4),
+                                               ("dit_me2_256", "euler", 5), ("dit_me2_256", "heun", 3)])
+@pytest.mark.parametrize("precision,tol", PARITY)
+def test_fused_sampler_vs_oracle(name, method, steps, precision, tol):
+    g, m, cfg, sd = build(name, precision)
     rng = np.random.default_rng(11)
     B = 6
     z0 = rng.standard_normal((B, 16, 16)).astype(np.float32)
     labs = {k: rng.integers(0, v, B).astype(np.int64) for k, v in cfg.class_vocab_sizes.items()}
-    scales = {k: 1.5 for k in cfg.class_vocab_sizes}
+    scales = {k: 1.5 - 0.4 * i for i, k in enumerate(sorted(cfg.class_vocab_sizes))}   # distinct per class (two passes for dit_me2_256)
     z2 = torch.from_numpy(np.concatenate([z0, z0]))
     cond2 = {k: torch.from_numpy(np.concatenate([v, v])) for k, v in labs.items()}
     ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales), steps, method)
     out = m.sample_ode_cfg(z2.cuda(), {k: v.cuda() for k, v in cond2.items()}, scales, steps, method)
-    assert max_abs_rel(out.cpu(), ref) < TOL_FP32
+    check_err(out.cpu(), ref, tol, f"fused sampler {name} {method} x{steps} [{precision}] vs oracle")
     # the generic reference-style call chain (Sampler -> lambda -> forward_with_cfg) gives the same trajectory end
     from scldm_amd.transport import Sampler, create_transport
     fn = Sampler(create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)).sample_ode(sampling_method=method, num_steps=steps)
     condc = {k: v.cuda() for k, v in cond2.items()}
     model_fn = lambda x, t, **kw: m.forward_with_cfg(x, t, **kw, cfg_scale=scales)
     traj = fn(z2.cuda(), model_fn, **{"condition": condc})
-    assert traj.shape[0] == steps and max_abs_rel(traj[-1].cpu(), ref) < TOL_FP32
+    assert traj.shape[0] == steps and max_abs_rel(traj[-1].cpu(), ref) < tol
     assert max_abs_rel(traj[-1].cpu(), out.cpu()) < 1e-5
 
 
@@ -282,7 +306,157 @@ def test_tile_group_launches_are_bit_identical(monkeypatch):
     lab = torch.randint(0, 14, (n,), device="cuda", generator=gen)
     with torch.no_grad():
         ref = m(x, t, {"clusters": lab})
-        monkeypatch.setenv("SCLDM_GROUPS", "2")
-        y = m(x, t, {"clusters": lab})
-        torch.cuda.synchronize()
-    assert torch.equal(y, ref)
+        for knob, val in (("SCLDM_GROUPS", "2"), ("SCLDM_LPL", "1"), ("SCLDM_LPL", "3")):
+            monkeypatch.setenv(knob, val)                  # run-time knobs are read once, when the native handle is created
+            _, m2, _, _ = build("dit_base", "bf16")
+            y = m2(x, t, {"clusters": lab})
+            torch.cuda.synchronize()
+            monkeypatch.delenv(knob)
+            assert torch.equal(y, ref), (knob, val)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# round-2 additions: configurations and boundary behaviour the round-1 review found untested
+# --------------------------------------------------------------------------------------------------------------------
+def test_dentate_b512_euler50_bf16_properties():
+    """BASELINE.json configs[1] (dentate_gyrus, batch 512, 50 Euler evaluations, bf16) at full size: finite, bit-repeatable,
+    split-batch == whole batch, the unconditional half does not depend on the labels, and 8 cells agree with the oracle chain."""
+    from scldm_amd.sampling import sample_latents
+    g, m, cfg, sd = build("dit_base", "bf16")
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    B = 512
+    z0 = torch.randn(B, 16, 16, device="cuda", generator=gen)
+    cond = {"clusters": torch.randint(0, 14, (B,), device="cuda", generator=gen)}
+    scales = {"clusters": 1.0}
+    out = sample_latents(m, z0, cond, scales, 51, "euler")
+    assert out.shape == (2 * B, 16, 16) and torch.isfinite(out).all()
+    assert torch.equal(out, sample_latents(m, z0, cond, scales, 51, "euler"))
+    half = sample_latents(m, z0[:200], {"clusters": cond["clusters"][:200]}, scales, 51, "euler")
+    assert torch.equal(half[:200], out[:200]) and torch.equal(half[200:], out[B:B + 200])
+    other = sample_latents(m, z0, {"clusters": (cond["clusters"] + 3) % 14}, scales, 51, "euler")
+    assert torch.equal(other[:B], out[:B]) and not torch.equal(other[B:], out[B:])
+    idx = torch.arange(0, B, 64, device="cuda")
+    z2 = torch.cat([z0[idx], z0[idx]]).cpu()
+    c2 = {"clusters": torch.cat([cond["clusters"][idx]] * 2).cpu()}
+    ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, c2, scales), 51, "euler")
+    got = torch.cat([out[idx], out[idx + B]]).cpu()
+    check_err(got, ref, TOL_BF16, "dentate b512 x 50 Euler [bf16] vs oracle chain (8 cells)")
+
+
+def test_dit_l_depth_parity_fp32():
+    """A DiT-L (1024 wide, 24 layers, 16 heads - BASELINE.json configs[4] names it; not a reference config) on the
+    generic HIP path: fp32 parity of forward and forward_with_cfg on 3 cells at full depth."""
+    from scldm_amd.nnets import DiT
+    vocab = {"cell_line": 4, "gene": 2024}
+    kw = dict(n_embed=1024, n_embed_input=16, n_layer=24, n_head=16, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+              multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes=vocab, cfg_dropout_prob=0.8, condition_strategy="joint")
+    m = DiT(**kw)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 77)
+    sd = {k: (v * 0.4 if k.endswith("weight") and v.dim() == 2 and v.shape[1] >= 1024 else v) for k, v in sd.items()}   # keep 24 layers O(1)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    cfg = DiTConfig(n_embed=1024, n_layer=24, n_head=16, class_vocab_sizes=vocab, condition_strategy="joint")
+    gen = torch.Generator().manual_seed(9)
+    x, t = torch.randn(3, 16, 16, generator=gen), torch.rand(3, generator=gen)
+    cond = {"cell_line": torch.randint(0, 4, (3,), generator=gen), "gene": torch.randint(0, 2024, (3,), generator=gen)}
+    with torch.no_grad():
+        y = m(x.cuda(), t.cuda(), {k: v.cuda() for k, v in cond.items()})
+    check_err(y.cpu(), dit_forward(sd, cfg, x, t, cond), TOL_FP32, "DiT-L (24 layers) forward fp32 vs oracle")
+    x2, t2 = torch.cat([x, x]), torch.full((6,), 0.3)
+    c2 = {k: torch.cat([v, v]) for k, v in cond.items()}
+    scales = {"cell_line": 1.5, "gene": 2.5}
+    with torch.no_grad():
+        y2 = m.forward_with_cfg(x2.cuda(), t2.cuda(), {k: v.cuda() for k, v in c2.items()}, scales)
+    check_err(y2.cpu(), dit_forward_with_cfg(sd, cfg, x2, t2, c2, scales), TOL_FP32, "DiT-L forward_with_cfg fp32 vs oracle")
+
+
+def test_model_without_null_rows():
+    """cfg_dropout_prob == 0: the class tables have `vocab` rows (nnets.py:241-243).  forward with full labels works and is
+    exact; everything that needs a null token raises (the reference's nn.Embedding raises IndexError there) instead of
+    reading past the table."""
+    from scldm_amd.nnets import DiT
+    kw = dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+              multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes={"clusters": 14}, cfg_dropout_prob=0.0)
+    m = DiT(**kw)
+    assert m.class_embeddings["clusters"].weight.shape == (14, 256)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 88)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    cfg = DiTConfig(n_layer=2, class_vocab_sizes={"clusters": 14})
+    gen = torch.Generator().manual_seed(3)
+    x, t = torch.randn(5, 16, 16, generator=gen), torch.rand(5, generator=gen)
+    lab = torch.tensor([0, 13, 5, 13, 7])
+    y = m(x.cuda(), t.cuda(), {"clusters": lab.cuda()})
+    check_err(y.cpu(), dit_forward(sd, cfg, x, t, {"clusters": lab}), TOL_FP32, "forward without null rows")
+    with pytest.raises(IndexError):
+        m.forward_with_cfg(torch.cat([x, x]).cuda(), torch.full((10,), 0.5).cuda(), {"clusters": torch.cat([lab, lab]).cuda()}, {"clusters": 1.0})
+    with pytest.raises(IndexError):
+        m.sample_ode_cfg(torch.cat([x, x]).cuda(), {"clusters": torch.cat([lab, lab]).cuda()}, {"clusters": 1.0}, 3, "euler")
+    # training path: gradients of the 14-row table land inside it (the round-1 kernel wrote a 15th row)
+    m.train()
+    xg = x.cuda()
+    pred = m(xg, t.cuda(), {"clusters": lab.cuda()}, force_drop_ids=False)
+    guard = torch.full((4096,), 7.0, device="cuda")   # likely neighbour of the gradient allocation
+    pred.square().mean().backward()
+    gtab = m.class_embeddings["clusters"].weight.grad
+    assert gtab.shape == (14, 256) and torch.isfinite(gtab).all() and bool((guard == 7.0).all())
+    from oracle.train import training_grads  # noqa: F401  (gradient parity itself: tests/test_gpu_train.py)
+    with pytest.raises(IndexError):
+        m(xg, t.cuda(), {"clusters": lab.cuda()}, force_drop_ids=True)   # label dropout needs the null row
+
+
+def test_out_of_range_labels_are_reported_not_read():
+    g, m, cfg, sd = build("dit_base")
+    x, t = cu(g["cfg_x"]), cu(g["cfg_t"])
+    n = x.shape[0]
+    bad = torch.full((n,), 99, dtype=torch.long, device="cuda")
+    with pytest.raises(IndexError):
+        m.sample_ode_cfg(x, {"clusters": bad}, {"clusters": 1.0}, 3, "euler")          # caught host-side with the de-duplicated rows
+    y = m(x, t, {"clusters": bad})                                                       # plain forward: clamped on device, counted
+    assert torch.isfinite(y).all()
+    with pytest.raises(IndexError):
+        m.check_labels()
+    assert m.check_labels() == 0                                                         # the counter was reset
+
+
+def test_deepcopy_and_pickle_after_forward():
+    """ema_pytorch deep-copies the model (reference models.py:446); after a first forward the module holds a native handle,
+    which must not travel (VERDICT r1 robustness #12)."""
+    import copy
+    import pickle
+    g, m, cfg, sd = build("dit_base")
+    cond = {k: cu(g[f"fwd_label_{k}"]) for k in golden_json(g, "fwd_classes")}
+    x, t = cu(g["fwd_x"]), cu(g["fwd_t"])
+    y = m(x, t, cond)
+    m2 = copy.deepcopy(m)
+    m3 = pickle.loads(pickle.dumps(m))
+    assert m2._handle is None and m3._handle is None and m._handle is not None
+    assert torch.equal(m2(x, t, cond), y) and torch.equal(m3.cuda()(x, t, cond), y) and torch.equal(m(x, t, cond), y)
+    with torch.no_grad():                      # the copies are independent models
+        for p in m2.parameters():
+            p.mul_(1.01)
+    assert not torch.equal(m2(x, t, cond), y) and torch.equal(m(x, t, cond), y)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+def test_inplace_data_updates_are_picked_up(precision):
+    """EMA-style updates through `.data` change neither the storage nor torch's version counter: the fused path
+    must still see them (device-side fingerprint in scldm_dit_refresh_weights), for every packed precision."""
+    g, m, cfg, sd = build("dit_base", precision)
+    cond = {k: cu(g[f"fwd_label_{k}"]) for k in golden_json(g, "fwd_classes")}
+    x, t = cu(g["fwd_x"]), cu(g["fwd_t"])
+    y0 = m(x, t, cond)
+    versions = [p._version for p in m.parameters()]
+    other = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 999)
+    for k, p in m.state_dict().items():
+        p.data.lerp_(other[k].cuda(), 0.5)       # what ema_pytorch does
+    assert [p._version for p in m.parameters()] == versions
+    y1 = m(x, t, cond)
+    assert not torch.equal(y1, y0)
+    sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    tol = TOL_BF16 if precision == "bf16" else TOL_FP32
+    check_err(y1.cpu(), dit_forward(sd2, cfg, x.cpu(), t.cpu(), {k: v.cpu() for k, v in cond.items()}), tol, f"after .data update [{precision}]")
+    m.blocks[3].mlp.w1.weight.data[5, 7] += 1.0     # a single element: outside the sampled fingerprint by design ...
+    m.invalidate_weights()                            # ... which is what invalidate_weights() is for
+    y2 = m(x, t, cond)
+    assert not torch.equal(y2, y1)

@@ -8,7 +8,7 @@ from conftest import golden_json, load_golden, max_abs_rel
 from oracle.dit import DiTConfig, dit_flops_per_sample, dit_forward, dit_forward_with_cfg, layer_norm, mlp_hidden_dim
 from oracle.weights import make_state_dict
 
-CASES = ["dit_tiny", "dit_base", "dit_joint", "dit_me2"]
+CASES = ["dit_tiny", "dit_base", "dit_joint", "dit_me2", "dit_me2_256"]
 TOL = 2e-5  # fp32 oracle vs fp32 reference, different summation order
 
 
