@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 TOL_FP32 = 1e-4
 TOL_BF16 = 3e-2
 PARITY = [("fp32", TOL_FP32), ("bf16x3", TOL_FP32)]
+# bound on the floored ELEMENTWISE relative error (an element at 1 % of the output scale): fp32 measures <= 1.3e-4, split-bf16
+# <= 1.5e-3 (its scale-relative error is 1-2e-5; CFG with scale 2 doubles differences), bf16 is reported only
+FLOOR_TOL = {"fp32": 1e-3, "bf16x3": 5e-3, "bf16": float("inf")}
 
 
 def build(name, precision="fp32"):
@@ -49,7 +52,7 @@ def test_forward_matches_reference_golden(name, precision, tol):
     cond = {k: cu(g[f"fwd_label_{k}"]) for k in golden_json(g, "fwd_classes")}
     y = m(cu(g["fwd_x"]), cu(g["fwd_t"]), cond)
     assert y.shape == g["fwd_out"].shape and torch.isfinite(y).all()
-    check_err(y.cpu(), g["fwd_out"], tol, f"forward {name} [{precision}] vs reference golden")
+    check_err(y.cpu(), g["fwd_out"], tol, f"forward {name} [{precision}] vs reference golden", FLOOR_TOL[precision])
 
 
 @pytest.mark.parametrize("name", ["dit_base", "dit_joint", "dit_me2_256"])
@@ -64,10 +67,10 @@ def test_forward_with_cfg_matches_reference_golden(name, tag, precision, tol):
     x, t = cu(g["cfg_x"]), cu(g["cfg_t"])
     m.detect_uniform_t = False
     y = m.forward_with_cfg(x, t, cond, scales)           # per-sample-t path: one conditioning row per sample-forward
-    check_err(y.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] per-sample t")
+    check_err(y.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] per-sample t", FLOOR_TOL[precision])
     m.detect_uniform_t = True                              # dense uniform t: detected on device -> shared rows + label de-duplication
     y2 = m.forward_with_cfg(x, t, cond, scales)
-    check_err(y2.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] dense uniform t")
+    check_err(y2.cpu(), g[f"cfg_out_{tag}"], tol, f"forward_with_cfg {name}/{tag} [{precision}] dense uniform t", FLOOR_TOL[precision])
     y3 = m.forward_with_cfg(x, t[:1].expand(t.shape[0]), cond, scales)   # stride-0 view (what scldm_amd.transport passes): no sync
     assert torch.equal(y3, y2)
 
@@ -95,7 +98,7 @@ def test_ragged_batches_vs_oracle(n, precision, tol):
     lab = rng.integers(0, 14, n).astype(np.int64)
     ref = dit_forward(sd, cfg, torch.from_numpy(x), torch.from_numpy(t), {"clusters": torch.from_numpy(lab)})
     y = m(cu(x), cu(t), {"clusters": cu(lab)})
-    check_err(y.cpu(), ref, tol, f"ragged n={n} [{precision}] vs oracle")
+    check_err(y.cpu(), ref, tol, f"ragged n={n} [{precision}] vs oracle", FLOOR_TOL[precision])
 
 
 def test_bf16_vs_oracle_medium_batch():
@@ -124,7 +127,7 @@ def test_fused_sampler_vs_oracle(name, method, steps, precision, tol):
     cond2 = {k: torch.from_numpy(np.concatenate([v, v])) for k, v in labs.items()}
     ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, cond2, scales), steps, method)
     out = m.sample_ode_cfg(z2.cuda(), {k: v.cuda() for k, v in cond2.items()}, scales, steps, method)
-    check_err(out.cpu(), ref, tol, f"fused sampler {name} {method} x{steps} [{precision}] vs oracle")
+    check_err(out.cpu(), ref, tol, f"fused sampler {name} {method} x{steps} [{precision}] vs oracle", FLOOR_TOL[precision])
     # the generic reference-style call chain (Sampler -> lambda -> forward_with_cfg) gives the same trajectory end
     from scldm_amd.transport import Sampler, create_transport
     fn = Sampler(create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)).sample_ode(sampling_method=method, num_steps=steps)
@@ -455,7 +458,7 @@ def test_inplace_data_updates_are_picked_up(precision):
     assert not torch.equal(y1, y0)
     sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     tol = TOL_BF16 if precision == "bf16" else TOL_FP32
-    check_err(y1.cpu(), dit_forward(sd2, cfg, x.cpu(), t.cpu(), {k: v.cpu() for k, v in cond.items()}), tol, f"after .data update [{precision}]")
+    check_err(y1.cpu(), dit_forward(sd2, cfg, x.cpu(), t.cpu(), {k: v.cpu() for k, v in cond.items()}), tol, f"after .data update [{precision}]", FLOOR_TOL[precision])
     m.blocks[3].mlp.w1.weight.data[5, 7] += 1.0     # a single element: outside the sampled fingerprint by design ...
     m.invalidate_weights()                            # ... which is what invalidate_weights() is for
     y2 = m(x, t, cond)
