@@ -60,133 +60,166 @@ __global__ void pack_frag_wc_kernel(const float* __restrict__ Wc, int H, float* 
   out[(size_t)u * 512 + ((r >> 2) * 64 + l) * 4 + (r & 3)] = (hid < H) ? Wc[(l & 31) * H + hid] : 0.f;
 }
 
-// ------------------------------------------------------------------------------------------------
-// The 16-token trunk: n_layer non-adaLN Blocks (affine LN, 8 heads x 4, SwiGLU, no biases) on one cell's
-// (16, 32) state held in LDS.  One wave per cell; exact fp32 on the VALU (3.3 MFLOP per cell: never the bottleneck).
-// Packed per-layer weights (floats): ln1_w 32 | ln1_b 32 | attn (96,32) | proj (32,32) | ln2_w 32 | ln2_b 32 |
-//                                    w1 (H,32) | w2 (H,32) | c_proj (32,H)
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int trunk_layer_floats(int H) { return 64 + 96 * 32 + 32 * 32 + 64 + 2 * H * 32 + 32 * H; }
+// plain matrix W (rows x K, ld) zero-padded to a 32 x 32 tile: rows >= `rows` and k >= K are zero
+__global__ void pack_frag32_pad_kernel(const float* __restrict__ W, int ld, int rows, int K, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 16 * 64) return;
+  const int l = idx & 63, j = idx >> 6, row = l & 31, k = acc_row(j, l >> 5);
+  out[((j >> 2) * 64 + l) * 4 + (j & 3)] = (row < rows && k < K) ? W[row * ld + k] : 0.f;
+}
 
-struct TrunkSmem {
-  float h[kNI][kE + 1];
-  float n[kNI][kE + 1];
-  float qkv[kNI][96 + 1];
-  float hid[kNI][kHPad + 1];
-};
+// ------------------------------------------------------------------------------------------------
+// The 16-token trunk: n_layer non-adaLN Blocks (affine LN, 8 heads x 4, SwiGLU, no biases; layers.py:222-226) on the
+// (16, 32) state of a cell.  One wave carries TWO cells as one 32-token MFMA tile through the whole network, a workgroup
+// of four waves eight cells (round 1 ran one cell per 64-thread workgroup on the VALU with an LDS read per FMA: a flat
+// 0.5 ms per call, 10-25 % of decode).  The state lives in registers in accumulator layout - lane = token (cell = token >> 4),
+// register r <-> feature acc_row(r, lane >> 5) - which is directly the B operand of the next Linear, so every Linear is a
+// chain of exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) whose A operands are pre-packed weight fragments read straight from
+// L2 (53 KB per layer, shared by every wave).  Only the 16 x 16 attention of the 8 four-dimensional heads goes through LDS
+// (per wave, no workgroup barrier): on the matrix pipe its block-sparse P V would cost 8x the useful work.
+// Packed per-layer weights (floats): ln1_w 32 | ln1_b 32 | ln2_w 32 | ln2_b 32 | qkv 3 tiles x 1024 | proj 1024 |
+//                                    w12 6 tiles x 1024 | c_proj 6 tiles x 512
+// ------------------------------------------------------------------------------------------------
+enum : int { T_LN1W = 0, T_LN1B = 32, T_LN2W = 64, T_LN2B = 96, T_QKV = 128, T_PROJ = T_QKV + 3 * 1024, T_W12 = T_PROJ + 1024,
+             T_WC = T_W12 + kHTiles * 1024, kTrunkLayerFloats = T_WC + kHTiles * 512 };
+constexpr int kTrunkLd = 100;                    // floats per token row of the per-wave attention scratch (q | k | v, 16-byte aligned rows)
+constexpr int kTrunkWaves = 4;
+constexpr int kTrunkSmemFloats = kTrunkWaves * 32 * kTrunkLd;
 
-// LayerNorm of the 16 rows of src (width W <= 32) into dst; lane -> (token = l & 15, part = l >> 4)
-template <int W>
-__device__ __forceinline__ void trunk_ln(const float (*src)[kE + 1], float (*dst)[kE + 1], const float* w, const float* b, float eps, int lane) {
-  const int t = lane & 15, part = lane >> 4;
-  constexpr int PER = W / 4;
-  float v[PER], s = 0.f;
+// LDS traffic of ONE wave needs no workgroup barrier; the fence keeps the compiler from moving the reads above the writes
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc += W-tile (16 steps = K 32, fragments from global memory) x[16] (accumulator-order registers)
+__device__ __forceinline__ f32x16 chain16(const float* __restrict__ frag, const float (&x)[16], f32x16 acc, int lane) {
+  const f32x4* F = reinterpret_cast<const f32x4*>(frag);
+  f32x4 w[4];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { v[i] = src[t][part * PER + i]; s += v[i]; }
-  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-  const float mean = s * (1.0f / W);
+  for (int g4 = 0; g4 < 4; ++g4) w[g4] = F[g4 * 64 + lane];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma2(w[g4][i], x[g4 * 4 + i], acc);
+  return acc;
+}
+__device__ __forceinline__ f32x16 chain8(const float* __restrict__ frag, const float (&x)[8], f32x16 acc, int lane) {
+  const f32x4* F = reinterpret_cast<const f32x4*>(frag);
+  const f32x4 w0 = F[lane], w1 = F[64 + lane];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = mfma2(w0[i], x[i], acc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = mfma2(w1[i], x[4 + i], acc);
+  return acc;
+}
+
+// LayerNorm over the first `width` features of every token (registers beyond `width` must be zero); affine if w != nullptr
+__device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], const float* __restrict__ w, const float* __restrict__ b,
+                                        int width, float eps, int hh) {
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += x[r];
+  const float mean = xor32_sum(s) / (float)width;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { v[i] -= mean; ss += v[i] * v[i]; }
-  ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-  const float rstd = 1.0f / sqrtf(ss * (1.0f / W) + eps);
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int k = part * PER + i;
-    float y = v[i] * rstd;
-    if (w) y = y * w[k] + b[k];
-    dst[t][k] = y;
+  for (int r = 0; r < 16; ++r) {
+    const float d = (acc_row(r, hh) < width) ? x[r] - mean : 0.f;
+    y[r] = d;
+    ss += d * d;
   }
-}
-
-// out[t][n] (+)= sum_k in[t][k] * W[n][k] for n in [n0, n0+64) restricted to n < N; lane owns row n0 + lane.
-template <int K, int LDI, int LDO, bool ACCUM>
-__device__ __forceinline__ void trunk_linear(const float (*in)[LDI], float (*out)[LDO], const float* W, int ldw, int N, int n0, int lane) {
-  const int n = n0 + lane;
-  if (n < N) {
-    float wr[K];
+  const float rstd = 1.0f / sqrtf(xor32_sum(ss) / (float)width + eps);
 #pragma unroll
-    for (int k = 0; k < K; ++k) wr[k] = W[(size_t)n * ldw + k];
-    for (int t = 0; t < kNI; ++t) {
-      float acc = 0.f;
-#pragma unroll
-      for (int k = 0; k < K; ++k) acc += in[t][k] * wr[k];
-      if (ACCUM) out[t][n] += acc; else out[t][n] = acc;
+  for (int q = 0; q < 4; ++q) {
+    f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (w) {
+      w4 = *reinterpret_cast<const f32x4*>(w + q * 8 + hh * 4);
+      b4 = *reinterpret_cast<const f32x4*>(b + q * 8 + hh * 4);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[q * 4 + i] = y[q * 4 + i] * rstd * w4[i] + b4[i];
   }
 }
 
-__device__ __forceinline__ void trunk_blocks(TrunkSmem& sm, const float* wts, int n_layer, int H, float eps, int lane) {
+// SwiGLU MLP on a normalised tile: x += c_proj( silu(w1 yn) * (w2 yn) ), six 16-unit hidden tiles (88 padded to 96 with zeros)
+__device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const float* __restrict__ wc, const float (&yn)[16],
+                                            float (&x)[16], int lane) {
+  f32x16 mo = zero16();
+#pragma unroll 1
+  for (int u = 0; u < kHTiles; ++u) {
+    const f32x16 ht = chain16(w12 + u * 1024, yn, zero16(), lane);   // rows 0-15 = w1 units, 16-31 = the matching w2 units
+    float hv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) hv[r] = (ht[r] / (1.0f + expf(-ht[r]))) * ht[r + 8];
+    mo = chain8(wc + u * 512, hv, mo, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] += mo[r];
+}
+
+// n_layer plain Blocks on the wave's 32-token tile x (in place); S = this wave's LDS scratch [32][kTrunkLd]
+__device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, const float* __restrict__ wts, int n_layer,
+                                             float eps, int lane) {
+  const int c32 = lane & 31, hh = lane >> 5;
   for (int layer = 0; layer < n_layer; ++layer) {
-    const float* w = wts + (size_t)layer * trunk_layer_floats(H);
-    const float *ln1w = w, *ln1b = w + 32, *attn = w + 64, *proj = attn + 96 * 32, *ln2w = proj + 32 * 32, *ln2b = ln2w + 32;
-    const float *w1 = ln2b + 32, *w2 = w1 + H * 32, *cp = w2 + H * 32;
-    trunk_ln<kE>(sm.h, sm.n, ln1w, ln1b, eps, lane);
-    __syncthreads();
-    trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, attn, kE, 96, 0, lane);
-    trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, attn, kE, 96, 64, lane);
-    __syncthreads();
-    // attention: 8 heads x 16 queries = 128 (head, query) pairs, 2 per lane; q,k,v split order q|k|v (layers.py:147)
+    const float* w = wts + (size_t)layer * kTrunkLayerFloats;
+    float yn[16];
+    tile_ln(x, yn, w + T_LN1W, w + T_LN1B, kE, eps, hh);
+    // q | k | v (split order of layers.py:147) -> scratch rows [token][q 32 | k 32 | v 32]
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const int hq = lane + 64 * rep, hd = hq >> 4, qi = hq & 15;
-      float q[4], sc[16], m = -3.0e38f;
+    for (int t = 0; t < 3; ++t) {
+      const f32x16 o = chain16(w + T_QKV + t * 1024, yn, zero16(), lane);
 #pragma unroll
-      for (int d = 0; d < 4; ++d) q[d] = sm.qkv[qi][hd * 4 + d];
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
+    }
+    wave_lds_sync();
+    // attention: 2 cells x 8 heads x 16 queries = 256 (cell, head, query) triples, four per lane; the output replaces q in place
+#pragma unroll 1
+    for (int rep = 0; rep < 4; ++rep) {
+      const int p = lane + 64 * rep, cell = p >> 7, hd = (p >> 4) & 7, qi = p & 15;
+      const float* base = S + (cell * 16) * kTrunkLd + hd * 4;
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(base + qi * kTrunkLd);
+      float sc[16], m = -3.0e38f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) s += q[d] * sm.qkv[j][32 + hd * 4 + d];
-        sc[j] = s * 0.5f;  // 1/sqrt(4)
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(base + j * kTrunkLd + 32);
+        sc[j] = (qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3]) * 0.5f;   // 1 / sqrt(head_dim 4)
         m = fmaxf(m, sc[j]);
       }
-      float sum = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+      float sum = 0.f;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float p = expf(sc[j] - m);
-        sum += p;
+        const float pj = expf(sc[j] - m);
+        sum += pj;
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(base + j * kTrunkLd + 64);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) o[d] += p * sm.qkv[j][64 + hd * 4 + d];
+        for (int d = 0; d < 4; ++d) o[d] += pj * vv[d];
       }
       const float inv = 1.0f / sum;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) sm.n[qi][hd * 4 + d] = o[d] * inv;  // n is free: reuse as the attention output
+      *reinterpret_cast<f32x4*>(S + (cell * 16 + qi) * kTrunkLd + hd * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
     }
-    __syncthreads();
-    trunk_linear<kE, kE + 1, kE + 1, true>(sm.n, sm.h, proj, kE, kE, 0, lane);  // h += proj(att)
-    __syncthreads();
-    trunk_ln<kE>(sm.h, sm.n, ln2w, ln2b, eps, lane);
-    __syncthreads();
-    // SwiGLU: hid = silu(w1 n) * (w2 n); lane owns hidden rows lane, lane + 64
-    for (int j0 = 0; j0 < H; j0 += 64) {
-      const int j = j0 + lane;
-      if (j < H) {
-        float a1[kE], a2[kE];
+    wave_lds_sync();
+    float ao[16];
 #pragma unroll
-        for (int k = 0; k < kE; ++k) { a1[k] = w1[j * kE + k]; a2[k] = w2[j * kE + k]; }
-        for (int t = 0; t < kNI; ++t) {
-          float u = 0.f, g = 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 t4 = *reinterpret_cast<const f32x4*>(S + c32 * kTrunkLd + q * 8 + hh * 4);
 #pragma unroll
-          for (int k = 0; k < kE; ++k) { u += sm.n[t][k] * a1[k]; g += sm.n[t][k] * a2[k]; }
-          sm.hid[t][j] = (u / (1.0f + expf(-u))) * g;
-        }
-      }
+      for (int i = 0; i < 4; ++i) ao[q * 4 + i] = t4[i];
     }
-    __syncthreads();
-    if (lane < kE) {
-      for (int t = 0; t < kNI; ++t) {
-        float acc = 0.f;
-        for (int k = 0; k < H; ++k) acc += sm.hid[t][k] * cp[lane * H + k];
-        sm.h[t][lane] += acc;
-      }
-    }
-    __syncthreads();
+    wave_lds_sync();   // the scratch is rewritten by the next layer's q | k | v
+    const f32x16 po = chain16(w + T_PROJ, ao, zero16(), lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] += po[r];
+    tile_ln(x, yn, w + T_LN2W, w + T_LN2B, kE, eps, hh);
+    tile_swiglu(w + T_W12, w + T_WC, yn, x, lane);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decoder, per cell (one wave): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
+// Decoder, per cell pair (one wave): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
 // packed as MFMA A-operand fragments for the per-gene kernel (48 fragments = 12 KiB per cell):
 //   K tile t (heads 2t, 2t+1), step jj < 8:  lane(row = hl*16 + key, hh): K[key][k] if head(k) == 2t + hl else 0,
 //                                             k = acc_row(8t + jj, hh)
@@ -194,56 +227,65 @@ __device__ __forceinline__ void trunk_blocks(TrunkSmem& sm, const float* wts, in
 // ------------------------------------------------------------------------------------------------
 struct DecCellArgs {
   const float* z;        // (B, 16, n_lat)
-  const float* lat_w;    // decoder_latent_input.1.weight (32, n_lat)
+  const float* lat_frag; // decoder_latent_input.1.weight (32, n_lat) as a K-padded fragment tile
   const float* trunk;    // packed trunk weights
   const float* ca_ln1_w; const float* ca_ln1_b;  // decoder_cross_attention.ln_1
-  const float* ca_attn;  // decoder_cross_attention.attn.c_attn.weight (64, 32): k | v
+  const float* kv_frag;  // decoder_cross_attention.attn.c_attn.weight (64, 32): K tile | V tile fragments
   float* kvfrag;         // (B, 48*64) floats
-  int n_lat, n_layer, H;
+  int B, n_lat, n_layer;
   float eps;
 };
-__global__ __launch_bounds__(64) void dec_cell_kernel(const DecCellArgs a) {
-  __shared__ TrunkSmem sm;
-  const int lane = threadIdx.x, cell = blockIdx.x;
-  // LN (no affine) over the n_lat latent channels of each of the 16 tokens, then Linear n_lat -> 32 (no bias)
-  if (lane < kNI) {
-    const float* zr = a.z + ((size_t)cell * kNI + lane) * a.n_lat;
-    float s = 0.f;
-    for (int k = 0; k < a.n_lat; ++k) s += zr[k];
-    const float mean = s / a.n_lat;
-    float ss = 0.f;
-    for (int k = 0; k < a.n_lat; ++k) { const float d = zr[k] - mean; ss += d * d; }
-    const float rstd = 1.0f / sqrtf(ss / a.n_lat + a.eps);
-    for (int k = 0; k < a.n_lat; ++k) sm.n[lane][k] = (zr[k] - mean) * rstd;
+__global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCellArgs a) {
+  __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int pair = blockIdx.x * kTrunkWaves + wave;
+  if (pair * 2 >= a.B) return;   // wave-uniform; no workgroup barrier anywhere in this kernel
+  float* S = SM + wave * 32 * kTrunkLd;
+  const int cell = min(pair * 2 + (c32 >> 4), a.B - 1);   // an odd batch pads its last tile with a copy of the last cell
+  // LN (no affine) over the n_lat latent channels of every token, then Linear n_lat -> 32 (no bias)
+  float zr[16], zn[16], x[16];
+  const float* zrow = a.z + ((size_t)cell * kNI + (c32 & 15)) * a.n_lat;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int f = acc_row(r, hh);
+    zr[r] = f < a.n_lat ? zrow[f] : 0.f;
   }
-  __syncthreads();
-  if (lane < kE) {
-    for (int t = 0; t < kNI; ++t) {
-      float acc = 0.f;
-      for (int k = 0; k < a.n_lat; ++k) acc += sm.n[t][k] * a.lat_w[lane * a.n_lat + k];
-      sm.h[t][lane] = acc;
-    }
+  tile_ln(zr, zn, nullptr, nullptr, a.n_lat, a.eps, hh);
+  {
+    const f32x16 h0 = chain16(a.lat_frag, zn, zero16(), lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = h0[r];
   }
-  __syncthreads();
-  trunk_blocks(sm, a.trunk, a.n_layer, a.H, a.eps, lane);
-  trunk_ln<kE>(sm.h, sm.n, a.ca_ln1_w, a.ca_ln1_b, a.eps, lane);
-  __syncthreads();
-  trunk_linear<kE, kE + 1, 97, false>(sm.n, sm.qkv, a.ca_attn, kE, 64, 0, lane);  // qkv[:, 0:32] = K, [:, 32:64] = V
-  __syncthreads();
-  float* out = a.kvfrag + (size_t)cell * 48 * 64;
-  const int row = lane & 31, hh = lane >> 5;
-  for (int t = 0; t < 2; ++t)
-    for (int jj = 0; jj < 8; ++jj) {
-      const int hl = row >> 4, key = row & 15, k = acc_row(8 * t + jj, hh);
-      const int j = t * 8 + jj;
-      out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((k >> 3) == 2 * t + hl) ? sm.qkv[key][k] : 0.f;
-    }
-  for (int t = 0; t < 2; ++t)
-    for (int r = 0; r < 16; ++r) {
-      const int rr = acc_row(r, hh), hl = rr >> 4, key = rr & 15;
-      const int j = 16 + t * 16 + r;
-      out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((row >> 3) == 2 * t + hl) ? sm.qkv[key][32 + row] : 0.f;
-    }
+  trunk_blocks(x, S, a.trunk, a.n_layer, a.eps, lane);
+  float yn[16];
+  tile_ln(x, yn, a.ca_ln1_w, a.ca_ln1_b, kE, a.eps, hh);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {   // scratch rows [token][K 32 | V 32]
+    const f32x16 o = chain16(a.kv_frag + t * 1024, yn, zero16(), lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
+  }
+  wave_lds_sync();
+  const int row = lane & 31;
+  for (int c = 0; c < 2; ++c) {
+    if (pair * 2 + c >= a.B) break;
+    float* out = a.kvfrag + (size_t)(pair * 2 + c) * 48 * 64;
+    const float* Sc = S + c * 16 * kTrunkLd;
+    for (int t = 0; t < 2; ++t)
+      for (int jj = 0; jj < 8; ++jj) {
+        const int hl = row >> 4, key = row & 15, k = acc_row(8 * t + jj, hh);
+        const int j = t * 8 + jj;
+        out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((k >> 3) == 2 * t + hl) ? Sc[key * kTrunkLd + k] : 0.f;
+      }
+    for (int t = 0; t < 2; ++t)
+      for (int r = 0; r < 16; ++r) {
+        const int rr = acc_row(r, hh), hl = rr >> 4, key = rr & 15;
+        const int j = 16 + t * 16 + r;
+        out[((j >> 2) * 64 + lane) * 4 + (j & 3)] = ((row >> 3) == 2 * t + hl) ? Sc[key * kTrunkLd + 32 + row] : 0.f;
+      }
+  }
 }
 
 // Per-gene query table (run once per weight load): Qtab[g] = c_attn_q(LN_1q(emb[g])) / sqrt(8)
@@ -649,75 +691,66 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
   }
 }
 
-// Encoder tail, per cell (one wave): c_proj + inducing-point residual -> LN2 -> SwiGLU -> (+pos_embed) -> trunk ->
-// Linear 32 -> n_lat -> LN (no affine)  (layers.py:326-330, nnets.py:139-144)
+// Encoder tail, per cell pair (one wave): c_proj + inducing-point residual -> LN2 -> SwiGLU -> (+pos_embed) -> trunk ->
+// Linear 32 -> n_lat -> LN (no affine)  (layers.py:326-330, nnets.py:139-144); same register-resident tile as the trunk
 struct EncCellArgs {
   const float* pooled;     // (B, 16, 32)
   const float* ind;        // encoder.ca_layer.inducing_points (16, 32)
-  const float* ca_proj;    // encoder.ca_layer.attn.c_proj.weight (32, 32)
+  const float* proj_frag;  // encoder.ca_layer.attn.c_proj.weight (32, 32) fragments
   const float* ca_ln2_w; const float* ca_ln2_b;
-  const float* ca_w1; const float* ca_w2; const float* ca_cp;  // encoder.ca_layer.mlp
+  const float* w12_frag; const float* wc_frag;  // encoder.ca_layer.mlp fragments
   const float* pos;        // encoder.pos_embed (16, 32) or nullptr
   const float* trunk;
-  const float* lat_w;      // encoder_latent_input.0.weight (n_lat, 32)
+  const float* lat_frag;   // encoder_latent_input.0.weight (n_lat, 32) as a row-padded fragment tile
   float* z;                // (B, 16, n_lat)
-  int n_lat, n_layer, H;
+  int B, n_lat, n_layer;
   float eps;
 };
-__global__ __launch_bounds__(64) void enc_cell_kernel(const EncCellArgs a) {
-  __shared__ TrunkSmem sm;
-  const int lane = threadIdx.x, cell = blockIdx.x;
-  for (int i = lane; i < kNI * kE; i += 64) {
-    sm.n[i >> 5][i & 31] = a.pooled[(size_t)cell * kNI * kE + i];
-    sm.h[i >> 5][i & 31] = a.ind[i];
+__global__ __launch_bounds__(64 * kTrunkWaves) void enc_cell_kernel(const EncCellArgs a) {
+  __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int pair = blockIdx.x * kTrunkWaves + wave;
+  if (pair * 2 >= a.B) return;
+  float* S = SM + wave * 32 * kTrunkLd;
+  const int cell_raw = pair * 2 + (c32 >> 4), cell = min(cell_raw, a.B - 1), tok = c32 & 15;
+  float att[16], x[16], yn[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 p4 = *reinterpret_cast<const f32x4*>(a.pooled + ((size_t)cell * kNI + tok) * kE + q * 8 + hh * 4);
+    const f32x4 i4 = *reinterpret_cast<const f32x4*>(a.ind + tok * kE + q * 8 + hh * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { att[q * 4 + i] = p4[i]; x[q * 4 + i] = i4[i]; }
   }
-  __syncthreads();
-  trunk_linear<kE, kE + 1, kE + 1, true>(sm.n, sm.h, a.ca_proj, kE, kE, 0, lane);  // h = inducing + c_proj(att)
-  __syncthreads();
-  trunk_ln<kE>(sm.h, sm.n, a.ca_ln2_w, a.ca_ln2_b, a.eps, lane);
-  __syncthreads();
-  for (int j0 = 0; j0 < a.H; j0 += 64) {
-    const int j = j0 + lane;
-    if (j < a.H) {
-      float a1[kE], a2[kE];
+  {
+    const f32x16 po = chain16(a.proj_frag, att, zero16(), lane);   // h = inducing + c_proj(att): the residual is the QUERY (layers.py:327)
 #pragma unroll
-      for (int k = 0; k < kE; ++k) { a1[k] = a.ca_w1[j * kE + k]; a2[k] = a.ca_w2[j * kE + k]; }
-      for (int t = 0; t < kNI; ++t) {
-        float u = 0.f, g = 0.f;
+    for (int r = 0; r < 16; ++r) x[r] += po[r];
+  }
+  tile_ln(x, yn, a.ca_ln2_w, a.ca_ln2_b, kE, a.eps, hh);
+  tile_swiglu(a.w12_frag, a.wc_frag, yn, x, lane);
+  if (a.pos) {
 #pragma unroll
-        for (int k = 0; k < kE; ++k) { u += sm.n[t][k] * a1[k]; g += sm.n[t][k] * a2[k]; }
-        sm.hid[t][j] = (u / (1.0f + expf(-u))) * g;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 p4 = *reinterpret_cast<const f32x4*>(a.pos + tok * kE + q * 8 + hh * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[q * 4 + i] += p4[i];
     }
   }
-  __syncthreads();
-  if (lane < kE) {
-    for (int t = 0; t < kNI; ++t) {
-      float acc = 0.f;
-      for (int k = 0; k < a.H; ++k) acc += sm.hid[t][k] * a.ca_cp[lane * a.H + k];
-      sm.h[t][lane] += acc + (a.pos ? a.pos[t * kE + lane] : 0.f);
-    }
-  }
-  __syncthreads();
-  trunk_blocks(sm, a.trunk, a.n_layer, a.H, a.eps, lane);
-  // latent head: Linear 32 -> n_lat (no bias), LN without affine over the n_lat channels
-  if (lane < a.n_lat) {
-    for (int t = 0; t < kNI; ++t) {
-      float acc = 0.f;
+  trunk_blocks(x, S, a.trunk, a.n_layer, a.eps, lane);
+  // latent head: Linear 32 -> n_lat (no bias; fragment rows >= n_lat are zero), LN without affine over the n_lat channels
+  const f32x16 lt = chain16(a.lat_frag, x, zero16(), lane);
+  float lv[16], ln[16];
 #pragma unroll
-      for (int k = 0; k < kE; ++k) acc += sm.h[t][k] * a.lat_w[lane * kE + k];
-      sm.n[t][lane] = acc;
+  for (int r = 0; r < 16; ++r) lv[r] = lt[r];
+  tile_ln(lv, ln, nullptr, nullptr, a.n_lat, a.eps, hh);
+  if (cell_raw < a.B) {
+    float* zrow = a.z + ((size_t)cell * kNI + tok) * a.n_lat;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = acc_row(r, hh);
+      if (f < a.n_lat) zrow[f] = ln[r];
     }
-  }
-  __syncthreads();
-  if (lane < kNI) {
-    float s = 0.f;
-    for (int k = 0; k < a.n_lat; ++k) s += sm.n[lane][k];
-    const float mean = s / a.n_lat;
-    float ss = 0.f;
-    for (int k = 0; k < a.n_lat; ++k) { const float d = sm.n[lane][k] - mean; ss += d * d; }
-    const float rstd = 1.0f / sqrtf(ss / a.n_lat + a.eps);
-    for (int k = 0; k < a.n_lat; ++k) a.z[((size_t)cell * kNI + lane) * a.n_lat + k] = (sm.n[lane][k] - mean) * rstd;
   }
 }
 

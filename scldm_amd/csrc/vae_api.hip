@@ -11,8 +11,9 @@ struct scldm_vae {
   scldm_vae_config cfg;
   bool loaded;
   // owned device buffers
-  float* enc_trunk;   // n_layer * trunk_layer_floats(H)
+  float* enc_trunk;   // n_layer * kTrunkLayerFloats (LayerNorm vectors + MFMA fragments of every Linear)
   float* dec_trunk;
+  float* frag_cell;   // fragments of the per-cell Linears around the trunks (layout: F_* below)
   float* frag_dec;    // c_proj 16 | w12 96 | wc 48 fragments (160*64 floats)
   float* frag_enc_k;  // 16*64
   float* frag_enc_v;  // 16*64
@@ -22,6 +23,17 @@ struct scldm_vae {
   // borrowed (caller-owned, must stay alive): the big tables
   const float* emb;
   const float* theta;
+};
+
+// offsets (floats) into `frag_cell`
+enum : int {
+  F_DEC_LAT = 0,                        // decoder_latent_input.1.weight (32, n_lat), K padded to 32
+  F_DEC_KV = F_DEC_LAT + 1024,          // decoder_cross_attention.attn.c_attn: K tile | V tile
+  F_ENC_PROJ = F_DEC_KV + 2048,         // encoder.ca_layer.attn.c_proj
+  F_ENC_W12 = F_ENC_PROJ + 1024,        // encoder.ca_layer.mlp w1 | w2, six hidden tiles
+  F_ENC_WC = F_ENC_W12 + kHTiles * 1024,
+  F_ENC_LAT = F_ENC_WC + kHTiles * 512, // encoder_latent_input.0.weight (n_lat, 32), rows padded to 32
+  F_TOTAL = F_ENC_LAT + 1024
 };
 
 // offsets (floats) into `small`
@@ -45,9 +57,10 @@ extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
   scldm_vae* h = new scldm_vae();
   memset(h, 0, sizeof(*h));
   h->cfg = *cfg;
-  const size_t tl = (size_t)(cfg->n_layer > 0 ? cfg->n_layer : 1) * trunk_layer_floats(cfg->hidden_dim) * 4;
+  const size_t tl = (size_t)(cfg->n_layer > 0 ? cfg->n_layer : 1) * kTrunkLayerFloats * 4;
   hipError_t e = hipMalloc((void**)&h->enc_trunk, tl);
   if (e == hipSuccess) e = hipMalloc((void**)&h->dec_trunk, tl);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_cell, (size_t)F_TOTAL * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_dec, 160 * 64 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_k, 16 * 64 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_v, 16 * 64 * 4);
@@ -66,7 +79,7 @@ extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
 
 extern "C" void scldm_vae_destroy(scldm_vae* h) {
   if (!h) return;
-  float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_dec, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
+  float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_cell, h->frag_dec, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -79,20 +92,17 @@ static int copy_d2d(float* dst, const float* src, size_t n, hipStream_t st) {
 
 static int pack_trunk(float* dst, const scldm_vae_block* blocks, int n_layer, int H, hipStream_t st) {
   for (int i = 0; i < n_layer; ++i) {
-    float* w = dst + (size_t)i * trunk_layer_floats(H);
+    float* w = dst + (size_t)i * kTrunkLayerFloats;
     const scldm_vae_block& b = blocks[i];
     int rc;
-    if ((rc = copy_d2d(w, b.ln1_w, 32, st))) return rc;
-    if ((rc = copy_d2d(w + 32, b.ln1_b, 32, st))) return rc;
-    if ((rc = copy_d2d(w + 64, b.attn_w, 96 * 32, st))) return rc;
-    float* proj = w + 64 + 96 * 32;
-    if ((rc = copy_d2d(proj, b.proj_w, 32 * 32, st))) return rc;
-    if ((rc = copy_d2d(proj + 1024, b.ln2_w, 32, st))) return rc;
-    if ((rc = copy_d2d(proj + 1024 + 32, b.ln2_b, 32, st))) return rc;
-    float* w1 = proj + 1024 + 64;
-    if ((rc = copy_d2d(w1, b.w1, (size_t)H * 32, st))) return rc;
-    if ((rc = copy_d2d(w1 + (size_t)H * 32, b.w2, (size_t)H * 32, st))) return rc;
-    if ((rc = copy_d2d(w1 + (size_t)2 * H * 32, b.cproj, (size_t)32 * H, st))) return rc;
+    if ((rc = copy_d2d(w + T_LN1W, b.ln1_w, 32, st)) || (rc = copy_d2d(w + T_LN1B, b.ln1_b, 32, st)) ||
+        (rc = copy_d2d(w + T_LN2W, b.ln2_w, 32, st)) || (rc = copy_d2d(w + T_LN2B, b.ln2_b, 32, st)))
+      return rc;
+    for (int t = 0; t < 3; ++t) pack_frag32_kernel<<<4, 256, 0, st>>>(b.attn_w + t * 32 * 32, 32, w + T_QKV + t * 1024);   // q | k | v rows
+    pack_frag32_kernel<<<4, 256, 0, st>>>(b.proj_w, 32, w + T_PROJ);
+    pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(b.w1, b.w2, H, w + T_W12);
+    pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(b.cproj, H, w + T_WC);
+    LAUNCH_CHECK();
   }
   return SCLDM_OK;
 }
@@ -124,6 +134,14 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
     if ((rc = copy_d2d(s + S_ENC_POS, w->enc_pos_embed, 512, st))) return rc;
   }
   // MFMA fragments
+  float* fc = h->frag_cell;
+  pack_frag32_pad_kernel<<<4, 256, 0, st>>>(w->dec_latent_w, nl, 32, nl, fc + F_DEC_LAT);
+  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_kv, 32, fc + F_DEC_KV);
+  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_kv + 32 * 32, 32, fc + F_DEC_KV + 1024);
+  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_proj, 32, fc + F_ENC_PROJ);
+  pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(ec.w1, ec.w2, H, fc + F_ENC_W12);
+  pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(ec.cproj, H, fc + F_ENC_WC);
+  pack_frag32_pad_kernel<<<4, 256, 0, st>>>(w->enc_latent_w, 32, nl, 32, fc + F_ENC_LAT);
   pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec);                                  // 16 fragments
   pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(dc.w1, dc.w2, H, h->frag_dec + 16 * 64);  // 96
   pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(dc.cproj, H, h->frag_dec + (16 + 96) * 64); // 48
@@ -174,13 +192,13 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
   else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
   LAUNCH_CHECK();
   EncCellArgs e;
-  e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.ca_proj = h->small + S_ENC_PROJ;
+  e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.proj_frag = h->frag_cell + F_ENC_PROJ;
   e.ca_ln2_w = h->small + S_ENC_LN2W; e.ca_ln2_b = h->small + S_ENC_LN2B;
-  e.ca_w1 = h->small + S_ENC_W1; e.ca_w2 = h->small + S_ENC_W2; e.ca_cp = h->small + S_ENC_CP;
+  e.w12_frag = h->frag_cell + F_ENC_W12; e.wc_frag = h->frag_cell + F_ENC_WC;
   e.pos = c.positional_encoding ? h->small + S_ENC_POS : nullptr;
-  e.trunk = h->enc_trunk; e.lat_w = h->small + S_ENC_LAT; e.z = z;
-  e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.H = c.hidden_dim; e.eps = c.layernorm_eps;
-  enc_cell_kernel<<<B, 64, 0, st>>>(e);
+  e.trunk = h->enc_trunk; e.lat_frag = h->frag_cell + F_ENC_LAT; e.z = z;
+  e.B = B; e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.eps = c.layernorm_eps;
+  enc_cell_kernel<<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(e);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -196,10 +214,10 @@ extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* gen
   float* kv = (float*)ws_;
   float* part = (float*)((char*)ws_ + align256((size_t)B * 48 * 64 * 4));
   DecCellArgs d;
-  d.z = z; d.lat_w = h->small + S_DEC_LAT; d.trunk = h->dec_trunk;
-  d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.ca_attn = h->small + S_DEC_KV;
-  d.kvfrag = kv; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.H = c.hidden_dim; d.eps = c.layernorm_eps;
-  dec_cell_kernel<<<B, 64, 0, st>>>(d);
+  d.z = z; d.lat_frag = h->frag_cell + F_DEC_LAT; d.trunk = h->dec_trunk;
+  d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.kv_frag = h->frag_cell + F_DEC_KV;
+  d.kvfrag = kv; d.B = B; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.eps = c.layernorm_eps;
+  dec_cell_kernel<<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
   LAUNCH_CHECK();
   const int nch = dec_chunks(G);
   DecGeneArgs g;

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_json, load_golden, max_abs_rel
+from conftest import check_err, golden_json, load_golden, max_abs_rel
 from oracle.vae import VAEConfig, decode, encode
 from oracle.weights import make_state_dict
 from test_abi_cpu import _build_vae
@@ -151,3 +151,68 @@ def test_bf16_encode_close_to_fp32():
     vae.precision = "bf16"
     z = vae.encode(cu(g["counts"]), cu(g["genes"]), counts, genes)
     assert max_abs_rel(z.cpu(), ref.cpu()) < 3e-2 and max_abs_rel(z.cpu(), g["z"]) < 3e-2
+
+
+def _fresh_vae(G, seed):
+    from test_abi_cpu import _build_vae as bv
+    vae = bv(G)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, seed)
+    vae.load_state_dict(sd, strict=True)
+    return vae.cuda().eval(), sd, VAEConfig(n_genes=G)
+
+
+def test_hlca_size_encode_decode_vs_oracle():
+    """hlca shape (G = 27 997 genes out, S = 10 186 tokens in; experiments/configs/datamodule/default.yaml:60-64), the largest
+    MCAB configuration of the reference: 3 cells (an odd batch: the last trunk tile is half padding) against the oracle,
+    mu rows sum to the library size, bit-repeatable."""
+    G, S, B = 27997, 10186, 3
+    vae, sd, cfg = _fresh_vae(G, 91)
+    rng = np.random.default_rng(17)
+    genes = np.tile(np.arange(G, dtype=np.int64), (B, 1))
+    counts = rng.poisson(0.5, (B, G)).astype(np.float32)
+    sub = np.stack([np.sort(rng.permutation(G)[:S]) for _ in range(B)])
+    lib = counts.sum(1, keepdims=True) + 1
+    cs, gs = np.take_along_axis(counts, sub, 1), np.take_along_axis(genes, sub, 1)
+    z = vae.encode(cu(cs), cu(gs))
+    z_ref = encode(sd, cfg, torch.from_numpy(cs), torch.from_numpy(gs))
+    check_err(z.cpu(), z_ref, TOL, "hlca encode (S=10186) vs oracle")
+    nb = vae.decode(z, cu(genes), cu(lib))
+    mu_ref, th_ref = decode(sd, cfg, z.cpu(), torch.from_numpy(genes), torch.from_numpy(lib))
+    check_err(nb.mu.cpu(), mu_ref, TOL, "hlca decode mu (G=27997) vs oracle")
+    assert max_abs_rel(nb.theta.cpu(), th_ref) < 1e-5
+    assert torch.allclose(nb.mu.sum(1), cu(lib[:, 0]), rtol=2e-4)
+    assert torch.equal(vae.decode(z, cu(genes), cu(lib)).mu, nb.mu) and torch.equal(vae.encode(cu(cs), cu(gs)), z)
+
+
+@pytest.mark.parametrize("B", [1, 2, 7, 9, 64])
+def test_trunk_tiles_any_batch(B):
+    """The per-cell trunks run two cells per 32-token MFMA tile, eight per workgroup: batches around those boundaries."""
+    g, vae, sd, cfg = build("vae_2000")
+    rng = np.random.default_rng(B)
+    S, G = 40, 70
+    genes_s = rng.integers(0, 2000, (B, S)).astype(np.int64)
+    counts_s = rng.poisson(1.5, (B, S)).astype(np.float32)
+    genes = np.stack([rng.permutation(2001)[:G] for _ in range(B)]).astype(np.int64)
+    lib = rng.uniform(100, 2000, (B, 1)).astype(np.float32)
+    zr = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    check_err(vae.encode(cu(counts_s), cu(genes_s)).cpu(), encode(sd, cfg, torch.from_numpy(counts_s), torch.from_numpy(genes_s)), TOL, f"encode B={B}")
+    mu_ref, _ = decode(sd, cfg, torch.from_numpy(zr), torch.from_numpy(genes), torch.from_numpy(lib))
+    check_err(vae.decode(cu(zr), cu(genes), cu(lib)).mu.cpu(), mu_ref, TOL, f"decode B={B}")
+
+
+def test_vae_deepcopy_and_inplace_update():
+    import copy
+    g, vae, sd, cfg = build("vae_2000")
+    z, genes, lib = cu(g["z"]), cu(g["genes"]), cu(g["library_size"])
+    mu0 = vae.decode(z, genes, lib).mu
+    v2 = copy.deepcopy(vae)
+    assert v2._handle is None and torch.equal(v2.decode(z, genes, lib).mu, mu0)
+    versions = [p._version for p in vae.parameters()]
+    for p in vae.decoder.parameters():
+        p.data.mul_(1.02)                      # EMA-style update: no version bump
+    assert [p._version for p in vae.parameters()] == versions
+    mu1 = vae.decode(z, genes, lib).mu
+    assert not torch.equal(mu1, mu0)
+    sd2 = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    mu_ref, _ = decode(sd2, cfg, z.cpu(), genes.cpu(), lib.cpu())
+    check_err(mu1.cpu(), mu_ref, TOL, "decode after an in-place .data update")
