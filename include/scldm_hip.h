@@ -276,6 +276,17 @@ int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, in
 int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
                      float* theta, int precision, void* ws, void* stream);
 
+/* TransformerVAE.decode followed by the negative-binomial draw of LatentDiffusion.sample (src/scldm/models.py:819,
+ * `nb.sample()` on the distribution vae.py:87 builds): counts (B,G) fp32 ~ Poisson(Gamma(concentration = theta,
+ * rate = theta / mu)), the Gamma-Poisson mixture scvi-tools' NegativeBinomial samples.  The draw happens inside the pass that
+ * normalises the logits, so mu / theta are never written to HBM.  Philox4x32-10 keyed by `seed`, one counter per output element:
+ * reproducible for a given (seed, B, G), independent of the launch geometry.  RNG-dependent: outside the bit-parity claim. */
+int scldm_vae_decode_sample(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
+                            float* counts, unsigned long long seed, int precision, void* ws, void* stream);
+
+/* The same draw from explicit parameter tensors: out[i] ~ NB(mu[i], theta[i]), i < n  (NegativeBinomial(mu, theta).sample()). */
+int scldm_nb_sample(const float* mu, const float* theta, float* out, size_t n, unsigned long long seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Encoder input path: tokenize_cells(sample_genes="expressed"),
  * reference src/scldm/datamodule.py:660-731.  counts: device (N,G) fp32; gene_idx: device int64 token ids,

@@ -112,6 +112,9 @@ def lib() -> C.CDLL:
     L.scldm_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.scldm_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_vae_decode_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
+                                          C.c_int, C.c_void_p, C.c_void_p]
+    L.scldm_nb_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p]
     L.scldm_tokenize_expressed.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.scldm_csr_count.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -129,7 +132,7 @@ EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_d
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes",
            "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",
-           "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",
+           "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_vae_decode_sample", "scldm_nb_sample", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",
            "scldm_mmd_kernel_sum"]
 
 

@@ -17,6 +17,7 @@
 // use the same one.  Weights are pre-packed into matching A/B fragment order ("k = acc_row(step, lane>>5)").
 #pragma once
 #include "common.hpp"
+#include "nb_sample.hpp"
 
 namespace scldm {
 
@@ -115,6 +116,39 @@ __device__ __forceinline__ f32x16 chain8(const float* __restrict__ frag, const f
   return acc;
 }
 
+// The same with the fragments already in registers: inside the trunk the NEXT tile's fragments are requested before the
+// current chain runs (an L2 round trip per 16-step chain would otherwise sit in front of every one of its 26 chains per layer)
+struct Frag16 { f32x4 w[4]; };
+struct Frag8 { f32x4 w[2]; };
+__device__ __forceinline__ Frag16 load16(const float* __restrict__ frag, int lane) {
+  const f32x4* F = reinterpret_cast<const f32x4*>(frag);
+  Frag16 f;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) f.w[g4] = F[g4 * 64 + lane];
+  return f;
+}
+__device__ __forceinline__ Frag8 load8(const float* __restrict__ frag, int lane) {
+  const f32x4* F = reinterpret_cast<const f32x4*>(frag);
+  Frag8 f;
+  f.w[0] = F[lane];
+  f.w[1] = F[64 + lane];
+  return f;
+}
+__device__ __forceinline__ f32x16 chain16(const Frag16& f, const float (&x)[16], f32x16 acc) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma2(f.w[g4][i], x[g4 * 4 + i], acc);
+  return acc;
+}
+__device__ __forceinline__ f32x16 chain8(const Frag8& f, const float (&x)[8], f32x16 acc) {
+#pragma unroll
+  for (int g4 = 0; g4 < 2; ++g4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma2(f.w[g4][i], x[g4 * 4 + i], acc);
+  return acc;
+}
+
 // LayerNorm over the first `width` features of every token (registers beyond `width` must be zero); affine if w != nullptr
 __device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], const float* __restrict__ w, const float* __restrict__ b,
                                         int width, float eps, int hh) {
@@ -129,7 +163,7 @@ __device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], co
     y[r] = d;
     ss += d * d;
   }
-  const float rstd = 1.0f / sqrtf(xor32_sum(ss) / (float)width + eps);
+  const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) / (float)width + eps);   // v_rsq_f32, 1 ulp
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 w4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
@@ -151,7 +185,7 @@ __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const
     const f32x16 ht = chain16(w12 + u * 1024, yn, zero16(), lane);   // rows 0-15 = w1 units, 16-31 = the matching w2 units
     float hv[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) hv[r] = (ht[r] / (1.0f + expf(-ht[r]))) * ht[r + 8];
+    for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];
     mo = chain8(wc + u * 512, hv, mo, lane);
   }
 #pragma unroll
@@ -162,6 +196,8 @@ __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const
 __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, const float* __restrict__ wts, int n_layer,
                                              float eps, int lane) {
   const int c32 = lane & 31, hh = lane >> 5;
+  if (n_layer <= 0) return;
+  Frag16 nxt = load16(wts + T_QKV, lane);   // fragments of the next chain, always one chain ahead
   for (int layer = 0; layer < n_layer; ++layer) {
     const float* w = wts + (size_t)layer * kTrunkLayerFloats;
     float yn[16];
@@ -169,7 +205,9 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
     // q | k | v (split order of layers.py:147) -> scratch rows [token][q 32 | k 32 | v 32]
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const f32x16 o = chain16(w + T_QKV + t * 1024, yn, zero16(), lane);
+      const Frag16 cur = nxt;
+      nxt = load16(t < 2 ? w + T_QKV + (t + 1) * 1024 : w + T_PROJ, lane);
+      const f32x16 o = chain16(cur, yn, zero16());
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
@@ -185,20 +223,20 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const f32x4 kv = *reinterpret_cast<const f32x4*>(base + j * kTrunkLd + 32);
-        sc[j] = (qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3]) * 0.5f;   // 1 / sqrt(head_dim 4)
+        sc[j] = (qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3]) * (0.5f * 1.4426950408889634f);   // log2(e) / sqrt(head_dim 4)
         m = fmaxf(m, sc[j]);
       }
       float sum = 0.f;
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float pj = expf(sc[j] - m);
+        const float pj = __builtin_amdgcn_exp2f(sc[j] - m);
         sum += pj;
         const f32x4 vv = *reinterpret_cast<const f32x4*>(base + j * kTrunkLd + 64);
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] += pj * vv[d];
       }
-      const float inv = 1.0f / sum;
+      const float inv = __builtin_amdgcn_rcpf(sum);
       *reinterpret_cast<f32x4*>(S + (cell * 16 + qi) * kTrunkLd + hd * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
     }
     wave_lds_sync();
@@ -210,11 +248,31 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
       for (int i = 0; i < 4; ++i) ao[q * 4 + i] = t4[i];
     }
     wave_lds_sync();   // the scratch is rewritten by the next layer's q | k | v
-    const f32x16 po = chain16(w + T_PROJ, ao, zero16(), lane);
+    {
+      const Frag16 cur = nxt;                     // proj
+      nxt = load16(w + T_W12, lane);
+      const f32x16 po = chain16(cur, ao, zero16());
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] += po[r];
+      for (int r = 0; r < 16; ++r) x[r] += po[r];
+    }
     tile_ln(x, yn, w + T_LN2W, w + T_LN2B, kE, eps, hh);
-    tile_swiglu(w + T_W12, w + T_WC, yn, x, lane);
+    // SwiGLU: six 16-unit hidden tiles, each consumed by the down-projection as soon as it exists
+    f32x16 mo = zero16();
+    const bool last = layer + 1 == n_layer;
+#pragma unroll
+    for (int u = 0; u < kHTiles; ++u) {
+      const Frag16 cur = nxt;
+      const Frag8 wcf = load8(w + T_WC + u * 512, lane);
+      if (u + 1 < kHTiles) nxt = load16(w + T_W12 + (u + 1) * 1024, lane);
+      else if (!last) nxt = load16(w + kTrunkLayerFloats + T_QKV, lane);
+      const f32x16 ht = chain16(cur, yn, zero16());   // rows 0-15 = w1 units, 16-31 = the matching w2 units
+      float hv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];
+      mo = chain8(wcf, hv, mo);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] += mo[r];
   }
 }
 
@@ -325,7 +383,7 @@ struct DecGeneArgs {
   const float* ln2_w; const float* ln2_b;  // decoder_cross_attention.ln_2
   const float* head_w; const float* head_b;  // decoder_head.params (1,32), (1)
   float* logits;          // (B, G)  (aliases mu)
-  float* theta;           // (B, G)
+  float* theta;           // (B, G), or nullptr when the caller only wants drawn counts (scldm_vae_decode_sample)
   float* part;            // (B, n_chunks, 2): running (max, sum exp) of logit / temperature per chunk
   int G, n_chunks, tiles_per_wave;
   float eps, inv_temp;
@@ -335,21 +393,30 @@ struct DecGeneArgs {
 // (v_mfma_f32_32x32x16_bf16, fp32 accumulate; softmax / LayerNorm / SiLU / logits stay fp32): eight consecutive fp32 steps
 // contract exactly the 16 k-values of one bf16 MFMA in the same (step, half-wave) order, so the packed fragments are the
 // fp32 ones converted eight steps at a time and every activation operand is its accumulator registers 0-7 / 8-15.
+// Workgroup = kDecWaves waves sharing one LDS copy of the weight fragments.  Eight waves with the register budget of four
+// waves per SIMD (two workgroups per CU; 52 KB of LDS each): the chain of one tile is strictly dependent (MFMA -> softmax
+// / LayerNorm / SiLU -> MFMA), so the matrix pipe is kept busy by OTHER waves - three per SIMD left it idle a third of the
+// time (r2 PMC: SQ_VALU_MFMA_BUSY_CYCLES 67 % of the kernel, 68 % of wave cycles waiting on the pipe).
+#ifndef SCLDM_DEC_WAVES
+#define SCLDM_DEC_WAVES 8
+#endif
+constexpr int kDecWaves = SCLDM_DEC_WAVES;
+constexpr int kDecThreads = 64 * kDecWaves;
 template <bool BF>
-__global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
+__global__ __launch_bounds__(kDecThreads, kDecWaves == 8 ? 4 : 1) void dec_gene_kernel(const DecGeneArgs a) {
   constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : 12 * 64, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
   __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4
   __shared__ f32x4 KV[kKV4];    // fp32: this cell's 48 K/V fragments
   __shared__ bf16x8 WFh[kWF8];  // bf16: the same, 8 steps per 16-byte fragment
   __shared__ bf16x8 KVh[kKV8];
   __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
-  __shared__ float RED[4][2];
+  __shared__ float RED[kDecWaves][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hh = lane >> 5;
   const int cell = blockIdx.y, chunk = blockIdx.x;
   if constexpr (BF) {
     auto cvt = [&](const float* src, bf16x8* dst, int nfrag8) {
-      for (int i = tid; i < nfrag8 * 64; i += 256) {
+      for (int i = tid; i < nfrag8 * 64; i += kDecThreads) {
         const int f = i >> 6, l = i & 63;
         const f32x4 lo = reinterpret_cast<const f32x4*>(src)[(2 * f) * 64 + l], hi = reinterpret_cast<const f32x4*>(src)[(2 * f + 1) * 64 + l];
         float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -359,8 +426,8 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     cvt(a.wfrag, WFh, 20);
     cvt(a.kvfrag + (size_t)cell * 48 * 64, KVh, 6);
   } else {
-    for (int i = tid; i < 40 * 64; i += 256) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
-    for (int i = tid; i < 12 * 64; i += 256) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
+    for (int i = tid; i < 40 * 64; i += kDecThreads) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
+    for (int i = tid; i < 12 * 64; i += kDecThreads) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
   }
   if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
   __syncthreads();
@@ -380,7 +447,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
   };
   const float hb = a.head_b[0];
   float run_m = -3.0e38f, run_s = 0.f;
-  const int tile0 = (chunk * 4 + wave) * a.tiles_per_wave;
+  const int tile0 = (chunk * kDecWaves + wave) * a.tiles_per_wave;
   for (int ti = 0; ti < a.tiles_per_wave; ++ti) {
     const int gi = (tile0 + ti) * 32 + c32;
     if ((tile0 + ti) * 32 >= a.G) break;  // wave-uniform
@@ -418,7 +485,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
           sum += p;
         }
         sum = xor32_sum(sum);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[t][8 * hl + i] *= inv;
       }
@@ -448,7 +515,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     float ss = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const float d = y[r] - mean; ss += d * d; }
-    const float rstd = 1.0f / sqrtf(xor32_sum(ss) * (1.0f / kE) + a.eps);
+    const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) * (1.0f / kE) + a.eps);
     float yn[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -463,7 +530,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
       ht = mm8(WF, WFh, 16 + 16 * u + 8, yn + 8, ht);
       float hv[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) hv[r] = (ht[r] / (1.0f + __expf(-ht[r]))) * ht[r + 8];
+      for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];   // x * v_rcp(1 + v_exp(-x)): 4 VALU ops, not ~15
       mo = mm8(WF, WFh, 16 + 16 * kHTiles + 8 * u, hv, mo);
     }
     // NB head: logit = w . (y + mlp) + b
@@ -473,7 +540,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
     lg = (xor32_sum(lg) + hb) * a.inv_temp;
     if (valid && hh == 0) {
       a.logits[(size_t)cell * a.G + gi] = lg;
-      a.theta[(size_t)cell * a.G + gi] = expf(a.theta_emb[g]);
+      if (a.theta) a.theta[(size_t)cell * a.G + gi] = expf(a.theta_emb[g]);
     }
     if (valid) {  // online (max, sum exp) per lane; both half-waves carry the same value, count it once at the end
       const float nm = fmaxf(run_m, lg);
@@ -494,7 +561,7 @@ __global__ __launch_bounds__(256) void dec_gene_kernel(const DecGeneArgs a) {
   __syncthreads();
   if (tid == 0) {
     float M = RED[0][0], S = RED[0][1];
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < kDecWaves; ++w) {
       const float nm = fmaxf(M, RED[w][0]);
       S = S * __expf(M - nm) + RED[w][1] * __expf(RED[w][0] - nm);
       M = nm;
@@ -526,6 +593,41 @@ __global__ __launch_bounds__(256) void dec_finalize_kernel(float* __restrict__ m
     float* p = mu + (size_t)cell * G + i;
     *p = expf(*p - M) * scale;
   }
+}
+
+// The same pass with the negative-binomial draw fused in (nb_sample.hpp): out = count ~ NB(mu, theta = exp(theta_emb[gene])),
+// mu and theta stay in registers.  Element index for the RNG = cell * G + gene position.
+__global__ __launch_bounds__(256) void dec_finalize_sample_kernel(float* __restrict__ out, const float* __restrict__ part,
+                                                                  const float* __restrict__ library, const int64_t* __restrict__ genes,
+                                                                  const float* __restrict__ theta_emb, int G, int n_chunks,
+                                                                  unsigned long long seed) {
+  __shared__ float MS[2];
+  const int cell = blockIdx.y;
+  if (threadIdx.x == 0) {
+    float M = -3.0e38f, S = 0.f;
+    for (int c = 0; c < n_chunks; ++c) {
+      const float m = part[((size_t)cell * n_chunks + c) * 2], s = part[((size_t)cell * n_chunks + c) * 2 + 1];
+      const float nm = fmaxf(M, m);
+      S = S * expf(M - nm) + s * expf(m - nm);
+      M = nm;
+    }
+    MS[0] = M;
+    MS[1] = library[cell] / S;
+  }
+  __syncthreads();
+  const float M = MS[0], scale = MS[1];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < G; i += gridDim.x * 256) {
+    const size_t e = (size_t)cell * G + i;
+    const float mu = expf(out[e] - M) * scale;
+    const float theta = expf(theta_emb[genes[e]]);
+    out[e] = nb_draw(seed, e, mu, theta);
+  }
+}
+
+// Stand-alone draw from given (mu, theta) tensors (NegativeBinomial.sample() on the decode outputs; also the test hook)
+__global__ __launch_bounds__(256) void nb_sample_kernel(const float* __restrict__ mu, const float* __restrict__ theta, float* __restrict__ out,
+                                                        size_t n, unsigned long long seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = nb_draw(seed, i, mu[i], theta[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,7 +688,7 @@ __global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
     float ss = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { x[r] -= mean; ss += x[r] * x[r]; }
-    const float rstd = 1.0f / sqrtf(xor32_sum(ss) * (1.0f / kE) + a.eps);
+    const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) * (1.0f / kE) + a.eps);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const int f = acc_row(r, hh); x[r] = x[r] * rstd * VEC[f] + VEC[kE + f]; }
     // eight consecutive fp32 steps = the 16 k-values of one bf16 MFMA in the same order: fragment of steps [s0, s0+8)

@@ -1,4 +1,5 @@
 // C ABI of the TransformerVAE encode / decode path (see include/scldm_hip.h).
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -157,8 +158,8 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   return SCLDM_OK;
 }
 
-static const int kDecTilesPerWave = 8;  // 4 waves x 8 tiles x 32 genes = 1024 genes per workgroup
-static inline int dec_chunks(int G) { return cdiv(G, 4 * kDecTilesPerWave * 32); }
+static const int kDecTilesPerWave = 32 / kDecWaves;  // kDecWaves waves x tiles x 32 genes = 1024 genes per workgroup
+static inline int dec_chunks(int G) { return cdiv(G, kDecWaves * kDecTilesPerWave * 32); }
 
 extern "C" size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G) {
   if (!h) return 0;
@@ -203,12 +204,12 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
   return SCLDM_OK;
 }
 
-extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
-                                float* mu, float* theta, int precision, void* ws_, void* stream_) {
+static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
+                           float* theta, bool draw, unsigned long long seed, int precision, void* ws_, void* stream_) {
   int rc = vae_ready(h);
   if (rc) return rc;
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
-  if (B <= 0 || G <= 0 || !z || !genes || !library_size || !mu || !theta || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  if (B <= 0 || G <= 0 || !z || !genes || !library_size || !mu || (!theta && !draw) || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_vae_config& c = h->cfg;
   float* kv = (float*)ws_;
@@ -223,12 +224,32 @@ extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* gen
   DecGeneArgs g;
   g.genes = genes; g.emb = h->emb; g.qtab = h->qtab; g.theta_emb = h->theta; g.kvfrag = kv; g.wfrag = h->frag_dec;
   g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
-  g.logits = mu; g.theta = theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
+  g.logits = mu; g.theta = draw ? nullptr : theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
   g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
-  if (precision == SCLDM_PREC_BF16) dec_gene_kernel<true><<<dim3(nch, B), 256, 0, st>>>(g);
-  else dec_gene_kernel<false><<<dim3(nch, B), 256, 0, st>>>(g);
+  if (precision == SCLDM_PREC_BF16) dec_gene_kernel<true><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
+  else dec_gene_kernel<false><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
   LAUNCH_CHECK();
-  dec_finalize_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, G, nch);
+  if (draw) dec_finalize_sample_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, genes, h->theta, G, nch, seed);
+  else dec_finalize_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, G, nch);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
+                                float* mu, float* theta, int precision, void* ws_, void* stream_) {
+  return vae_decode_impl(h, z, genes, library_size, B, G, mu, theta, false, 0ull, precision, ws_, stream_);
+}
+
+extern "C" int scldm_vae_decode_sample(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
+                                       float* counts, unsigned long long seed, int precision, void* ws_, void* stream_) {
+  return vae_decode_impl(h, z, genes, library_size, B, G, counts, nullptr, true, seed, precision, ws_, stream_);
+}
+
+extern "C" int scldm_nb_sample(const float* mu, const float* theta, float* out, size_t n, unsigned long long seed, void* stream_) {
+  if (!mu || !theta || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (n == 0) return SCLDM_OK;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 32);
+  nb_sample_kernel<<<grid, 256, 0, (hipStream_t)stream_>>>(mu, theta, out, n, seed);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }

@@ -53,8 +53,10 @@ def sample_cells(dit, vae, condition, guidance_weight, batch_size: int, genes: t
     z = sample_latents(dit, z0, condition, guidance_weight, num_steps, sampling_method)
     genes2 = torch.cat([genes, genes], dim=0)
     lib = torch.exp(size_factors).view(-1, 1)
-    nb = vae.decode(z, genes2, torch.cat([lib, lib], dim=0))
-    return (nb.sample() if draw_counts else nb), z
+    lib2 = torch.cat([lib, lib], dim=0)
+    if draw_counts:   # models.py:819 `nb.sample()`: fused into the decoder's normalisation pass (mu / theta stay on chip)
+        return vae.decode_sample(z, genes2, lib2), z
+    return vae.decode(z, genes2, lib2), z
 
 
 @torch.no_grad()

@@ -40,10 +40,22 @@ class NegativeBinomial(torch.distributions.Distribution):
         return self.mu
 
     @torch.no_grad()
-    def sample(self, sample_shape=torch.Size()):
-        # counts ~ Poisson(Gamma(concentration=theta, rate=theta/mu))  (the parameterisation scvi-tools uses)
+    def sample(self, sample_shape=torch.Size(), seed: int | None = None):
+        """counts ~ Poisson(Gamma(concentration=theta, rate=theta/mu)) (the parameterisation scvi-tools uses), drawn by the HIP
+        kernel behind scldm_nb_sample (Philox4x32-10 + Marsaglia-Tsang + PTRS).  `seed` defaults to a draw from torch's global
+        generator, so torch.manual_seed makes it reproducible.  Device tensors only: there is no CPU path."""
+        import ctypes as C
+
+        from . import _lib
         shape = self._extended_shape(sample_shape)
-        theta = self.theta.expand(shape)
-        mu = self.mu.expand(shape)
-        gamma = torch.distributions.Gamma(concentration=theta, rate=theta / torch.clamp(mu, min=1e-8)).sample()
-        return torch.poisson(torch.clamp(gamma, max=1e8))
+        mu = self.mu.expand(shape).contiguous().float()
+        theta = self.theta.expand(shape).contiguous().float()
+        if not mu.is_cuda:
+            raise RuntimeError("NegativeBinomial.sample draws on the MI355X (scldm_nb_sample); mu / theta must be CUDA (ROCm) tensors")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        out = torch.empty_like(mu)
+        with torch.cuda.device(mu.device):
+            _lib.check(_lib.lib().scldm_nb_sample(mu.data_ptr(), theta.data_ptr(), out.data_ptr(), mu.numel(), C.c_uint64(seed),
+                                                  torch.cuda.current_stream().cuda_stream), "scldm_nb_sample")
+        return out

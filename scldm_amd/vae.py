@@ -161,6 +161,29 @@ class TransformerVAE(nn.Module):
         return NegativeBinomial(mu=mu, theta=theta)
 
     @torch.no_grad()
+    def decode_sample(self, z: torch.Tensor, genes: torch.Tensor, library_size: torch.Tensor, seed: int | None = None) -> torch.Tensor:
+        """`decode(z, genes, library_size).sample()` in one call (models.py:819 after vae.py:71-87): the negative-binomial draw is
+        fused into the decoder's normalisation pass, mu / theta never reach HBM.  Returns counts (B, G) fp32."""
+        L, h = self._native()
+        z = _require_cuda_f32("z", z)
+        if not genes.is_cuda:
+            raise RuntimeError("genes must be a CUDA (ROCm) tensor")
+        g = genes.to(torch.long).contiguous()
+        lib = _require_cuda_f32("library_size", library_size).reshape(-1)
+        B, G = g.shape
+        if z.shape != (B, self.encoder.latent_dim, self.encoder.latent_embedding) or lib.shape[0] != B:
+            raise ValueError(f"expected z (B,{self.encoder.latent_dim},{self.encoder.latent_embedding}) and library_size (B,1); got "
+                             f"{tuple(z.shape)}, {tuple(library_size.shape)} for genes {tuple(g.shape)}")
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        counts = torch.empty(B, G, device=z.device, dtype=torch.float32)
+        ws = self._workspace(L, B, G)
+        with torch.cuda.device(z.device):
+            _lib.check(L.scldm_vae_decode_sample(h, z.data_ptr(), g.data_ptr(), lib.data_ptr(), B, G, counts.data_ptr(), C.c_uint64(seed),
+                                                 _lib.PRECISIONS[self.precision], ws, _stream_ptr()), "scldm_vae_decode_sample")
+        return counts
+
+    @torch.no_grad()
     def forward(self, counts, genes, library_size, counts_subset=None, genes_subset=None):
         """(params, z) with params = {"mu", "theta"} (vae.py:29-56).  Inference only: VAE training is out of scope."""
         z = self.encode(counts, genes, counts_subset, genes_subset)

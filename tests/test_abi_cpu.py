@@ -142,14 +142,13 @@ def test_vae_state_dict_is_checkpoint_compatible():
         vae.encode(torch.zeros(1, 4), torch.zeros(1, 4, dtype=torch.long))
 
 
-def test_negative_binomial_holder_samples_cpu():
+def test_negative_binomial_holder_has_no_cpu_draw():
+    """The draw is a HIP kernel (scldm_nb_sample); statistical tests live in tests/test_gpu_vae.py."""
     from scldm_amd.stochastic_layers import NegativeBinomial
-    torch.manual_seed(0)
-    mu = torch.full((4000, 3), 5.0)
-    nb = NegativeBinomial(mu=mu, theta=torch.full((4000, 3), 2.0))
-    x = nb.sample()
-    assert x.shape == mu.shape and (x >= 0).all() and (x == x.round()).all()
-    assert abs(float(x.mean()) - 5.0) < 0.3 and abs(float(x.var()) - (5.0 + 25.0 / 2.0)) < 2.5  # mean mu, var mu + mu^2/theta
+    nb = NegativeBinomial(mu=torch.full((4, 3), 5.0), theta=torch.full((4, 3), 2.0))
+    assert nb.mean.shape == (4, 3)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        nb.sample()
 
 
 def test_fresh_dit_matches_reference_initialisation():

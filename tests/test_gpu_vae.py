@@ -216,3 +216,71 @@ def test_vae_deepcopy_and_inplace_update():
     sd2 = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
     mu_ref, _ = decode(sd2, cfg, z.cpu(), genes.cpu(), lib.cpu())
     check_err(mu1.cpu(), mu_ref, TOL, "decode after an in-place .data update")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# negative-binomial draw on device (scldm_nb_sample / scldm_vae_decode_sample): RNG-dependent, so tested statistically
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mu,theta", [(5.0, 2.0), (0.05, 10.0), (200.0, 0.5), (30.0, 50.0), (0.7, 0.3)])
+def test_nb_draw_matches_the_analytic_distribution(mu, theta):
+    """counts ~ Poisson(Gamma(theta, rate theta/mu)) is NB(n = theta, p = theta / (theta + mu)): chi-square of 400 000 draws against
+    the analytic pmf (covers Gamma shape < 1 and >= 1, Poisson by inversion and by PTRS), plus mean / variance."""
+    from scipy import stats
+    from scldm_amd.stochastic_layers import NegativeBinomial
+    n = 400_000
+    nb = NegativeBinomial(mu=torch.full((n,), mu, device="cuda"), theta=torch.full((n,), theta, device="cuda"))
+    x = nb.sample(seed=1234).cpu().numpy()
+    assert (x >= 0).all() and (x == np.round(x)).all()
+    var = mu + mu * mu / theta
+    assert abs(x.mean() - mu) < 6 * np.sqrt(var / n)
+    assert abs(x.var() - var) < 0.05 * var + 6 * var * np.sqrt(2.0 / n) * 3
+    dist = stats.nbinom(theta, theta / (theta + mu))
+    hi = int(dist.ppf(1 - 1e-4)) + 1
+    edges = np.unique(np.round(dist.ppf(np.linspace(0, 1 - 1e-4, 30))).astype(int))
+    edges = np.concatenate([[0], edges[edges > 0], [hi + 1]])
+    obs, exp = [], []
+    for lo_, hi_ in zip(edges[:-1], edges[1:]):
+        p = dist.cdf(hi_ - 1) - (dist.cdf(lo_ - 1) if lo_ > 0 else 0.0)
+        if p * n < 20:
+            continue
+        obs.append(((x >= lo_) & (x < hi_)).sum())
+        exp.append(p * n)
+    obs, exp = np.array(obs, float), np.array(exp, float)
+    chi2 = ((obs - exp) ** 2 / exp).sum()
+    assert chi2 < stats.chi2(len(obs)).ppf(1 - 1e-6), (chi2, len(obs))
+
+
+def test_nb_draw_is_reproducible_and_seeded():
+    from scldm_amd.stochastic_layers import NegativeBinomial
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    mu = torch.rand(1000, 37, device="cuda", generator=gen) * 20
+    theta = torch.rand(1000, 37, device="cuda", generator=gen) * 5 + 0.1
+    nb = NegativeBinomial(mu=mu, theta=theta)
+    a, b, c = nb.sample(seed=7), nb.sample(seed=7), nb.sample(seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    torch.manual_seed(3); d = nb.sample()
+    torch.manual_seed(3); e = nb.sample()
+    assert torch.equal(d, e)                        # default seed comes from torch's global generator
+    assert float((nb.sample(seed=9)[mu == 0]).sum()) == 0.0
+    # the first 1000 elements do not depend on how many more are drawn (counter = element index)
+    flat = NegativeBinomial(mu=mu.reshape(-1)[:1000], theta=theta.reshape(-1)[:1000]).sample(seed=7)
+    assert torch.equal(flat, a.reshape(-1)[:1000])
+
+
+def test_decode_sample_fuses_decode_and_draw():
+    """decode_sample(z, genes, lib, seed) == NegativeBinomial(decode(z, genes, lib)).sample(seed): same parameters (recomputed in
+    registers), same counter-based stream - equal except where the two passes' mu differ by an ulp and flip an accept/reject."""
+    g, vae, sd, cfg = build("vae_2000")
+    z, genes, lib = cu(g["z"]), cu(g["genes"]), cu(g["library_size"])
+    counts = vae.decode_sample(z, genes, lib, seed=42)
+    nb = vae.decode(z, genes, lib)
+    ref = nb.sample(seed=42)
+    assert counts.shape == nb.mu.shape and (counts >= 0).all() and torch.equal(counts, counts.round())
+    assert float((counts != ref).float().mean()) < 1e-3
+    assert torch.equal(vae.decode_sample(z, genes, lib, seed=42), counts)
+    # many draws average to mu
+    acc = torch.zeros_like(counts)
+    for s in range(64):
+        acc += vae.decode_sample(z, genes, lib, seed=100 + s)
+    rel = (acc.sum(1) / 64 - lib.view(-1)).abs() / lib.view(-1)
+    assert float(rel.max()) < 0.05
