@@ -317,9 +317,24 @@ int scldm_csr_fill(const float* dense, int N, int G, const int64_t* indptr, int3
 #define SCLDM_MMD_BRAYCURTIS 1  /* 1 - sum|x - y| / (sum|x + y| + 1e-8), :24-37 */
 #define SCLDM_MMD_TANIMOTO 2    /* sum xy / (sum(x + y - xy) + 1e-8), :40-53 */
 #define SCLDM_MMD_RUZICKA 3     /* sum min / (sum max + 1e-8), :56-69 */
+#define SCLDM_MMD_SQDIST 4      /* |x - y|^2: the cost matrix of wasserstein(power=2), :103-105 */
+#define SCLDM_MMD_DIST 5        /* |x - y|  (torch.cdist): wasserstein(power=1) */
 size_t scldm_mmd_workspace_bytes(int nx, int ny);
 int scldm_mmd_kernel_sum(const float* x, int nx, const float* y, int ny, int D, int kind, float scale, double* sum_out,
                          float* kmat, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Entropic optimal transport for the Wasserstein generation metrics: wasserstein(x0, x1, method="sinkhorn", reg, power) of
+ * src/scldm/evaluations.py:85-108 (models.py:47-48 binds power 1 and 2) up to the final sqrt: uniform marginals,
+ * M = cdist(x0, x1) ** power, Sinkhorn-Knopp scaling as third-party POT's ot.sinkhorn2 iterates it (error checked every
+ * 10th iteration against stop_thr; POT default 1e-9), returns the HOST double *cost_out = <P, M>.  POT is not vendored:
+ * parity unpinned, pinned to oracle/evaluations.py.  x0 (n,D), x1 (m,D) device fp32.  Synchronises the stream (the error
+ * check is a host decision).  status: 0 converged, 1 iteration limit reached, 2 a scaling became zero / non-finite (as in
+ * POT the previous scalings are kept and the loop ends - what reg = 0.05 on 17k-dimensional inputs usually does).
+ * ------------------------------------------------------------------------------------------------ */
+size_t scldm_sinkhorn_workspace_bytes(int n, int m);
+int scldm_wasserstein_sinkhorn(const float* x0, int n, const float* x1, int m, int D, int power, float reg, long long num_iter_max,
+                               float stop_thr, double* cost_out, long long* iters_out, int* status_out, void* ws, void* stream);
 
 /* Debug hook (tools/phase_timing.py): device buffer receiving 16 x u64 s_memtime phase stamps per
  * (workgroup, wave) of each fused-block launch.  Only builds with -DSCLDM_PHASE_TIMING record; the

@@ -123,6 +123,10 @@ def lib() -> C.CDLL:
     L.scldm_mmd_workspace_bytes.restype = C.c_size_t
     L.scldm_mmd_kernel_sum.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]
+    L.scldm_sinkhorn_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    L.scldm_sinkhorn_workspace_bytes.restype = C.c_size_t
+    L.scldm_wasserstein_sinkhorn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_longlong, C.c_float,
+                                             C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -133,7 +137,7 @@ EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_d
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes",
            "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",
            "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_vae_decode_sample", "scldm_nb_sample", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",
-           "scldm_mmd_kernel_sum"]
+           "scldm_mmd_kernel_sum", "scldm_sinkhorn_workspace_bytes", "scldm_wasserstein_sinkhorn"]
 
 
 def check(rc: int, what: str) -> None:

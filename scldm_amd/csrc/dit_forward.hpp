@@ -49,6 +49,10 @@
 #ifndef SCLDM_SETPRIO
 #define SCLDM_SETPRIO 1
 #endif
+// k-steps of run-ahead of the activation-fragment LDS reads in the one-tile up-projection pass (1 or 2)
+#ifndef SCLDM_BPF
+#define SCLDM_BPF 1
+#endif
 
 namespace scldm {
 
@@ -248,17 +252,34 @@ __device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, P
   Frag bcur[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) bcur[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb);
+#if SCLDM_BPF >= 2
+  // activation fragments two k-steps ahead: one k-step of this pass is only NTT MFMAs (64 cycles at NTT = 2), less than an
+  // LDS round trip with eight waves reading
+  Frag bmid[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) bmid[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + 16);
+#endif
   auto unit = [&](int u, int s, bool first) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int ks = 2 * u + half;
       Frag bnext[NTT];
+#if SCLDM_BPF >= 2
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 2) * 16);
+#else
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 1) * 16);
+#endif
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) acc[tt] = OP::mma(ws.ring[s][half], bcur[tt], (first && half == 0) ? zero : acc[tt]);
+#if SCLDM_BPF >= 2
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) { bcur[tt] = bmid[tt]; bmid[tt] = bnext[tt]; }
+#else
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
+#endif
       if (half == 1) {
         ws.ring[s][0] = ws.p[0];
         ws.ring[s][1] = ws.p[64];

@@ -9,7 +9,8 @@
 
 namespace scldm {
 
-enum MmdKind { kMmdRbf = 0, kMmdBrayCurtis = 1, kMmdTanimoto = 2, kMmdRuzicka = 3 };
+enum MmdKind { kMmdRbf = 0, kMmdBrayCurtis = 1, kMmdTanimoto = 2, kMmdRuzicka = 3,
+               kMmdSqDist = 4, kMmdDist = 5 };   // |x - y|^2 and |x - y|: the cost matrices of evaluations.py:103-105 (torch.cdist)
 
 constexpr int kMmdTile = 64;   // pairs per side of a workgroup tile
 constexpr int kMmdDC = 32;     // feature chunk staged per trip
@@ -52,19 +53,19 @@ __global__ __launch_bounds__(256) void mmd_tile_kernel(const float* __restrict__
       const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, yb[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        if (KIND == kMmdRbf) rxc[a] += xa[a] * xa[a];
+        if (KIND == kMmdRbf || KIND == kMmdSqDist || KIND == kMmdDist) rxc[a] += xa[a] * xa[a];
         if (KIND == kMmdTanimoto) rxc[a] += xa[a];
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        if (KIND == kMmdRbf) ryc[b] += yb[b] * yb[b];
+        if (KIND == kMmdRbf || KIND == kMmdSqDist || KIND == kMmdDist) ryc[b] += yb[b] * yb[b];
         if (KIND == kMmdTanimoto) ryc[b] += yb[b];
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          if (KIND == kMmdRbf || KIND == kMmdTanimoto) pc[a][b] += xa[a] * yb[b];
+          if (KIND == kMmdRbf || KIND == kMmdTanimoto || KIND == kMmdSqDist || KIND == kMmdDist) pc[a][b] += xa[a] * yb[b];
           if (KIND == kMmdBrayCurtis) {
             pc[a][b] += fabsf(xa[a] - yb[b]);
             qc[a][b] += fabsf(xa[a] + yb[b]);
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256) void mmd_tile_kernel(const float* __restrict__
       const int i = i0 + 4 * ti + a, j = j0 + 4 * tj + b;
       float k;
       if (KIND == kMmdRbf) k = expf(-scale * (rx[a] - 2.f * p[a][b] + ry[b]));             // evaluations.py:17-21
+      else if (KIND == kMmdSqDist) k = fmaxf(rx[a] - 2.f * p[a][b] + ry[b], 0.f);
+      else if (KIND == kMmdDist) k = sqrtf(fmaxf(rx[a] - 2.f * p[a][b] + ry[b], 0.f));
       else if (KIND == kMmdBrayCurtis) k = 1.f - p[a][b] / (q[a][b] + 1e-8f);              // :34-37
       else if (KIND == kMmdTanimoto) k = p[a][b] / ((rx[a] + ry[b] - p[a][b]) + 1e-8f);    // :50-53
       else k = p[a][b] / (q[a][b] + 1e-8f);                                                // :66-69

@@ -306,10 +306,104 @@ extern "C" int scldm_mmd_kernel_sum(const float* x, int nx, const float* y, int 
     case kMmdBrayCurtis: hipLaunchKernelGGL(mmd_tile_kernel<kMmdBrayCurtis>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
     case kMmdTanimoto: hipLaunchKernelGGL(mmd_tile_kernel<kMmdTanimoto>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
     case kMmdRuzicka: hipLaunchKernelGGL(mmd_tile_kernel<kMmdRuzicka>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    case kMmdSqDist: hipLaunchKernelGGL(mmd_tile_kernel<kMmdSqDist>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
+    case kMmdDist: hipLaunchKernelGGL(mmd_tile_kernel<kMmdDist>, grid, dim3(256), 0, st, x, nx, y, ny, D, scale, partial, kmat); break;
     default: return fail(SCLDM_ERR_SHAPE, "unknown MMD kernel kind %d", kind);
   }
   LAUNCH_CHECK();
   hipLaunchKernelGGL(mmd_sum_kernel, dim3(1), dim3(256), 0, st, partial, (int)(grid.x * grid.y), sum_out);
   LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+// ---- entropic optimal transport (Sinkhorn) for the Wasserstein generation metrics -----------------------------------
+#include "sinkhorn.hpp"
+
+static size_t sk_layout(int n, int m, size_t* off) {   // M | K | u | v | ktu | part | rowcost | scalars
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
+  off[0] = take((size_t)n * m * 4);
+  off[1] = take((size_t)n * m * 4);
+  off[2] = take((size_t)n * 4);
+  off[3] = take((size_t)m * 4);
+  off[4] = take((size_t)m * 4);
+  off[5] = take((size_t)kSkRowSplit * m * 4);
+  off[6] = take((size_t)n * 4);
+  off[7] = take(256);
+  off[8] = take(scldm_mmd_workspace_bytes(n, m));
+  return o;
+}
+extern "C" size_t scldm_sinkhorn_workspace_bytes(int n, int m) {
+  if (n < 1 || m < 1) return 0;
+  size_t off[9];
+  return sk_layout(n, m, off);
+}
+
+extern "C" int scldm_wasserstein_sinkhorn(const float* x0, int n, const float* x1, int m, int D, int power, float reg,
+                                          long long num_iter_max, float stop_thr, double* cost_out, long long* iters_out,
+                                          int* status_out, void* ws, void* stream_) {
+  if (!x0 || !x1 || !cost_out || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
+  if (n < 1 || m < 1 || D < 1) return fail(SCLDM_ERR_SHAPE, "need n, m, D >= 1 (got %d, %d, %d)", n, m, D);
+  if (power != 1 && power != 2) return fail(SCLDM_ERR_SHAPE, "power must be 1 or 2 (evaluations.py:92)");
+  if (!(reg > 0.f)) return fail(SCLDM_ERR_SHAPE, "reg must be positive");
+  hipStream_t st = (hipStream_t)stream_;
+  size_t off[9];
+  sk_layout(n, m, off);
+  char* base = (char*)ws;
+  float *M = (float*)(base + off[0]), *K = (float*)(base + off[1]), *u = (float*)(base + off[2]), *v = (float*)(base + off[3]);
+  float *ktu = (float*)(base + off[4]), *part = (float*)(base + off[5]), *rowcost = (float*)(base + off[6]);
+  float* err2 = (float*)(base + off[7]);
+  int* flag = (int*)(base + off[7] + 64);
+  double* dsum = (double*)(base + off[7] + 128);
+  void* mmd_ws = base + off[8];
+  // M = cdist(x0, x1) ** power  (evaluations.py:103-105)
+  int rc = scldm_mmd_kernel_sum(x0, n, x1, m, D, power == 2 ? kMmdSqDist : kMmdDist, 1.0f, dsum, M, mmd_ws, st);
+  if (rc) return rc;
+  const size_t nm = (size_t)n * m;
+  sk_gibbs_kernel<<<(int)std::min<size_t>((nm + 255) / 256, 256 * 16), 256, 0, st>>>(M, K, nm, -1.0f / reg);
+  const float a = 1.0f / n, b = 1.0f / m;
+  sk_fill_kernel<<<cdiv(n, 256), 256, 0, st>>>(u, n, a);
+  sk_fill_kernel<<<cdiv(m, 256), 256, 0, st>>>(v, m, b);
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, st));
+  LAUNCH_CHECK();
+  // an iteration computes candidate scalings and commits them on device unless one of them was singular: the state then
+  // freezes at the last good (u, v), which is what POT's per-iteration "numerical errors" exit returns
+  float *u_new = nullptr, *v_new = nullptr;
+  HIP_TRY(hipMalloc((void**)&u_new, (size_t)n * 4));
+  HIP_TRY(hipMalloc((void**)&v_new, (size_t)m * 4));
+  long long it = 0;
+  int status = 0;   // 0 converged, 1 iteration limit, 2 numerical breakdown (previous scalings kept)
+  bool have_ktu = false;
+  const dim3 gk(cdiv(m, 256), kSkRowSplit);
+  for (; it < num_iter_max; ++it) {
+    if (!have_ktu) sk_ktu_kernel<<<gk, 256, 0, st>>>(K, u, n, m, part);
+    sk_v_update_kernel<<<cdiv(m, 256), 256, 0, st>>>(part, m, b, ktu, v_new, flag);
+    sk_u_update_kernel<<<cdiv(n, 4), 256, 0, st>>>(K, v_new, n, m, a, u_new, flag);
+    sk_commit_kernel<<<cdiv(std::max(n, m), 256), 256, 0, st>>>(u, u_new, n, v, v_new, m, flag);
+    have_ktu = false;
+    if (it % 10 == 0) {
+      sk_ktu_kernel<<<gk, 256, 0, st>>>(K, u, n, m, part);   // K^T u for the committed u: the error term now, the next iteration's input
+      have_ktu = true;
+      sk_err_kernel<<<1, 256, 0, st>>>(part, v, m, b, err2);
+      LAUNCH_CHECK();
+      float h_err2 = 0.f;
+      int h_flag = 0;
+      HIP_TRY(hipMemcpyAsync(&h_err2, err2, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (h_flag) { status = 2; break; }
+      if (!(sqrtf(h_err2) >= stop_thr)) { ++it; break; }   // converged
+    }
+  }
+  if (it >= num_iter_max && status == 0) status = 1;
+  sk_cost_kernel<<<cdiv(n, 4), 256, 0, st>>>(K, M, u, v, n, m, rowcost);
+  mmd_sum_kernel<<<1, 256, 0, st>>>(rowcost, n, dsum);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(cost_out, dsum, 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(u_new);
+  (void)hipFree(v_new);
+  if (iters_out) *iters_out = it;
+  if (status_out) *status_out = status;
   return SCLDM_OK;
 }

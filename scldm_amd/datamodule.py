@@ -72,3 +72,64 @@ def dense_to_csr(dense: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch
         data = torch.empty(max(nnz, 1), dtype=torch.float32, device=dense.device)
         _lib.check(L.scldm_csr_fill(dense.data_ptr(), N, G, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), st), "scldm_csr_fill")
     return indptr, indices[:nnz], data[:nnz]
+
+
+def tokenize_cells(counts: torch.Tensor, gene_idx: torch.Tensor, genes_seq_len: int, sample_genes: str, mask_token_idx: int = 0,
+                   gene_means: torch.Tensor | None = None, generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
+    """Device-side `scldm.datamodule.tokenize_cells` for every `sample_genes` mode (src/scldm/datamodule.py:652-805); dict keys as
+    in the reference ("genes", "counts", "library_size", and "genes_subset" / "counts_subset" where it has them).
+
+      "expressed"        the HIP stream-compaction kernel above (deterministic: bit-exact with the reference)
+      "none"             pass-through + library size (:795-800)
+      "random"           `genes_seq_len` genes per cell, uniformly without replacement (:787-793)
+      "weighted"         without replacement with probability ~ (count + 1) / gene mean (:697-709); needs `gene_means` (G,)
+      "expressed_zero"   a random permutation stably sorted by the expressed flag, first `genes_seq_len` kept - the reference's
+                         argsort puts the NON-expressed genes first (:733-752), and so does this
+      "random_expressed" up to `genes_seq_len` expressed genes uniformly without replacement, padded with the mask token (:754-785)
+
+    The random modes draw with torch's device generator instead of the reference's per-batch `np.random.default_rng(seed)`: the
+    same distributions (uniform / Plackett-Luce subsets via random keys and the Gumbel top-k identity), not the same streams -
+    parity for them is distributional by construction.  CUDA (ROCm) tensors only."""
+    if sample_genes == "expressed":
+        out = tokenize_cells_expressed(counts, gene_idx, genes_seq_len, mask_token_idx)
+        out.pop("num_expressed")
+        return out
+    if counts.device.type != "cuda" or gene_idx.device != counts.device:
+        raise RuntimeError("tokenize_cells works on CUDA (ROCm) tensors; there is no CPU path")
+    if counts.dim() != 2:
+        raise ValueError("counts must be (N, G)")
+    N, G = counts.shape
+    S = int(genes_seq_len)
+    gene_idx = gene_idx.to(torch.long)
+    genes = gene_idx if gene_idx.shape == (N, G) else gene_idx.unsqueeze(0).expand(N, G)
+    lib = counts.sum(1, keepdim=True)
+    rand = lambda: torch.rand((N, G), device=counts.device, generator=generator)
+    if sample_genes == "none":
+        return {"genes": genes, "counts": counts, "library_size": lib}
+    if sample_genes in ("random", "weighted"):
+        if S > G:
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        if sample_genes == "random":
+            keys = rand()
+        else:
+            if gene_means is None:
+                raise ValueError("encoder.metadata_genes must be set for weighted sampling")
+            p = (counts + 1) / gene_means.to(counts).view(1, G)
+            keys = torch.log(p) - torch.log(-torch.log(rand().clamp_min(1e-20)))   # Gumbel top-k = successive sampling without replacement
+            keys = -keys
+        idx = keys.argsort(dim=1)[:, :S]
+        return {"genes": genes.gather(1, idx), "counts": counts.gather(1, idx), "library_size": lib}
+    expressed = counts > 0
+    if sample_genes == "expressed_zero":
+        order = (expressed.to(counts.dtype) + rand()).argsort(dim=1)[:, :S]          # zeros (flag 0) first, each group in random order
+        return {"genes": genes, "counts": counts, "genes_subset": genes.gather(1, order), "counts_subset": counts.gather(1, order),
+                "library_size": lib}
+    if sample_genes == "random_expressed":
+        order = ((~expressed).to(counts.dtype) * 2 + rand()).argsort(dim=1)[:, :S]   # expressed genes first, random order
+        take = torch.arange(S, device=counts.device).unsqueeze(0) < expressed.sum(1, keepdim=True)
+        g = torch.where(take, genes.gather(1, order), torch.full_like(order, int(mask_token_idx)))
+        c = torch.where(take, counts.gather(1, order), torch.zeros((), dtype=counts.dtype, device=counts.device))
+        if S > G:
+            raise ValueError("genes_seq_len exceeds the number of genes")
+        return {"genes": g, "counts": c, "library_size": lib}
+    raise ValueError(f"Invalid sample_genes value: {sample_genes}")

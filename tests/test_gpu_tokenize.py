@@ -98,3 +98,68 @@ def test_dense_to_csr_matches_scipy(N, G, density):
     assert np.array_equal(data.cpu().numpy(), ref.data)
     back = sparse.csr_matrix((data.cpu().numpy(), indices.cpu().numpy(), indptr.cpu().numpy()), shape=(N, G)).toarray()
     assert np.array_equal(back, dense)
+
+
+# ---- the other sample_genes modes (src/scldm/datamodule.py:697-800): random samplers, so invariants and distributions -----
+def _toy(N=64, G=300, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    counts = torch.poisson(torch.full((N, G), 0.4), generator=g)
+    counts[0] = 0                                     # a cell with nothing expressed
+    gene_idx = torch.arange(G) + 5
+    return counts.cuda(), gene_idx.cuda()
+
+
+def test_tokenize_mode_none_and_errors():
+    from scldm_amd.datamodule import tokenize_cells
+    counts, gene_idx = _toy()
+    out = tokenize_cells(counts, gene_idx, 50, "none")
+    assert torch.equal(out["counts"], counts) and torch.equal(out["genes"][3], gene_idx) and torch.equal(out["library_size"], counts.sum(1, keepdim=True))
+    with pytest.raises(ValueError):
+        tokenize_cells(counts, gene_idx, 50, "all")                        # the reference raises on unknown modes too (:802-803)
+    with pytest.raises(ValueError):
+        tokenize_cells(counts, gene_idx, 50, "weighted")                   # needs gene means (:698-699)
+    with pytest.raises(ValueError):
+        tokenize_cells(counts, gene_idx, 301, "random")
+    ref = tokenize_cells(counts[:, :60].contiguous(), gene_idx[:60].contiguous(), 60, "expressed", mask_token_idx=1)
+    assert set(ref) == {"genes", "counts", "genes_subset", "counts_subset", "library_size"}
+
+
+@pytest.mark.parametrize("mode", ["random", "weighted"])
+def test_tokenize_random_subsets(mode):
+    from scldm_amd.datamodule import tokenize_cells
+    counts, gene_idx = _toy(N=2000, G=40, seed=1)
+    means = torch.linspace(0.2, 2.0, 40).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    out = tokenize_cells(counts, gene_idx, 10, mode, gene_means=means, generator=gen)
+    g, c = out["genes"], out["counts"]
+    assert g.shape == (2000, 10) and c.shape == (2000, 10)
+    assert all(len(set(row.tolist())) == 10 for row in g[:50])             # without replacement
+    assert torch.equal(c, counts.gather(1, g - 5))                          # counts follow their genes
+    freq = torch.bincount((g - 5).flatten(), minlength=40).double() / (2000 * 10)
+    if mode == "random":
+        assert float((freq - 1 / 40).abs().max()) < 0.006                  # uniform inclusion
+    else:
+        w = ((counts + 1) / means.view(1, -1)).double()
+        first = w / w.sum(1, keepdim=True)                                  # exact probabilities of the FIRST draw
+        got_first = torch.bincount((g[:, 0] - 5), minlength=40).double() / 2000
+        assert float((got_first - first.mean(0)).abs().max()) < 0.02
+        assert float(freq[:5].mean()) > float(freq[-5:].mean())           # rare-mean genes are favoured
+
+
+def test_tokenize_expressed_zero_and_random_expressed():
+    from scldm_amd.datamodule import tokenize_cells
+    counts, gene_idx = _toy(N=256, G=300, seed=2)
+    n_zero = (counts == 0).sum(1)
+    out = tokenize_cells(counts, gene_idx, 200, "expressed_zero")
+    cs = out["counts_subset"]
+    for i in (0, 1, 17, 255):
+        z = int(min(n_zero[i], 200))
+        assert bool((cs[i, :z] == 0).all()) and bool((cs[i, z:] > 0).all())     # the non-expressed genes come first (:745-747)
+        assert torch.equal(cs[i], counts[i].gather(0, out["genes_subset"][i] - 5))
+    out2 = tokenize_cells(counts, gene_idx, 150, "random_expressed", mask_token_idx=1)
+    n_exp = (counts > 0).sum(1)
+    for i in (0, 1, 17, 255):
+        k = int(min(n_exp[i], 150))
+        assert bool((out2["counts"][i, :k] > 0).all()) and bool((out2["counts"][i, k:] == 0).all())
+        assert bool((out2["genes"][i, k:] == 1).all())
+        assert len(set(out2["genes"][i, :k].tolist())) == k
