@@ -52,7 +52,7 @@ def test_gpu_sinkhorn_matches_oracle(n, m, D, power, reg):
     got = wasserstein(x0.cuda(), x1.cuda(), method="sinkhorn", reg=reg, power=power, num_iter_max=3000)
     stats = wasserstein.last_stats
     print(f"[parity] sinkhorn n={n} m={m} D={D} power={power} reg={reg}: hip {got:.7f} ({stats}) oracle {ref:.7f} ({it_ref} its, status {st_ref})")
-    assert stats["status"] in (0, 1)
+    assert stats["status"] == 0 and stats["iterations"] <= 3000   # stop_thr or the fp32 floor, not the iteration limit
     assert abs(got - ref) <= 1e-4 * abs(ref) + 1e-6
 
 
