@@ -80,6 +80,10 @@ struct OpBF16 {
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  // SwiGLU with the w1 rows packed times -log2(e) and the w2 rows times -1/log2(e) (kW1Scale / kW2Scale, applied by the weight
+  // packer): the up-projection delivers a' = -log2(e) a and b' = -b / log2(e), so silu(a) b = a' b' / (1 + 2^a') - one multiply less
+  static constexpr float kW1Scale = -1.4426950408889634f, kW2Scale = -0.6931471805599453f;
+  static __device__ __forceinline__ float swiglu(float a, float b) { return (a * b) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
   // 4 consecutive features starting at feature f (multiple of 4) of an activation row
   static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
   static __device__ __forceinline__ Frag pack8(const float* v) {
@@ -110,6 +114,8 @@ struct OpF32 {
   static constexpr int kRing = 2;
   static constexpr int kFragLoads = 2;
   static constexpr int kMmaOps = 8;
+  static constexpr float kW1Scale = 1.0f, kW2Scale = 1.0f;
+  static __device__ __forceinline__ float swiglu(float a, float b) { return silu_f(a) * b; }
   static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
   // exact fp32: 8 x v_mfma_f32_32x32x2_f32 (each contracts k-groups 0 and 1 of one element slot)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
@@ -153,6 +159,8 @@ struct OpBF16x3 {
   static constexpr int kRing = 2;
   static constexpr int kFragLoads = 2;
   static constexpr int kMmaOps = 3;
+  static constexpr float kW1Scale = 1.0f, kW2Scale = 1.0f;
+  static __device__ __forceinline__ float swiglu(float a, float b) { return silu_f(a) * b; }
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);   // small terms first
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);

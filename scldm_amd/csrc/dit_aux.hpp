@@ -17,9 +17,11 @@ namespace scldm {
 // Hidden indices >= H are zero (exact padding of 684 -> 768).
 // ------------------------------------------------------------------------------------------------
 // One element of a layer's packed stream (index documented above); FT = 32-row tiles per wave.
+// s1 / s2: factors applied to the w1 / w2 rows (OP::kW1Scale / kW2Scale of the stream's precision policy)
 __device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, const float* __restrict__ Wproj,
                                                 const float* __restrict__ W1, const float* __restrict__ W2,
-                                                const float* __restrict__ Wcp, long long idx, int H, int n_chunks, int half, int FT) {
+                                                const float* __restrict__ Wcp, long long idx, int H, int n_chunks, int half, int FT,
+                                                float s1, float s2) {
   // FT = 32-row tiles per wave (2: four waves, 1: eight waves); a unit holds FT fragments of 512 elements
   const int UL = units_per_layer(n_chunks, half), unit_elems = 512 * FT;
   const int j = idx & 7, l = (idx >> 3) & 63, ft = (int)((idx >> 9) % FT);
@@ -44,7 +46,7 @@ __device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, 
     if (vh < 8) {
       const int ks = 2 * vh + ft, hid = hid0 + w * 16 + (r & 15);
       const float* src = (r < 16) ? W1 : W2;
-      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] : 0.f;
+      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] * ((r < 16) ? s1 : s2) : 0.f;
     } else {
       const int hid = hid0 + (vh - 8) * 16 + k8;
       val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;
@@ -57,7 +59,7 @@ __device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, 
       const int ks = (FT == 2) ? (2 * (vv & 7) + ft) : vv;
       const int hid = c * kHC + (w * FT + tile) * 16 + (r & 15);
       const float* src = (r < 16) ? W1 : W2;
-      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] : 0.f;
+      val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] * ((r < 16) ? s1 : s2) : 0.f;
     } else {
       const int hid = c * kHC + (vv - 16) * 16 + k8;
       val = (hid < H) ? Wcp[(size_t)frow * H + hid] : 0.f;
@@ -117,7 +119,10 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       break;
     }
     case kPackLayer:
-      pack_store(j.d, j.d_off + idx, pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3]), j.p[4]);
+      pack_store(j.d, j.d_off + idx,
+                 pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3],
+                                j.p[4] == 1 ? OpBF16::kW1Scale : 1.0f, j.p[4] == 1 ? OpBF16::kW2Scale : 1.0f),
+                 j.p[4]);
       break;
     case kPackFinal: {  // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
       const int jj = idx & 7, l = (idx >> 3) & 63, ks = (int)(idx >> 9);

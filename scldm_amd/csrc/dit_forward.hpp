@@ -53,6 +53,11 @@
 #ifndef SCLDM_BPF
 #define SCLDM_BPF 1
 #endif
+// 1: Linear biases enter as the INITIAL accumulator of their GEMM pass (the MFMA's C operand) instead of a VALU add per output
+// element afterwards; 2 fewer VALU ops per LayerNorm element (scale and offset folded per token).  A/B switch.
+#ifndef SCLDM_LEAN_VALU
+#define SCLDM_LEAN_VALU 1
+#endif
 
 namespace scldm {
 
@@ -164,15 +169,35 @@ struct Prefetch {  // k-steps of run-ahead of the weight ring
 template <typename OP, int PF, int FT>
 struct WStream {
   using Frag = typename OP::Frag;
-  const Frag* p;  // next unit to fetch (lane offset folded in)
+  // The stream is read through a buffer descriptor (SRSRC in SGPRs): address = wave-uniform base + scalar running offset
+  // (advanced on the scalar unit) + this lane's constant byte offset + an immediate - no per-k-step 64-bit VALU pointer
+  // arithmetic (128 v_lshl_add_u64 per layer with a per-lane pointer), and no address VGPR pair.
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned soff;       // running byte offset of the next unit (wave-uniform)
+  unsigned lane_off;   // lane * sizeof(Frag)
   Frag ring[PF][FT];
-  __device__ __forceinline__ void init(const Frag* base) {
-    p = base;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  __device__ __forceinline__ Frag fetch(int ft) const {
+    static_assert(sizeof(Frag) == 16 || sizeof(Frag) == 32, "fragment = one or two 16-byte loads per lane");
+    union { Frag f; u32x4 q[sizeof(Frag) / 16]; } u;
+#pragma unroll
+    for (int h = 0; h < (int)(sizeof(Frag) / 16); ++h)
+      u.q[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + ft * 64 * (int)sizeof(Frag) + h * 16, soff, 0);
+    return u.f;
+  }
+  __device__ __forceinline__ void advance(int frags) { soff += frags * 64 * (unsigned)sizeof(Frag); }
+  __device__ __forceinline__ void init(const Frag* unit0, int lane) {
+    // the descriptor inputs are made provably wave-uniform (a lane-tainted pointer makes hipcc wrap every load in a waterfall loop)
+    const unsigned long long b = reinterpret_cast<unsigned long long>(unit0);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+    soff = 0;
+    lane_off = (unsigned)lane * (unsigned)sizeof(Frag);
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
 #pragma unroll
-      for (int ft = 0; ft < FT; ++ft) ring[s][ft] = p[ft * 64];
-      p += 64 * FT;
+      for (int ft = 0; ft < FT; ++ft) ring[s][ft] = fetch(ft);
+      advance(FT);
     }
   }
 };
@@ -187,7 +212,8 @@ struct WStream {
 // (refill of the ring slot just consumed = PF k-steps ahead).
 template <typename OP, int NTT, int FT, int KSTEPS, bool SWAP, bool ZERO, int PF>
 __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF, FT>& ws,
-                                          const typename OP::E* __restrict__ bsm, int ldb, int lane) {
+                                          const typename OP::E* __restrict__ bsm, int ldb, int lane, const f32x16* init = nullptr) {
+  // ZERO with init != nullptr: tile (ft, *) starts from init[ft] (a per-row bias tile) instead of zero
   using Frag = typename OP::Frag;
   // a pass shorter than the ring (the trailing half chunk's down-projection) is legal only as the LAST pass of the stream
   static_assert(KSTEPS % PF == 0 || KSTEPS < PF, "KSTEPS must be a multiple of the prefetch depth (or a final short pass)");
@@ -206,13 +232,13 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
     for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) {
-        if (SWAP) acc[ft][tt] = OP::mma(bcur[tt], ws.ring[s][ft], first ? zero : acc[ft][tt]);
-        else acc[ft][tt] = OP::mma(ws.ring[s][ft], bcur[tt], first ? zero : acc[ft][tt]);
+        if (SWAP) acc[ft][tt] = OP::mma(bcur[tt], ws.ring[s][ft], first ? (init ? init[ft] : zero) : acc[ft][tt]);
+        else acc[ft][tt] = OP::mma(ws.ring[s][ft], bcur[tt], first ? (init ? init[ft] : zero) : acc[ft][tt]);
       }
     }
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.p[ft * 64];  // refill the slot just consumed: PF k-steps ahead
-    ws.p += 64 * FT;
+    for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.fetch(ft);  // refill the slot just consumed: PF k-steps ahead
+    ws.advance(FT);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
     if (OP::kPin) {
@@ -281,9 +307,9 @@ __device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, P
       for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
 #endif
       if (half == 1) {
-        ws.ring[s][0] = ws.p[0];
-        ws.ring[s][1] = ws.p[64];
-        ws.p += 128;
+        ws.ring[s][0] = ws.fetch(0);
+        ws.ring[s][1] = ws.fetch(1);
+        ws.advance(2);
       }
       if (OP::kPin) {
         __builtin_amdgcn_sched_group_barrier(0x100, NTT * OP::kFragLoads, 0);
@@ -429,8 +455,18 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
     }
     const int f = (wave * FT + ft) * 32 + q * 8 + hh * 4;
     float y[4];
+    if (SCLDM_LEAN_VALU && !OP::kTwoPassLN) {
+      // (v - mean) * rstd * (1 + sc) + sh  =  v * A + B  with  A = rstd * (1 + sc),  B = sh - mean * A   (3 ops, was 5); the parity
+      // policies keep the centred form (v - mean is formed first: no cancellation between v * A and mean * A)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+      for (int i = 0; i < 4; ++i) {
+        const float A = fmaf(rstd[tt], sc[i], rstd[tt]);
+        y[i] = fmaf(v[ft][tt][q * 4 + i], A, fmaf(-mean[tt], A, sh[i]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+    }
     OP::store_quad(dst + (tt * 32 + c32) * ldd, f, OP::pack4(y[0], y[1], y[2], y[3]));
   }
 }
@@ -468,7 +504,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
   constexpr int kModLd = (NS * kModBlock / 4 + NT - 1) / NT;  // float4 of adaLN vectors per thread
   // the weight stream starts first: its first PF units fly while the prologue runs
   WStream<OP, PF, FT> ws;
-  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
+  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT, lane);
 
   // samples past n_fwd (tile padding) recompute the last real sample and are never stored to `out`
   // residual hand-off buffer: lane-linear, quad j = (tt*FT + ft)*4 + q  (padded to whole tiles: no predication)
@@ -699,6 +735,27 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
       }
     };
     // accumulator tile (feature rows x token cols) + per-row bias -> the two k-halves of an MFMA operand
+    // the per-row bias of a feature tile as an accumulator tile (register r <-> row acc_row(r, hh)): the pass's initial C operand
+    auto bias_tile = [&](const float* brow) {
+      f32x16 t;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + q * 8 + hh * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[q * 4 + i] = b4[i];
+      }
+      return t;
+    };
+    auto to_frags_nobias = [&](const f32x16 (&t_acc)[NTT], Frag (&F)[NTT][2]) {
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = t_acc[tt][r];
+        F[tt][0] = OP::pack8(t);
+        F[tt][1] = OP::pack8(t + 8);
+      }
+    };
     auto to_frags = [&](const f32x16 (&t_acc)[NTT], const float* brow, Frag (&F)[NTT][2]) {
       float bias[16];
 #pragma unroll
@@ -724,9 +781,16 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) {
         Frag QFh[NTT][2], KFh[NTT][2];
+#if SCLDM_LEAN_VALU
+        const f32x16 qk_bias[2] = {bias_tile(bq + 0 * kD + fbase + ft * 32), bias_tile(bq + 1 * kD + fbase + ft * 32)};
+        gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane, qk_bias);  // acc[0] = Q^T + b_q, acc[1] = K^T + b_k of head ft
+        to_frags_nobias(acc[0], QFh);
+        to_frags_nobias(acc[1], KFh);
+#else
         gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, XA, L::XA_LD, lane);  // acc[0] = Q^T, acc[1] = K^T of head ft
         to_frags(acc[0], bq + 0 * kD + fbase + ft * 32, QFh);
         to_frags(acc[1], bq + 1 * kD + fbase + ft * 32, KFh);
+#endif
         if (ft == 0) SCLDM_STAMP(2);
         if (ft == 0) SCLDM_STAMP(3);
         scores(QFh, KFh, Pf[ft]);
@@ -749,14 +813,25 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
     gemm_pass<OP, NTT, FT, 16, true, true, PF>(acc, ws, XA, L::XA_LD, lane);
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
+#if SCLDM_LEAN_VALU
+      // the V bias is added AFTER the P V product, as the initial accumulator: every query's probabilities sum to one over its
+      // sample's keys (the cross-sample blocks of P are exact zeros), so P (V + 1 b^T) = P V + b per output row d
+      const f32x16 ot0 = bias_tile(bq + 2 * kD + fbase + ft * 32);
+#else
       const float bv = bq[2 * kD + fbase + ft * 32 + c32];
+      const f32x16 ot0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
         float t[16];
 #pragma unroll
+#if SCLDM_LEAN_VALU
+        for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r];
+#else
         for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bv;
+#endif
         const Frag v0 = OP::pack8(t), v1 = OP::pack8(t + 8);
-        f32x16 ot = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 ot = ot0;
         ot = OP::mma(v0, Pf[ft][tt][0], ot);  // O^T[d][query], k = keys
         ot = OP::mma(v1, Pf[ft][tt][1], ot);
         acc[ft][tt] = ot;
@@ -777,6 +852,31 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
   SCLDM_STAMP(6);
 
   // ---- attention projection, gated residual (a2), LN2 + modulate(a3 = scale, a4 = shift) -> XA ----
+#if SCLDM_LEAN_VALU
+  {
+    f32x16 pbias[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + fbase + ft * 32 + q * 8 + hh * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pbias[ft][q * 4 + i] = b4[i];
+      }
+    gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane, pbias);   // c_proj(attention) + bias
+  }
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = fbase + ft * 32 + q * 8 + hh * 4;
+        const f32x4 g = OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + 2 * kD + f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = fmaf(g[i], acc[ft][tt][q * 4 + i], xr[ft][tt][q * 4 + i]);
+      }
+#else
   gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
@@ -790,6 +890,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #pragma unroll
         for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * (acc[ft][tt][q * 4 + i] + b4[i]);
       }
+#endif
   SCLDM_STAMP(7);
   // (the statistics barrier inside also guarantees every wave has finished reading AO before XA is rewritten)
   ln_modulate_store<OP, NTT, FT, 16>(xr, MOD, 3, 4, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
@@ -815,7 +916,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         for (int q = 0; q < 2; ++q) {
           float h[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h[i] = silu_f(t_acc[tt][q * 4 + i]) * t_acc[tt][8 + q * 4 + i];
+          for (int i = 0; i < 4; ++i) h[i] = OP::swiglu(t_acc[tt][q * 4 + i], t_acc[tt][8 + q * 4 + i]);
           out[tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
         }
     };
@@ -865,7 +966,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
   const bool next_here = layer + 1 < a.n_layer && li + 1 < a.n_here;
   if (next_here)
     ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)(li + 1) * (a.w_layer_elems / 8) +
-            (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT + lane);
+            (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT, lane);
 
   // ---- gated residual (a5) ----
 #pragma unroll
