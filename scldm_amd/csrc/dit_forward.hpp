@@ -59,6 +59,11 @@
 #define SCLDM_LEAN_VALU 1
 #endif
 
+// Floating-point contraction is OFF in this file and every fused multiply-add is written out (fmaf): the layer body is
+// instantiated once per layer slot of a launch, and with the default contract(fast) hipcc is free to fuse a * b + c in one
+// slot's schedule and not in another's - results then depend on which slot (i.e. on SCLDM_LPL) a layer happens to run in.
+#pragma clang fp contract(off)
+
 namespace scldm {
 
 constexpr int kD = 256;        // n_embed
@@ -385,7 +390,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float d = v[ft][tt][r] - mean[tt];
-          s += d * d;
+          s = fmaf(d, d, s);
         }
       s = xor32_sum(s);
       if (hh == 0) red_b[wave * TM + t] = s;
@@ -410,7 +415,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           s += v[ft][tt][r];
-          ss += v[ft][tt][r] * v[ft][tt][r];
+          ss = fmaf(v[ft][tt][r], v[ft][tt][r], ss);
         }
       s = xor32_sum(s);
       ss = xor32_sum(ss);
@@ -433,10 +438,13 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
         e2 += red_b[w * TM + t];
       }
       mean[tt] = m * (1.0f / kD);
-      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(e2 * (1.0f / kD) - mean[tt] * mean[tt], 0.f) + eps);
+      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean[tt], mean[tt], e2 * (1.0f / kD)), 0.f) + eps);
     }
   }
   const int sp = c32 >> 4;
+  float nmr[NTT];   // -mean * rstd
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) nmr[tt] = -mean[tt] * rstd[tt];
   // 16 (scale, shift) quads per lane: the LDS reads of quad b+1 are issued before quad b is computed (hipcc otherwise emits
   // read -> wait -> compute -> write per quad, ~130 stalled cycles each)
   constexpr int NB = NTT * FT * 4;
@@ -455,18 +463,21 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
     }
     const int f = (wave * FT + ft) * 32 + q * 8 + hh * 4;
     float y[4];
-    if (SCLDM_LEAN_VALU && !OP::kTwoPassLN) {
-      // (v - mean) * rstd * (1 + sc) + sh  =  v * A + B  with  A = rstd * (1 + sc),  B = sh - mean * A   (3 ops, was 5); the parity
-      // policies keep the centred form (v - mean is formed first: no cancellation between v * A and mean * A)
+#if SCLDM_LEAN_VALU
+    // the LDS copy of a scale vector already holds 1 + scale (added once when the vectors are staged), so an element costs
+    //   bf16 path:   n = v * rstd + (-mean * rstd);  y = n * S + sh                      (2 ops)
+    //   parity paths: n = (v - mean) * rstd (centred first: no cancellation);  y = n * S + sh   (3 ops)
+    if (!OP::kTwoPassLN) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float A = fmaf(rstd[tt], sc[i], rstd[tt]);
-        y[i] = fmaf(v[ft][tt][q * 4 + i], A, fmaf(-mean[tt], A, sh[i]));
-      }
+      for (int i = 0; i < 4; ++i) y[i] = fmaf(fmaf(v[ft][tt][q * 4 + i], rstd[tt], nmr[tt]), sc[i], sh[i]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+      for (int i = 0; i < 4; ++i) y[i] = fmaf((v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt], sc[i], sh[i]);
     }
+#else
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
+#endif
     OP::store_quad(dst + (tt * 32 + c32) * ldd, f, OP::pack4(y[0], y[1], y[2], y[3]));
   }
 }
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
   const int tid = wave * 64 + lane;
   const int c32 = lane & 31, hh = lane >> 5;
   const int sp = c32 >> 4;  // which of a 32-token tile's two samples this lane's token belongs to
-  if (layer == 0) {
+  if (li == 0 && layer == 0) {   // (only the first slot of a launch can be layer 0: later slots carry no copy of this code)
     // ---- input projection + positional embedding (nnets.py:290-291) ----
     const int p16 = c32 & 15;  // token position inside its sample
     const float* zrow[NTT];
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #pragma unroll
             for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += w4[i] * zk[tt];
+              for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = fmaf(w4[i], zk[tt], xr[ft][tt][q * 4 + i]);
           }
       }
     }
@@ -683,7 +694,13 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
   ln_modulate_store<OP, NTT, FT, 22>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
 #pragma unroll
     for (int j = 0; j < kModLd; ++j)
-      if (tid + NT * j < NS * kModBlock / 4) OP::store_mod4(MOD + (size_t)(tid + NT * j) * 4, mstage[j]);
+      if (tid + NT * j < NS * kModBlock / 4) {
+#if SCLDM_LEAN_VALU
+        const int vec = ((tid + NT * j) % (kModBlock / 4)) / (kD / 4);   // which of the six vectors this float4 belongs to
+        if (vec == 0 || vec == 3) mstage[j] += 1.0f;                      // a0 / a3 act as SCALES (F7): stored as 1 + scale
+#endif
+        OP::store_mod4(MOD + (size_t)(tid + NT * j) * 4, mstage[j]);
+      }
 #pragma unroll
     for (int j = 0; j < kBiasLd; ++j)
       if (tid + NT * j < 4 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + (size_t)(tid + NT * j) * 4) = bstage[j];
@@ -716,9 +733,10 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         for (int i = 1; i < 8; ++i) m = fmaxf(m, sv[i]);
         m = xor32_max(m);
         float sum = 0.f;
+        const float nms = -m * a.attn_scale_log2e;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          sv[i] = __builtin_amdgcn_exp2f((sv[i] - m) * a.attn_scale_log2e);
+          sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], a.attn_scale_log2e, nms));
           sum += sv[i];
         }
         sum = xor32_sum(sum);
@@ -888,7 +906,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + f);
         const f32x4 g = OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + 2 * kD + f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * (acc[ft][tt][q * 4 + i] + b4[i]);
+        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = fmaf(g[i], acc[ft][tt][q * 4 + i] + b4[i], xr[ft][tt][q * 4 + i]);
       }
 #endif
   SCLDM_STAMP(7);
@@ -978,7 +996,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         const int f = fbase + ft * 32 + q * 8 + hh * 4;
         const f32x4 g = OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + 5 * kD + f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] += g[i] * accp[ft][tt][q * 4 + i];
+        for (int i = 0; i < 4; ++i) xr[ft][tt][q * 4 + i] = fmaf(g[i], accp[ft][tt][q * 4 + i], xr[ft][tt][q * 4 + i]);
       }
   SCLDM_STAMP(10);
 
@@ -1004,6 +1022,9 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #pragma unroll
     for (int j = 0; j < kFinLd; ++j) {
       const int idx = tid + NT * j, sl = idx / (2 * kD / 4), w4 = idx % (2 * kD / 4);
+#if SCLDM_LEAN_VALU
+      if (w4 >= kD / 4) fstage[j] += 1.0f;   // the final layer's second chunk is its scale (layers.py:398-399)
+#endif
       if (idx < NS * 2 * kD / 4) OP::store_mod4(MOD + sl * kModBlock + w4 * 4, fstage[j]);
     }
     ln_modulate_store<OP, NTT, FT>(xr, MOD, 1, 0, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, nothing);
@@ -1040,3 +1061,5 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 }
 
 }  // namespace scldm
+
+#pragma clang fp contract(fast)

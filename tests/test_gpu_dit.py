@@ -463,3 +463,32 @@ def test_inplace_data_updates_are_picked_up(precision):
     m.invalidate_weights()                            # ... which is what invalidate_weights() is for
     y2 = m(x, t, cond)
     assert not torch.equal(y2, y1)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+@pytest.mark.parametrize("knobs", [{}, {"SCLDM_LPL": "1"}, {"SCLDM_LPL": "2"}, {"SCLDM_LPL": "3"}, {"SCLDM_FT": "1", "SCLDM_X3_FT": "1"},
+                                   {"SCLDM_FT": "1", "SCLDM_NTT": "4"}])
+def test_bit_repeatability_across_shapes_and_launch_groupings(precision, knobs, monkeypatch):
+    """run-to-run differences were once bisected to codegen (packed f32 math in the LayerNorm sweep).  Every precision,
+    every kernel shape and every layers-per-launch grouping must give the same bytes on repeated runs with two workgroups per CU
+    busy (n = 2049: ragged last tile), and the grouping must not change the bytes at all (floating-point contraction is off in the
+    fused kernel, so a layer computes the same values whichever slot of a launch it runs in)."""
+    g, m0, cfg, sd = build("dit_base", precision)
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    n = 2049
+    x = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    t = torch.rand(n, device="cuda", generator=gen)
+    lab = {"clusters": torch.randint(0, 14, (n,), device="cuda", generator=gen)}
+    with torch.no_grad():
+        ref = m0(x, t, lab)
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        _, m, _, _ = build("dit_base", precision)
+        ys = [m(x, t, lab) for _ in range(4)]
+        torch.cuda.synchronize()
+    assert all(torch.equal(y, ys[0]) for y in ys[1:])
+    if not any(k in knobs for k in ("SCLDM_FT", "SCLDM_X3_FT", "SCLDM_NTT")):
+        assert torch.equal(ys[0], ref)            # same kernel shape, other grouping: identical
+    else:
+        tol = TOL_BF16 if precision == "bf16" else TOL_FP32
+        assert max_abs_rel(ys[0].cpu(), ref.cpu()) < tol   # another reduction tree: close, not identical
