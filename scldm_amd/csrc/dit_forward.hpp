@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #if SCLDM_LEAN_VALU
       // the V bias is added AFTER the P V product, as the initial accumulator: every query's probabilities sum to one over its
       // sample's keys (the cross-sample blocks of P are exact zeros), so P (V + 1 b^T) = P V + b per output row d
-      const f32x16 ot0 = bias_tile(bq + 2 * kD + fbase + ft * 32);
+      const float* vb_row = bq + 2 * kD + fbase + ft * 32;
 #else
       const float bv = bq[2 * kD + fbase + ft * 32 + c32];
       const f32x16 ot0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -849,7 +849,13 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         for (int r = 0; r < 16; ++r) t[r] = acc[ft][tt][r] + bv;
 #endif
         const Frag v0 = OP::pack8(t), v1 = OP::pack8(t + 8);
+#if SCLDM_LEAN_VALU
+        const float* vb = vb_row;
+        asm volatile("" : "+v"(vb));        // re-read per token tile: holding the bias tile across both costs 16 registers where pressure peaks
+        f32x16 ot = bias_tile(vb);
+#else
         f32x16 ot = ot0;
+#endif
         ot = OP::mma(v0, Pf[ft][tt][0], ot);  // O^T[d][query], k = keys
         ot = OP::mma(v1, Pf[ft][tt][1], ot);
         acc[ft][tt] = ot;
