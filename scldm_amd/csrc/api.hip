@@ -46,6 +46,7 @@ static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
     if (h->force_ntt == 4 && *ft == 1) *ntt = 4;
   } else if (prec == SCLDM_PREC_BF16X3) {
     if (h->force_x3_ft == 1) *ft = 1;
+    else if (h->force_x3_ntt == 1) *ntt = 1;   // 32-token tiles: 79 KB of LDS, two workgroups per CU
   }
 }
 
@@ -81,6 +82,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
+  if (const char* e = getenv("SCLDM_X3_NTT")) h->force_x3_ntt = atoi(e);
   h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..4 for A/B runs)
   if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   h->groups = 1;
@@ -372,7 +374,8 @@ static int launch_fwd_t(const FwdArgs& a, hipStream_t st) {
 
 static int launch_fwd(int prec, int ntt, int ft, const FwdArgs& a, hipStream_t st) {
   if (prec == SCLDM_PREC_FP32) return launch_fwd_t<OpF32, 2, 2>(a, st);
-  if (prec == SCLDM_PREC_BF16X3) return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
+  if (prec == SCLDM_PREC_BF16X3)
+    return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : ntt == 1 ? launch_fwd_t<OpBF16x3, 1, 2>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
   if (ft == 1) return ntt == 4 ? launch_fwd_t<OpBF16, 4, 1>(a, st) : launch_fwd_t<OpBF16, 2, 1>(a, st);
   return launch_fwd_t<OpBF16, 2, 2>(a, st);
 }

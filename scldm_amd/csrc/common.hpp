@@ -37,6 +37,16 @@ __device__ __forceinline__ float xor32_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// Lanes l and l + 32 of an accumulator tile hold adjacent 4-feature groups of the SAME token (features 8q + 4 (l >> 5) ..+3).
+// Given one packed dword of quad q (a) and of quad q + 1 (b), the half-wave exchange below leaves lane l < 32 with both halves
+// of quad q's 8 features and lane l >= 32 with both halves of quad q + 1's: one 16-byte LDS store per lane instead of two
+// 8-byte ones (whose row stride, a multiple of 16 bytes, makes them 2-way bank conflicted: r2 PMC, 47 % of LDS-active cycles).
+__device__ __forceinline__ void halfwave_pair(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];   // l < 32: own a (features 8q..8q+3)          l >= 32: lane l-32's b (features 8(q+1)..+3)
+  b = r[1];   // l < 32: lane l+32's a (features 8q+4..+7)   l >= 32: own b (features 8(q+1)+4..+7)
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries an all-address-space release fence: with
 // global stores (or LDS-bound DMA) in flight it drains vmcnt(0) - and with it the weight-stream prefetch ring.
 __device__ __forceinline__ void lds_barrier() {
@@ -86,6 +96,15 @@ struct OpBF16 {
   static __device__ __forceinline__ float swiglu(float a, float b) { return (a * b) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
   // 4 consecutive features starting at feature f (multiple of 4) of an activation row
   static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
+  // quads q (q0) and q + 1 (q1) of a feature tile, f8 = first feature of quad q's 8-feature group: one 16-byte store per lane
+  static __device__ __forceinline__ void store_quad_pair(E* row, int f8, int hh, const Quad& q0, const Quad& q1) {
+    union { Quad q; unsigned u[2]; } a, b;
+    a.q = q0; b.q = q1;
+    halfwave_pair(a.u[0], b.u[0]);
+    halfwave_pair(a.u[1], b.u[1]);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    *reinterpret_cast<u32x4*>(row + f8 + 8 * hh) = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+  }
   static __device__ __forceinline__ Frag pack8(const float* v) {
     Frag f;
 #pragma unroll
@@ -117,6 +136,10 @@ struct OpF32 {
   static constexpr float kW1Scale = 1.0f, kW2Scale = 1.0f;
   static __device__ __forceinline__ float swiglu(float a, float b) { return silu_f(a) * b; }
   static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
+  static __device__ __forceinline__ void store_quad_pair(E* row, int f8, int hh, const Quad& q0, const Quad& q1) {
+    store_quad(row, f8 + hh * 4, q0);        // 16-byte stores already
+    store_quad(row, f8 + 8 + hh * 4, q1);
+  }
   // exact fp32: 8 x v_mfma_f32_32x32x2_f32 (each contracts k-groups 0 and 1 of one element slot)
   static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
 #pragma unroll
@@ -197,6 +220,19 @@ struct OpBF16x3 {
     char* b = reinterpret_cast<char*>(row) + (f >> 3) * 32 + (f & 7) * 2;
     *reinterpret_cast<bf16x4*>(b) = q.hi;
     *reinterpret_cast<bf16x4*>(b + 16) = q.lo;
+  }
+  // the k-group of 8 features is [hi x 8][lo x 8]: after the half-wave exchange a lane holds a whole group -> two 16-byte stores
+  static __device__ __forceinline__ void store_quad_pair(E* row, int f8, int hh, const Quad& q0, const Quad& q1) {
+    union { bf16x4 q; unsigned u[2]; } ah, bh, al, bl;
+    ah.q = q0.hi; bh.q = q1.hi; al.q = q0.lo; bl.q = q1.lo;
+    halfwave_pair(ah.u[0], bh.u[0]);
+    halfwave_pair(ah.u[1], bh.u[1]);
+    halfwave_pair(al.u[0], bl.u[0]);
+    halfwave_pair(al.u[1], bl.u[1]);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    char* b = reinterpret_cast<char*>(row) + ((f8 >> 3) + hh) * 32;
+    *reinterpret_cast<u32x4*>(b) = u32x4{ah.u[0], ah.u[1], bh.u[0], bh.u[1]};
+    *reinterpret_cast<u32x4*>(b + 16) = u32x4{al.u[0], al.u[1], bl.u[0], bl.u[1]};
   }
 };
 

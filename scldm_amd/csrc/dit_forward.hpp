@@ -58,6 +58,11 @@
 #ifndef SCLDM_LEAN_VALU
 #define SCLDM_LEAN_VALU 1
 #endif
+// 1: activation tiles are stored to LDS as 16-byte pieces after a half-wave exchange (common.hpp: halfwave_pair) instead of
+// 8-byte pieces (2-way bank conflicted on 16-byte-aligned rows).  A/B switch.
+#ifndef SCLDM_PAIR_STORE
+#define SCLDM_PAIR_STORE 1
+#endif
 
 // Floating-point contraction is OFF in this file and every fused multiply-add is written out (fmaf): the layer body is
 // instantiated once per layer slot of a launch, and with the default contract(fast) hipcc is free to fuse a * b + c in one
@@ -453,6 +458,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
     return msm + (tt * 2 + sp) * kModBlock + vec * kD + (wave * FT + ft) * 32 + q * 8 + hh * 4;
   };
   f32x4 sc_n = OP::load_mod4(quad_ptr(0, sc_v)), sh_n = OP::load_mod4(quad_ptr(0, sh_v));
+  typename OP::Quad held;   // the even quad of a pair, kept until its odd neighbour is ready (SCLDM_PAIR_STORE)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int tt = b / (FT * 4), ft = (b / 4) % FT, q = b % 4;
@@ -478,12 +484,18 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
 #pragma unroll
     for (int i = 0; i < 4; ++i) y[i] = (v[ft][tt][q * 4 + i] - mean[tt]) * rstd[tt] * (1.0f + sc[i]) + sh[i];
 #endif
+#if SCLDM_PAIR_STORE
+    const typename OP::Quad packed = OP::pack4(y[0], y[1], y[2], y[3]);
+    if ((q & 1) == 0) held = packed;
+    else OP::store_quad_pair(dst + (tt * 32 + c32) * ldd, (wave * FT + ft) * 32 + (q - 1) * 8, hh, held, packed);
+#else
     OP::store_quad(dst + (tt * 32 + c32) * ldd, f, OP::pack4(y[0], y[1], y[2], y[3]));
+#endif
   }
 }
 
 template <typename OP, int NTT, int FT>
-__global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 1) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
   using L = FwdLayout<OP, NTT, FT>;
   using E = typename OP::E;
   using Frag = typename OP::Frag;
@@ -741,15 +753,20 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
         }
         sum = xor32_sum(sum);
         const float inv = __builtin_amdgcn_rcpf(sum);
-        float p[16];
+        // P of the query's own sample is packed ONCE; the two k-halves of the operand (keys of sample 0 | keys of sample 1) are
+        // that fragment or zero, selected per packed dword: cross-sample blocks of the shared 32x32 tile are exactly zero
+        float p[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float pv = sv[i] * inv;
-          p[i] = sp ? 0.f : pv;       // cross-sample blocks of the shared 32x32 tile are exactly zero
-          p[8 + i] = sp ? pv : 0.f;
+        for (int i = 0; i < 8; ++i) p[i] = sv[i] * inv;
+        union FragBits { Frag f; unsigned u[sizeof(Frag) / 4]; } own, lo_half, hi_half;
+        own.f = OP::pack8(p);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Frag) / 4); ++i) {
+          lo_half.u[i] = sp ? 0u : own.u[i];
+          hi_half.u[i] = sp ? own.u[i] : 0u;
         }
-        Ph[tt][0] = OP::pack8(p);
-        Ph[tt][1] = OP::pack8(p + 8);
+        Ph[tt][0] = lo_half.f;
+        Ph[tt][1] = hi_half.f;
       }
     };
     // accumulator tile (feature rows x token cols) + per-row bias -> the two k-halves of an MFMA operand
@@ -869,9 +886,16 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
+#if SCLDM_PAIR_STORE
+      for (int q = 0; q < 4; q += 2)
+        OP::store_quad_pair(AO + (tt * 32 + c32) * L::XA_LD, fbase + ft * 32 + q * 8, hh,
+                            OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]),
+                            OP::pack4(acc[ft][tt][q * 4 + 4], acc[ft][tt][q * 4 + 5], acc[ft][tt][q * 4 + 6], acc[ft][tt][q * 4 + 7]));
+#else
       for (int q = 0; q < 4; ++q)
         OP::store_quad(AO + (tt * 32 + c32) * L::XA_LD, fbase + ft * 32 + q * 8 + hh * 4,
                        OP::pack4(acc[ft][tt][q * 4 + 0], acc[ft][tt][q * 4 + 1], acc[ft][tt][q * 4 + 2], acc[ft][tt][q * 4 + 3]));
+#endif
   lds_barrier();  // AO complete
   SCLDM_STAMP(6);
 
@@ -968,10 +992,15 @@ __global__ __launch_bounds__(64 * (8 / FT), (OP::kTwoWG && NTT <= 2) ? 2 : 1) vo
     for (int ft = 0; ft < TILES; ++ft) {
       const int col0 = HALF ? wave * 16 : (wave * FT + ft) * 16;
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
+      for (int tt = 0; tt < NTT; ++tt) {
+#if SCLDM_PAIR_STORE
+        OP::store_quad_pair(HBc + (tt * 32 + c32) * L::HB_LD, col0, hh, hq[ft][tt][0], hq[ft][tt][1]);
+#else
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           OP::store_quad(HBc + (tt * 32 + c32) * L::HB_LD, col0 + q * 8 + hh * 4, hq[ft][tt][q]);
+#endif
+      }
     }
     if (c == 0) SCLDM_STAMP(11);
     lds_barrier();

@@ -403,7 +403,7 @@ struct DecGeneArgs {
 constexpr int kDecWaves = SCLDM_DEC_WAVES;
 constexpr int kDecThreads = 64 * kDecWaves;
 template <bool BF>
-__global__ __launch_bounds__(kDecThreads, kDecWaves == 8 ? 4 : 1) void dec_gene_kernel(const DecGeneArgs a) {
+__global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
   constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : 12 * 64, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
   __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4
   __shared__ f32x4 KV[kKV4];    // fp32: this cell's 48 K/V fragments
