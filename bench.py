@@ -338,8 +338,8 @@ def cpu_baseline(m, wl, target_s=6.0):
     """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on this box's host
     cores over a bounded sample of the SAME workload: the full number of CFG evaluations on a reduced cell count (chosen from a
     short calibration so that one solve takes about `target_s` seconds), warm-up 1 solve, median of 3 - measured, not
-    extrapolated.  Thread count: all host cores, unless the calibration shows that 32 or 16 threads are faster on these small
-    GEMMs (oversubscribed OpenMP teams are slower, not faster); `cores` reports the count actually used."""
+    extrapolated.  Thread count: the fastest of 16 / 32 / 64 threads (or all host threads when there are fewer) in a short
+    calibration; `cores` reports the count actually used, `host_cores` what the box has."""
     from oracle.dit import DiTConfig, dit_forward_with_cfg
     from oracle.transport import sample_ode_fixed
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -355,7 +355,11 @@ def cpu_baseline(m, wl, target_s=6.0):
 
     all_cores = os.cpu_count() or 1
     tried = {}
-    for nt in sorted({all_cores, min(all_cores, 32), min(all_cores, 16)}):      # small teams first: they bound what "slow" means
+    # team sizes: 16, 32, 64 and all host threads when there are at most 64 of them - an oversubscribed OpenMP team on these
+    # 1.5k-row GEMMs is pathological (256 threads of the GPU boxes' EPYC 9575F host: 3-18 s per cell-evaluation against 1-3 ms
+    # with 16-32, measured in round 2), so larger teams are not even probed
+    cand = {min(all_cores, 16), min(all_cores, 32), min(all_cores, 64)}
+    for nt in sorted(cand):                             # small teams first: they bound what "slow" means
         torch.set_num_threads(nt)
         probe = solve(2, 2) / 2                         # 2 cells x 1 evaluation: first touch + a cheap look at this team size
         if tried and probe > 8 * min(tried.values()):   # oversubscribed OpenMP team (e.g. 256 threads on 1.5k-row GEMMs): seconds
