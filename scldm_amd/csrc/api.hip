@@ -34,16 +34,16 @@ static const int kNPrec = 3;
 
 // Kernel shape: (token tiles of 32*NTT, FT feature tiles per wave => 8/FT waves per workgroup).
 //   fp32   : NTT=2, FT=2 (4 waves, one per SIMD, 512-register budget)
-//   bf16   : NTT=2, FT=2, two workgroups per CU by default; FT=1 (8 waves, one head each) and the 128-token tile of the
-//            8-wave shape (NTT=4, FT=1: each weight fragment feeds four token tiles) remain selectable through
-//            SCLDM_FT / SCLDM_NTT for A/B runs
+//   bf16   : NTT=2, FT=2, two workgroups per CU by default; FT=1 (8 waves, one head each) stays selectable through SCLDM_FT
+//            for A/B runs.  128-token tiles (NTT=4) were measured with both wave shapes and dropped: FT=2 needs the 512-register
+//            budget of one wave per SIMD and loses the second workgroup (450 vs 337 us per layer, round 1), FT=1 keeps eight
+//            lockstep waves and still spills (1594 vs 1270 us per 4-layer launch, round 2)
 //   bf16x3 : NTT=2, FT=2 (one workgroup per CU: 155 KB of LDS); SCLDM_X3_FT=1 selects the 8-wave shape
 static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
   *ntt = 2;
   *ft = 2;
   if (prec == SCLDM_PREC_BF16) {
     if (h->force_ft == 1 || h->force_ft == 2) *ft = h->force_ft;
-    if (h->force_ntt == 4 && *ft == 1) *ntt = 4;
   } else if (prec == SCLDM_PREC_BF16X3) {
     if (h->force_x3_ft == 1) *ft = 1;
     else if (h->force_x3_ntt == 1) *ntt = 1;   // 32-token tiles: 79 KB of LDS, two workgroups per CU
@@ -79,7 +79,6 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
     return SCLDM_OK;
   }
   // run-time knobs are read ONCE, here (they select kernel shapes and therefore which weight streams exist)
-  if (const char* e = getenv("SCLDM_NTT")) h->force_ntt = atoi(e);
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_NTT")) h->force_x3_ntt = atoi(e);
@@ -376,7 +375,7 @@ static int launch_fwd(int prec, int ntt, int ft, const FwdArgs& a, hipStream_t s
   if (prec == SCLDM_PREC_FP32) return launch_fwd_t<OpF32, 2, 2>(a, st);
   if (prec == SCLDM_PREC_BF16X3)
     return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : ntt == 1 ? launch_fwd_t<OpBF16x3, 1, 2>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
-  if (ft == 1) return ntt == 4 ? launch_fwd_t<OpBF16, 4, 1>(a, st) : launch_fwd_t<OpBF16, 2, 1>(a, st);
+  if (ft == 1) return launch_fwd_t<OpBF16, 2, 1>(a, st);
   return launch_fwd_t<OpBF16, 2, 2>(a, st);
 }
 

@@ -40,6 +40,6 @@ struct scldm_dit {
   int* d_dirty;    // [0] re-pack flag written by the compare kernel, [1] force flag
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
   hipEvent_t fork_ev, join_ev[3];
-  int force_ntt, force_ft, force_x3_ft, force_x3_ntt;
+  int force_ft, force_x3_ft, force_x3_ntt;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
 };
