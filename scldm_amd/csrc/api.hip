@@ -169,10 +169,7 @@ extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h-
 // fingerprint the parameter tensors, compare with the fingerprint of the packed copies, re-pack if they differ (all on
 // device, in stream order; `force` makes the first pack after scldm_dit_load_weights unconditional)
 static int run_pack(scldm_dit* h, bool force, hipStream_t st) {
-  if (force) {
-    const int one = 1;
-    HIP_TRY(hipMemcpyAsync(h->d_dirty + 1, &one, 4, hipMemcpyHostToDevice, st));
-  }
+  if (force) set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);   // (not a memcpy from a host stack variable: it must stay stream-ordered and asynchronous)
   fingerprint_kernel<<<h->n_fp, 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
   fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
   pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty);

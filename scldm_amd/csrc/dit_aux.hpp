@@ -141,6 +141,7 @@ struct FpSrc {
 };
 __global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
   const FpSrc s = src[blockIdx.x];
+  if (s.n <= 0) return;
   const long long cnt = s.n < 4096 ? s.n : 4096;
   const long long step = s.n / cnt;
   unsigned long long hsum = 0;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restric
   if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
 }
 // state[0] = accumulator of the current pass, state[1] = fingerprint of the packed weights; dirty[0] = re-pack?, dirty[1] = force
+__global__ void set_word_kernel(int* p, int v) { *p = v; }
 __global__ void fingerprint_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty) {
   dirty[0] = (state[0] != state[1]) || dirty[1];
   dirty[1] = 0;

@@ -319,7 +319,7 @@ extern "C" int scldm_mmd_kernel_sum(const float* x, int nx, const float* y, int 
 // ---- entropic optimal transport (Sinkhorn) for the Wasserstein generation metrics -----------------------------------
 #include "sinkhorn.hpp"
 
-static size_t sk_layout(int n, int m, size_t* off) {   // M | K | u | v | ktu | part | rowcost | scalars
+static size_t sk_layout(int n, int m, size_t* off) {   // M | K | u | v | ktu | part | rowcost | scalars | mmd scratch | u_new | v_new
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
   off[0] = take((size_t)n * m * 4);
@@ -331,11 +331,13 @@ static size_t sk_layout(int n, int m, size_t* off) {   // M | K | u | v | ktu | 
   off[6] = take((size_t)n * 4);
   off[7] = take(256);
   off[8] = take(scldm_mmd_workspace_bytes(n, m));
+  off[9] = take((size_t)n * 4);
+  off[10] = take((size_t)m * 4);
   return o;
 }
 extern "C" size_t scldm_sinkhorn_workspace_bytes(int n, int m) {
   if (n < 1 || m < 1) return 0;
-  size_t off[9];
+  size_t off[11];
   return sk_layout(n, m, off);
 }
 
@@ -347,7 +349,7 @@ extern "C" int scldm_wasserstein_sinkhorn(const float* x0, int n, const float* x
   if (power != 1 && power != 2) return fail(SCLDM_ERR_SHAPE, "power must be 1 or 2 (evaluations.py:92)");
   if (!(reg > 0.f)) return fail(SCLDM_ERR_SHAPE, "reg must be positive");
   hipStream_t st = (hipStream_t)stream_;
-  size_t off[9];
+  size_t off[11];
   sk_layout(n, m, off);
   char* base = (char*)ws;
   float *M = (float*)(base + off[0]), *K = (float*)(base + off[1]), *u = (float*)(base + off[2]), *v = (float*)(base + off[3]);
@@ -368,9 +370,7 @@ extern "C" int scldm_wasserstein_sinkhorn(const float* x0, int n, const float* x
   LAUNCH_CHECK();
   // an iteration computes candidate scalings and commits them on device unless one of them was singular: the state then
   // freezes at the last good (u, v), which is what POT's per-iteration "numerical errors" exit returns
-  float *u_new = nullptr, *v_new = nullptr;
-  HIP_TRY(hipMalloc((void**)&u_new, (size_t)n * 4));
-  HIP_TRY(hipMalloc((void**)&v_new, (size_t)m * 4));
+  float *u_new = (float*)(base + off[9]), *v_new = (float*)(base + off[10]);   // (in the caller's workspace: no allocation in the call)
   long long it = 0;
   int status = 0;   // 0 converged, 1 iteration limit, 2 numerical breakdown (previous scalings kept)
   bool have_ktu = false;
@@ -408,8 +408,6 @@ extern "C" int scldm_wasserstein_sinkhorn(const float* x0, int n, const float* x
   LAUNCH_CHECK();
   HIP_TRY(hipMemcpyAsync(cost_out, dsum, 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  (void)hipFree(u_new);
-  (void)hipFree(v_new);
   if (iters_out) *iters_out = it;
   if (status_out) *status_out = status;
   return SCLDM_OK;
