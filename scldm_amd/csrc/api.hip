@@ -151,7 +151,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty};
+                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -168,14 +168,23 @@ extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h-
 
 // fingerprint the parameter tensors, compare with the fingerprint of the packed copies, re-pack if they differ (all on
 // device, in stream order; `force` makes the first pack after scldm_dit_load_weights unconditional)
-static int run_pack(scldm_dit* h, bool force, hipStream_t st) {
+// prec_mask: which streams to refresh (bit p: precision p's forward stream; 0x100: the backward stream); anything but "all"
+// leaves the other streams stale, so the next full refresh is forced
+static const unsigned kPackAll = 0x1ffu;
+int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st) {
+  if (prec_mask == kPackAll && h->partial_pack) {
+    force = true;
+    h->partial_pack = false;
+  }
+  if (prec_mask != kPackAll) h->partial_pack = true;
   if (force) set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);   // (not a memcpy from a host stack variable: it must stay stream-ordered and asynchronous)
   fingerprint_kernel<<<h->n_fp, 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
   fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
-  pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty);
+  pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty, prec_mask);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
+static int run_pack(scldm_dit* h, bool force, hipStream_t st) { return scldm_run_pack(h, force, kPackAll, st); }
 
 extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* stream_) {
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
@@ -184,8 +193,24 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
                 "this shape is served by scldm_dit_train_forward / _backward only", h->cfg.n_embed, h->cfg.n_head, h->cfg.seq_len,
                 h->cfg.n_embed_input);
   hipStream_t st = (hipStream_t)stream_;
+  h->tables_built = false;   // an explicit load always rebuilds the tables (the caller may have re-allocated its parameters in place)
+  int rc = scldm_build_pack_tables(h, w, st);
+  if (rc) return rc;
+  if ((rc = run_pack(h, true, st))) return rc;
+  h->loaded = true;
+  return SCLDM_OK;
+}
+
+int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   const scldm_dit_config& c = h->cfg;
   const int L = c.n_layer, din = c.n_embed_input, H = c.hidden_dim, mw = h->mod_w;
+  // the per-layer members are host arrays (re-created by the caller for every call): the key is the device pointers themselves
+  std::vector<const void*> key = {w->pos_embed, w->t_w0, w->t_b0, w->t_w2, w->t_b2, w->in_w, w->in_b, w->fin_w, w->fin_b, w->fin_ada_w,
+                                  w->fin_ada_b, h->bwd_stream};
+  for (int ci = 0; ci < c.n_classes; ++ci) key.push_back(w->class_emb[ci]);
+  for (int i = 0; i < L; ++i)
+    for (const float* const* arr : {w->attn_w, w->attn_b, w->proj_w, w->proj_b, w->w1, w->w2, w->cproj, w->ada_w, w->ada_b}) key.push_back(arr[i]);
+  if (h->tables_built && key == h->table_key) return SCLDM_OK;
   std::vector<PackJob> jobs;
   std::vector<FpSrc> fps;
   int blocks = 0;
@@ -215,6 +240,10 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
         const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
         add(kPackLayer, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->stream[p][f], {H, nc, hf, f + 1, p}, npk * i);
       }
+    if (h->bwd_stream) {
+      const long long npk = (long long)8 * kBwdUnitsLayer * 512;
+      add(kPackLayerBwd, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->bwd_stream, {H}, npk * i);
+    }
     add(kPackCopy, 768, {src(w->attn_b[i], 768)}, h->b_qkv + (size_t)i * 768, {});
     add(kPackCopy, 256, {src(w->proj_b[i], 256)}, h->b_proj + (size_t)i * 256, {});
     // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
@@ -257,9 +286,8 @@ extern "C" int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, 
   h->n_jobs = (int)jobs.size();
   h->job_blocks = blocks;
   h->n_fp = (int)fps.size();
-  int rc = run_pack(h, true, st);
-  if (rc) return rc;
-  h->loaded = true;
+  h->table_key = key;
+  h->tables_built = true;
   return SCLDM_OK;
 }
 
@@ -384,7 +412,7 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   int ntt, ft;
   pick_shape(h, prec, &ntt, &ft);
   const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks[ft - 1], h->half[ft - 1]) * 1024;
-  FwdArgs a;
+  FwdArgs a{};
   a.z = x;
   a.out = out;
   a.x = hbuf;

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.hpp"
 #include "dit_forward.hpp"
+#include "bwd_layout.hpp"
 
 namespace scldm {
 
@@ -68,6 +69,44 @@ __device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, 
   return val;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight stream of the fused BACKWARD layer (dit_backward.hpp; bf16, eight waves, one 32-row tile per wave: a unit is ONE
+// fragment of 512 elements, element (gu, l, j) at (gu*64 + l)*8 + j, row l&31, k = ks*16 + (l>>5)*8 + j).  Wave w, units
+//   chunk c (3 chunks of 256 hidden units, hid = c*256 + w*32 + r; hid >= H is exact zero padding):
+//     0-15  c_proj^T   row r = hidden unit hid,        k = output feature            (d hid = c_proj^T dy2)
+//     16-31 w1         row r = hidden unit hid,        k = input feature             (recompute a)
+//     32-47 w2         row r = hidden unit hid,        k = input feature             (recompute b)
+//     48-79 [w1^T|w2^T] row r = feature w*32 + r,      k < 256: w1 unit c*256 + k, else w2 unit c*256 + k - 256   (d h2)
+//   240-255 c_proj(attn)^T  row = feature w*32 + r (head w's d), k = output feature  (d ao = c_proj^T dy1)
+//   256-303 c_attn rows p*256 + w*32 + r, p = q, k, v (16 units each)                (recompute q, k, v of head w)
+//   304-351 c_attn^T  row = feature w*32 + r,          k = c_attn output row (768)   (d h1 = c_attn^T d qkv)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pack_bwd_val(const float* __restrict__ Wqkv, const float* __restrict__ Wproj,
+                                              const float* __restrict__ W1, const float* __restrict__ W2,
+                                              const float* __restrict__ Wcp, long long idx, int H) {
+  const int j = idx & 7, l = (idx >> 3) & 63;
+  const int gu = (int)(idx >> 9), w = gu / kBwdUnitsLayer, u = gu % kBwdUnitsLayer;
+  const int r = l & 31, k8 = (l >> 5) * 8 + j;
+  const int frow = w * 32 + r;
+  if (u < kBwdChunks * kBwdUnitsChunk) {
+    const int c = u / kBwdUnitsChunk, v = u % kBwdUnitsChunk;
+    const int hid = c * kBwdChunk + w * 32 + r;
+    if (v < 16) return hid < H ? Wcp[(size_t)(v * 16 + k8) * H + hid] : 0.f;
+    if (v < 32) return hid < H ? W1[(size_t)hid * 256 + (v - 16) * 16 + k8] : 0.f;
+    if (v < 48) return hid < H ? W2[(size_t)hid * 256 + (v - 32) * 16 + k8] : 0.f;
+    const int kk = (v - 48) * 16 + k8;                      // 0..511
+    const int hk = c * kBwdChunk + (kk & 255);
+    return hk < H ? (kk < 256 ? W1 : W2)[(size_t)hk * 256 + frow] : 0.f;
+  }
+  const int v = u - kBwdChunks * kBwdUnitsChunk;
+  if (v < 16) return Wproj[(size_t)(v * 16 + k8) * 256 + frow];
+  if (v < 64) {
+    const int p = (v - 16) >> 4, ks = (v - 16) & 15;
+    return Wqkv[(size_t)(p * 256 + frow) * 256 + ks * 16 + k8];
+  }
+  return Wqkv[(size_t)((v - 64) * 16 + k8) * 256 + frow];
+}
+
 // Store packed element `idx` (fragment-major: 8 consecutive indices = one lane's 8 k-values) in the stream's precision.
 //   prec 0: fp32   1: bf16   2: split-bf16 (the 8 hi values then the 8 lo values of a lane: 32 bytes per lane-fragment)
 __device__ __forceinline__ void pack_store(void* out, long long idx, float val, int prec) {
@@ -88,7 +127,7 @@ __device__ __forceinline__ void pack_store(void* out, long long idx, float val, 
 // All packing of one scldm_dit_load_weights call is ONE launch over a table of jobs (was ~80 launches), so that it can
 // also be re-run conditionally, on device, by scldm_dit_refresh_weights: every block first reads the `dirty` word.
 // ------------------------------------------------------------------------------------------------
-enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFinal = 3 };
+enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFinal = 3, kPackLayerBwd = 4 };
 struct PackJob {
   int kind;
   int first_block;      // first 256-thread block of this job
@@ -98,7 +137,10 @@ struct PackJob {
   int p[6];             // kind-specific: copy -; transpose N,K,ldo,col0; layer H,n_chunks,half,FT,prec; final din,prec
   long long d_off;      // element offset added to the destination index (layer: start of the layer's stream)
 };
-__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty) {
+// prec_mask: bit p set = pack the streams of precision p (kPackLayer / kPackFinal jobs of other precisions are skipped - the
+// training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty,
+                                                        unsigned prec_mask) {
   if (dirty && *dirty == 0) return;
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {
@@ -118,13 +160,19 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       reinterpret_cast<float*>(j.d)[(size_t)k * ldo + col0 + n] = j.s[0][(size_t)n * K + k];
       break;
     }
+    case kPackLayerBwd:
+      if (!(prec_mask & 0x100u)) return;
+      reinterpret_cast<__bf16*>(j.d)[j.d_off + idx] = (__bf16)pack_bwd_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0]);
+      break;
     case kPackLayer:
+      if (!((prec_mask >> j.p[4]) & 1u)) return;
       pack_store(j.d, j.d_off + idx,
                  pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3],
                                 j.p[4] == 1 ? OpBF16::kW1Scale : 1.0f, j.p[4] == 1 ? OpBF16::kW2Scale : 1.0f),
                  j.p[4]);
       break;
     case kPackFinal: {  // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
+      if (!((prec_mask >> j.p[1]) & 1u)) return;
       const int jj = idx & 7, l = (idx >> 3) & 63, ks = (int)(idx >> 9);
       const int row = l & 31, k = ks * 16 + (l >> 5) * 8 + jj;
       pack_store(j.d, idx, (row < j.p[0]) ? j.s[0][row * 256 + k] : 0.f, j.p[1]);

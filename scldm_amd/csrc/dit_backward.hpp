@@ -1,0 +1,574 @@
+// Fused BACKWARD of one adaLN-Zero DiT layer for gfx950 (training path, bf16 operands / fp32 accumulation): one launch =
+// one transformer block over all samples, one workgroup per 64-token tile (4 samples).  The only saved state it reads is the
+// record the REC forward kernel wrote (dit_forward.hpp): the layer's input residual (fp32) and the two gated branch outputs
+// y1, y2 (bf16); everything else (LayerNorms, q/k/v, softmax, SwiGLU pre-activations) is recomputed in registers / LDS.
+//
+// Differentiates (reference arithmetic): Block.forward adaLN branch src/scldm/layers.py:208-221, modulate :91-94,
+// SelfAttention.forward :143-158, MLP.forward :161-174.  The reference gets these gradients from torch autograd.
+//
+// Outputs: the gradient w.r.t. the layer input (in place, same private tile layout as the residual hand-off), the gradient
+// w.r.t. the six adaLN vectors of every sample (dmod), and - for the weight gradients, which are sums over ALL tokens and so
+// cannot be owned by a tile - the bf16 operand pairs (dY, X) of the layer's five weight-gradient GEMMs in plain [token][feature]
+// layout; wgrad_bf16_kernel (train_fused.hip) contracts them over the token axis afterwards.
+//
+// Shape: 8 waves, wave w owns the 32 features [32w, 32w+32) = attention head w; GEMMs are computed transposed exactly as in
+// the forward kernel (weights streamed L2 -> VGPR ring as pre-packed fragments, activations as [token][feature] bf16 LDS
+// images), so every matrix product below is a gemm_pass over a different packed stream (dit_aux.hpp: pack_bwd_val).
+#pragma once
+#include "bwd_layout.hpp"
+#include "dit_forward.hpp"
+
+namespace scldm {
+namespace bwd {
+
+using OP = OpBF16;
+using E = __bf16;
+using Frag = bf16x8;
+using Quad = bf16x4;
+constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
+constexpr int PF = 4;
+constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;   // bf16 elements per image row (+16 B pad)
+constexpr int R0_OFF = 0;                                   // h2 image, later h1 image
+constexpr int R1_OFF = R0_OFF + TM * XA_LD * 2;             // dy2 image, later dy1 image
+constexpr int R2_OFF = R1_OFF + TM * XA_LD * 2;             // [da | db] image of one chunk
+constexpr int R_END = R2_OFF + TM * DADB_LD * 2;
+constexpr int DQKV_BYTES = TM * DQKV_LD * 2;                // aliases R0..R2 once the q/k/v/dao passes are done
+constexpr int TR_LD = 36;                                   // elements per row of a wave's 32x32 transpose scratch (72 B: conflict-free ds_read_b64)
+constexpr int TR_OFF = DQKV_BYTES;                          // inside R2's tail, behind the dqkv image
+constexpr int TR_BYTES = 32 * TR_LD * 2;
+static_assert(TR_OFF + NW * TR_BYTES <= R_END && TR_OFF % 8 == 0, "transpose scratch must fit behind the dqkv image");
+constexpr int MOD_OFF = R_END;
+constexpr int MOD_BYTES = NS * kModBlock * 2;               // fp16 copies of the six adaLN vectors of the tile's samples
+constexpr int RED_OFF = MOD_OFF + MOD_BYTES;
+constexpr int RED_BYTES = 2 * NW * TM * 4;
+constexpr int BIAS_OFF = RED_OFF + RED_BYTES;
+constexpr int LDS_BYTES = BIAS_OFF + 3 * kD * 4;
+
+struct BwdArgs {
+  const float* x_in;      // record: residual entering this layer (tile layout of the 4-wave forward kernel)
+  const __bf16* y1;       // record: c_proj(attention) + bias
+  const __bf16* y2;       // record: MLP output
+  float* dx;              // in: gradient w.r.t. the layer output; out: w.r.t. the layer input (tile layout)
+  const float* mod;       // (n, mod_stride) adaLN vectors; this layer's six at mod_off
+  float* dmod;            // same indexing: gradient w.r.t. the adaLN vectors
+  int mod_stride, mod_off;
+  const __bf16* w_stream; // this layer's backward stream (pack_bwd_val)
+  const float* b_qkv;     // (768) c_attn bias of this layer
+  // operand pairs of the weight-gradient GEMMs, plain [token][ld] bf16
+  __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
+  int n;                  // samples (multiple of 4)
+  float eps, attn_scale, attn_scale_log2e;
+};
+
+__device__ __forceinline__ void wave_sync() {   // orders this wave's LDS writes before its following LDS reads (compiler + hardware)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// sum over the 16 lanes of a DPP row (= the 16 tokens of one sample), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+
+// quads q (q0) and q+1 (q1) of a 32-feature tile -> 16 bytes per lane (features f8 + 8*hh .. +7 of the lane's token), stored
+// to the LDS image row and, when grow != nullptr, to the same position of the plain global operand array
+__device__ __forceinline__ void put_pair(E* lrow, E* grow, int f8, int hh, const Quad& q0, const Quad& q1) {
+  union { Quad q; unsigned u[2]; } a, b;
+  a.q = q0; b.q = q1;
+  halfwave_pair(a.u[0], b.u[0]);
+  halfwave_pair(a.u[1], b.u[1]);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 v = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+  if (lrow) *reinterpret_cast<u32x4*>(lrow + f8 + 8 * hh) = v;
+  if (grow) *reinterpret_cast<u32x4*>(grow + f8 + 8 * hh) = v;
+}
+// a whole accumulator tile (32 features x 32 tokens of token tile tt) -> image / operand array columns [col0, col0 + 32)
+__device__ __forceinline__ void put_tile(const float (&t)[16], E* lrow, E* grow, int col0, int hh) {
+#pragma unroll
+  for (int q = 0; q < 4; q += 2)
+    put_pair(lrow, grow, col0 + q * 8, hh, OP::pack4(t[q * 4 + 0], t[q * 4 + 1], t[q * 4 + 2], t[q * 4 + 3]),
+             OP::pack4(t[q * 4 + 4], t[q * 4 + 5], t[q * 4 + 6], t[q * 4 + 7]));
+}
+
+// accumulator tile X^T[row = acc_row(r, hh)][col = c32] -> the wave's transpose scratch T[row][col]
+__device__ __forceinline__ void tr_write(E* T, const f32x16& x, int c32, int hh) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) T[acc_row(r, hh) * TR_LD + c32] = (E)x[r];
+}
+// the query's eight own-sample values (keys 16 sp + acc_row(i, hh)) -> T[key][query]; the other sample's keys are zero
+__device__ __forceinline__ void tr_write_own(E* T, const float (&v)[8], int sp, int c32, int hh) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    T[(16 * sp + acc_row(i, hh)) * TR_LD + c32] = (E)v[i];
+    T[(16 * (1 - sp) + acc_row(i, hh)) * TR_LD + c32] = (E)0.f;
+  }
+}
+// fragment h (columns 16h .. 16h+15 as the k axis) of row c32, k slots in the accumulator's row order (slot (hh, j) <-> column
+// 16h + (j&3) + 8 (j>>2) + 4 hh): the order pack8() gives the register-built partner operand
+__device__ __forceinline__ Frag tr_read(const E* T, int c32, int hh, int h) {
+  const E* p = T + c32 * TR_LD + 16 * h + 4 * hh;
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p), b = *reinterpret_cast<const bf16x4*>(p + 8);
+  Frag f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+  return f;
+}
+
+__global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  E* R0 = reinterpret_cast<E*>(smem + R0_OFF);
+  E* R1 = reinterpret_cast<E*>(smem + R1_OFF);
+  E* R2 = reinterpret_cast<E*>(smem + R2_OFF);
+  E* DQKV = reinterpret_cast<E*>(smem);
+  using ModE = OP::ModE;
+  ModE* MOD = reinterpret_cast<ModE*>(smem + MOD_OFF);
+  float* RED = reinterpret_cast<float*>(smem + RED_OFF);
+  float* BIAS = reinterpret_cast<float*>(smem + BIAS_OFF);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c32 = lane & 31, hh = lane >> 5, sp = c32 >> 4;
+  const int tile = blockIdx.x;
+  const int tok0 = tile * TM, smp0 = tile * NS;
+  const int fb = wave * 32;   // first feature / head dimension owned by this wave
+  E* TR = reinterpret_cast<E*>(smem + TR_OFF + wave * TR_BYTES);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  WStream<OP, PF, 1> ws;
+  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
+
+  // record / gradient tiles in the 4-wave forward kernel's layout: forward wave = wave >> 1, its feature tile = wave & 1
+  auto tile_off = [&](int tt, int q) { return ((size_t)((tile * 4 + (wave >> 1)) * 16 + (tt * 2 + (wave & 1)) * 4 + q) * 64 + lane) * 4; };
+  auto load_f32 = [&](const float* base, float (&dst)[NTT][16]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(base + tile_off(tt, q));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = t4[i];
+      }
+  };
+  auto load_bf16 = [&](const __bf16* base, float (&dst)[NTT][16]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(base + tile_off(tt, q));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = (float)t4[i];
+      }
+  };
+  // adaLN vector `vec` of the lane's sample, the four features of register quad q
+  auto mod4 = [&](int tt, int vec, int q) { return OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + vec * kD + fb + q * 8 + hh * 4); };
+  // sum over the 16 tokens of each sample of a per-(feature, token) quantity -> dmod[sample][vec][feature]
+  auto dmod_store = [&](const float (&v)[NTT][16], int vec) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float tot[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[r] = row16_sum(v[tt][r]);
+      if ((c32 & 15) == 0) {
+        float* dst = a.dmod + (size_t)(smp0 + tt * 2 + sp) * a.mod_stride + a.mod_off + vec * kD + fb + hh * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + q * 8) = f32x4{tot[q * 4], tot[q * 4 + 1], tot[q * 4 + 2], tot[q * 4 + 3]};
+      }
+    }
+  };
+  // LayerNorm statistics of every token of the tile (one sweep; fp32): in-lane sums -> half-wave exchange -> 8-way LDS combine
+  auto ln_stats = [&](const float (&v)[NTT][16], float (&mean)[NTT], float (&rstd)[NTT]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s += v[tt][r];
+        ss = fmaf(v[tt][r], v[tt][r], ss);
+      }
+      s = xor32_sum(s);
+      ss = xor32_sum(ss);
+      if (hh == 0) {
+        RED[wave * TM + tt * 32 + c32] = s;
+        RED[NW * TM + wave * TM + tt * 32 + c32] = ss;
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float m = 0.f, e2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        m += RED[w * TM + tt * 32 + c32];
+        e2 += RED[NW * TM + w * TM + tt * 32 + c32];
+      }
+      mean[tt] = m * (1.0f / kD);
+      rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean[tt], mean[tt], e2 * (1.0f / kD)), 0.f) + a.eps);
+    }
+    lds_barrier();   // RED may be rewritten by the next reduction
+  };
+  // y = LN(v) * S + shift (S = 1 + scale, staged) -> LDS image + operand array
+  auto ln_modulate = [&](const float (&v)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v, int sh_v, E* img, E* gout) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const float nmr = -mean[tt] * rstd[tt];
+      float y[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = mod4(tt, sc_v, q), sh = mod4(tt, sh_v, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[q * 4 + i] = fmaf(fmaf(v[tt][q * 4 + i], rstd[tt], nmr), sc[i], sh[i]);
+      }
+      put_tile(y, img + (tt * 32 + c32) * XA_LD, gout + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+    }
+  };
+  // backward of y = LN(x) * S + shift given dh = d y (accumulator tiles): dres += d x; dmod[sc_v] = sum_t dh xhat, dmod[sh_v] = sum_t dh
+  auto ln_backward = [&](const f32x16 (&dh)[NTT], const float (&x)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v,
+                         int sh_v, float (&dres)[NTT][16]) {
+    float t1[NTT][16];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      const float nmr = -mean[tt] * rstd[tt];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = mod4(tt, sc_v, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = q * 4 + i;
+          const float xh = fmaf(x[tt][r], rstd[tt], nmr), g = dh[tt][r] * sc[i];
+          s1 += g;
+          s2 = fmaf(g, xh, s2);
+          t1[tt][r] = dh[tt][r] * xh;
+        }
+      }
+      s1 = xor32_sum(s1);
+      s2 = xor32_sum(s2);
+      if (hh == 0) {
+        RED[wave * TM + tt * 32 + c32] = s1;
+        RED[NW * TM + wave * TM + tt * 32 + c32] = s2;
+      }
+    }
+    dmod_store(t1, sc_v);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t1[tt][r] = dh[tt][r];
+    dmod_store(t1, sh_v);
+    lds_barrier();
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        s1 += RED[w * TM + tt * 32 + c32];
+        s2 += RED[NW * TM + w * TM + tt * 32 + c32];
+      }
+      s1 *= (1.0f / kD);
+      s2 *= (1.0f / kD);
+      const float nmr = -mean[tt] * rstd[tt];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sc = mod4(tt, sc_v, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = q * 4 + i;
+          const float xh = fmaf(x[tt][r], rstd[tt], nmr), g = dh[tt][r] * sc[i];
+          dres[tt][r] = fmaf(rstd[tt], g - s1 - xh * s2, dres[tt][r]);
+        }
+      }
+    }
+    lds_barrier();
+  };
+  auto bias_tile = [&](const float* brow) {
+    f32x16 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + q * 8 + hh * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[q * 4 + i] = b4[i];
+    }
+    return t;
+  };
+  auto to_frags = [&](const f32x16& t_acc, Frag (&F)[2]) {
+    float t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = t_acc[r];
+    F[0] = OP::pack8(t);
+    F[1] = OP::pack8(t + 8);
+  };
+  // eight own-sample values of a query lane -> the two k-halves (keys of sample 0 | sample 1) of an MFMA operand, cross-sample zeros
+  auto masked_frags = [&](const float (&v)[8], Frag (&F)[2]) {
+    union FragBits { Frag f; unsigned u[4]; } own, lo_half, hi_half;
+    own.f = OP::pack8(v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo_half.u[i] = sp ? 0u : own.u[i];
+      hi_half.u[i] = sp ? own.u[i] : 0u;
+    }
+    F[0] = lo_half.f;
+    F[1] = hi_half.f;
+  };
+
+  // ---- stage the adaLN vectors (scales as 1 + scale) and the c_attn bias ----
+  {
+    constexpr int kModLd = NS * kModBlock / 4 / NT;   // 3 float4 per thread
+    static_assert(NS * kModBlock / 4 % NT == 0, "whole float4 per thread");
+#pragma unroll
+    for (int j = 0; j < kModLd; ++j) {
+      const int idx = tid + NT * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+      f32x4 m = *reinterpret_cast<const f32x4*>(a.mod + (size_t)(smp0 + sl) * a.mod_stride + a.mod_off + w4 * 4);
+      const int vec = w4 / (kD / 4);
+      if (vec == 0 || vec == 3) m += 1.0f;
+      OP::store_mod4(MOD + (size_t)idx * 4, m);
+    }
+    if (tid < 3 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + tid * 4) = *reinterpret_cast<const f32x4*>(a.b_qkv + tid * 4);
+  }
+  float dxr[NTT][16];   // gradient of the residual stream (d x_out, then d x_mid, then d x_in)
+  float xr[NTT][16];    // x_mid, later x_in
+  load_f32(a.dx, dxr);
+  lds_barrier();
+
+  // ================= MLP branch: x_out = x_mid + a5 * c_proj(silu(w1 h2) * (w2 h2)),  h2 = LN(x_mid) (1 + a3) + a4 =================
+  {
+    float t[NTT][16];
+    load_bf16(a.y2, t);   // y2
+    // d a5 = sum_t d x_out * y2;  d y2 = a5 * d x_out -> image R1 + operand array
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float dy[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = mod4(tt, 5, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dy[q * 4 + i] = g[i] * dxr[tt][q * 4 + i];
+          t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
+        }
+      }
+      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, a.e_dy2 + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+    }
+    dmod_store(t, 5);
+    // x_mid = x_in + a2 * y1
+    load_f32(a.x_in, xr);
+    load_bf16(a.y1, t);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = mod4(tt, 2, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[tt][q * 4 + i] = fmaf(g[i], t[tt][q * 4 + i], xr[tt][q * 4 + i]);
+      }
+  }
+  float mean2[NTT], rstd2[NTT];
+  ln_stats(xr, mean2, rstd2);
+  ln_modulate(xr, mean2, rstd2, 3, 4, R0, a.e_h2);
+  lds_barrier();   // h2 and dy2 images complete
+
+  f32x16 dh[1][NTT];   // d h2 (this phase), later d h1
+  for (int c = 0; c < kBwdChunks; ++c) {
+    f32x16 ad[1][NTT], aa[1][NTT], ab[1][NTT];
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ad, ws, R1, XA_LD, lane);   // d hid^T = c_proj^T d y2 (this wave's 32 hidden units)
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(aa, ws, R0, XA_LD, lane);   // a^T = w1 h2
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ab, ws, R0, XA_LD, lane);   // b^T = w2 h2
+    if (c > 0) lds_barrier();   // every wave has finished the previous chunk's d h2 pass over R2
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float da[16], db[16], hid[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float av = aa[0][tt][r], bv = ab[0][tt][r], d = ad[0][tt][r];
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * av));
+        const float sl = av * s;
+        hid[r] = sl * bv;
+        da[r] = d * bv * (s * fmaf(av, 1.0f - s, 1.0f));
+        db[r] = d * sl;
+      }
+      const size_t grow = (size_t)(tok0 + tt * 32 + c32) * (kBwdChunks * kBwdChunk) + c * kBwdChunk;
+      put_tile(da, R2 + (tt * 32 + c32) * DADB_LD, a.e_da + grow, fb, hh);
+      put_tile(db, R2 + (tt * 32 + c32) * DADB_LD + kBwdChunk, a.e_db + grow, fb, hh);
+      put_tile(hid, nullptr, a.e_hid + grow, fb, hh);
+    }
+    lds_barrier();
+    if (c == 0) gemm_pass<OP, NTT, 1, 32, false, true, PF>(dh, ws, R2, DADB_LD, lane);    // d h2^T (+)= [w1^T | w2^T] [da | db]
+    else gemm_pass<OP, NTT, 1, 32, false, false, PF>(dh, ws, R2, DADB_LD, lane);
+  }
+  // d x_mid = d x_out + LN2-backward(d h2);  d a3, d a4
+  ln_backward(dh[0], xr, mean2, rstd2, 3, 4, dxr);
+
+  // ================= attention branch: x_mid = x_in + a2 * (c_proj(attention(c_attn(h1))) + b),  h1 = LN(x_in) (1 + a0) + a1 =================
+  {
+    float t[NTT][16];
+    load_bf16(a.y1, t);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float dy[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = mod4(tt, 2, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dy[q * 4 + i] = g[i] * dxr[tt][q * 4 + i];
+          t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
+        }
+      }
+      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, a.e_dy1 + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);   // d y1 (R1's last reader was chunk 2's d hid pass)
+    }
+    dmod_store(t, 2);
+  }
+  load_f32(a.x_in, xr);
+  float mean1[NTT], rstd1[NTT];
+  ln_stats(xr, mean1, rstd1);
+  ln_modulate(xr, mean1, rstd1, 0, 1, R0, a.e_h1);   // h1 (R0's last readers were chunk 2's a / b passes)
+  lds_barrier();
+
+  // q, k, v, d ao of head `wave`: as (token, k = head dim) operands straight from the accumulator tiles, and transposed
+  // ((head dim, k = token), through the wave's LDS scratch - R2's tail is free since the last d h2 pass)
+  Frag QF[NTT][2], KF[NTT][2], VF[NTT][2], GF[NTT][2];
+  Frag QT[NTT][2], KT[NTT][2], VT[NTT][2], GT[NTT][2];
+  {
+    f32x16 acc[1][NTT];
+    auto both = [&](Frag (&F)[NTT][2], Frag (&T)[NTT][2]) {
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        to_frags(acc[0][tt], F[tt]);
+        tr_write(TR, acc[0][tt], c32, hh);
+        wave_sync();
+        T[tt][0] = tr_read(TR, c32, hh, 0);
+        T[tt][1] = tr_read(TR, c32, hh, 1);
+        wave_sync();
+      }
+    };
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R1, XA_LD, lane);   // d ao^T = c_proj^T d y1
+    both(GF, GT);
+    f32x16 b = bias_tile(BIAS + 0 * kD + fb);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
+    both(QF, QT);
+    b = bias_tile(BIAS + 1 * kD + fb);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
+    both(KF, KT);
+    b = bias_tile(BIAS + 2 * kD + fb);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
+    both(VF, VT);
+  }
+  lds_barrier();   // every wave is done with the h1 / dy1 images: the dqkv image and the transpose scratch may overwrite them
+
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    // S^T[key][query] = K Q^T, softmax over the query's own sample
+    f32x16 st = OP::mma(KF[tt][0], QF[tt][0], zero16);
+    st = OP::mma(KF[tt][1], QF[tt][1], st);
+    float p[8];
+    {
+      float sv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float lo = st[i], hi = st[8 + i];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        sv[i] = sp ? hi : lo;
+      }
+      float m = sv[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m = fmaxf(m, sv[i]);
+      m = xor32_max(m);
+      float sum = 0.f;
+      const float nms = -m * a.attn_scale_log2e;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], a.attn_scale_log2e, nms));
+        sum += sv[i];
+      }
+      sum = xor32_sum(sum);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = sv[i] * inv;
+    }
+    Frag Ph[2];
+    masked_frags(p, Ph);
+    // O^T[d][query] = V^T P^T (operand for the c_proj weight gradient)
+    {
+      f32x16 ot = OP::mma(VT[tt][0], Ph[0], zero16);
+      ot = OP::mma(VT[tt][1], Ph[1], ot);
+      float o[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = ot[r];
+      put_tile(o, nullptr, a.e_ao + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+    }
+    // dP^T[key][query] = V dAO^T;  dS = P (dP - sum_key P dP) / sqrt(d)
+    f32x16 dpt = OP::mma(VF[tt][0], GF[tt][0], zero16);
+    dpt = OP::mma(VF[tt][1], GF[tt][1], dpt);
+    float ds[8];
+    {
+      float dp[8], dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float lo = dpt[i], hi = dpt[8 + i];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        dp[i] = sp ? hi : lo;
+        dot = fmaf(p[i], dp[i], dot);
+      }
+      dot = xor32_sum(dot);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ds[i] = p[i] * (dp[i] - dot) * a.attn_scale;
+    }
+    Frag dSh[2];
+    masked_frags(ds, dSh);
+    float o[16];
+    E* lrow = DQKV + (tt * 32 + c32) * DQKV_LD;
+    E* grow = a.e_dqkv + (size_t)(tok0 + tt * 32 + c32) * (3 * kD);
+    // dQ^T[d][query] = K^T dS^T
+    {
+      f32x16 dq = OP::mma(KT[tt][0], dSh[0], zero16);
+      dq = OP::mma(KT[tt][1], dSh[1], dq);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = dq[r];
+      put_tile(o, lrow, grow, fb, hh);
+    }
+    // dK^T[d][key] = Q^T dS
+    Frag T1[2];
+    tr_write_own(TR, ds, sp, c32, hh);
+    wave_sync();
+    T1[0] = tr_read(TR, c32, hh, 0);
+    T1[1] = tr_read(TR, c32, hh, 1);
+    wave_sync();
+    {
+      f32x16 dk = OP::mma(QT[tt][0], T1[0], zero16);
+      dk = OP::mma(QT[tt][1], T1[1], dk);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = dk[r];
+      put_tile(o, lrow, grow, kD + fb, hh);
+    }
+    // dV^T[d][key] = dAO^T P
+    tr_write_own(TR, p, sp, c32, hh);
+    wave_sync();
+    T1[0] = tr_read(TR, c32, hh, 0);
+    T1[1] = tr_read(TR, c32, hh, 1);
+    wave_sync();
+    {
+      f32x16 dv = OP::mma(GT[tt][0], T1[0], zero16);
+      dv = OP::mma(GT[tt][1], T1[1], dv);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = dv[r];
+      put_tile(o, lrow, grow, 2 * kD + fb, hh);
+    }
+  }
+  lds_barrier();   // dqkv image complete
+  gemm_pass<OP, NTT, 1, 48, false, true, PF>(dh, ws, DQKV, DQKV_LD, lane);   // d h1^T = c_attn^T d qkv
+  // d x_in = d x_mid + LN1-backward(d h1);  d a0, d a1
+  ln_backward(dh[0], xr, mean1, rstd1, 0, 1, dxr);
+
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(a.dx + tile_off(tt, q)) = f32x4{dxr[tt][q * 4], dxr[tt][q * 4 + 1], dxr[tt][q * 4 + 2], dxr[tt][q * 4 + 3]};
+}
+
+}  // namespace bwd
+}  // namespace scldm

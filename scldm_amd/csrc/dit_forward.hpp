@@ -122,6 +122,13 @@ struct FwdArgs {
   int mod_stride;
   float eps;
   float attn_scale_log2e;   // log2(e) / sqrt(head_dim)
+  // Training record (REC kernels only; dit_backward.hpp reads it): per layer the residual entering it (rec_x[layer], fp32;
+  // rec_x[n_layer] = the final layer's input) and the two gated branch outputs y1 = c_proj(attention) + b, y2 = MLP (bf16),
+  // all in the hand-off buffer's private tile layout.  rec_stride = elements per layer (= padded tokens * 256).
+  float* rec_x;
+  __bf16* rec_y1;
+  __bf16* rec_y2;
+  long rec_stride;
   unsigned long long* dbg;  // phase stamps [block][wave][kDbgStamps]; only -DSCLDM_PHASE_TIMING builds write
 };
 
@@ -494,7 +501,7 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
   }
 }
 
-template <typename OP, int NTT, int FT>
+template <typename OP, int NTT, int FT, bool REC = false>
 __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 1) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
   using L = FwdLayout<OP, NTT, FT>;
   using E = typename OP::E;
@@ -565,6 +572,35 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
 #pragma unroll
           for (int i = 0; i < 4; ++i) t4[i] = src[ft][tt][q * 4 + i];
           *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
+        }
+  };
+  // training record (REC): same lane-linear tile layout as the hand-off buffer
+  auto rec_store_x = [&](const float (&src)[FT][NTT][16], int layer_idx) {
+    float* xw = a.rec_x + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t4[i] = src[ft][tt][q * 4 + i];
+          *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
+        }
+  };
+  auto rec_store_y = [&](const f32x16 (&src)[FT][NTT], __bf16* base, int layer_idx) {
+    __bf16* yw = base + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bf16x4 t4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t4[i] = (__bf16)src[ft][tt][q * 4 + i];
+          *reinterpret_cast<bf16x4*>(yw + ((tt * FT + ft) * 4 + q) * 256) = t4;
         }
   };
   // Up to four consecutive layers per launch: the body below is instantiated once per layer slot (compile-time `li`), the
@@ -670,6 +706,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
   } else if (li == 0) {
     load_x(xr);
   }
+  if constexpr (REC) rec_store_x(xr, layer);
 
   // the tile's six adaLN vectors per sample: coalesced loads (issued AFTER the residual loads: the row_index -> mod
   // lookup is a dependent chain and would otherwise hold them back), parked in LDS during LN1 (16 lanes share every
@@ -913,6 +950,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
       }
     gemm_pass<OP, NTT, FT, 16, false, true, PF>(acc, ws, AO, L::XA_LD, lane, pbias);   // c_proj(attention) + bias
   }
+  if constexpr (REC) rec_store_y(acc, a.rec_y1, layer);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -1021,6 +1059,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
     ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)(li + 1) * (a.w_layer_elems / 8) +
             (size_t)wave * units_per_layer(a.n_chunks, a.half_chunk) * 64 * FT, lane);
 
+  if constexpr (REC) rec_store_y(accp, a.rec_y2, layer);
   // ---- gated residual (a5) ----
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
@@ -1045,6 +1084,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
     }
   } else {
     // ---- final layer (layers.py:397-401): LN -> *(1+scale)+shift with (shift, scale) = chunks (0,1) -> Linear 256->din ----
+    if constexpr (REC) rec_store_x(xr, a.n_layer);
     constexpr int kFinLd = (NS * 2 * kD / 4 + NT - 1) / NT;  // float4 per thread for the tile's (shift, scale) vectors
     f32x4 fstage[kFinLd];
 #pragma unroll

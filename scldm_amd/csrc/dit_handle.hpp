@@ -42,4 +42,13 @@ struct scldm_dit {
   hipEvent_t fork_ev, join_ev[3];
   int force_ft, force_x3_ft, force_x3_ntt;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
+  // fused training path (train_fused.hip)
+  void* bwd_stream;         // bf16 backward weight stream [layer][8 waves][kBwdUnitsLayer][512] (+ ring slack); allocated on first use
+  std::vector<const void*> table_key;  // every device pointer of the scldm_dit_weights the job / fingerprint tables were built from
+  bool tables_built;
+  bool partial_pack;        // the last pack refreshed only some precisions' streams: the next inference refresh is unconditional
 };
+
+// api.hip internals shared with train_fused.hip
+int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // (re)builds the device job tables if `w` changed
+int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st);

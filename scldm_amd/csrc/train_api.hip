@@ -7,6 +7,7 @@
 #include "api_common.hpp"
 #include "dit_handle.hpp"
 #include "train.hpp"
+#include "train_fused.hpp"
 
 using namespace scldm;
 using namespace scldm::train;
@@ -262,7 +263,8 @@ extern "C" size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n) {
 }
 extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
   if (!h || n < 1) return 0;
-  return carve_scratch(h, n, nullptr).bytes;
+  // the fused bf16 path (train_fused.hpp) carves its own scratch behind the generic one
+  return carve_scratch(h, n, nullptr).bytes + (h->fused ? fused::carve_scratch(h, (n + 3) / 4 * 4, nullptr).bytes : 0);
 }
 
 extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
@@ -304,6 +306,14 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     TRY(linear_fwd(st, s.sc, kD, w->ada_w[l], n, 6 * kD, kD, w->ada_b[l], s.mod + (long)l * 6 * kD, mw, k));
   TRY(linear_fwd(st, s.sc, kD, w->fin_ada_w, n, 2 * kD, kD, w->fin_ada_b, s.mod + (long)L * 6 * kD, mw, k));
 
+  if (fused::eligible(h, n, precision)) {
+    // base shape, bf16 operands: the whole trunk is the fused inference kernel with a training record (layer inputs + the two
+    // gated branch outputs; 32 KB per cell per layer) instead of ~290 KB of saved activations
+    const fused::Record rec = fused::carve_record(h, n, s.layer[0].x_in);
+    const fused::Scratch fs = fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes);
+    TRY(fused::prepare(h, w, st));
+    return fused::forward(h, x, s.mod, n, out, rec, fs, st);
+  }
   // x_0 = input_proj(x) + pos_embed (nnets.py:290)
   float* x0 = L > 0 ? s.layer[0].x_in : s.x_last;
   TRY(linear_fwd(st, x, din, w->in_w, (int)T, kD, din, w->in_b, x0, kD, k));
@@ -349,13 +359,25 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   Saved s = carve_saved(h, n, saved_);
   Scratch k = carve_scratch(h, n, ws);
 
+  const bool use_fused = fused::eligible(h, n, precision);
+  const fused::Record rec = use_fused ? fused::carve_record(h, n, s.layer[0].x_in) : fused::Record{};
+  const fused::Scratch fs = use_fused ? fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes) : fused::Scratch{};
   // ---- final layer ----
   const int of = L * 6 * kD;
+  if (use_fused) {   // the record holds the final layer's input in tile layout; its LayerNorm output is recomputed
+    TRY(fused::to_plain(rec.x + (size_t)L * T * kD, s.x_last, n, st));
+    TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
+  }
   TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k, g->fin_b));
   TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
   TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
 
-  for (int l = L - 1; l >= 0; --l) {
+  if (use_fused) {
+    TRY(fused::to_tile(k.dx, fs.dx, n, st));
+    TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st));
+    TRY(fused::to_plain(fs.dx, k.dx, n, st));
+  }
+  for (int l = use_fused ? -1 : L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4

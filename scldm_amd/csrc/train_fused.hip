@@ -1,0 +1,430 @@
+// Fused training path of the base DiT shape (see train_fused.hpp): REC forward launches, the fused backward layer
+// (dit_backward.hpp) and the batched bf16 weight-gradient GEMMs.  gfx950 only.
+#include "train_fused.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "api_common.hpp"
+#include "dit_backward.hpp"
+#include "dit_forward.hpp"
+
+namespace scldm {
+namespace fused {
+
+namespace {
+
+constexpr int kSplits = 8;          // token-axis splits of the weight-gradient GEMMs (deterministic two-stage sum)
+constexpr int kHP = kBwdChunks * kBwdChunk;   // padded hidden width of the operand arrays (768)
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align256(count * sizeof(T));
+    return p;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// plain [token][256] fp32 <-> the forward kernel's tile layout [tile][wave 0..3][quad j 0..15][lane][4],
+// quad j = (tt*2 + ft)*4 + q holds features wave*64 + ft*32 + q*8 + (lane>>5)*4 .. +3 of token tile*64 + tt*32 + (lane&31)
+// ---------------------------------------------------------------------------------------------------------------
+template <bool TO_TILE>
+__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, long quads) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= quads) return;
+  const int lane = (int)(i & 63), j = (int)((i >> 6) & 15), wave = (int)((i >> 10) & 3);
+  const long tile = i >> 12;
+  const int tt = j >> 3, ft = (j >> 2) & 1, q = j & 3;
+  const long tok = tile * 64 + tt * 32 + (lane & 31);
+  const int f = wave * 64 + ft * 32 + q * 8 + (lane >> 5) * 4;
+  if (TO_TILE) *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(src + tok * kD + f);
+  else *reinterpret_cast<f32x4*>(dst + tok * kD + f) = *reinterpret_cast<const f32x4*>(src + i * 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched weight-gradient GEMM: C_j[m][n] = sum_t A_j[t][m] * B_j[t][n] for the five products of a layer in one launch.
+// Operands are bf16 [token][ld] (what dit_backward_kernel emits); a workgroup owns one 128x128 output tile of one job and one
+// of kSplits token ranges, stages 32 tokens at a time ([feature][token] LDS images, transposed in registers on the way:
+// each thread gathers 8 tokens of its two features), and writes its partial tile to part[job][split][M][N].
+// Optional row sums of A (bias gradients) ride along in the workgroups of the first column of tiles.
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradJob {
+  const __bf16* A; int lda;
+  const __bf16* B; int ldb;
+  int M, N;
+  int tile0, tiles_n;     // first linear tile of this job, tiles along N
+  long part_off;          // floats: partials [split][M][N]
+  long rs_off;            // floats: row-sum partials [split][M] (-1: none)
+};
+struct WgradArgs {
+  WgradJob job[5];
+  int n_jobs, T, kchunk;
+  float* part;
+};
+constexpr int kWK = 32;            // tokens per staged tile
+constexpr int kWLD = kWK + 8;      // bf16 elements per LDS row (80 B: the 32 rows of a fragment read fall on distinct 16-byte slots)
+
+struct OperandLoader {   // 128 features x 32 tokens
+  uint32_t d[8];
+  __device__ __forceinline__ void load(const __bf16* __restrict__ P, int ld, int m0, int t0) {
+    const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const __bf16* p = P + (size_t)(t0 + tg * 8) * ld + m0 + 2 * fp;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ld);
+  }
+  __device__ __forceinline__ void add_rowsum(float (&rs)[2]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rs[0] += __uint_as_float(d[i] << 16);
+      rs[1] += __uint_as_float(d[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    u32x4 lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lo[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
+      hi[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
+    }
+    *reinterpret_cast<u32x4*>(S + (2 * fp) * kWLD + tg * 8) = lo;
+    *reinterpret_cast<u32x4*>(S + (2 * fp + 1) * kWLD + tg * 8) = hi;
+  }
+};
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * kWLD];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * kWLD];
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < 5; ++k)
+    if (k < g.n_jobs && (int)blockIdx.x >= g.job[k].tile0) ji = k;
+  const WgradJob& j = g.job[ji];
+  const int tl = blockIdx.x - j.tile0, tm = tl / j.tiles_n, tn = tl % j.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int z = blockIdx.y;
+  const int t_beg = z * g.kchunk, t_end = min(g.T, t_beg + g.kchunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+  OperandLoader la, lb;
+  const bool want_rs = j.rs_off >= 0 && tn == 0;
+  float rs[2] = {0.f, 0.f};
+  la.load(j.A, j.lda, m0, t_beg);
+  lb.load(j.B, j.ldb, n0, t_beg);
+  if (want_rs) la.add_rowsum(rs);
+  la.store(As[0]);
+  lb.store(Bs[0]);
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = t_beg; t0 < t_end; t0 += kWK) {
+    const bool more = t0 + kWK < t_end;
+    if (more) {
+      la.load(j.A, j.lda, m0, t0 + kWK);
+      lb.load(j.B, j.ldb, n0, t0 + kWK);
+    }
+    const __bf16* __restrict__ as = As[buf] + (wm * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
+    const __bf16* __restrict__ bs = Bs[buf] + (wn * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
+#pragma unroll
+    for (int kk = 0; kk < kWK; kk += 16) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kWLD + kk);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) bf[k] = *reinterpret_cast<const bf16x8*>(bs + k * 32 * kWLD + kk);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[k], acc[i][k], 0, 0, 0);
+    }
+    if (more) {
+      if (want_rs) la.add_rowsum(rs);
+      la.store(As[buf ^ 1]);
+      lb.store(Bs[buf ^ 1]);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (want_rs) {   // the four token groups (tid >> 6) of a feature pair hold partial sums of the same two rows
+    float* red = reinterpret_cast<float*>(&As[0][0]);
+    red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 0] = rs[0];
+    red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 1] = rs[1];
+    __syncthreads();
+    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < j.M)
+      g.part[j.rs_off + (long)z * j.M + m0 + threadIdx.x] =
+          (red[threadIdx.x] + red[128 + threadIdx.x]) + (red[256 + threadIdx.x] + red[384 + threadIdx.x]);
+  }
+  float* __restrict__ C = g.part + j.part_off + (long)z * j.M * j.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int n = n0 + wn * 64 + k * 32 + (lane & 31);
+      if (n >= j.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane >> 5);
+        if (m < j.M) C[(long)m * j.N + n] = acc[i][k][r];
+      }
+    }
+}
+
+// dst_j[m*ldc + n] = sum_z part_j[z][m][n] for up to seven jobs (five weight gradients, two bias gradients) in one launch
+struct ReduceJob {
+  long part_off, first;   // first linear element of this job
+  float* dst;
+  int M, N, ldc;
+};
+struct ReduceArgs {
+  ReduceJob job[7];
+  int n_jobs, splits;
+  long total;
+  const float* part;
+};
+__global__ void wgrad_reduce_kernel(const ReduceArgs g) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < g.total; i += (long)gridDim.x * blockDim.x) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+      if (k < g.n_jobs && i >= g.job[k].first) ji = k;
+    const ReduceJob& j = g.job[ji];
+    const long e = i - j.first, mn = (long)j.M * j.N;
+    float s = 0.f;
+    for (int z = 0; z < g.splits; ++z) s += g.part[j.part_off + z * mn + e];
+    j.dst[(e / j.N) * j.ldc + (e % j.N)] = s;
+  }
+}
+
+__global__ void iota32_kernel(int32_t* __restrict__ ri, int n) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n) ri[s] = s;
+}
+
+bool fused_enabled() {   // SCLDM_TRAIN_FUSED=0: the generic GEMM-based path also for the base shape (A/B runs, tests)
+  const char* e = getenv("SCLDM_TRAIN_FUSED");
+  return !(e && atoi(e) == 0);
+}
+
+}  // namespace
+
+Record carve_record(const scldm_dit* h, int n, void* base) {
+  const size_t TD = (size_t)n * 16 * kD, L = h->cfg.n_layer;
+  Carver c{reinterpret_cast<char*>(base)};
+  Record r;
+  r.x = c.take<float>((L + 1) * TD);
+  r.y1 = c.take<__bf16>(L * TD);
+  r.y2 = c.take<__bf16>(L * TD);
+  r.bytes = c.off;
+  return r;
+}
+
+static size_t part_floats(const scldm_dit* h) {
+  const size_t H = h->cfg.hidden_dim;
+  return (size_t)kSplits * (3 * kD * kD + kD * kD + 3 * H * kD + 3 * kD + kD);
+}
+
+Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
+  const size_t T = (size_t)n * 16;
+  Carver c{reinterpret_cast<char*>(base)};
+  Scratch s;
+  s.handoff = c.take<float>(T * kD);
+  s.dx = c.take<float>(T * kD);
+  s.ridx = c.take<int32_t>(n);
+  s.e_h1 = c.take<__bf16>(T * kD);
+  s.e_dqkv = c.take<__bf16>(T * 3 * kD);
+  s.e_ao = c.take<__bf16>(T * kD);
+  s.e_dy1 = c.take<__bf16>(T * kD);
+  s.e_h2 = c.take<__bf16>(T * kD);
+  s.e_da = c.take<__bf16>(T * kHP);
+  s.e_db = c.take<__bf16>(T * kHP);
+  s.e_hid = c.take<__bf16>(T * kHP);
+  s.e_dy2 = c.take<__bf16>(T * kD);
+  s.part = c.take<float>(part_floats(h));
+  s.bytes = c.off;
+  return s;
+}
+
+bool eligible(const scldm_dit* h, int n, int precision) {
+  return fused_enabled() && h && h->fused && precision == SCLDM_PREC_BF16 && n >= 4 && n % 4 == 0 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
+         h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1;
+}
+
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+  if (!h->bwd_stream) {
+    const size_t elems = ((size_t)h->cfg.n_layer * bwd::NW * kBwdUnitsLayer + kMaxPF) * 512;   // + ring over-read slack
+    HIP_TRY(hipMalloc(&h->bwd_stream, elems * sizeof(__bf16)));
+    HIP_TRY(hipMemset(h->bwd_stream, 0, elems * sizeof(__bf16)));
+  }
+  int rc = scldm_build_pack_tables(h, w, st);
+  if (rc) return rc;
+  return scldm_run_pack(h, true, (1u << SCLDM_PREC_BF16) | 0x100u, st);
+}
+
+int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st) {
+  using L = FwdLayout<OpBF16, 2, 2>;
+  auto kern = dit_forward_kernel<OpBF16, 2, 2, true>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const scldm_dit_config& c = h->cfg;
+  iota32_kernel<<<cdiv(n, 256), 256, 0, st>>>(s.ridx, n);
+  LAUNCH_CHECK();
+  const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks[1], h->half[1]) * 1024;
+  FwdArgs a{};
+  a.z = x;
+  a.out = out;
+  a.x = s.handoff;
+  a.mod = mod;
+  a.row_index = s.ridx;
+  a.w_final = h->wfinal[SCLDM_PREC_BF16];
+  a.in_wt = h->in_wt;
+  a.in_w = h->in_w;
+  a.in_b = h->in_b;
+  a.pos = h->pos;
+  a.fin_b = h->fin_b;
+  a.n_fwd = n;
+  a.n_direct = n;
+  a.rep = 1;
+  a.din = c.n_embed_input;
+  a.n_layer = c.n_layer;
+  a.n_chunks = h->n_chunks[1];
+  a.half_chunk = h->half[1];
+  a.mod_stride = h->mod_w;
+  a.eps = c.layernorm_eps;
+  a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
+  a.w_layer_elems = (long)layer_elems;
+  a.rec_x = rec.x;
+  a.rec_y1 = rec.y1;
+  a.rec_y2 = rec.y2;
+  a.rec_stride = (long)n * 16 * kD;
+  const int tiles = n / 4;
+  for (int i = 0; i < c.n_layer; i += h->lpl) {
+    a.layer = i;
+    a.n_here = std::min(h->lpl, c.n_layer - i);
+    a.w_stream = (const char*)h->stream[SCLDM_PREC_BF16][1] + (size_t)i * layer_elems * 2;
+    a.b_qkv = h->b_qkv + (size_t)i * 768;
+    a.b_proj = h->b_proj + (size_t)i * 256;
+    kern<<<tiles, L::NT, L::LDS_BYTES, st>>>(a);
+    LAUNCH_CHECK();
+  }
+  return SCLDM_OK;
+}
+
+int to_tile(const float* plain, float* tile, int n, hipStream_t st) {
+  const long quads = (long)n * 16 * kD / 4;
+  relayout_kernel<true><<<cdiv(quads, 256), 256, 0, st>>>(plain, tile, quads);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+int to_plain(const float* tile, float* plain, int n, hipStream_t st) {
+  const long quads = (long)n * 16 * kD / 4;
+  relayout_kernel<false><<<cdiv(quads, 256), 256, 0, st>>>(tile, plain, quads);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
+                    hipStream_t st) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)bwd::dit_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bwd::LDS_BYTES));
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const scldm_dit_config& c = h->cfg;
+  const int T = n * 16, H = c.hidden_dim;
+  const size_t TD = (size_t)T * kD;
+  const size_t bwd_layer_elems = (size_t)bwd::NW * kBwdUnitsLayer * 512;
+  for (int l = c.n_layer - 1; l >= 0; --l) {
+    bwd::BwdArgs a{};
+    a.x_in = rec.x + (size_t)l * TD;
+    a.y1 = rec.y1 + (size_t)l * TD;
+    a.y2 = rec.y2 + (size_t)l * TD;
+    a.dx = s.dx;
+    a.mod = mod;
+    a.dmod = dmod;
+    a.mod_stride = h->mod_w;
+    a.mod_off = l * kModBlock;
+    a.w_stream = reinterpret_cast<const __bf16*>(h->bwd_stream) + (size_t)l * bwd_layer_elems;
+    a.b_qkv = h->b_qkv + (size_t)l * 768;
+    a.e_h1 = s.e_h1; a.e_dqkv = s.e_dqkv; a.e_ao = s.e_ao; a.e_dy1 = s.e_dy1; a.e_h2 = s.e_h2;
+    a.e_da = s.e_da; a.e_db = s.e_db; a.e_hid = s.e_hid; a.e_dy2 = s.e_dy2;
+    a.n = n;
+    a.eps = c.layernorm_eps;
+    a.attn_scale = 1.0f / sqrtf(32.0f);
+    a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
+    bwd::dit_backward_kernel<<<n / 4, bwd::NT, bwd::LDS_BYTES, st>>>(a);
+    LAUNCH_CHECK();
+
+    // the layer's five weight gradients (+ two bias gradients as row sums of dqkv / dy1)
+    WgradArgs wa{};
+    ReduceArgs ra{};
+    struct Spec { const __bf16* A; int lda; const __bf16* B; int ldb; int M, N; float* dst; float* bias; };
+    const Spec specs[5] = {
+        {s.e_dqkv, 3 * kD, s.e_h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]},
+        {s.e_dy1, kD, s.e_ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]},
+        {s.e_da, kHP, s.e_h2, kD, H, kD, g->w1[l], nullptr},
+        {s.e_db, kHP, s.e_h2, kD, H, kD, g->w2[l], nullptr},
+        {s.e_dy2, kD, s.e_hid, kHP, kD, H, g->cproj[l], nullptr},
+    };
+    long part_off = 0, first = 0;
+    int tile0 = 0, nr = 0;
+    for (int k = 0; k < 5; ++k) {
+      const Spec& sp = specs[k];
+      WgradJob& j = wa.job[k];
+      j.A = sp.A; j.lda = sp.lda; j.B = sp.B; j.ldb = sp.ldb; j.M = sp.M; j.N = sp.N;
+      j.tile0 = tile0;
+      j.tiles_n = cdiv(sp.N, 128);
+      tile0 += cdiv(sp.M, 128) * j.tiles_n;
+      j.part_off = part_off;
+      ReduceJob& r = ra.job[nr++];
+      r.part_off = part_off; r.first = first; r.dst = sp.dst; r.M = sp.M; r.N = sp.N; r.ldc = sp.N;
+      first += (long)sp.M * sp.N;
+      part_off += (long)kSplits * sp.M * sp.N;
+      j.rs_off = -1;
+      if (sp.bias) {
+        j.rs_off = part_off;
+        ReduceJob& rb = ra.job[nr++];
+        rb.part_off = part_off; rb.first = first; rb.dst = sp.bias; rb.M = sp.M; rb.N = 1; rb.ldc = 1;
+        first += sp.M;
+        part_off += (long)kSplits * sp.M;
+      }
+    }
+    wa.n_jobs = 5;
+    wa.T = T;
+    wa.kchunk = cdiv(cdiv(T, kSplits), kWK) * kWK;
+    wa.part = s.part;
+    const int splits = cdiv(T, wa.kchunk);
+    wgrad_bf16_kernel<<<dim3(tile0, splits), 256, 0, st>>>(wa);
+    LAUNCH_CHECK();
+    ra.n_jobs = nr;
+    ra.splits = splits;
+    ra.total = first;
+    ra.part = s.part;
+    wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, st>>>(ra);
+    LAUNCH_CHECK();
+  }
+  return SCLDM_OK;
+}
+
+}  // namespace fused
+}  // namespace scldm

@@ -1,0 +1,49 @@
+// Fused training path of the base DiT shape (n_embed 256, 8 heads, seq_len 16) with bf16 operands: host interface between
+// train_api.hip (conditioning, final layer, input projection: the small GEMM-based pieces) and train_fused.hip (the fused
+// forward with a training record, the fused backward layer, the batched weight-gradient GEMMs).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dit_handle.hpp"
+
+namespace scldm {
+namespace fused {
+
+// Activation record of one training step: (L+1) fp32 residuals + 2L bf16 branch outputs per token row of 256 features,
+// in the forward kernel's tile layout.  n must be a multiple of 4 (whole 64-token tiles).
+struct Record {
+  float* x;        // [L+1][T*256]
+  __bf16* y1;      // [L][T*256]
+  __bf16* y2;      // [L][T*256]
+  size_t bytes;
+};
+Record carve_record(const scldm_dit* h, int n, void* base);
+
+// Per-step scratch: residual hand-off between forward launches, the gradient of the residual stream (tile layout), the
+// operand pairs of one layer's weight-gradient GEMMs and their split-K partial sums.
+struct Scratch {
+  float* handoff;   // [T*256]
+  float* dx;        // [T*256] tile layout
+  int32_t* ridx;    // [n]
+  __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
+  float* part;      // split-K partials of one layer's five weight gradients + two bias gradients
+  size_t bytes;
+};
+Scratch carve_scratch(const scldm_dit* h, int n, void* base);
+
+bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision and batch served by the fused path
+
+// refresh the packed forward (bf16) and backward weight streams from the live parameters
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);
+// trunk forward (input projection .. final layer) with the record; mod = (n, mod_w) adaLN vectors
+int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st);
+// plain [T][256] fp32 <-> tile layout
+int to_tile(const float* plain, float* tile, int n, hipStream_t st);
+int to_plain(const float* tile, float* plain, int n, hipStream_t st);
+// all L layers, last to first: s.dx (tile layout) holds d loss / d x_L on entry and d loss / d x_0 on return; dmod gets the
+// gradients of the layers' adaLN vectors; g receives attn_w/attn_b/proj_w/proj_b/w1/w2/cproj of every layer
+int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
+                    hipStream_t st);
+
+}  // namespace fused
+}  // namespace scldm
