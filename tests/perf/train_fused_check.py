@@ -69,3 +69,5 @@ if __name__ == "__main__":
             print(f"{k:50s} fused {e1[k]:.3e}   generic {e0[k]:.3e}{flag}")
     if what in ("all", "time"):
         print(f"step ms: fused {timing(True):.3f}   generic {timing(False):.3f}")
+    if what == "fused":     # profile target: only the fused path
+        print(f"step ms: fused {timing(True, steps=20):.3f}")
