@@ -302,16 +302,23 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   LAUNCH_CHECK();
   hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
   LAUNCH_CHECK();
-  for (int l = 0; l < L; ++l)
-    TRY(linear_fwd(st, s.sc, kD, w->ada_w[l], n, 6 * kD, kD, w->ada_b[l], s.mod + (long)l * 6 * kD, mw, k));
-  TRY(linear_fwd(st, s.sc, kD, w->fin_ada_w, n, 2 * kD, kD, w->fin_ada_b, s.mod + (long)L * 6 * kD, mw, k));
+  const bool use_fused = fused::eligible(h, n, precision);
+  if (use_fused) {
+    // every adaLN Linear of the network in ONE GEMM over the handle's all-layer transposed copy (ada_t is (D, mod_w), refreshed
+    // from the live parameters by prepare()): mod = SiLU(c) W_all^T + b_all
+    TRY(fused::prepare(h, w, st));
+    TRY(gemm(st, s.sc, kD, 1, h->ada_t, 1, mw, s.mod, mw, n, mw, kD, h->ada_b, false, k.part, k.part_floats));
+  } else {
+    for (int l = 0; l < L; ++l)
+      TRY(linear_fwd(st, s.sc, kD, w->ada_w[l], n, 6 * kD, kD, w->ada_b[l], s.mod + (long)l * 6 * kD, mw, k));
+    TRY(linear_fwd(st, s.sc, kD, w->fin_ada_w, n, 2 * kD, kD, w->fin_ada_b, s.mod + (long)L * 6 * kD, mw, k));
+  }
 
-  if (fused::eligible(h, n, precision)) {
+  if (use_fused) {
     // base shape, bf16 operands: the whole trunk is the fused inference kernel with a training record (layer inputs + the two
     // gated branch outputs; 32 KB per cell per layer) instead of ~290 KB of saved activations
     const fused::Record rec = fused::carve_record(h, n, s.layer[0].x_in);
     const fused::Scratch fs = fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes);
-    TRY(fused::prepare(h, w, st));
     return fused::forward(h, x, s.mod, n, out, rec, fs, st);
   }
   // x_0 = input_proj(x) + pos_embed (nnets.py:290)
@@ -409,7 +416,16 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   if (dx_out) TRY(linear_dgrad(st, k.dx, kD, w->in_w, (int)T, kD, din, dx_out, din, false, k));
 
   // ---- adaLN Linears: mod_l = SiLU(c) W_l^T + b_l ----
-  for (int l = 0; l <= L; ++l) {
+  if (use_fused) {
+    // all layers at once: d SiLU(c) = dmod W_all (K = mod_w), d W_all = dmod^T SiLU(c) (+ row sums = bias gradients) into a
+    // contiguous (mod_w, D) scratch, scattered to the per-layer gradient tensors by one kernel
+    float* dw_all = fs.ada_dw;
+    float* db_all = fs.ada_dw + (size_t)mw * kD;
+    TRY(gemm(st, k.dmod, mw, 1, h->ada_t, mw, 1, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
+    TRY(gemm(st, k.dmod, 1, mw, s.sc, 1, kD, dw_all, kD, mw, kD, n, nullptr, false, k.part, k.part_floats, db_all));
+    TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, st));
+  }
+  for (int l = use_fused ? L + 1 : 0; l <= L; ++l) {
     const int width = l < L ? 6 * kD : 2 * kD;
     const float* dm = k.dmod + (long)l * 6 * kD;
     float* gw = l < L ? g->ada_w[l] : g->fin_ada_w;

@@ -214,6 +214,25 @@ __global__ void iota32_kernel(int32_t* __restrict__ ri, int n) {
   if (s < n) ri[s] = s;
 }
 
+constexpr int kMaxScatterLayers = 64;
+struct ScatterArgs {
+  float* w[kMaxScatterLayers + 1];   // [L] = final layer
+  float* b[kMaxScatterLayers + 1];
+  int n_layer;
+};
+__global__ void scatter_ada_kernel(const float* __restrict__ dw_all, const float* __restrict__ db_all, const ScatterArgs a) {
+  const int mw = a.n_layer * kModBlock + 2 * kD;
+  const long total = (long)mw * (kD + 1);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const bool is_b = i >= (long)mw * kD;
+    const long e = is_b ? i - (long)mw * kD : i;
+    const int row = (int)(is_b ? e : e / kD);
+    const int l = min(row / kModBlock, a.n_layer), r = row - l * kModBlock;
+    if (is_b) a.b[l][r] = db_all[e];
+    else a.w[l][(long)r * kD + (e % kD)] = dw_all[e];
+  }
+}
+
 bool fused_enabled() {   // SCLDM_TRAIN_FUSED=0: the generic GEMM-based path also for the base shape (A/B runs, tests)
   const char* e = getenv("SCLDM_TRAIN_FUSED");
   return !(e && atoi(e) == 0);
@@ -254,13 +273,14 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.e_hid = c.take<__bf16>(T * kHP);
   s.e_dy2 = c.take<__bf16>(T * kD);
   s.part = c.take<float>(part_floats(h));
+  s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.bytes = c.off;
   return s;
 }
 
 bool eligible(const scldm_dit* h, int n, int precision) {
   return fused_enabled() && h && h->fused && precision == SCLDM_PREC_BF16 && n >= 4 && n % 4 == 0 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
-         h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1;
+         h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
 int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
@@ -337,6 +357,22 @@ int to_tile(const float* plain, float* tile, int n, hipStream_t st) {
 int to_plain(const float* tile, float* plain, int n, hipStream_t st) {
   const long quads = (long)n * 16 * kD / 4;
   relayout_kernel<false><<<cdiv(quads, 256), 256, 0, st>>>(tile, plain, quads);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st) {
+  const int L = h->cfg.n_layer;
+  if (L > kMaxScatterLayers) return fail(SCLDM_ERR_SHAPE, "fused training path supports up to %d layers", kMaxScatterLayers);
+  ScatterArgs a{};
+  for (int l = 0; l < L; ++l) {
+    a.w[l] = g->ada_w[l];
+    a.b[l] = g->ada_b[l];
+  }
+  a.w[L] = g->fin_ada_w;
+  a.b[L] = g->fin_ada_b;
+  a.n_layer = L;
+  scatter_ada_kernel<<<2048, 256, 0, st>>>(dw_all, db_all, a);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }

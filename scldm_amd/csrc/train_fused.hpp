@@ -27,6 +27,7 @@ struct Scratch {
   int32_t* ridx;    // [n]
   __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
   float* part;      // split-K partials of one layer's five weight gradients + two bias gradients
+  float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   size_t bytes;
 };
 Scratch carve_scratch(const scldm_dit* h, int n, void* base);
@@ -44,6 +45,9 @@ int to_plain(const float* tile, float* plain, int n, hipStream_t st);
 // gradients of the layers' adaLN vectors; g receives attn_w/attn_b/proj_w/proj_b/w1/w2/cproj of every layer
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
                     hipStream_t st);
+
+// (mod_w, 256) stacked weight gradient + (mod_w) stacked bias gradient -> g->ada_w[l] / ada_b[l] / fin_ada_w / fin_ada_b
+int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st);
 
 }  // namespace fused
 }  // namespace scldm
