@@ -26,7 +26,7 @@ using E = __bf16;
 using Frag = bf16x8;
 using Quad = bf16x4;
 constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
-constexpr int PF = 4;
+constexpr int PF = 8;   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
 constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;   // bf16 elements per image row (+16 B pad)
 constexpr int R0_OFF = 0;                                   // h2 image, later h1 image
 constexpr int R1_OFF = R0_OFF + TM * XA_LD * 2;             // dy2 image, later dy1 image
@@ -58,6 +58,7 @@ struct BwdArgs {
   __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
   int n;                  // samples (multiple of 4)
   float eps, attn_scale, attn_scale_log2e;
+  unsigned long long* dbg;   // optional phase stamps [block][wave][16] (SCLDM_BWD_DBG=1; nullptr otherwise)
 };
 
 __device__ __forceinline__ void wave_sync() {   // orders this wave's LDS writes before its following LDS reads (compiler + hardware)
@@ -140,6 +141,11 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   E* TR = reinterpret_cast<E*>(smem + TR_OFF + wave * TR_BYTES);
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+#define BWD_STAMP(i)                                                                                                        \
+  do {                                                                                                                      \
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = __builtin_readcyclecounter();             \
+  } while (0)
+  BWD_STAMP(0);
   WStream<OP, PF, 1> ws;
   ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
 
@@ -329,8 +335,14 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     }
     if (tid < 3 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + tid * 4) = *reinterpret_cast<const f32x4*>(a.b_qkv + tid * 4);
   }
-  float dxr[NTT][16];   // gradient of the residual stream (d x_out, then d x_mid, then d x_in)
-  float xr[NTT][16];    // x_mid, later x_in
+  // The residual x and its gradient are NOT kept in registers across the GEMM phases (the up-projection tiles, the operand
+  // fragments of the attention core and the weight ring need them): each phase re-reads what it needs from the record / from
+  // a.dx (L2-resident, 64 KB per tile) - the compiler otherwise parks the same values in scratch, whose traffic shares the
+  // in-order vmcnt queue with the weight ring.
+  float mean2[NTT], rstd2[NTT];
+  float xr[NTT][16];    // x_mid: stays in registers across the MLP chunks (the LayerNorm-2 backward needs it again)
+  {
+  float dxr[NTT][16];
   load_f32(a.dx, dxr);
   lds_barrier();
 
@@ -366,10 +378,12 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
         for (int i = 0; i < 4; ++i) xr[tt][q * 4 + i] = fmaf(g[i], t[tt][q * 4 + i], xr[tt][q * 4 + i]);
       }
   }
-  float mean2[NTT], rstd2[NTT];
+  BWD_STAMP(1);
   ln_stats(xr, mean2, rstd2);
   ln_modulate(xr, mean2, rstd2, 3, 4, R0, a.e_h2);
+  }
   lds_barrier();   // h2 and dy2 images complete
+  BWD_STAMP(2);
 
   f32x16 dh[1][NTT];   // d h2 (this phase), later d h1
   for (int c = 0; c < kBwdChunks; ++c) {
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     gemm_pass<OP, NTT, 1, 16, false, true, PF>(ad, ws, R1, XA_LD, lane);   // d hid^T = c_proj^T d y2 (this wave's 32 hidden units)
     gemm_pass<OP, NTT, 1, 16, false, true, PF>(aa, ws, R0, XA_LD, lane);   // a^T = w1 h2
     gemm_pass<OP, NTT, 1, 16, false, true, PF>(ab, ws, R0, XA_LD, lane);   // b^T = w2 h2
+    if (c == 0) BWD_STAMP(3);
     if (c > 0) lds_barrier();   // every wave has finished the previous chunk's d h2 pass over R2
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -395,13 +410,22 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       put_tile(db, R2 + (tt * 32 + c32) * DADB_LD + kBwdChunk, a.e_db + grow, fb, hh);
       put_tile(hid, nullptr, a.e_hid + grow, fb, hh);
     }
+    if (c == 0) BWD_STAMP(4);
     lds_barrier();
+    if (c == 0) BWD_STAMP(5);
     if (c == 0) gemm_pass<OP, NTT, 1, 32, false, true, PF>(dh, ws, R2, DADB_LD, lane);    // d h2^T (+)= [w1^T | w2^T] [da | db]
     else gemm_pass<OP, NTT, 1, 32, false, false, PF>(dh, ws, R2, DADB_LD, lane);
+    if (c == 0) BWD_STAMP(6);
   }
+  BWD_STAMP(7);
   // d x_mid = d x_out + LN2-backward(d h2);  d a3, d a4
+  float mean1[NTT], rstd1[NTT];
+  {
+  float dxr[NTT][16];
+  load_f32(a.dx, dxr);
   ln_backward(dh[0], xr, mean2, rstd2, 3, 4, dxr);
 
+  BWD_STAMP(8);
   // ================= attention branch: x_mid = x_in + a2 * (c_proj(attention(c_attn(h1))) + b),  h1 = LN(x_in) (1 + a0) + a1 =================
   {
     float t[NTT][16];
@@ -422,12 +446,19 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     }
     dmod_store(t, 2);
   }
+  // d x_mid waits in a.dx for the LayerNorm-1 backward at the end
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<f32x4*>(a.dx + tile_off(tt, q)) = f32x4{dxr[tt][q * 4], dxr[tt][q * 4 + 1], dxr[tt][q * 4 + 2], dxr[tt][q * 4 + 3]};
   load_f32(a.x_in, xr);
-  float mean1[NTT], rstd1[NTT];
   ln_stats(xr, mean1, rstd1);
   ln_modulate(xr, mean1, rstd1, 0, 1, R0, a.e_h1);   // h1 (R0's last readers were chunk 2's a / b passes)
+  }
   lds_barrier();
 
+  BWD_STAMP(9);
   // q, k, v, d ao of head `wave`: as (token, k = head dim) operands straight from the accumulator tiles, and transposed
   // ((head dim, k = token), through the wave's LDS scratch - R2's tail is free since the last d h2 pass)
   Frag QF[NTT][2], KF[NTT][2], VF[NTT][2], GF[NTT][2];
@@ -457,6 +488,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
     both(VF, VT);
   }
+  BWD_STAMP(10);
   lds_barrier();   // every wave is done with the h1 / dy1 images: the dqkv image and the transpose scratch may overwrite them
 
 #pragma unroll
@@ -558,9 +590,14 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       put_tile(o, lrow, grow, 2 * kD + fb, hh);
     }
   }
+  BWD_STAMP(11);
   lds_barrier();   // dqkv image complete
   gemm_pass<OP, NTT, 1, 48, false, true, PF>(dh, ws, DQKV, DQKV_LD, lane);   // d h1^T = c_attn^T d qkv
+  BWD_STAMP(12);
   // d x_in = d x_mid + LN1-backward(d h1);  d a0, d a1
+  float dxr[NTT][16];
+  load_f32(a.x_in, xr);
+  load_f32(a.dx, dxr);
   ln_backward(dh[0], xr, mean1, rstd1, 0, 1, dxr);
 
 #pragma unroll
@@ -568,6 +605,8 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<f32x4*>(a.dx + tile_off(tt, q)) = f32x4{dxr[tt][q * 4], dxr[tt][q * 4 + 1], dxr[tt][q * 4 + 2], dxr[tt][q * 4 + 3]};
+  BWD_STAMP(13);
+#undef BWD_STAMP
 }
 
 }  // namespace bwd

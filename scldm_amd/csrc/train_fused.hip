@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "api_common.hpp"
 #include "dit_backward.hpp"
@@ -408,8 +410,23 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     a.eps = c.layernorm_eps;
     a.attn_scale = 1.0f / sqrtf(32.0f);
     a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
+    static unsigned long long* dbg_buf = nullptr;   // SCLDM_BWD_DBG=1: phase stamps of layer 0's launch, printed per step (debug aid)
+    const bool want_dbg = l == 0 && getenv("SCLDM_BWD_DBG") != nullptr;
+    if (want_dbg && !dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, (size_t)16384 * bwd::NW * 16 * 8));
+    a.dbg = (want_dbg && n / 4 <= 16384) ? dbg_buf : nullptr;
     bwd::dit_backward_kernel<<<n / 4, bwd::NT, bwd::LDS_BYTES, st>>>(a);
     LAUNCH_CHECK();
+    if (a.dbg) {
+      HIP_TRY(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hst((size_t)(n / 4) * bwd::NW * 16);
+      HIP_TRY(hipMemcpy(hst.data(), dbg_buf, hst.size() * 8, hipMemcpyDeviceToHost));
+      double acc[16] = {0};
+      for (int b = 0; b < n / 4; ++b)
+        for (int i = 1; i < 14; ++i) acc[i] += (double)(hst[((size_t)b * bwd::NW) * 16 + i] - hst[((size_t)b * bwd::NW) * 16 + i - 1]);
+      fprintf(stderr, "[bwd phases, wave 0, mean cycles]");
+      for (int i = 1; i < 14; ++i) fprintf(stderr, " %d:%.0f", i, acc[i] / (n / 4));
+      fprintf(stderr, "\n");
+    }
 
     // the layer's five weight gradients (+ two bias gradients as row sums of dqkv / dy1)
     WgradArgs wa{};
