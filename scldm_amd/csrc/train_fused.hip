@@ -69,41 +69,52 @@ struct WgradArgs {
   int n_jobs, T, kchunk;
   float* part;
 };
-constexpr int kWK = 32;            // tokens per staged tile
-constexpr int kWLD = kWK + 8;      // bf16 elements per LDS row (80 B: the 32 rows of a fragment read fall on distinct 16-byte slots)
+constexpr int kWK = 64;            // tokens per staged tile (the kernel is latency bound: a stage is what one workgroup keeps in flight)
+constexpr int kWLD = kWK + 8;      // bf16 elements per LDS row (144 B: 16 consecutive rows of a fragment read fall on distinct 16-byte slots)
+constexpr int kWG = kWK / 32;      // 8-token groups per thread
 
-struct OperandLoader {   // 128 features x 32 tokens
-  uint32_t d[8];
+struct OperandLoader {   // 128 features x kWK tokens: thread -> (feature pair tid & 63, token groups (tid >> 6) + 4 g)
+  uint32_t d[kWG][8];
   __device__ __forceinline__ void load(const __bf16* __restrict__ P, int ld, int m0, int t0) {
     const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
-    const __bf16* p = P + (size_t)(t0 + tg * 8) * ld + m0 + 2 * fp;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ld);
+    for (int g = 0; g < kWG; ++g) {
+      const __bf16* p = P + (size_t)(t0 + (tg + 4 * g) * 8) * ld + m0 + 2 * fp;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) d[g][i] = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ld);
+    }
   }
   __device__ __forceinline__ void add_rowsum(float (&rs)[2]) const {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      rs[0] += __uint_as_float(d[i] << 16);
-      rs[1] += __uint_as_float(d[i] & 0xffff0000u);
-    }
+    for (int g = 0; g < kWG; ++g)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rs[0] += __uint_as_float(d[g][i] << 16);
+        rs[1] += __uint_as_float(d[g][i] & 0xffff0000u);
+      }
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
-    u32x4 lo, hi;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lo[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
-      hi[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
+    for (int g = 0; g < kWG; ++g) {
+      u32x4 lo, hi;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] = __builtin_amdgcn_perm(d[g][2 * i + 1], d[g][2 * i], 0x05040100u);
+        hi[i] = __builtin_amdgcn_perm(d[g][2 * i + 1], d[g][2 * i], 0x07060302u);
+      }
+      *reinterpret_cast<u32x4*>(S + (2 * fp) * kWLD + (tg + 4 * g) * 8) = lo;
+      *reinterpret_cast<u32x4*>(S + (2 * fp + 1) * kWLD + (tg + 4 * g) * 8) = hi;
     }
-    *reinterpret_cast<u32x4*>(S + (2 * fp) * kWLD + tg * 8) = lo;
-    *reinterpret_cast<u32x4*>(S + (2 * fp + 1) * kWLD + tg * 8) = hi;
   }
 };
 
+constexpr int kWgradLds = 2 * 2 * 128 * kWLD * 2;   // two buffers x two operands
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][128 * kWLD];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][128 * kWLD];
+  extern __shared__ __attribute__((aligned(16))) char wgrad_smem[];
+  auto As = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + b * (128 * kWLD); };
+  auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + (2 + b) * (128 * kWLD); };
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < 5; ++k)
@@ -129,8 +140,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   la.load(j.A, j.lda, m0, t_beg);
   lb.load(j.B, j.ldb, n0, t_beg);
   if (want_rs) la.add_rowsum(rs);
-  la.store(As[0]);
-  lb.store(Bs[0]);
+  la.store(As(0));
+  lb.store(Bs(0));
   __syncthreads();
   int buf = 0;
   for (int t0 = t_beg; t0 < t_end; t0 += kWK) {
@@ -139,8 +150,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
       la.load(j.A, j.lda, m0, t0 + kWK);
       lb.load(j.B, j.ldb, n0, t0 + kWK);
     }
-    const __bf16* __restrict__ as = As[buf] + (wm * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
-    const __bf16* __restrict__ bs = Bs[buf] + (wn * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
+    const __bf16* __restrict__ as = As(buf) + (wm * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
+    const __bf16* __restrict__ bs = Bs(buf) + (wn * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
 #pragma unroll
     for (int kk = 0; kk < kWK; kk += 16) {
       bf16x8 af[2], bf[2];
@@ -155,14 +166,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
     }
     if (more) {
       if (want_rs) la.add_rowsum(rs);
-      la.store(As[buf ^ 1]);
-      lb.store(Bs[buf ^ 1]);
+      la.store(As(buf ^ 1));
+      lb.store(Bs(buf ^ 1));
     }
     __syncthreads();
     buf ^= 1;
   }
   if (want_rs) {   // the four token groups (tid >> 6) of a feature pair hold partial sums of the same two rows
-    float* red = reinterpret_cast<float*>(&As[0][0]);
+    float* red = reinterpret_cast<float*>(wgrad_smem);
     red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 0] = rs[0];
     red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 1] = rs[1];
     __syncthreads();
@@ -388,6 +399,11 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     HIP_TRY(hipFuncSetAttribute((const void*)bwd::dit_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bwd::LDS_BYTES));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
+  static bool wattr_set[64] = {};
+  if (dev < 0 || dev >= 64 || !wattr_set[dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds));
+    if (dev >= 0 && dev < 64) wattr_set[dev] = true;
+  }
   const scldm_dit_config& c = h->cfg;
   const int T = n * 16, H = c.hidden_dim;
   const size_t TD = (size_t)T * kD;
@@ -467,7 +483,7 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     wa.kchunk = cdiv(cdiv(T, kSplits), kWK) * kWK;
     wa.part = s.part;
     const int splits = cdiv(T, wa.kchunk);
-    wgrad_bf16_kernel<<<dim3(tile0, splits), 256, 0, st>>>(wa);
+    wgrad_bf16_kernel<<<dim3(tile0, splits), 256, kWgradLds, st>>>(wa);
     LAUNCH_CHECK();
     ra.n_jobs = nr;
     ra.splits = splits;
