@@ -52,7 +52,13 @@ class Transport:
     def sample(self, x1: torch.Tensor):
         """x0 ~ N(0, I), t ~ U[0, 1] (transport.py:97-108)."""
         x0 = torch.randn_like(x1)
-        t = torch.rand((x1.shape[0],)).to(x1)
+        if x1.is_cuda:
+            # same CPU generator draw as the reference's `torch.rand((B,)).to(x1)`, but through pinned memory and an asynchronous
+            # copy: a pageable host-to-device copy blocks the host until everything queued on the stream has finished, which
+            # serialises the host's kernel enqueueing with the previous step's device work
+            t = torch.rand((x1.shape[0],), pin_memory=True).to(x1, non_blocking=True)
+        else:
+            t = torch.rand((x1.shape[0],)).to(x1)
         return t, x0, x1
 
     def training_losses(self, model, x1, model_kwargs=None):
