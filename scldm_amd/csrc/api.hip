@@ -151,7 +151,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream};
+                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -176,7 +176,13 @@ int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st)
     force = true;
     h->partial_pack = false;
   }
-  if (prec_mask != kPackAll) h->partial_pack = true;
+  if (prec_mask != kPackAll) {
+    // training step: only the streams it reads, from the dense training table, unconditionally (no fingerprint pass)
+    h->partial_pack = true;
+    pack_jobs_kernel<<<h->tjob_blocks, 256, 0, st>>>((const PackJob*)h->d_tjobs, h->n_tjobs, nullptr, prec_mask);
+    LAUNCH_CHECK();
+    return SCLDM_OK;
+  }
   if (force) set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);   // (not a memcpy from a host stack variable: it must stay stream-ordered and asynchronous)
   fingerprint_kernel<<<h->n_fp, 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
   fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
@@ -211,9 +217,10 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
   for (int i = 0; i < L; ++i)
     for (const float* const* arr : {w->attn_w, w->attn_b, w->proj_w, w->proj_b, w->w1, w->w2, w->cproj, w->ada_w, w->ada_b}) key.push_back(arr[i]);
   if (h->tables_built && key == h->table_key) return SCLDM_OK;
-  std::vector<PackJob> jobs;
+  std::vector<PackJob> jobs, tjobs;   // tjobs: the subset the fused bf16 training step reads (its own dense block numbering)
   std::vector<FpSrc> fps;
-  int blocks = 0;
+  int blocks = 0, tblocks = 0;
+  bool train = false;   // current job also goes into the training table
   auto add = [&](int kind, long long n, std::initializer_list<const float*> src, void* dst, std::initializer_list<int> par,
                  long long d_off = 0) {
     PackJob j{};
@@ -228,6 +235,11 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
     j.d_off = d_off;
     blocks += cdiv(n, 256);
     jobs.push_back(j);
+    if (train) {
+      j.first_block = tblocks;
+      tblocks += cdiv(n, 256);
+      tjobs.push_back(j);
+    }
   };
   auto src = [&](const float* p, long long n) { fps.push_back(FpSrc{(const uint32_t*)p, n}); return p; };
   for (int i = 0; i < L; ++i) {
@@ -238,31 +250,45 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
         if (!h->stream[p][f]) continue;
         const int nc = h->n_chunks[f], hf = h->half[f];
         const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
+        train = p == SCLDM_PREC_BF16 && f == 1;
         add(kPackLayer, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->stream[p][f], {H, nc, hf, f + 1, p}, npk * i);
+        train = false;
       }
     if (h->bwd_stream) {
       const long long npk = (long long)8 * kBwdUnitsLayer * 512;
+      train = true;
       add(kPackLayerBwd, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->bwd_stream, {H}, npk * i);
     }
+    train = true;
     add(kPackCopy, 768, {src(w->attn_b[i], 768)}, h->b_qkv + (size_t)i * 768, {});
     add(kPackCopy, 256, {src(w->proj_b[i], 256)}, h->b_proj + (size_t)i * 256, {});
     // adaLN of block i -> columns [i*1536, (i+1)*1536) of the all-layer matrix
     add(kPackTranspose, 1536 * 256, {src(w->ada_w[i], 1536 * 256)}, h->ada_t, {1536, 256, mw, i * 1536});
     add(kPackCopy, 1536, {src(w->ada_b[i], 1536)}, h->ada_b + i * 1536, {});
+    train = false;
   }
+  train = true;
   add(kPackTranspose, 512 * 256, {src(w->fin_ada_w, 512 * 256)}, h->ada_t, {512, 256, mw, L * 1536});
   add(kPackCopy, 512, {src(w->fin_ada_b, 512)}, h->ada_b + L * 1536, {});
+  train = false;
   add(kPackTranspose, 256 * 256, {src(w->t_w0, 256 * 256)}, h->w0t, {256, 256, 256, 0});
   add(kPackTranspose, 256 * 256, {src(w->t_w2, 256 * 256)}, h->w2t, {256, 256, 256, 0});
   add(kPackCopy, 256, {src(w->t_b0, 256)}, h->b0, {});
   add(kPackCopy, 256, {src(w->t_b2, 256)}, h->b2, {});
   add(kPackTranspose, 256 * din, {src(w->in_w, 256 * din)}, h->in_wt, {256, din, 256, 0});
+  train = true;
   add(kPackCopy, 256 * din, {w->in_w}, h->in_w, {});
   add(kPackCopy, 256, {src(w->in_b, 256)}, h->in_b, {});
   add(kPackCopy, 16 * 256, {src(w->pos_embed, 16 * 256)}, h->pos, {});
+  train = false;
   src(w->fin_w, (long long)din * 256);
-  for (int p = 0; p < kNPrec; ++p) add(kPackFinal, 16 * 512, {w->fin_w}, h->wfinal[p], {din, p});
+  for (int p = 0; p < kNPrec; ++p) {
+    train = p == SCLDM_PREC_BF16;
+    add(kPackFinal, 16 * 512, {w->fin_w}, h->wfinal[p], {din, p});
+  }
+  train = true;
   add(kPackCopy, din, {src(w->fin_b, din)}, h->fin_b, {});
+  train = false;
   for (int ci = 0; ci < c.n_classes; ++ci) {
     const int n = h->tab_rows[ci] * 256;
     add(kPackCopy, n, {src(w->class_emb[ci], n)}, h->emb + (size_t)h->emb_row0[ci] * 256, {});
@@ -282,6 +308,12 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
     h->fp_cap = (int)fps.size();
   }
   HIP_TRY(hipMemcpy(h->d_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  if (h->d_tjobs) (void)hipFree(h->d_tjobs);
+  h->d_tjobs = nullptr;
+  HIP_TRY(hipMalloc(&h->d_tjobs, tjobs.size() * sizeof(PackJob)));
+  HIP_TRY(hipMemcpy(h->d_tjobs, tjobs.data(), tjobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  h->n_tjobs = (int)tjobs.size();
+  h->tjob_blocks = tblocks;
   HIP_TRY(hipMemcpy(h->d_fp_src, fps.data(), fps.size() * sizeof(FpSrc), hipMemcpyHostToDevice));
   h->n_jobs = (int)jobs.size();
   h->job_blocks = blocks;
