@@ -85,52 +85,57 @@ class Decoder(nn.Module):
 
 class _DiTTrainFn(torch.autograd.Function):
     """DiT.forward with a HIP backward: scldm_dit_train_forward / scldm_dit_train_backward (include/scldm_hip.h).
-    Replaces torch autograd over scldm.nnets.DiT.forward (nnets.py:273-297) inside Transport.training_losses."""
+    Replaces torch autograd over scldm.nnets.DiT.forward (nnets.py:273-297) inside Transport.training_losses.
+
+    Host-side cost matters here (a base-DiT step at 1 024 cells is ~2 ms of device time): the parameter list, the pointer
+    struct of the weights and the layout of the flat gradient buffer are cached on the module; every gradient is a view of ONE
+    allocation."""
 
     @staticmethod
     def forward(ctx, module, x, t, labels, label_keep, *params):
         L, h = module._native_handle()
-        module._check_params()
         n = x.shape[0]
         dev = x.device
         x = x.detach().contiguous()
         saved = torch.empty(L.scldm_dit_train_saved_bytes(h, n), dtype=torch.uint8, device=dev)
         ws = torch.empty(L.scldm_dit_train_workspace_bytes(h, n), dtype=torch.uint8, device=dev)
-        w, keep = module._param_struct(lambda p: p.data_ptr())
+        w, _ = module._weights_struct(params)
         out = torch.empty_like(x)
         prec = module._prec()
         with torch.cuda.device(dev):
             _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
                                                  out.data_ptr(), prec, saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
                        "scldm_dit_train_forward")
-        del keep
         ctx.module, ctx.saved, ctx.ws, ctx.x, ctx.n, ctx.prec = module, saved, ws, x, n, prec
         ctx.labels, ctx.label_keep = labels, label_keep
+        ctx.params = params
         ctx.param_versions = [p._version for p in params]
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        module, n = ctx.module, ctx.n
+        module, n, params = ctx.module, ctx.n, ctx.params
         L, h = module._native_handle()
-        params = [p for _, p in module.named_parameters()]
         if [p._version for p in params] != ctx.param_versions:
             raise RuntimeError("DiT parameters were modified between forward and backward (the HIP backward reads them live)")
         dout = dout.contiguous().float()
-        grads = {id(p): torch.empty_like(p) for p in params if p is not module.pos_embed}
-        w, keep_w = module._param_struct(lambda p: p.data_ptr())
-        need_pos = ctx.needs_input_grad[5 + [id(p) for p in params].index(id(module.pos_embed))]
+        w, _ = module._weights_struct(params)
+        pos_i = module._pos_index(params)
+        need_pos = ctx.needs_input_grad[5 + pos_i]
+        flat = torch.empty(module._grad_numel, dtype=torch.float32, device=dout.device)   # every gradient is a view of this buffer
+        base = flat.data_ptr()
+        offs = module._grad_offsets
         gpos = torch.empty_like(module.pos_embed) if need_pos else None
         g, keep_g = module._param_struct(lambda p: (gpos.data_ptr() if gpos is not None else None) if p is module.pos_embed
-                                         else grads[id(p)].data_ptr())
+                                         else base + 4 * offs[id(p)])
         dx = torch.empty_like(ctx.x) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(dout.device):
             _lib.check(L.scldm_dit_train_backward(h, C.byref(w), C.byref(g), ctx.x.data_ptr(), C.cast(ctx.labels, _lib.c_void_pp),
                                                   dout.data_ptr(), n, dx.data_ptr() if dx is not None else None,
                                                   ctx.prec, ctx.saved.data_ptr(), ctx.ws.data_ptr(), _stream_ptr()),
                        "scldm_dit_train_backward")
-        del keep_w, keep_g
+        del keep_g
         ctx.saved = ctx.ws = None
         out = []
         for i, p in enumerate(params):
@@ -139,7 +144,8 @@ class _DiTTrainFn(torch.autograd.Function):
             elif p is module.pos_embed:
                 out.append(gpos)
             else:
-                out.append(grads[id(p)])
+                o = offs[id(p)]
+                out.append(flat[o:o + p.numel()].view(p.shape))
         return (None, dx, None, None, None, *out)
 
 
@@ -297,6 +303,8 @@ class DiT(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
+        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_pos_idx", "_param_list"):
+            state.pop(k, None)
         return state
 
     def __setstate__(self, state):
@@ -326,6 +334,26 @@ class DiT(nn.Module):
             class_emb=cast(keep[0]), attn_w=cast(keep[1]), attn_b=cast(keep[2]), proj_w=cast(keep[3]), proj_b=cast(keep[4]),
             w1=cast(keep[5]), w2=cast(keep[6]), cproj=cast(keep[7]), ada_w=cast(keep[8]), ada_b=cast(keep[9]))
         return w, keep
+
+    def _weights_struct(self, params):
+        """scldm_dit_weights of the live parameters, rebuilt only when a parameter's storage moved (the optimizer updates in place)."""
+        key = tuple(p.data_ptr() for p in params)
+        c = self.__dict__.get("_wstruct_cache")
+        if c is None or c[0] != key:
+            self._check_params()
+            w, keep = self._param_struct(lambda t: t.data_ptr())
+            offs, total = {}, 0
+            for p in params:
+                if p is not self.pos_embed:
+                    offs[id(p)] = total
+                    total += (p.numel() + 63) // 64 * 64       # 256-byte aligned views
+            self.__dict__["_wstruct_cache"] = c = (key, w, keep)
+            self.__dict__["_grad_offsets"], self.__dict__["_grad_numel"] = offs, total
+            self.__dict__["_pos_idx"] = next(i for i, p in enumerate(params) if p is self.pos_embed)
+        return c[1], c[2]
+
+    def _pos_index(self, params):
+        return self.__dict__["_pos_idx"]
 
     def _check_params(self):
         for p in self.parameters():
@@ -470,7 +498,11 @@ class DiT(nn.Module):
             # differentiable path (Transport.training_losses -> loss.backward()): forward with saved activations + HIP backward.
             # In eval mode the fused inference kernel runs unless the input itself requires grad: an eval-mode output is not
             # differentiable w.r.t. the parameters (loss.backward() then fails loudly, it never returns silent zeros).
-            params = [p for _, p in self.named_parameters()]
+            params = tuple(self.parameters())     # one traversal per step: the identity of every Parameter object is re-checked
+            cached = self.__dict__.get("_param_list")
+            if cached is None or len(cached) != len(params) or any(a is not b for a, b in zip(cached, params)):
+                self.__dict__["_param_list"] = params
+                self.__dict__.pop("_wstruct_cache", None)
             return _DiTTrainFn.apply(self, x, t, labels, keep, *params)
         if not self.fused_shape:
             return self._generic_forward(x, t, labels)

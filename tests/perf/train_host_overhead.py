@@ -39,3 +39,43 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+
+# ---- host-time split of one step (no device sync inside: pure enqueue cost) ----
+import collections
+from scldm_amd import nnets as _nn
+seg = collections.Counter()
+_orig_fwd, _orig_bwd = _nn._DiTTrainFn.forward, _nn._DiTTrainFn.backward
+L_, h_ = m._native_handle()
+_cf, _cb = L_.scldm_dit_train_forward, L_.scldm_dit_train_backward
+
+
+def timed(name, fn):
+    def w(*a, **k):
+        t = time.perf_counter()
+        r = fn(*a, **k)
+        seg[name] += time.perf_counter() - t
+        return r
+    return w
+
+
+class _LibProxy:
+    def __init__(self, lib):
+        self._lib = lib
+        self.scldm_dit_train_forward = timed("C forward", lib.scldm_dit_train_forward)
+        self.scldm_dit_train_backward = timed("C backward", lib.scldm_dit_train_backward)
+
+    def __getattr__(self, k):
+        return getattr(self._lib, k)
+
+
+proxy = _LibProxy(L_)
+m._native_handle = lambda: (proxy, h_)
+torch.cuda.synchronize()
+for _ in range(N):
+    t = time.perf_counter(); opt.zero_grad(set_to_none=True); seg["zero_grad"] += time.perf_counter() - t
+    t = time.perf_counter(); loss = tr.training_losses(m, x1, {"condition": cond})["loss"].mean(); seg["training_losses (incl. fwd)"] += time.perf_counter() - t
+    t = time.perf_counter(); loss.backward(); seg["backward (incl. C)"] += time.perf_counter() - t
+    t = time.perf_counter(); opt.step(); seg["opt.step"] += time.perf_counter() - t
+torch.cuda.synchronize()
+for k, v in seg.items():
+    print(f"{k:32s} {1e3 * v / N:.3f} ms/step (host)")

@@ -1,0 +1,25 @@
+"""Training step wall time vs batch size (host-bound if the time does not grow with the batch)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import bench
+from scldm_amd.training import train_step
+from scldm_amd.transport import create_transport
+dev = torch.device("cuda:0")
+for B in (256, 512, 1024, 2048, 4096):
+    wl = dict(bench.TRAIN_WORKLOADS["replogle_train_b1024"]); wl["B"] = B
+    m = bench.make_model(wl, "bf16", dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(B, 16, 16, generator=g).to(dev)
+    cond = {k: torch.randint(0, v, (B,), generator=g).to(dev) for k, v in wl["vocab"].items()}
+    for _ in range(5):
+        train_step(m, tr, opt, x1, cond)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        train_step(m, tr, opt, x1, cond)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    print(f"B={B:5d}  {1e3 * dt:.3f} ms/step  {B / dt / 1e3:.1f} k cells/s")
