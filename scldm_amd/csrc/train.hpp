@@ -472,6 +472,53 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   dtable[(long)row * D + f] = s;
 }
 
+// Same result (same summation order: ascending sample index), organised by SAMPLE instead of by table row: the table is zeroed
+// first (hipMemsetAsync), workgroup i exits unless sample i is the first one carrying its label, and then sums that label's
+// samples.  With n samples << table rows (replogle: 1 024 cells, 2 025 gene rows) the row-wise kernel above spends its time
+// on 2 025 workgroups that each scan every label to find nothing.  grid (n, D/256).
+__global__ __launch_bounds__(256) void embed_bwd_by_sample_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels,
+                                                                  int vocab, int n, int D, float* __restrict__ dtable) {
+  __shared__ unsigned long long hit[4];
+  __shared__ int earlier;
+  const int i = blockIdx.x, tid = threadIdx.x, f = blockIdx.y * 256 + tid, wave = tid >> 6;
+  auto label_of = [&](int s) {
+    long l = labels ? (long)labels[s] : (long)vocab;
+    return l < 0 ? 0L : (l > vocab ? (long)vocab : l);
+  };
+  const long mine = label_of(i);
+  if (tid == 0) earlier = 0;
+  __syncthreads();
+  bool found = false;
+  for (int s = tid; s < i; s += 256) found |= label_of(s) == mine;
+  if (found) earlier = 1;   // benign race: every writer stores 1
+  __syncthreads();
+  if (earlier) return;
+  float sum = 0.f;
+  for (int i0 = (i / 256) * 256; i0 < n; i0 += 256) {
+    const int s = i0 + tid;
+    const unsigned long long m = __ballot(s >= i && s < n && label_of(s) == mine);
+    if ((tid & 63) == 0) hit[wave] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long mm = hit[w];
+      while (mm) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
+          mm &= mm - 1;
+          v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * D + f] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
+      }
+    }
+    __syncthreads();
+  }
+  dtable[mine * D + f] = sum;
+}
+
 // x[t][f] += pos[t % 16][f]
 __global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, long tokens, int D) {
   const long total = tokens * D, period = (long)kS * D;

@@ -439,8 +439,14 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
   for (int c = 0; c < cfg.n_classes; ++c) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
-                       h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+    if (h->tab_rows[c] > n) {   // more table rows than samples: organise the sum by sample (same order, same bits)
+      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), st));
+      hipLaunchKernelGGL(embed_bwd_by_sample_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
+                         h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+    } else {
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
+                         h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+    }
     LAUNCH_CHECK();
   }
   TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k, g->t_b2));
