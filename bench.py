@@ -548,7 +548,9 @@ def main():
             tprec = "bf16" if args.precision == "bf16" else "fp32"
             dtt, _ = time_training(tw, tprec, device, 10, 5, False, 1)
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
-                                       "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec}
+                                       "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
+                                       "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
+                                                "per layer (DESIGN 4.4a)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.4)"}
             note("training step done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
