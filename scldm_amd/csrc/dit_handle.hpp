@@ -46,6 +46,8 @@ struct scldm_dit {
   void* bwd_stream;         // bf16 backward weight stream [layer][8 waves][kBwdUnitsLayer][512] (+ ring slack); allocated on first use
   std::vector<const void*> table_key;  // every device pointer of the scldm_dit_weights the job / fingerprint tables were built from
   bool tables_built;
+  int32_t* iota;            // identity row index 0..iota_n-1 (the training forward's conditioning rows are the samples themselves)
+  int iota_n;
   void* d_tjobs;            // device PackJob table of the training step's subset
   int n_tjobs, tjob_blocks;
   bool partial_pack;        // the last pack refreshed only some precisions' streams: the next inference refresh is unconditional

@@ -67,7 +67,7 @@ struct WgradJob {
 };
 struct WgradArgs {
   WgradJob job[5];
-  int n_jobs, T, kchunk;
+  int n_jobs, T, kchunk, splits;
   float* part;
 };
 constexpr int kWK = 64;            // tokens per staged tile (the kernel is latency bound: a stage is what one workgroup keeps in flight)
@@ -116,14 +116,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) char wgrad_smem[];
   auto As = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + b * (128 * kWLD); };
   auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + (2 + b) * (128 * kWLD); };
+  // XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin by linear id, so with id = tile * splits + split every
+  // XCD gets ONE token range (for 8 splits) of all tiles: the tiles that share operand rows re-read them from that XCD's L2
+  // instead of 2-6 times from the fabric (436 MB of tile loads per launch against 139 MB of operands).
+  const int z = blockIdx.x % g.splits, tile_id = blockIdx.x / g.splits;
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < 5; ++k)
-    if (k < g.n_jobs && (int)blockIdx.x >= g.job[k].tile0) ji = k;
+    if (k < g.n_jobs && tile_id >= g.job[k].tile0) ji = k;
   const WgradJob& j = g.job[ji];
-  const int tl = blockIdx.x - j.tile0, tm = tl / j.tiles_n, tn = tl % j.tiles_n;
+  const int tl = tile_id - j.tile0, tm = tl / j.tiles_n, tn = tl % j.tiles_n;
   const int m0 = tm * 128, n0 = tn * 128;
-  const int z = blockIdx.y;
   const int t_beg = z * g.kchunk, t_end = min(g.T, t_beg + g.kchunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
 
@@ -135,21 +138,29 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-  OperandLoader la, lb;
+  // Two register stages per operand: the loads of stage i+2 are issued while stage i is multiplied and stage i+1 (requested one
+  // whole iteration earlier) is written to LDS - a single stage left ~1.5 k cycles of every ~2.3 k-cycle iteration waiting for
+  // HBM.  Barriers order LDS only (lds_barrier): __syncthreads() would drain the loads in flight.
+  OperandLoader la[2], lb[2];
   const bool want_rs = j.rs_off >= 0 && tn == 0;
   float rs[2] = {0.f, 0.f};
-  la.load(j.A, j.lda, m0, t_beg);
-  lb.load(j.B, j.ldb, n0, t_beg);
-  if (want_rs) la.add_rowsum(rs);
-  la.store(As(0));
-  lb.store(Bs(0));
-  __syncthreads();
-  int buf = 0;
-  for (int t0 = t_beg; t0 < t_end; t0 += kWK) {
-    const bool more = t0 + kWK < t_end;
-    if (more) {
-      la.load(j.A, j.lda, m0, t0 + kWK);
-      lb.load(j.B, j.ldb, n0, t0 + kWK);
+  const int n_it = (t_end - t_beg + kWK - 1) / kWK;
+  la[0].load(j.A, j.lda, m0, t_beg);
+  lb[0].load(j.B, j.ldb, n0, t_beg);
+  if (n_it > 1) {
+    la[1].load(j.A, j.lda, m0, t_beg + kWK);
+    lb[1].load(j.B, j.ldb, n0, t_beg + kWK);
+  }
+  if (want_rs) la[0].add_rowsum(rs);
+  la[0].store(As(0));
+  lb[0].store(Bs(0));
+  lds_barrier();
+  auto iteration = [&](int it, auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;     // register slot of stage `it` (already in LDS buffer it & 1): free again
+    const int buf = it & 1;
+    if (it + 2 < n_it) {
+      la[SLOT].load(j.A, j.lda, m0, t_beg + (it + 2) * kWK);
+      lb[SLOT].load(j.B, j.ldb, n0, t_beg + (it + 2) * kWK);
     }
     const __bf16* __restrict__ as = As(buf) + (wm * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
     const __bf16* __restrict__ bs = Bs(buf) + (wn * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
@@ -165,19 +176,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[k], acc[i][k], 0, 0, 0);
     }
-    if (more) {
-      if (want_rs) la.add_rowsum(rs);
-      la.store(As(buf ^ 1));
-      lb.store(Bs(buf ^ 1));
+    if (it + 1 < n_it) {
+      if (want_rs) la[SLOT ^ 1].add_rowsum(rs);
+      la[SLOT ^ 1].store(As(buf ^ 1));
+      lb[SLOT ^ 1].store(Bs(buf ^ 1));
     }
-    __syncthreads();
-    buf ^= 1;
+    lds_barrier();
+  };
+  for (int it = 0; it < n_it; it += 2) {
+    iteration(it, std::integral_constant<int, 0>{});
+    if (it + 1 < n_it) iteration(it + 1, std::integral_constant<int, 1>{});
   }
   if (want_rs) {   // the four token groups (tid >> 6) of a feature pair hold partial sums of the same two rows
     float* red = reinterpret_cast<float*>(wgrad_smem);
     red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 0] = rs[0];
     red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 1] = rs[1];
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 128 && m0 + (int)threadIdx.x < j.M)
       g.part[j.rs_off + (long)z * j.M + m0 + threadIdx.x] =
           (red[threadIdx.x] + red[128 + threadIdx.x]) + (red[256 + threadIdx.x] + red[384 + threadIdx.x]);
@@ -319,15 +333,24 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
-  iota32_kernel<<<cdiv(n, 256), 256, 0, st>>>(s.ridx, n);
-  LAUNCH_CHECK();
+  if (h->iota_n < n) {   // identity row index, kept on the handle (grown on demand)
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h->iota) (void)hipFree(h->iota);
+    h->iota = nullptr;
+    h->iota_n = 0;
+    const int cap = std::max(n, 4096);
+    HIP_TRY(hipMalloc((void**)&h->iota, (size_t)cap * sizeof(int32_t)));
+    iota32_kernel<<<cdiv(cap, 256), 256, 0, st>>>(h->iota, cap);
+    LAUNCH_CHECK();
+    h->iota_n = cap;
+  }
   const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks[1], h->half[1]) * 1024;
   FwdArgs a{};
   a.z = x;
   a.out = out;
   a.x = s.handoff;
   a.mod = mod;
-  a.row_index = s.ridx;
+  a.row_index = h->iota;
   a.w_final = h->wfinal[SCLDM_PREC_BF16];
   a.in_wt = h->in_wt;
   a.in_w = h->in_w;
@@ -485,7 +508,8 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     wa.kchunk = cdiv(cdiv(T, splits_req), kWK) * kWK;
     wa.part = s.part;
     const int splits = cdiv(T, wa.kchunk);
-    wgrad_bf16_kernel<<<dim3(tile0, splits), 256, kWgradLds, st>>>(wa);
+    wa.splits = splits;
+    wgrad_bf16_kernel<<<tile0 * splits, 256, kWgradLds, st>>>(wa);
     LAUNCH_CHECK();
     ra.n_jobs = nr;
     ra.splits = splits;
