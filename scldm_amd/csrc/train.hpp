@@ -455,16 +455,16 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       unsigned long long mm = hit[w];
-      while (mm) {   // up to 8 matches per trip: the loads are independent, the adds keep sample order
-        float v[8];
+      while (mm) {   // up to 32 matches per trip: the loads are independent (a label shared by most of the batch - the null token
+        float v[32];  // under label dropout - is one long latency-bound chain otherwise), the adds keep sample order
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 32; ++j) {
           const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
           mm &= mm - 1;
           v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * D + f] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
+        for (int j = 0; j < 32; ++j) s += v[j];
       }
     }
     __syncthreads();
@@ -503,18 +503,90 @@ __global__ __launch_bounds__(256) void embed_bwd_by_sample_kernel(const float* _
     for (int w = 0; w < 4; ++w) {
       unsigned long long mm = hit[w];
       while (mm) {
-        float v[8];
+        float v[32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 32; ++j) {
           const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
           mm &= mm - 1;
           v[j] = bit >= 0 ? dc[(long)(i0 + w * 64 + bit) * D + f] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += v[j];
+        for (int j = 0; j < 32; ++j) sum += v[j];
       }
     }
     __syncthreads();
+  }
+  dtable[mine * D + f] = sum;
+}
+
+// Two-level variant for batches where ONE label can cover most of the samples (the null token under label dropout: 80 % of
+// 1 024 cells): the sums above are one latency-bound chain per label.  Level 1: workgroup i, if sample i is the first of its
+// label inside its 64-sample segment, sums the segment's samples of that label into part[i].  Level 2: workgroup i, if sample i
+// is the first of its label in the whole batch, adds the partials of the segments' first occurrences in segment order.
+// Deterministic (fixed order), but the order is segment-wise: the bits differ from the single-level kernels'.
+constexpr int kEmbSeg = 64;
+constexpr int kEmbMaxSegs = 1024;   // n <= 65 536
+__device__ __forceinline__ long emb_label(const int64_t* __restrict__ labels, int s, int vocab) {
+  const long l = labels ? (long)labels[s] : (long)vocab;
+  return l < 0 ? 0L : (l > vocab ? (long)vocab : l);
+}
+__global__ __launch_bounds__(256) void embed_bwd_seg_partial_kernel(const float* __restrict__ dc, const int64_t* __restrict__ labels,
+                                                                    int vocab, int n, int D, float* __restrict__ part) {
+  __shared__ unsigned long long seg_mask;
+  const int i = blockIdx.x, tid = threadIdx.x, f = blockIdx.y * 256 + tid, seg0 = (i / kEmbSeg) * kEmbSeg;
+  const long mine = emb_label(labels, i, vocab);
+  if (tid < 64) {
+    const int s = seg0 + tid;
+    const unsigned long long m = __ballot(s < n && emb_label(labels, s, vocab) == mine);
+    if (tid == 0) seg_mask = m;
+  }
+  __syncthreads();
+  unsigned long long mm = seg_mask;
+  if (mm & ((1ull << (i - seg0)) - 1ull)) return;   // an earlier sample of this segment owns the label
+  float sum = 0.f;
+  while (mm) {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int bit = mm ? __ffsll((long long)mm) - 1 : -1;
+      mm &= mm - 1;
+      v[j] = bit >= 0 ? dc[(long)(seg0 + bit) * D + f] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) sum += v[j];
+  }
+  part[(long)i * D + f] = sum;
+}
+__global__ __launch_bounds__(256) void embed_bwd_seg_final_kernel(const float* __restrict__ part, const int64_t* __restrict__ labels,
+                                                                  int vocab, int n, int D, float* __restrict__ dtable) {
+  __shared__ int first_in_seg[kEmbMaxSegs];
+  __shared__ int earlier;
+  const int i = blockIdx.x, tid = threadIdx.x, f = blockIdx.y * 256 + tid, wave = tid >> 6, lane = tid & 63;
+  const long mine = emb_label(labels, i, vocab);
+  if (tid == 0) earlier = 0;
+  __syncthreads();
+  bool found = false;
+  for (int s = tid; s < i; s += 256) found |= emb_label(labels, s, vocab) == mine;
+  if (found) earlier = 1;
+  __syncthreads();
+  if (earlier) return;
+  const int nseg = (n + kEmbSeg - 1) / kEmbSeg, seg_i = i / kEmbSeg;
+  for (int g0 = seg_i; g0 < nseg; g0 += 4) {   // four segments per trip, one per wave
+    const int g = g0 + wave, s = g * kEmbSeg + lane;
+    const unsigned long long m = __ballot(g < nseg && s < n && emb_label(labels, s, vocab) == mine);
+    if (lane == 0 && g < nseg) first_in_seg[g] = m ? g * kEmbSeg + (__ffsll((long long)m) - 1) : -1;
+  }
+  __syncthreads();
+  float sum = 0.f;
+  for (int g0 = seg_i; g0 < nseg; g0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int g = g0 + j, src = g < nseg ? first_in_seg[g] : -1;
+      v[j] = src >= 0 ? part[(long)src * D + f] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum += v[j];
   }
   dtable[mine * D + f] = sum;
 }

@@ -282,6 +282,8 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   Saved s = carve_saved(h, n, saved_);
   Scratch k = carve_scratch(h, n, ws);
 
+  const bool use_fused = fused::eligible(h, n, precision);
+  if (use_fused) TRY(fused::prepare(h, w, st));   // weight re-pack on a side stream, next to the conditioning below
   // conditioning: c = t_embedder(t) + sum class embeddings; every adaLN vector (layers.py:351-364,206-216,395-398)
   hipLaunchKernelGGL(t_freq_kernel, dim3(n), dim3(256), 0, st, t, n, s.freq);
   LAUNCH_CHECK();
@@ -304,11 +306,10 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   LAUNCH_CHECK();
   hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
   LAUNCH_CHECK();
-  const bool use_fused = fused::eligible(h, n, precision);
   if (use_fused) {
     // every adaLN Linear of the network in ONE GEMM over the handle's all-layer transposed copy (ada_t is (D, mod_w), refreshed
     // from the live parameters by prepare()): mod = SiLU(c) W_all^T + b_all
-    TRY(fused::prepare(h, w, st));
+    TRY(fused::prepare_join(h, st));
     TRY(gemm(st, s.sc, kD, 1, h->ada_t, 1, mw, s.mod, mw, n, mw, kD, h->ada_b, false, k.part, k.part_floats));
   } else {
     for (int l = 0; l < L; ++l)
@@ -441,13 +442,17 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
   for (int c = 0; c < cfg.n_classes; ++c) {
-    if (h->tab_rows[c] > n) {   // more table rows than samples: organise the sum by sample (same order, same bits)
+    const int64_t* lab = labels ? labels[c] : nullptr;
+    if (n >= 256 && n <= kEmbSeg * kEmbMaxSegs && (size_t)n * kD <= k.part_floats) {
+      // training-size batch: two-level sums (a label shared by most samples - the null token - is not one serial chain)
       HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), st));
-      hipLaunchKernelGGL(embed_bwd_by_sample_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
-                         h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+      hipLaunchKernelGGL(embed_bwd_seg_partial_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, k.part);
+      hipLaunchKernelGGL(embed_bwd_seg_final_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.part, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+    } else if (h->tab_rows[c] > n) {   // more table rows than samples: organise the sum by sample (same order, same bits)
+      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), st));
+      hipLaunchKernelGGL(embed_bwd_by_sample_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     } else {
-      hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, labels ? labels[c] : nullptr,
-                         h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     }
     LAUNCH_CHECK();
   }

@@ -319,7 +319,23 @@ int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   }
   int rc = scldm_build_pack_tables(h, w, st);
   if (rc) return rc;
-  return scldm_run_pack(h, true, (1u << SCLDM_PREC_BF16) | 0x100u, st);
+  // The re-pack (90 us, memory bound) runs on a side stream next to the conditioning MLP, which reads the live parameters:
+  // forked here, joined by prepare_join() before the first consumer of a packed copy.
+  if (!h->side[0]) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->side[0], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->join_ev[0], hipEventDisableTiming));
+  }
+  if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->fork_ev, st));            // everything queued so far (the previous step's optimizer update) comes first
+  HIP_TRY(hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
+  rc = scldm_run_pack(h, true, (1u << SCLDM_PREC_BF16) | 0x100u, h->side[0]);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->join_ev[0], h->side[0]));
+  return SCLDM_OK;
+}
+int prepare_join(scldm_dit* h, hipStream_t st) {
+  HIP_TRY(hipStreamWaitEvent(st, h->join_ev[0], 0));
+  return SCLDM_OK;
 }
 
 int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st) {

@@ -35,7 +35,8 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base);
 bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision and batch served by the fused path
 
 // refresh the packed forward (bf16) and backward weight streams from the live parameters
-int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // forks the re-pack onto a side stream
+int prepare_join(scldm_dit* h, hipStream_t st);                           // `st` waits for it (before the first packed copy is read)
 // trunk forward (input projection .. final layer) with the record; mod = (n, mod_w) adaLN vectors
 int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st);
 // plain [T][256] fp32 <-> tile layout
