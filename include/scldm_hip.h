@@ -205,6 +205,16 @@ int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scl
                              const int64_t* const* labels, const float* dout, int n, float* dx, int precision, void* saved,
                              void* ws, void* stream);
 
+/* Flow-matching training step around the model call (Transport.training_losses, src/scldm/transport/transport.py:110-150 with
+ * ICPlan.plan, path.py:148-151): the eager reference spends ~20 elementwise launches here per step.
+ *   scldm_fm_mix:      xt = t*x1 + (1-t)*x0 (each product and the sum rounded separately, as eager torch does), ut = x1 - x0;
+ *                      x1, x0, xt, ut are (n, e) fp32, t is (n).
+ *   scldm_fm_loss:     loss[b] = mean_e (pred - ut)^2                              (mean_flat, utils.py:15-17)
+ *   scldm_fm_loss_bwd: dpred[b][:] = gloss[b] * 2/e * (pred - ut)                  (its gradient w.r.t. pred) */
+int scldm_fm_mix(const float* x1, const float* x0, const float* t, float* xt, float* ut, int n, int e, void* stream);
+int scldm_fm_loss(const float* pred, const float* ut, float* loss, int n, int e, void* stream);
+int scldm_fm_loss_bwd(const float* pred, const float* ut, const float* gloss, float* dpred, int n, int e, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * TransformerVAE encode / decode (MCAB pooling / unpooling + negative-binomial head), fp32.
  * Shape family of the reference (experiments/configs/model/vae_base.yaml:8-19,64-73): n_embed 32, 16 inducing

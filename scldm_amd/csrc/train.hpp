@@ -948,5 +948,40 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int splits, 
   out[c] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Flow-matching interpolation and loss around the model call (transport.py:110-150, path.py:148-151, utils.py:15-17).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void fm_mix_kernel(const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ t,
+                              float* __restrict__ xt, float* __restrict__ ut, long total, int e) {
+#pragma clang fp contract(off)   // te * x1 + (1 - te) * x0 with every intermediate rounded (no fused multiply-add): the eager reference's bits
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float tv = t[i / e], a = x1[i], b = x0[i];
+    const float p1 = tv * a, om = 1.0f - tv;
+    const float p0 = om * b;
+    xt[i] = p1 + p0;
+    ut[i] = a - b;
+  }
+}
+// one workgroup per sample: loss[b] = mean_e (pred - ut)^2 (fixed-order tree: deterministic)
+__global__ __launch_bounds__(256) void fm_loss_kernel(const float* __restrict__ pred, const float* __restrict__ ut, float* __restrict__ loss, int e) {
+  __shared__ float red[4];
+  const long b = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < e; i += 256) {
+    const float d = pred[b * e + i] - ut[b * e + i];
+    s = fmaf(d, d, s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)e;
+}
+__global__ void fm_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ ut, const float* __restrict__ gloss,
+                                   float* __restrict__ dpred, long total, int e) {
+  const float k = 2.0f / (float)e;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    dpred[i] = gloss[i / e] * k * (pred[i] - ut[i]);
+}
+
 }  // namespace train
 }  // namespace scldm

@@ -463,3 +463,24 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
   return SCLDM_OK;
 }
+
+extern "C" int scldm_fm_mix(const float* x1, const float* x0, const float* t, float* xt, float* ut, int n, int e, void* stream_) {
+  if (!x1 || !x0 || !t || !xt || !ut || n < 1 || e < 1) return fail(SCLDM_ERR_SHAPE, "scldm_fm_mix: bad argument");
+  const long total = (long)n * e;
+  hipLaunchKernelGGL(fm_mix_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream_, x1, x0, t, xt, ut, total, e);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_fm_loss(const float* pred, const float* ut, float* loss, int n, int e, void* stream_) {
+  if (!pred || !ut || !loss || n < 1 || e < 1) return fail(SCLDM_ERR_SHAPE, "scldm_fm_loss: bad argument");
+  hipLaunchKernelGGL(fm_loss_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream_, pred, ut, loss, e);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_fm_loss_bwd(const float* pred, const float* ut, const float* gloss, float* dpred, int n, int e, void* stream_) {
+  if (!pred || !ut || !gloss || !dpred || n < 1 || e < 1) return fail(SCLDM_ERR_SHAPE, "scldm_fm_loss_bwd: bad argument");
+  const long total = (long)n * e;
+  hipLaunchKernelGGL(fm_loss_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream_, pred, ut, gloss, dpred, total, e);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
