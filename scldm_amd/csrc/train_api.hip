@@ -374,18 +374,22 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   const fused::Scratch fs = use_fused ? fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes) : fused::Scratch{};
   // ---- final layer ----
   const int of = L * 6 * kD;
-  if (use_fused) {   // the record holds the final layer's input in tile layout; its LayerNorm output is recomputed
-    TRY(fused::to_plain(rec.x + (size_t)L * T * kD, s.x_last, n, st));
-    TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
+  const bool edge = use_fused && fused::edge_kernels_available(h);   // both ends of the backward as single kernels on the tile layout
+  if (edge) {
+    TRY(fused::final_backward(h, rec.x + (size_t)L * T * kD, s.mod, dout, w->fin_w, n, fs.dx, k.dmod, g->fin_w, g->fin_b, fs.edge_part, st));
+  } else {
+    if (use_fused) {   // the record holds the final layer's input in tile layout; its LayerNorm output is recomputed
+      TRY(fused::to_plain(rec.x + (size_t)L * T * kD, s.x_last, n, st));
+      TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
+    }
+    TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k, g->fin_b));
+    TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
+    TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
+    if (use_fused) TRY(fused::to_tile(k.dx, fs.dx, n, st));
   }
-  TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k, g->fin_b));
-  TRY(linear_dgrad(st, dout, din, w->fin_w, (int)T, din, kD, k.dh, kD, false, k));
-  TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
-
   if (use_fused) {
-    TRY(fused::to_tile(k.dx, fs.dx, n, st));
     TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st));
-    TRY(fused::to_plain(fs.dx, k.dx, n, st));
+    if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
   for (int l = use_fused ? -1 : L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
@@ -414,8 +418,12 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   }
 
   // ---- input projection + pos_embed ----
-  TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k, g->in_b));
-  if (g->pos_embed) TRY(colsum(st, k.dx, n, kS * kD, (long)kS * kD, g->pos_embed, k));
+  if (edge) {
+    TRY(fused::inproj_backward(h, fs.dx, x, n, g->in_w, g->in_b, g->pos_embed, fs.edge_part, st));
+  } else {
+    TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k, g->in_b));
+    if (g->pos_embed) TRY(colsum(st, k.dx, n, kS * kD, (long)kS * kD, g->pos_embed, k));
+  }
   if (dx_out) TRY(linear_dgrad(st, k.dx, kD, w->in_w, (int)T, kD, din, dx_out, din, false, k));
 
   // ---- adaLN Linears: mod_l = SiLU(c) W_l^T + b_l ----

@@ -242,6 +242,147 @@ __global__ void iota32_kernel(int32_t* __restrict__ ri, int n) {
   if (s < n) ri[s] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two ends of the backward, each as ONE kernel on the tile layout (they were eight and four small launches: relayouts,
+// LayerNorm forward / backward, two skinny GEMMs with K = all tokens and their split-K reductions).
+// Shape: a workgroup walks samples b, b + grid, ...; wave w takes tokens 4w .. 4w+3 of the sample, lane l features 4l .. 4l+3.
+// The skinny weight gradients (din x 256) are accumulated in registers across the workgroup's samples and leave as one
+// partial per wave; edge_reduce_kernel sums the partials in a fixed order.  fp32 arithmetic throughout (din <= 32).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kEdgeMaxDin = 32;
+__device__ __forceinline__ size_t tile_addr(long tok, int f) {   // float offset of feature f (multiple of 4) of token tok in the tile layout
+  const long tile = tok >> 6;
+  const int tt = (int)(tok >> 5) & 1, c32 = (int)tok & 31;
+  const int wave = f >> 6, ft = (f >> 5) & 1, q = (f >> 3) & 3, hh = (f >> 2) & 1;
+  return ((size_t)((tile * 4 + wave) * 16 + (tt * 2 + ft) * 4 + q) * 64 + c32 + 32 * hh) * 4;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Final layer (layers.py:397-401): out = (LN(x) (1 + scale) + shift) fin_w^T + b.  Given dout: d x (tile layout), the final adaLN
+// vectors' gradients, and per-wave partials of d fin_w (din x 256) and d fin_b (din).
+template <int DIN>
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ x_last, const float* __restrict__ mod, int mod_stride, int of,
+                                                        const float* __restrict__ dout, const float* __restrict__ fin_w, float eps, int n,
+                                                        float* __restrict__ dx, float* __restrict__ dmod, float* __restrict__ part) {
+  __shared__ f32x4 red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = lane * 4;
+  f32x4 wq[DIN];
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) wq[c] = *reinterpret_cast<const f32x4*>(fin_w + (size_t)c * kD + f);
+  f32x4 accw[DIN];
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) accw[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb = 0.f;   // lane c < DIN: sum_t dout[t][c]
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    const f32x4 shift = *reinterpret_cast<const f32x4*>(mod + (size_t)b * mod_stride + of + f);
+    f32x4 scale = *reinterpret_cast<const f32x4*>(mod + (size_t)b * mod_stride + of + kD + f);
+    scale += 1.0f;
+    f32x4 dsc = {0.f, 0.f, 0.f, 0.f}, dsh = {0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < 4; ++tt) {
+      const long tok = (long)b * 16 + wave * 4 + tt;
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x_last + tile_addr(tok, f));
+      const float mean = wave_sum64((xv[0] + xv[1]) + (xv[2] + xv[3])) * (1.0f / kD);
+      f32x4 xh = xv - mean;
+      const float rstd = 1.0f / sqrtf(wave_sum64((xh[0] * xh[0] + xh[1] * xh[1]) + (xh[2] * xh[2] + xh[3] * xh[3])) * (1.0f / kD) + eps);
+      xh *= rstd;
+      const f32x4 hv = xh * scale + shift;
+      const float dlane = lane < DIN ? dout[tok * DIN + lane] : 0.f;
+      accb += dlane;
+      f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < DIN; ++c) {
+        const float d = __shfl(dlane, c);
+        dh += d * wq[c];
+        accw[c] += d * hv;
+      }
+      dsc += dh * xh;
+      dsh += dh;
+      const f32x4 g = dh * scale;
+      const float s1 = wave_sum64((g[0] + g[1]) + (g[2] + g[3])) * (1.0f / kD);
+      const float s2 = wave_sum64((g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3])) * (1.0f / kD);
+      *reinterpret_cast<f32x4*>(dx + tile_addr(tok, f)) = rstd * (g - s1 - xh * s2);
+    }
+    red[0][wave][lane] = dsc;
+    red[1][wave][lane] = dsh;
+    __syncthreads();
+    if (wave < 2) {
+      const f32x4 t = (red[wave][0][lane] + red[wave][1][lane]) + (red[wave][2][lane] + red[wave][3][lane]);
+      // (shift, scale) = chunks (0, 1) of the final adaLN vector
+      *reinterpret_cast<f32x4*>(dmod + (size_t)b * mod_stride + of + (wave == 0 ? kD : 0) + f) = t;
+    }
+    __syncthreads();
+  }
+  float* p = part + (size_t)(blockIdx.x * 4 + wave) * (DIN * kD + kEdgeMaxDin);
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) *reinterpret_cast<f32x4*>(p + c * kD + f) = accw[c];
+  if (lane < kEdgeMaxDin) p[DIN * kD + lane] = lane < DIN ? accb : 0.f;
+}
+
+// Input projection (nnets.py:290): x0 = x in_w^T + in_b + pos.  Given d x0 (tile layout): per-wave partials of d in_w (256 x din,
+// stored [c][f]), d in_b (256) and d pos_embed (16 x 256: wave w owns token positions 4w .. 4w+3).
+template <int DIN>
+__global__ __launch_bounds__(256) void inproj_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ x, int n, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, f = lane * 4;
+  f32x4 accw[DIN], accp[4], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) accw[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) accp[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const long tok = (long)b * 16 + wave * 4 + tt;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dx + tile_addr(tok, f));
+      const float xl = lane < DIN ? x[tok * DIN + lane] : 0.f;
+      accb += d;
+      accp[tt] += d;
+#pragma unroll
+      for (int c = 0; c < DIN; ++c) accw[c] += __shfl(xl, c) * d;
+    }
+  }
+  // partial row: [DIN][256] weight | [256] bias | [16][256] positions (this wave's four rows, zeros elsewhere are implied by the reducer)
+  float* p = part + (size_t)(blockIdx.x * 4 + wave) * ((DIN + 1 + 4) * kD);
+#pragma unroll
+  for (int c = 0; c < DIN; ++c) *reinterpret_cast<f32x4*>(p + c * kD + f) = accw[c];
+  *reinterpret_cast<f32x4*>(p + DIN * kD + f) = accb;
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(p + (DIN + 1 + tt) * kD + f) = accp[tt];
+}
+
+// out[j] = sum_p part[p * ld + j] (p ascending), 16 columns x 16 row phases per workgroup; `period` > 0: only rows p with
+// p % period == phase0 contribute (the per-wave position rows of inproj_bwd_kernel)
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restrict__ part, int rows, int ld, int cols, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
+  float s = 0.f;
+  if (c < cols)
+    for (int p = ph; p < rows; p += 16) s += part[(size_t)p * ld + c];
+  red[ph][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (ph == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    out[c] = t;
+  }
+}
+// d in_w arrives as [c][f] (the kernel's accumulation order); the parameter is (256, din): out[f * din + c]
+__global__ void transpose_small_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows * cols) dst[(i % cols) * rows + i / cols] = src[i];
+}
+// d pos_embed[p][f] = sum over workgroups of the partial of wave p / 4, row p % 4
+__global__ __launch_bounds__(256) void pos_reduce_kernel(const float* __restrict__ part, int groups, int ld, int off, float* __restrict__ out) {
+  const int p = blockIdx.x, f = threadIdx.x;   // p = token position 0..15
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += part[(size_t)(g * 4 + p / 4) * ld + off + (p % 4) * kD + f];
+  out[p * kD + f] = s;
+}
+
 constexpr int kMaxScatterLayers = 64;
 struct ScatterArgs {
   float* w[kMaxScatterLayers + 1];   // [L] = final layer
@@ -279,6 +420,7 @@ Record carve_record(const scldm_dit* h, int n, void* base) {
   return r;
 }
 
+size_t edge_part_floats(const scldm_dit* h);
 static size_t part_floats(const scldm_dit* h) {
   const size_t H = h->cfg.hidden_dim;
   return (size_t)kSplits * (3 * kD * kD + kD * kD + 3 * H * kD + 3 * kD + kD);
@@ -302,6 +444,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.e_dy2 = c.take<__bf16>(T * kD);
   s.part = c.take<float>(part_floats(h));
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
+  s.edge_part = c.take<float>(edge_part_floats(h));
   s.bytes = c.off;
   return s;
 }
@@ -412,6 +555,60 @@ int to_plain(const float* tile, float* plain, int n, hipStream_t st) {
   relayout_kernel<false><<<cdiv(quads, 256), 256, 0, st>>>(tile, plain, quads);
   LAUNCH_CHECK();
   return SCLDM_OK;
+}
+
+template <int DIN>
+static int final_backward_t(scldm_dit* h, const float* x_last, const float* mod, const float* dout, const float* fin_w, int n, float* dx,
+                            float* dmod, float* gw, float* gb, float* part, hipStream_t st) {
+  const int of = h->cfg.n_layer * kModBlock, groups = std::min(n, 256), rows = groups * 4, ld = DIN * kD + kEdgeMaxDin;
+  final_bwd_kernel<DIN><<<groups, 256, 0, st>>>(x_last, mod, h->mod_w, of, dout, fin_w, h->cfg.layernorm_eps, n, dx, dmod, part);
+  LAUNCH_CHECK();
+  float* red = part + (size_t)rows * ld;   // [DIN*256 + 32] reduced, then split into the two parameters
+  edge_reduce_kernel<<<cdiv(ld, 16), 256, 0, st>>>(part, rows, ld, ld, red);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(gw, red, (size_t)DIN * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(gb, red + DIN * kD, (size_t)DIN * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SCLDM_OK;
+}
+int final_backward(scldm_dit* h, const float* x_last, const float* mod, const float* dout, const float* fin_w, int n, float* dx,
+                   float* dmod, float* gw, float* gb, float* part, hipStream_t st) {
+  switch (h->cfg.n_embed_input) {
+    case 16: return final_backward_t<16>(h, x_last, mod, dout, fin_w, n, dx, dmod, gw, gb, part, st);
+    case 32: return final_backward_t<32>(h, x_last, mod, dout, fin_w, n, dx, dmod, gw, gb, part, st);
+    case 8: return final_backward_t<8>(h, x_last, mod, dout, fin_w, n, dx, dmod, gw, gb, part, st);
+    default: return fail(SCLDM_ERR_SHAPE, "fused edge kernels are instantiated for n_embed_input 8 / 16 / 32");
+  }
+}
+bool edge_kernels_available(const scldm_dit* h) { const int d = h->cfg.n_embed_input; return d == 8 || d == 16 || d == 32; }
+size_t edge_part_floats(const scldm_dit* h) {
+  const size_t din = h->cfg.n_embed_input;
+  return (size_t)256 * 4 * ((din + 5) * kD + kEdgeMaxDin) + (din + 5) * kD + kEdgeMaxDin;
+}
+
+template <int DIN>
+static int inproj_backward_t(const float* dx, const float* x, int n, float* gw, float* gb, float* gpos, float* part, hipStream_t st) {
+  const int groups = std::min(n, 256), rows = groups * 4, ld = (DIN + 5) * kD;
+  inproj_bwd_kernel<DIN><<<groups, 256, 0, st>>>(dx, x, n, part);
+  LAUNCH_CHECK();
+  float* red = part + (size_t)rows * ld;   // [(DIN + 1) * 256] reduced: d in_w as [c][f], then d in_b
+  edge_reduce_kernel<<<cdiv((DIN + 1) * kD, 16), 256, 0, st>>>(part, rows, ld, (DIN + 1) * kD, red);
+  LAUNCH_CHECK();
+  transpose_small_kernel<<<cdiv(DIN * kD, 256), 256, 0, st>>>(red, DIN, kD, gw);
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(gb, red + DIN * kD, (size_t)kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (gpos) {
+    pos_reduce_kernel<<<16, 256, 0, st>>>(part, groups, ld, (DIN + 1) * kD, gpos);
+    LAUNCH_CHECK();
+  }
+  return SCLDM_OK;
+}
+int inproj_backward(scldm_dit* h, const float* dx, const float* x, int n, float* gw, float* gb, float* gpos, float* part, hipStream_t st) {
+  switch (h->cfg.n_embed_input) {
+    case 16: return inproj_backward_t<16>(dx, x, n, gw, gb, gpos, part, st);
+    case 32: return inproj_backward_t<32>(dx, x, n, gw, gb, gpos, part, st);
+    case 8: return inproj_backward_t<8>(dx, x, n, gw, gb, gpos, part, st);
+    default: return fail(SCLDM_ERR_SHAPE, "fused edge kernels are instantiated for n_embed_input 8 / 16 / 32");
+  }
 }
 
 int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st) {

@@ -28,6 +28,7 @@ struct Scratch {
   __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
   float* part;      // split-K partials of one layer's five weight gradients + two bias gradients
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
+  float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
   size_t bytes;
 };
 Scratch carve_scratch(const scldm_dit* h, int n, void* base);
@@ -46,6 +47,14 @@ int to_plain(const float* tile, float* plain, int n, hipStream_t st);
 // gradients of the layers' adaLN vectors; g receives attn_w/attn_b/proj_w/proj_b/w1/w2/cproj of every layer
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
                     hipStream_t st);
+
+// The two ends of the backward as single kernels on the tile layout (n_embed_input 8 / 16 / 32):
+//   final_backward: LayerNorm + Linear of the final layer: dx (tile layout), d(shift, scale) into dmod, d fin_w, d fin_b
+//   inproj_backward: d in_w, d in_b and (gpos != NULL) d pos_embed from d x0 (tile layout) and the input latents x
+bool edge_kernels_available(const scldm_dit* h);
+int final_backward(scldm_dit* h, const float* x_last, const float* mod, const float* dout, const float* fin_w, int n, float* dx,
+                   float* dmod, float* gw, float* gb, float* part, hipStream_t st);
+int inproj_backward(scldm_dit* h, const float* dx, const float* x, int n, float* gw, float* gb, float* gpos, float* part, hipStream_t st);
 
 // (mod_w, 256) stacked weight gradient + (mod_w) stacked bias gradient -> g->ada_w[l] / ada_b[l] / fin_ada_w / fin_ada_b
 int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st);

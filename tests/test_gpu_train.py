@@ -249,6 +249,7 @@ def test_fused_training_input_gradient_matches_oracle(monkeypatch):
     monkeypatch.setenv("SCLDM_TRAIN_FUSED", "1")
     m, sd, cfg = build({"clusters": 14}, "mutually_exclusive", 4, 78)
     m.precision = "bf16"
+    m.pos_embed.requires_grad_(True)     # frozen in the reference; its gradient comes out of the fused input-projection backward
     n = 8
     gen = torch.Generator().manual_seed(6)
     x = torch.randn(n, 16, 16, generator=gen)
@@ -262,6 +263,11 @@ def test_fused_training_input_gradient_matches_oracle(monkeypatch):
     xo = x.clone().requires_grad_(True)
     (dit_forward(p, cfg, xo, t, {"clusters": lab}) * wgt).sum().backward()
     assert float((xg.grad.cpu().double() - xo.grad.double()).norm() / xo.grad.double().norm()) < 3e-2
+    gp, rp = m.pos_embed.grad.cpu().double(), p["pos_embed"].grad.double()
+    assert float((gp - rp).norm() / rp.norm()) < 3e-2
+    for name in ("input_proj.weight", "input_proj.bias", "final_layer.linear.weight", "final_layer.linear.bias"):
+        ours, ref = dict(m.named_parameters())[name].grad.cpu().double(), p[name].grad.double()
+        assert float((ours - ref).norm() / ref.norm()) < 3e-2, name
 
 
 @pytest.mark.parametrize("n_embed,n_head,n_layer,n", [(512, 8, 2, 9), (512, 16, 2, 5), (1024, 16, 2, 6)])   # head_dim 64 / 32 / 64 (DiT-L width)
