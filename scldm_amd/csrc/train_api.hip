@@ -418,8 +418,14 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   }
 
   // ---- input projection + pos_embed ----
+  // Fused route: three independent tails follow the layers - the input projection (reads d x0), the stacked adaLN weight
+  // gradient (reads dmod) and the chain d SiLU(c) -> embeddings / timestep MLP.  They are small, latency-bound kernels with
+  // disjoint scratch, so the first two go to side streams and the chain stays on `st`.
+  hipStream_t s_in = st, s_ada = st;
+  if (edge && !dx_out) TRY(fused::fork_side(h, st, 0, &s_in));
+  if (use_fused) TRY(fused::fork_side(h, st, 1, &s_ada));
   if (edge) {
-    TRY(fused::inproj_backward(h, fs.dx, x, n, g->in_w, g->in_b, g->pos_embed, fs.edge_part, st));
+    TRY(fused::inproj_backward(h, fs.dx, x, n, g->in_w, g->in_b, g->pos_embed, fs.edge_part, s_in));
   } else {
     TRY(linear_wgrad(st, k.dx, kD, x, din, (int)T, kD, din, g->in_w, k, g->in_b));
     if (g->pos_embed) TRY(colsum(st, k.dx, n, kS * kD, (long)kS * kD, g->pos_embed, k));
@@ -432,9 +438,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     // contiguous (mod_w, D) scratch, scattered to the per-layer gradient tensors by one kernel
     float* dw_all = fs.ada_dw;
     float* db_all = fs.ada_dw + (size_t)mw * kD;
+    // (200 output tiles, K = n: no split-K, so this GEMM needs no partial buffer and can run beside the chain below)
+    TRY(gemm(s_ada, k.dmod, 1, mw, s.sc, 1, kD, dw_all, kD, mw, kD, n, nullptr, false, nullptr, 0, db_all));
+    TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, s_ada));
     TRY(gemm(st, k.dmod, mw, 1, h->ada_t, mw, 1, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
-    TRY(gemm(st, k.dmod, 1, mw, s.sc, 1, kD, dw_all, kD, mw, kD, n, nullptr, false, k.part, k.part_floats, db_all));
-    TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, st));
   }
   for (int l = use_fused ? L + 1 : 0; l <= L; ++l) {
     const int width = l < L ? 6 * kD : 2 * kD;
@@ -469,6 +476,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
   LAUNCH_CHECK();
   TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
+  if (s_in != st) TRY(fused::join_side(h, st, 0));
+  if (s_ada != st) TRY(fused::join_side(h, st, 1));
   return SCLDM_OK;
 }
 

@@ -476,6 +476,23 @@ int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   HIP_TRY(hipEventRecord(h->join_ev[0], h->side[0]));
   return SCLDM_OK;
 }
+// side stream k (created on first use) ordered after everything queued on `st` so far / `st` ordered after side stream k
+int fork_side(scldm_dit* h, hipStream_t st, int k, hipStream_t* out) {
+  if (!h->side[k]) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming));
+  }
+  if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(h->fork_ev, st));
+  HIP_TRY(hipStreamWaitEvent(h->side[k], h->fork_ev, 0));
+  *out = h->side[k];
+  return SCLDM_OK;
+}
+int join_side(scldm_dit* h, hipStream_t st, int k) {
+  HIP_TRY(hipEventRecord(h->join_ev[k], h->side[k]));
+  HIP_TRY(hipStreamWaitEvent(st, h->join_ev[k], 0));
+  return SCLDM_OK;
+}
 int prepare_join(scldm_dit* h, hipStream_t st) {
   HIP_TRY(hipStreamWaitEvent(st, h->join_ev[0], 0));
   return SCLDM_OK;

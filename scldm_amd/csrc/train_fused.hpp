@@ -56,6 +56,10 @@ int final_backward(scldm_dit* h, const float* x_last, const float* mod, const fl
                    float* dmod, float* gw, float* gb, float* part, hipStream_t st);
 int inproj_backward(scldm_dit* h, const float* dx, const float* x, int n, float* gw, float* gb, float* gpos, float* part, hipStream_t st);
 
+// independent tails of the backward run next to each other: side stream k starts after what `st` holds / `st` waits for it
+int fork_side(scldm_dit* h, hipStream_t st, int k, hipStream_t* out);
+int join_side(scldm_dit* h, hipStream_t st, int k);
+
 // (mod_w, 256) stacked weight gradient + (mod_w) stacked bias gradient -> g->ada_w[l] / ada_b[l] / fin_ada_w / fin_ada_b
 int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st);
 
