@@ -352,3 +352,38 @@ def test_flow_matching_mix_and_loss_kernels_match_the_eager_formulas():
     w.grad = None
     (loss_ref * wts).sum().backward()
     assert max_abs_rel(g_fused.cpu(), w.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("din", [8, 24, 32])
+def test_fused_training_other_latent_widths(din, monkeypatch):
+    """n_embed_input other than 16: 8 / 32 have their own instantiation of the fused final-layer / input-projection backward
+    kernels, 24 takes the generic GEMMs around the fused layers - all against autograd over the oracle (bf16 tolerance)."""
+    from scldm_amd.nnets import DiT
+    monkeypatch.setenv("SCLDM_TRAIN_FUSED", "1")
+    vocab = {"clusters": 14}
+    m = DiT(n_embed=256, n_embed_input=din, n_layer=2, n_head=8, seq_len=16, class_vocab_sizes=vocab,
+            condition_strategy="mutually_exclusive", **COMMON)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 90 + din)
+    m.load_state_dict(sd, strict=True)
+    cfg = DiTConfig(n_embed_input=din, n_layer=2, class_vocab_sizes=vocab)
+    m = m.cuda().train()
+    m.cfg_dropout_prob = 0.0
+    m.precision = "bf16"
+    m.pos_embed.requires_grad_(True)
+    n = 12
+    gen = torch.Generator().manual_seed(din)
+    x = torch.randn(n, 16, din, generator=gen)
+    t = torch.rand(n, generator=gen)
+    lab = torch.randint(0, 14, (n,), generator=gen)
+    wgt = torch.randn(n, 16, din, generator=gen)
+    (m(x.cuda(), t.cuda(), {"clusters": lab.cuda()}, force_drop_ids=False) * wgt.cuda()).sum().backward()
+    from oracle.dit import dit_forward
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (dit_forward(p, cfg, x, t, {"clusters": lab}) * wgt).sum().backward()
+    bad = {}
+    for name, q in m.named_parameters():
+        ref = p[name].grad.double()
+        e = float((q.grad.cpu().double() - ref).norm() / ref.norm())
+        if not e < 3e-2:
+            bad[name] = e
+    assert not bad, bad
