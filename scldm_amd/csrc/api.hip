@@ -88,6 +88,10 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
   h->dbg_layer = -1;
   if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
+  h->train_fused = true;
+  if (const char* e = getenv("SCLDM_TRAIN_FUSED")) h->train_fused = atoi(e) != 0;
+  if (const char* e = getenv("SCLDM_WGRAD_SPLITS")) h->wgrad_splits = atoi(e);
+  h->bwd_dbg = getenv("SCLDM_BWD_DBG") != nullptr;
   h->n_chunks[0] = (cfg->hidden_dim + kHC - 1) / kHC;  // FT=1: pad the hidden dimension to whole chunks
   h->half[0] = 0;
   {
@@ -108,6 +112,11 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
     if ((e = alloc(&h->stream[p][f], elems * es)) != hipSuccess) break;
     if ((e = hipMemset(h->stream[p][f], 0, elems * es)) != hipSuccess) break;
     if ((e = alloc(&h->wfinal[p], 16 * 512 * es)) != hipSuccess) break;
+  }
+  if (e == hipSuccess && cfg->hidden_dim <= kBwdChunks * kBwdChunk) {   // backward weight stream of the fused training path (bf16, 23 MB at 8 layers)
+    const size_t elems = ((size_t)L * 8 * kBwdUnitsLayer + kMaxPF) * 512;   // + ring over-read slack
+    e = alloc(&h->bwd_stream, elems * 2);
+    if (e == hipSuccess) e = hipMemset(h->bwd_stream, 0, elems * 2);
   }
   if (e == hipSuccess) e = alloc((void**)&h->b_qkv, (size_t)L * 768 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->b_proj, (size_t)L * 256 * 4);

@@ -46,6 +46,9 @@ struct scldm_dit {
   void* bwd_stream;         // bf16 backward weight stream [layer][8 waves][kBwdUnitsLayer][512] (+ ring slack); allocated on first use
   std::vector<const void*> table_key;  // every device pointer of the scldm_dit_weights the job / fingerprint tables were built from
   bool tables_built;
+  bool train_fused;         // SCLDM_TRAIN_FUSED (read once at create; 0 keeps the base shape on the generic training path)
+  int wgrad_splits;         // SCLDM_WGRAD_SPLITS (read once at create; 0: default)
+  bool bwd_dbg;             // SCLDM_BWD_DBG (read once at create): print the backward kernel's phase stamps
   int32_t* iota;            // identity row index 0..iota_n-1 (the training forward's conditioning rows are the samples themselves)
   int iota_n;
   void* d_tjobs;            // device PackJob table of the training step's subset

@@ -402,10 +402,7 @@ __global__ void scatter_ada_kernel(const float* __restrict__ dw_all, const float
   }
 }
 
-bool fused_enabled() {   // SCLDM_TRAIN_FUSED=0: the generic GEMM-based path also for the base shape (A/B runs, tests)
-  const char* e = getenv("SCLDM_TRAIN_FUSED");
-  return !(e && atoi(e) == 0);
-}
+
 
 }  // namespace
 
@@ -450,17 +447,13 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
 }
 
 bool eligible(const scldm_dit* h, int n, int precision) {
-  return fused_enabled() && h && h->fused && precision == SCLDM_PREC_BF16 && n >= 4 && n % 4 == 0 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
+  // h->train_fused: SCLDM_TRAIN_FUSED=0 at handle creation keeps the base shape on the generic GEMM-based path (A/B runs, tests)
+  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 4 && n % 4 == 0 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
 int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
-  if (!h->bwd_stream) {
-    const size_t elems = ((size_t)h->cfg.n_layer * bwd::NW * kBwdUnitsLayer + kMaxPF) * 512;   // + ring over-read slack
-    HIP_TRY(hipMalloc(&h->bwd_stream, elems * sizeof(__bf16)));
-    HIP_TRY(hipMemset(h->bwd_stream, 0, elems * sizeof(__bf16)));
-  }
-  int rc = scldm_build_pack_tables(h, w, st);
+  int rc = scldm_build_pack_tables(h, w, st);   // (the backward stream itself is allocated with the handle)
   if (rc) return rc;
   // The re-pack (90 us, memory bound) runs on a side stream next to the conditioning MLP, which reads the live parameters:
   // forked here, joined by prepare_join() before the first consumer of a packed copy.
@@ -681,7 +674,7 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     a.attn_scale = 1.0f / sqrtf(32.0f);
     a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
     static unsigned long long* dbg_buf = nullptr;   // SCLDM_BWD_DBG=1: phase stamps of layer 0's launch, printed per step (debug aid)
-    const bool want_dbg = l == 0 && getenv("SCLDM_BWD_DBG") != nullptr;
+    const bool want_dbg = l == 0 && h->bwd_dbg;
     if (want_dbg && !dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, (size_t)16384 * bwd::NW * 16 * 8));
     a.dbg = (want_dbg && n / 4 <= 16384) ? dbg_buf : nullptr;
     bwd::dit_backward_kernel<<<n / 4, bwd::NT, bwd::LDS_BYTES, st>>>(a);
@@ -734,7 +727,7 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     }
     wa.n_jobs = 5;
     wa.T = T;
-    static const int splits_req = getenv("SCLDM_WGRAD_SPLITS") ? std::max(1, std::min(kSplits, atoi(getenv("SCLDM_WGRAD_SPLITS")))) : kSplitsDefault;
+    const int splits_req = h->wgrad_splits > 0 ? std::min(kSplits, h->wgrad_splits) : kSplitsDefault;
     wa.kchunk = cdiv(cdiv(T, splits_req), kWK) * kWK;
     wa.part = s.part;
     const int splits = cdiv(T, wa.kchunk);
