@@ -70,52 +70,60 @@ struct WgradArgs {
   int n_jobs, T, kchunk, splits;
   float* part;
 };
-constexpr int kWK = 64;            // tokens per staged tile (the kernel is latency bound: a stage is what one workgroup keeps in flight)
-constexpr int kWLD = kWK + 8;      // bf16 elements per LDS row (144 B: 16 consecutive rows of a fragment read fall on distinct 16-byte slots)
-constexpr int kWG = kWK / 32;      // 8-token groups per thread
+constexpr int kWK = 64;            // tokens per staged tile
+constexpr int kWLD = 128 + 32;     // bf16 elements per LDS row of a [token][feature] image (320 B: the 8-byte pieces of the transposing
+                                   // fragment reads of a 32-lane half - 2 groups x 4 token rows - fall on eight distinct 32-byte bank ranges)
 
-struct OperandLoader {   // 128 features x kWK tokens: thread -> (feature pair tid & 63, token groups (tid >> 6) + 4 g)
-  uint32_t d[kWG][8];
-  __device__ __forceinline__ void load(const __bf16* __restrict__ P, int ld, int m0, int t0) {
-    const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
+// 64 tokens x 128 features of a [token][ld] bf16 operand: 16-byte buffer loads (row offset on the scalar unit), stored to LDS as
+// they are; the k-major MFMA fragments come out of ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of the
+// 4 x 16 block whose 8-byte pieces the group's lanes address (verified on the part: lane i supplies row i/4, columns 4(i%4)..+3).
+// The first version gathered 4-byte pieces per token and transposed in registers: 64 VMEM + 32 permute instructions per wave
+// and stage against 16 + 0 here (timing proxies: the loads alone were 16 of its 55 us).
+struct OperandLoader {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 d[4];   // pass p: token 16 p + 4 wave + lane / 16, features 8 (lane % 16) .. +7
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int m0, int t0) {
+    const int lane = threadIdx.x & 63;
+    const unsigned voff = (unsigned)(lane >> 4) * (unsigned)ld * 2u + (unsigned)(lane & 15) * 16u;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-    for (int g = 0; g < kWG; ++g) {
-      const __bf16* p = P + (size_t)(t0 + (tg + 4 * g) * 8) * ld + m0 + 2 * fp;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) d[g][i] = *reinterpret_cast<const uint32_t*>(p + (size_t)i * ld);
-    }
+    for (int p = 0; p < 4; ++p)
+      d[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ((unsigned)(t0 + 16 * p + 4 * wave) * (unsigned)ld + (unsigned)m0) * 2u, 0);
   }
-  __device__ __forceinline__ void add_rowsum(float (&rs)[2]) const {
+  // rs[e] += the stage's values of feature 8 (lane % 16) + e (this thread's four tokens)
+  __device__ __forceinline__ void add_rowsum(float (&rs)[8]) const {
 #pragma unroll
-    for (int g = 0; g < kWG; ++g)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        rs[0] += __uint_as_float(d[g][i] << 16);
-        rs[1] += __uint_as_float(d[g][i] & 0xffff0000u);
+      for (int i = 0; i < 4; ++i) {
+        rs[2 * i] += __uint_as_float(d[p][i] << 16);
+        rs[2 * i + 1] += __uint_as_float(d[p][i] & 0xffff0000u);
       }
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    const int fp = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int g = 0; g < kWG; ++g) {
-      u32x4 lo, hi;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        lo[i] = __builtin_amdgcn_perm(d[g][2 * i + 1], d[g][2 * i], 0x05040100u);
-        hi[i] = __builtin_amdgcn_perm(d[g][2 * i + 1], d[g][2 * i], 0x07060302u);
-      }
-      *reinterpret_cast<u32x4*>(S + (2 * fp) * kWLD + (tg + 4 * g) * 8) = lo;
-      *reinterpret_cast<u32x4*>(S + (2 * fp + 1) * kWLD + (tg + 4 * g) * 8) = hi;
-    }
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(S + (16 * p + 4 * wave + (lane >> 4)) * kWLD + (lane & 15) * 8) = d[p];
   }
 };
+// fragment of the 32 features [f0, f0 + 32) (MFMA rows / columns) over the 16 tokens [kk, kk + 16) of a [token][feature] image
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* __restrict__ S, int f0, int kk, int lane) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  const int g = lane >> 4, i = lane & 15;
+  const __bf16* p = S + (kk + 8 * (g >> 1) + (i >> 2)) * kWLD + f0 + 16 * (g & 1) + 4 * (i & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kWLD));
+  union { s16x4 s[2]; bf16x8 f; } u;
+  u.s[0] = lo;
+  u.s[1] = hi;
+  return u.f;
+}
 
-constexpr int kWgradLds = 2 * 2 * 128 * kWLD * 2;   // two buffers x two operands
+constexpr int kWgradLds = 2 * 2 * kWK * kWLD * 2;   // two buffers x two operands = 80 KB: two workgroups per CU
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) char wgrad_smem[];
-  auto As = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + b * (128 * kWLD); };
-  auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + (2 + b) * (128 * kWLD); };
+  auto As = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + b * (kWK * kWLD); };
+  auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + (2 + b) * (kWK * kWLD); };
   // XCD-aware numbering: workgroups are dealt to the 8 XCDs round-robin by linear id, so with id = tile * splits + split every
   // XCD gets ONE token range (for 8 splits) of all tiles: the tiles that share operand rows re-read them from that XCD's L2
   // instead of 2-6 times from the fabric (436 MB of tile loads per launch against 139 MB of operands).
@@ -139,18 +147,21 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
   // Two register stages per operand: the loads of stage i+2 are issued while stage i is multiplied and stage i+1 (requested one
-  // whole iteration earlier) is written to LDS - a single stage left ~1.5 k cycles of every ~2.3 k-cycle iteration waiting for
-  // HBM.  Barriers order LDS only (lds_barrier): __syncthreads() would drain the loads in flight.
+  // whole iteration earlier) is written to LDS.  Barriers order LDS only (lds_barrier): __syncthreads() would drain the loads in flight.
   OperandLoader la[2], lb[2];
+  auto make_rsrc = [](const __bf16* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(j.A), rb = make_rsrc(j.B);
   const bool want_rs = j.rs_off >= 0 && tn == 0;
-  float rs[2] = {0.f, 0.f};
+  float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n_it = (t_end - t_beg + kWK - 1) / kWK;
-  la[0].load(j.A, j.lda, m0, t_beg);
-  lb[0].load(j.B, j.ldb, n0, t_beg);
-  if (n_it > 1) {
-    la[1].load(j.A, j.lda, m0, t_beg + kWK);
-    lb[1].load(j.B, j.ldb, n0, t_beg + kWK);
-  }
+  la[0].load(ra, j.lda, m0, t_beg);
+  lb[0].load(rb, j.ldb, n0, t_beg);
+  la[1].load(ra, j.lda, m0, t_beg + min(1, n_it - 1) * kWK);
+  lb[1].load(rb, j.ldb, n0, t_beg + min(1, n_it - 1) * kWK);
   if (want_rs) la[0].add_rowsum(rs);
   la[0].store(As(0));
   lb[0].store(Bs(0));
@@ -158,19 +169,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   auto iteration = [&](int it, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;     // register slot of stage `it` (already in LDS buffer it & 1): free again
     const int buf = it & 1;
-    if (it + 2 < n_it) {
-      la[SLOT].load(j.A, j.lda, m0, t_beg + (it + 2) * kWK);
-      lb[SLOT].load(j.B, j.ldb, n0, t_beg + (it + 2) * kWK);
-    }
-    const __bf16* __restrict__ as = As(buf) + (wm * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
-    const __bf16* __restrict__ bs = Bs(buf) + (wn * 64 + (lane & 31)) * kWLD + (lane >> 5) * 8;
+    // unconditional (the last two iterations re-request the last stage): with the loads under a branch the compiler's waitcnt
+    // pass must assume the path that issued none, and then waits for the NEW stage as well when it needs the old one
+    const int ahead = t_beg + min(it + 2, n_it - 1) * kWK;
+    la[SLOT].load(ra, j.lda, m0, ahead);
+    lb[SLOT].load(rb, j.ldb, n0, ahead);
 #pragma unroll
     for (int kk = 0; kk < kWK; kk += 16) {
       bf16x8 af[2], bf[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kWLD + kk);
+      for (int i = 0; i < 2; ++i) af[i] = tr_frag(As(buf), wm * 64 + i * 32, kk, lane);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) bf[k] = *reinterpret_cast<const bf16x8*>(bs + k * 32 * kWLD + kk);
+      for (int k = 0; k < 2; ++k) bf[k] = tr_frag(Bs(buf), wn * 64 + k * 32, kk, lane);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -187,14 +197,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
     iteration(it, std::integral_constant<int, 0>{});
     if (it + 1 < n_it) iteration(it + 1, std::integral_constant<int, 1>{});
   }
-  if (want_rs) {   // the four token groups (tid >> 6) of a feature pair hold partial sums of the same two rows
-    float* red = reinterpret_cast<float*>(wgrad_smem);
-    red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 0] = rs[0];
-    red[(threadIdx.x >> 6) * 128 + (threadIdx.x & 63) * 2 + 1] = rs[1];
+  if (want_rs) {   // the 16 threads (tid / 16) that share a feature chunk hold partial sums of the same eight rows
+    float* red = reinterpret_cast<float*>(wgrad_smem);   // [16][128]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(threadIdx.x >> 4) * 128 + (threadIdx.x & 15) * 8 + e] = rs[e];
     lds_barrier();
-    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < j.M)
-      g.part[j.rs_off + (long)z * j.M + m0 + threadIdx.x] =
-          (red[threadIdx.x] + red[128 + threadIdx.x]) + (red[256 + threadIdx.x] + red[384 + threadIdx.x]);
+    if (threadIdx.x < 128 && m0 + (int)threadIdx.x < j.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += red[q * 128 + threadIdx.x];
+      g.part[j.rs_off + (long)z * j.M + m0 + threadIdx.x] = t;
+    }
   }
   float* __restrict__ C = g.part + j.part_off + (long)z * j.M * j.N;
 #pragma unroll
