@@ -56,7 +56,7 @@ struct BwdArgs {
   const float* b_qkv;     // (768) c_attn bias of this layer
   // operand pairs of the weight-gradient GEMMs, plain [token][ld] bf16
   __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
-  int n;                  // samples (multiple of 4)
+  int n;                  // real samples; the last tile may be padded (its padding samples repeat the last real one, gradient zero)
   float eps, attn_scale, attn_scale_log2e;
   unsigned long long* dbg;   // optional phase stamps [block][wave][16] (SCLDM_BWD_DBG=1; nullptr otherwise)
 };
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       float tot[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[r] = row16_sum(v[tt][r]);
-      if ((c32 & 15) == 0) {
+      if ((c32 & 15) == 0 && smp0 + tt * 2 + sp < a.n) {
         float* dst = a.dmod + (size_t)(smp0 + tt * 2 + sp) * a.mod_stride + a.mod_off + vec * kD + fb + hh * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + q * 8) = f32x4{tot[q * 4], tot[q * 4 + 1], tot[q * 4 + 2], tot[q * 4 + 3]};
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 #pragma unroll
     for (int j = 0; j < kModLd; ++j) {
       const int idx = tid + NT * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
-      f32x4 m = *reinterpret_cast<const f32x4*>(a.mod + (size_t)(smp0 + sl) * a.mod_stride + a.mod_off + w4 * 4);
+      f32x4 m = *reinterpret_cast<const f32x4*>(a.mod + (size_t)min(smp0 + sl, a.n - 1) * a.mod_stride + a.mod_off + w4 * 4);
       const int vec = w4 / (kD / 4);
       if (vec == 0 || vec == 3) m += 1.0f;
       OP::store_mod4(MOD + (size_t)idx * 4, m);

@@ -370,16 +370,17 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   Scratch k = carve_scratch(h, n, ws);
 
   const bool use_fused = fused::eligible(h, n, precision);
+  const long T_pad = (long)((n + 3) / 4 * 4) * kS;   // tokens incl. the padding of the last 64-token tile (tile layouts)
   const fused::Record rec = use_fused ? fused::carve_record(h, n, s.layer[0].x_in) : fused::Record{};
   const fused::Scratch fs = use_fused ? fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes) : fused::Scratch{};
   // ---- final layer ----
   const int of = L * 6 * kD;
   const bool edge = use_fused && fused::edge_kernels_available(h);   // both ends of the backward as single kernels on the tile layout
   if (edge) {
-    TRY(fused::final_backward(h, rec.x + (size_t)L * T * kD, s.mod, dout, w->fin_w, n, fs.dx, k.dmod, g->fin_w, g->fin_b, fs.edge_part, st));
+    TRY(fused::final_backward(h, rec.x + (size_t)L * T_pad * kD, s.mod, dout, w->fin_w, n, fs.dx, k.dmod, g->fin_w, g->fin_b, fs.edge_part, st));
   } else {
     if (use_fused) {   // the record holds the final layer's input in tile layout; its LayerNorm output is recomputed
-      TRY(fused::to_plain(rec.x + (size_t)L * T * kD, s.x_last, n, st));
+      TRY(fused::to_plain(rec.x + (size_t)L * T_pad * kD, s.x_last, n, st));
       TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
     }
     TRY(linear_wgrad(st, dout, din, s.h_f, kD, (int)T, din, kD, g->fin_w, k, g->fin_b));

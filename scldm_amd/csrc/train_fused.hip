@@ -38,7 +38,7 @@ struct Carver {
 // quad j = (tt*2 + ft)*4 + q holds features wave*64 + ft*32 + q*8 + (lane>>5)*4 .. +3 of token tile*64 + tt*32 + (lane&31)
 // ---------------------------------------------------------------------------------------------------------------
 template <bool TO_TILE>
-__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, long quads) {
+__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, long quads, long real_tokens) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (i >= quads) return;
   const int lane = (int)(i & 63), j = (int)((i >> 6) & 15), wave = (int)((i >> 10) & 3);
@@ -46,8 +46,9 @@ __global__ void relayout_kernel(const float* __restrict__ src, float* __restrict
   const int tt = j >> 3, ft = (j >> 2) & 1, q = j & 3;
   const long tok = tile * 64 + tt * 32 + (lane & 31);
   const int f = wave * 64 + ft * 32 + q * 8 + (lane >> 5) * 4;
-  if (TO_TILE) *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(src + tok * kD + f);
-  else *reinterpret_cast<f32x4*>(dst + tok * kD + f) = *reinterpret_cast<const f32x4*>(src + i * 4);
+  // tokens past the real batch (tile padding): zeros into the tile layout, nothing out of it
+  if (TO_TILE) *reinterpret_cast<f32x4*>(dst + i * 4) = tok < real_tokens ? *reinterpret_cast<const f32x4*>(src + tok * kD + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+  else if (tok < real_tokens) *reinterpret_cast<f32x4*>(dst + tok * kD + f) = *reinterpret_cast<const f32x4*>(src + i * 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -419,8 +420,10 @@ __global__ void scatter_ada_kernel(const float* __restrict__ dw_all, const float
 
 }  // namespace
 
+static inline int pad4(int n) { return (n + 3) / 4 * 4; }   // whole 64-token tiles; samples past n are tile padding
+
 Record carve_record(const scldm_dit* h, int n, void* base) {
-  const size_t TD = (size_t)n * 16 * kD, L = h->cfg.n_layer;
+  const size_t TD = (size_t)pad4(n) * 16 * kD, L = h->cfg.n_layer;
   Carver c{reinterpret_cast<char*>(base)};
   Record r;
   r.x = c.take<float>((L + 1) * TD);
@@ -437,7 +440,7 @@ static size_t part_floats(const scldm_dit* h) {
 }
 
 Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
-  const size_t T = (size_t)n * 16;
+  const size_t T = (size_t)pad4(n) * 16;
   Carver c{reinterpret_cast<char*>(base)};
   Scratch s;
   s.handoff = c.take<float>(T * kD);
@@ -461,7 +464,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
 
 bool eligible(const scldm_dit* h, int n, int precision) {
   // h->train_fused: SCLDM_TRAIN_FUSED=0 at handle creation keeps the base shape on the generic GEMM-based path (A/B runs, tests)
-  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 4 && n % 4 == 0 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
+  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 1 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
@@ -553,8 +556,8 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
   a.rec_x = rec.x;
   a.rec_y1 = rec.y1;
   a.rec_y2 = rec.y2;
-  a.rec_stride = (long)n * 16 * kD;
-  const int tiles = n / 4;
+  a.rec_stride = (long)pad4(n) * 16 * kD;
+  const int tiles = pad4(n) / 4;   // the kernel clamps the samples past n to the last real one and never stores their output
   for (int i = 0; i < c.n_layer; i += h->lpl) {
     a.layer = i;
     a.n_here = std::min(h->lpl, c.n_layer - i);
@@ -568,14 +571,14 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
 }
 
 int to_tile(const float* plain, float* tile, int n, hipStream_t st) {
-  const long quads = (long)n * 16 * kD / 4;
-  relayout_kernel<true><<<cdiv(quads, 256), 256, 0, st>>>(plain, tile, quads);
+  const long quads = (long)pad4(n) * 16 * kD / 4;
+  relayout_kernel<true><<<cdiv(quads, 256), 256, 0, st>>>(plain, tile, quads, (long)n * 16);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
 int to_plain(const float* tile, float* plain, int n, hipStream_t st) {
-  const long quads = (long)n * 16 * kD / 4;
-  relayout_kernel<false><<<cdiv(quads, 256), 256, 0, st>>>(tile, plain, quads);
+  const long quads = (long)pad4(n) * 16 * kD / 4;
+  relayout_kernel<false><<<cdiv(quads, 256), 256, 0, st>>>(tile, plain, quads, (long)n * 16);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -584,6 +587,8 @@ template <int DIN>
 static int final_backward_t(scldm_dit* h, const float* x_last, const float* mod, const float* dout, const float* fin_w, int n, float* dx,
                             float* dmod, float* gw, float* gb, float* part, hipStream_t st) {
   const int of = h->cfg.n_layer * kModBlock, groups = std::min(n, 256), rows = groups * 4, ld = DIN * kD + kEdgeMaxDin;
+  if (n % 4)   // ragged batch: the padding samples of the last 64-token tile must enter the layers with a zero gradient
+    HIP_TRY(hipMemsetAsync(dx + (size_t)(n / 4) * 64 * kD, 0, (size_t)64 * kD * sizeof(float), st));
   final_bwd_kernel<DIN><<<groups, 256, 0, st>>>(x_last, mod, h->mod_w, of, dout, fin_w, h->cfg.layernorm_eps, n, dx, dmod, part);
   LAUNCH_CHECK();
   float* red = part + (size_t)rows * ld;   // [DIN*256 + 32] reduced, then split into the two parameters
@@ -665,7 +670,7 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     if (dev >= 0 && dev < 64) wattr_set[dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
-  const int T = n * 16, H = c.hidden_dim;
+  const int tiles = pad4(n) / 4, T = pad4(n) * 16, H = c.hidden_dim;   // the padding tokens carry zero gradients into the operand pairs
   const size_t TD = (size_t)T * kD;
   const size_t bwd_layer_elems = (size_t)bwd::NW * kBwdUnitsLayer * 512;
   for (int l = c.n_layer - 1; l >= 0; --l) {
@@ -689,18 +694,18 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     static unsigned long long* dbg_buf = nullptr;   // SCLDM_BWD_DBG=1: phase stamps of layer 0's launch, printed per step (debug aid)
     const bool want_dbg = l == 0 && h->bwd_dbg;
     if (want_dbg && !dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, (size_t)16384 * bwd::NW * 16 * 8));
-    a.dbg = (want_dbg && n / 4 <= 16384) ? dbg_buf : nullptr;
-    bwd::dit_backward_kernel<<<n / 4, bwd::NT, bwd::LDS_BYTES, st>>>(a);
+    a.dbg = (want_dbg && tiles <= 16384) ? dbg_buf : nullptr;
+    bwd::dit_backward_kernel<<<tiles, bwd::NT, bwd::LDS_BYTES, st>>>(a);
     LAUNCH_CHECK();
     if (a.dbg) {
       HIP_TRY(hipStreamSynchronize(st));
-      std::vector<unsigned long long> hst((size_t)(n / 4) * bwd::NW * 16);
+      std::vector<unsigned long long> hst((size_t)tiles * bwd::NW * 16);
       HIP_TRY(hipMemcpy(hst.data(), dbg_buf, hst.size() * 8, hipMemcpyDeviceToHost));
       double acc[16] = {0};
-      for (int b = 0; b < n / 4; ++b)
+      for (int b = 0; b < tiles; ++b)
         for (int i = 1; i < 14; ++i) acc[i] += (double)(hst[((size_t)b * bwd::NW) * 16 + i] - hst[((size_t)b * bwd::NW) * 16 + i - 1]);
       fprintf(stderr, "[bwd phases, wave 0, mean cycles]");
-      for (int i = 1; i < 14; ++i) fprintf(stderr, " %d:%.0f", i, acc[i] / (n / 4));
+      for (int i = 1; i < 14; ++i) fprintf(stderr, " %d:%.0f", i, acc[i] / tiles);
       fprintf(stderr, "\n");
     }
 
