@@ -30,6 +30,23 @@ def grad_buckets(params, bucket_bytes: int = 256 << 20):
     return buckets
 
 
+def _shared_flat_grad(params):
+    """One 1-D tensor spanning every .grad when all of them are contiguous views of the same storage (what
+    scldm_amd.nnets._DiTTrainFn.backward produces), else None."""
+    grads = [p.grad for p in params if p.requires_grad]
+    if not grads or any(g is None or not g.is_contiguous() for g in grads):
+        return None
+    g0 = grads[0]
+    st = g0.untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() or g.dtype != g0.dtype or g.device != g0.device for g in grads):
+        return None
+    lo = min(g.storage_offset() for g in grads)
+    hi = max(g.storage_offset() + g.numel() for g in grads)
+    if sum(g.numel() for g in grads) < 0.9 * (hi - lo):     # mostly gaps: not the flat layout this shortcut is for
+        return None
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, lo, (hi - lo,))
+
+
 @torch.no_grad()
 def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20, average: bool = True) -> int:
     """Sum (or average) .grad over the ranks of `group` with one all_reduce per bucket.  A parameter whose .grad is None on
@@ -40,7 +57,16 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20, avera
     if world == 1:
         return 0
     calls = 0
-    for bucket in grad_buckets(list(params), bucket_bytes):
+    params = list(params)
+    flat = _shared_flat_grad(params)
+    if flat is not None and flat.numel() * flat.element_size() <= bucket_bytes:
+        # the HIP backward returns every gradient as a view of ONE buffer: reduce that buffer in place (no gather / scatter
+        # copies; the alignment gaps between the views are reduced along with them and never read)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat.div_(world)
+        return 1
+    for bucket in grad_buckets(params, bucket_bytes):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         if average:

@@ -105,3 +105,46 @@ def test_gradient_allreduce_buckets(world, bucket_bytes):
     assert all(ok for _, ok, _, _ in results)
     assert all(calls == nb for _, _, calls, nb in results)
     assert results[0][3] == (1 if bucket_bytes > 1 << 20 else results[0][3]) and results[0][3] >= 1
+
+
+def _flat_grad_worker(rank, world, port, out_q):
+    from scldm_amd.training import _shared_flat_grad, allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(7, 5), (64, 64), (1, 16, 8), (11,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    # gradients as views of one buffer with alignment gaps, as the HIP backward returns them
+    offs, total = [], 0
+    for s in shapes:
+        offs.append(total)
+        total += (int(torch.Size(s).numel()) + 63) // 64 * 64
+    flat = torch.full((total,), float("nan"))            # the gaps hold garbage: they must not leak into any gradient
+    for i, (p, o) in enumerate(zip(params, offs)):
+        view = flat[o:o + p.numel()].view(p.shape)
+        view.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(100 * rank + i)))
+        p.grad = view
+    shared = _shared_flat_grad(params)
+    calls = allreduce_gradients(params)
+    exp = [sum(torch.randn(s, generator=torch.Generator().manual_seed(100 * r + i)) for r in range(world)) / world for i, s in enumerate(shapes)]
+    ok = shared is not None and all(torch.allclose(p.grad, e, atol=1e-6) for p, e in zip(params, exp))
+    ok = ok and all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params)   # reduced in place
+    out_q.put((rank, ok, calls))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_of_a_shared_flat_buffer():
+    """When every .grad is a view of one buffer (scldm_amd.nnets._DiTTrainFn.backward), the exchange is ONE in-place all-reduce."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in results)
+    assert all(calls == 1 for _, _, calls in results)
