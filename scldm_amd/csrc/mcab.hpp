@@ -43,6 +43,14 @@ __global__ void pack_frag32_kernel(const float* __restrict__ W, int ld, float* _
   const int l = idx & 63, j = idx >> 6;
   out[((j >> 2) * 64 + l) * 4 + (j & 3)] = W[(l & 31) * ld + acc_row(j, l >> 5)];
 }
+// the same with k = 16 (l >> 5) + j: the B operand then is "lane half hh holds features 16 hh .. 16 hh + 15" (the fp32 per-gene
+// decoder's attention output leaves the VALU in that order: heads 2 hh and 2 hh + 1)
+__global__ void pack_frag32_halves_kernel(const float* __restrict__ W, int ld, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 16 * 64) return;
+  const int l = idx & 63, j = idx >> 6;
+  out[((j >> 2) * 64 + l) * 4 + (j & 3)] = W[(l & 31) * ld + 16 * (l >> 5) + j];
+}
 // SwiGLU up-projection, tile u (16 hidden): rows 0-15 = w1[16u + r], rows 16-31 = w2[16u + r]; hidden >= H -> 0
 __global__ void pack_frag_w12_kernel(const float* __restrict__ W1, const float* __restrict__ W2, int H, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,7 +286,8 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Decoder, per cell pair (one wave): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
-// packed as MFMA A-operand fragments for the per-gene kernel (48 fragments = 12 KiB per cell):
+// PLAIN (fp32 per-gene kernel, whose attention runs on the VALU): written per cell as [key 16][K 32 | V 32] fp32 (4 KiB);
+// otherwise packed as MFMA A-operand fragments for the bf16-operand per-gene kernel (48 fragments = 12 KiB per cell):
 //   K tile t (heads 2t, 2t+1), step jj < 8:  lane(row = hl*16 + key, hh): K[key][k] if head(k) == 2t + hl else 0,
 //                                             k = acc_row(8t + jj, hh)
 //   V tile t, step r < 16: lane(row = f, hh): V[key][f] if head(f) == 2t + hl else 0, (hl, key) = acc_row(r, hh) >> 4, & 15
@@ -289,10 +298,11 @@ struct DecCellArgs {
   const float* trunk;    // packed trunk weights
   const float* ca_ln1_w; const float* ca_ln1_b;  // decoder_cross_attention.ln_1
   const float* kv_frag;  // decoder_cross_attention.attn.c_attn.weight (64, 32): K tile | V tile fragments
-  float* kvfrag;         // (B, 48*64) floats
+  float* kvfrag;         // (B, 48*64) floats (fragments) or (B, 16, 64) (PLAIN)
   int B, n_lat, n_layer;
   float eps;
 };
+template <bool PLAIN>
 __global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -326,6 +336,17 @@ __global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCel
       *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
   }
   wave_lds_sync();
+  if constexpr (PLAIN) {
+    for (int c = 0; c < 2; ++c) {
+      if (pair * 2 + c >= a.B) break;
+      float* out = a.kvfrag + (size_t)(pair * 2 + c) * (kNI * 64);
+      const int key = lane >> 2, col = (lane & 3) * 16;
+      const float* src = S + (c * 16 + key) * kTrunkLd + col;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(out + key * 64 + col + q * 4) = *reinterpret_cast<const f32x4*>(src + q * 4);
+    }
+    return;
+  }
   const int row = lane & 31;
   for (int c = 0; c < 2; ++c) {
     if (pair * 2 + c >= a.B) break;
@@ -378,8 +399,9 @@ struct DecGeneArgs {
   const float* emb;       // input_layer.gene_embedding.weight (n_genes+1, 32)
   const float* qtab;      // (n_genes+1, 32) pre-projected, pre-scaled queries
   const float* theta_emb; // decoder_head.theta.weight (n_genes+1, 1)
-  const float* kvfrag;    // (B, 48*64)
+  const float* kvfrag;    // bf16 path: (B, 48*64) K/V fragments; fp32 path: (B, 16, 64) plain K | V per inducing point
   const float* wfrag;     // packed c_proj (16 steps) | w12 (6*16) | wc (6*8) fragments = 160*64 floats
+  const float* wfrag_cproj_halves;   // fp32 path: the 16 c_proj fragments with k in lane-half order (pack_frag32_halves_kernel)
   const float* ln2_w; const float* ln2_b;  // decoder_cross_attention.ln_2
   const float* head_w; const float* head_b;  // decoder_head.params (1,32), (1)
   float* logits;          // (B, G)  (aliases mu)
@@ -404,11 +426,11 @@ constexpr int kDecWaves = SCLDM_DEC_WAVES;
 constexpr int kDecThreads = 64 * kDecWaves;
 template <bool BF>
 __global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
-  constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : 12 * 64, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
-  __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4
-  __shared__ f32x4 KV[kKV4];    // fp32: this cell's 48 K/V fragments
-  __shared__ bf16x8 WFh[kWF8];  // bf16: the same, 8 steps per 16-byte fragment
-  __shared__ bf16x8 KVh[kKV8];
+  constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : kNI * 16, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
+  __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4 (the 16 c_proj ones in lane-half k order)
+  __shared__ f32x4 KVP[kKV4];   // fp32: this cell's K | V, plain [key][64 floats]
+  __shared__ bf16x8 WFh[kWF8];  // bf16: the 160 fragments, 8 steps per 16-byte fragment
+  __shared__ bf16x8 KVh[kKV8];  // bf16: this cell's 48 K/V fragments
   __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
   __shared__ float RED[kDecWaves][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,8 +448,9 @@ __global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) vo
     cvt(a.wfrag, WFh, 20);
     cvt(a.kvfrag + (size_t)cell * 48 * 64, KVh, 6);
   } else {
-    for (int i = tid; i < 40 * 64; i += kDecThreads) WF[i] = reinterpret_cast<const f32x4*>(a.wfrag)[i];
-    for (int i = tid; i < 12 * 64; i += kDecThreads) KV[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * 48 * 64)[i];
+    for (int i = tid; i < 40 * 64; i += kDecThreads)
+      WF[i] = i < 4 * 64 ? reinterpret_cast<const f32x4*>(a.wfrag_cproj_halves)[i] : reinterpret_cast<const f32x4*>(a.wfrag)[i];
+    for (int i = tid; i < kNI * 16; i += kDecThreads) KVP[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * (kNI * 64))[i];
   }
   if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
   __syncthreads();
@@ -453,60 +476,126 @@ __global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) vo
     if ((tile0 + ti) * 32 >= a.G) break;  // wave-uniform
     const bool valid = gi < a.G;
     const long long g = valid ? a.genes[(size_t)cell * a.G + gi] : 0;
-    // q^T and the raw embedding in accumulator order: register r <-> feature acc_row(r, hh)
-    float q[16], y[16];
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.qtab + (size_t)g * kE + qd * 8 + hh * 4);
-      const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { q[qd * 4 + i] = t4[i]; y[qd * 4 + i] = e4[i]; }
-    }
-    // S^T[(head, key)][gene] = Kblk q^T  (block sparse: tile t only sees features 16t..16t+15)
-    f32x16 st[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      st[t] = mm8(KV, KVh, 8 * t, q + 8 * t, zero16());
-    }
-    // softmax over the 16 keys of each head: 8 keys in-lane (registers 8hl..8hl+7) + 8 in the other half-wave
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int hl = 0; hl < 2; ++hl) {
-        float m = st[t][8 * hl];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) m = fmaxf(m, st[t][8 * hl + i]);
-        m = xor32_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float p = __expf(st[t][8 * hl + i] - m);
-          st[t][8 * hl + i] = p;
-          sum += p;
-        }
-        sum = xor32_sum(sum);
-        const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st[t][8 * hl + i] *= inv;
-      }
-    // O^T[f][gene] = Vblk^T P^T
-    f32x16 ot = zero16();
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float pr[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pr[r] = st[t][r];
-      ot = mm8(KV, KVh, 16 + 16 * t, pr, ot);
-      ot = mm8(KV, KVh, 16 + 16 * t + 8, pr + 8, ot);
-    }
-    // y = q_raw + c_proj(O)   (residual from the query, layers.py:327)
+    float y[16];
     f32x16 yt = zero16();
-    {
-      float ov[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ov[r] = ot[r];
-      yt = mm8(WF, WFh, 0, ov, yt);
-      yt = mm8(WF, WFh, 8, ov + 8, yt);
+    if constexpr (BF) {
+      // q^T and the raw embedding in accumulator order: register r <-> feature acc_row(r, hh)
+      float q[16];
+  #pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.qtab + (size_t)g * kE + qd * 8 + hh * 4);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) { q[qd * 4 + i] = t4[i]; y[qd * 4 + i] = e4[i]; }
+      }
+      // S^T[(head, key)][gene] = Kblk q^T  (block sparse: tile t only sees features 16t..16t+15)
+      f32x16 st[2];
+  #pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st[t] = mm8(nullptr, KVh, 8 * t, q + 8 * t, zero16());
+      }
+      // softmax over the 16 keys of each head: 8 keys in-lane (registers 8hl..8hl+7) + 8 in the other half-wave
+  #pragma unroll
+      for (int t = 0; t < 2; ++t)
+  #pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          float m = st[t][8 * hl];
+  #pragma unroll
+          for (int i = 1; i < 8; ++i) m = fmaxf(m, st[t][8 * hl + i]);
+          m = xor32_max(m);
+          float sum = 0.f;
+  #pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float p = __expf(st[t][8 * hl + i] - m);
+            st[t][8 * hl + i] = p;
+            sum += p;
+          }
+          sum = xor32_sum(sum);
+          const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
+  #pragma unroll
+          for (int i = 0; i < 8; ++i) st[t][8 * hl + i] *= inv;
+        }
+      // O^T[f][gene] = Vblk^T P^T
+      f32x16 ot = zero16();
+  #pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float pr[16];
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] = st[t][r];
+        ot = mm8(nullptr, KVh, 16 + 16 * t, pr, ot);
+        ot = mm8(nullptr, KVh, 16 + 16 * t + 8, pr + 8, ot);
+      }
+      // y = q_raw + c_proj(O)   (residual from the query, layers.py:327)
+      {
+        float ov[16];
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ot[r];
+        yt = mm8(WF, WFh, 0, ov, yt);
+        yt = mm8(WF, WFh, 8, ov + 8, yt);
+      }
+    } else {
+      // the raw embedding in accumulator order (register r <-> feature acc_row(r, hh): it meets the c_proj output there); the
+      // pre-projected query as this lane half's two heads (features 16 hh .. 16 hh + 15)
+      float q[16];
+  #pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.qtab + (size_t)g * kE + hh * 16 + qd * 4);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) { q[qd * 4 + i] = t4[i]; y[qd * 4 + i] = e4[i]; }
+      }
+      // Cross attention of one gene over the cell's 16 inducing points, heads 2 hh and 2 hh + 1 in this lane (the other lane of
+      // the gene has the other two): 2 x 16 dot products of 8, an in-lane softmax, 2 x 8 outputs - 512 FMAs whose K / V operands
+      // are two-address LDS broadcasts.  On 32x32 MFMA tiles the same work cost 48 fp32 MFMAs (3 072 cycles of the matrix pipe,
+      // two thirds of them on structural zeros) plus four half-wave exchanges.
+      float o[16];
+      {
+        const f32x4* KP = KVP + hh * 4;
+        float sc[2][kNI];
+  #pragma unroll
+        for (int key = 0; key < kNI; ++key) {
+          const f32x4 k0 = KP[key * 16], k1 = KP[key * 16 + 1], k2 = KP[key * 16 + 2], k3 = KP[key * 16 + 3];
+          float s0 = q[0] * k0[0], s1 = q[8] * k2[0];
+  #pragma unroll
+          for (int i = 1; i < 4; ++i) { s0 = fmaf(q[i], k0[i], s0); s1 = fmaf(q[8 + i], k2[i], s1); }
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) { s0 = fmaf(q[4 + i], k1[i], s0); s1 = fmaf(q[12 + i], k3[i], s1); }
+          sc[0][key] = s0;
+          sc[1][key] = s1;
+        }
+  #pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          float m = sc[hl][0];
+  #pragma unroll
+          for (int key = 1; key < kNI; ++key) m = fmaxf(m, sc[hl][key]);
+          float sum = 0.f;
+  #pragma unroll
+          for (int key = 0; key < kNI; ++key) {
+            sc[hl][key] = __expf(sc[hl][key] - m);
+            sum += sc[hl][key];
+          }
+          const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
+  #pragma unroll
+          for (int key = 0; key < kNI; ++key) sc[hl][key] *= inv;
+        }
+  #pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = 0.f;
+        const f32x4* VP = KVP + 8 + hh * 4;
+  #pragma unroll
+        for (int key = 0; key < kNI; ++key) {
+          const f32x4 v0 = VP[key * 16], v1 = VP[key * 16 + 1], v2 = VP[key * 16 + 2], v3 = VP[key * 16 + 3];
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = fmaf(sc[0][key], v0[i], o[i]);
+            o[4 + i] = fmaf(sc[0][key], v1[i], o[4 + i]);
+            o[8 + i] = fmaf(sc[1][key], v2[i], o[8 + i]);
+            o[12 + i] = fmaf(sc[1][key], v3[i], o[12 + i]);
+          }
+        }
+      }
+      // y = q_raw + c_proj(O)   (residual from the query, layers.py:327); the c_proj fragments are packed for this k order
+      yt = mm8(WF, WFh, 0, o, yt);
+      yt = mm8(WF, WFh, 8, o + 8, yt);
     }
     float s = 0.f;
 #pragma unroll

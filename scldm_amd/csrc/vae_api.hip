@@ -16,6 +16,7 @@ struct scldm_vae {
   float* dec_trunk;
   float* frag_cell;   // fragments of the per-cell Linears around the trunks (layout: F_* below)
   float* frag_dec;    // c_proj 16 | w12 96 | wc 48 fragments (160*64 floats)
+  float* frag_dec_halves;   // the 16 c_proj fragments with k in lane-half order (fp32 per-gene kernel)
   float* frag_enc_k;  // 16*64
   float* frag_enc_v;  // 16*64
   float* frag_enc_q;  // 16*64
@@ -63,6 +64,7 @@ extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&h->dec_trunk, tl);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_cell, (size_t)F_TOTAL * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_dec, 160 * 64 * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->frag_dec_halves, 16 * 64 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_k, 16 * 64 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_v, 16 * 64 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->frag_enc_q, 16 * 64 * 4);
@@ -80,7 +82,7 @@ extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
 
 extern "C" void scldm_vae_destroy(scldm_vae* h) {
   if (!h) return;
-  float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_cell, h->frag_dec, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
+  float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_cell, h->frag_dec, h->frag_dec_halves, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -144,6 +146,7 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(ec.cproj, H, fc + F_ENC_WC);
   pack_frag32_pad_kernel<<<4, 256, 0, st>>>(w->enc_latent_w, 32, nl, 32, fc + F_ENC_LAT);
   pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec);                                  // 16 fragments
+  pack_frag32_halves_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec_halves);                    // the same, k in lane-half order (fp32 path)
   pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(dc.w1, dc.w2, H, h->frag_dec + 16 * 64);  // 96
   pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(dc.cproj, H, h->frag_dec + (16 + 96) * 64); // 48
   pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_kv, 32, h->frag_enc_k);                                   // K rows 0-31
@@ -218,11 +221,12 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   d.z = z; d.lat_frag = h->frag_cell + F_DEC_LAT; d.trunk = h->dec_trunk;
   d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.kv_frag = h->frag_cell + F_DEC_KV;
   d.kvfrag = kv; d.B = B; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.eps = c.layernorm_eps;
-  dec_cell_kernel<<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
+  if (precision == SCLDM_PREC_BF16) dec_cell_kernel<false><<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
+  else dec_cell_kernel<true><<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
   LAUNCH_CHECK();
   const int nch = dec_chunks(G);
   DecGeneArgs g;
-  g.genes = genes; g.emb = h->emb; g.qtab = h->qtab; g.theta_emb = h->theta; g.kvfrag = kv; g.wfrag = h->frag_dec;
+  g.genes = genes; g.emb = h->emb; g.qtab = h->qtab; g.theta_emb = h->theta; g.kvfrag = kv; g.wfrag = h->frag_dec; g.wfrag_cproj_halves = h->frag_dec_halves;
   g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
   g.logits = mu; g.theta = draw ? nullptr : theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
   g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
