@@ -425,7 +425,10 @@ struct DecGeneArgs {
 constexpr int kDecWaves = SCLDM_DEC_WAVES;
 constexpr int kDecThreads = 64 * kDecWaves;
 template <bool BF>
-__global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
+#ifndef SCLDM_DEC_MINW
+#define SCLDM_DEC_MINW 4
+#endif
+__global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 : 1) : SCLDM_DEC_MINW) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
   constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : kNI * 16, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
   __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4 (the 16 c_proj ones in lane-half k order)
   __shared__ f32x4 KVP[kKV4];   // fp32: this cell's K | V, plain [key][64 floats]
@@ -569,9 +572,10 @@ __global__ __launch_bounds__(kDecThreads, kDecWaves >= 8 ? kDecWaves / 2 : 1) vo
   #pragma unroll
           for (int key = 1; key < kNI; ++key) m = fmaxf(m, sc[hl][key]);
           float sum = 0.f;
-  #pragma unroll
+          const float nm = -m * 1.4426950408889634f;
+#pragma unroll
           for (int key = 0; key < kNI; ++key) {
-            sc[hl][key] = __expf(sc[hl][key] - m);
+            sc[hl][key] = __builtin_amdgcn_exp2f(fmaf(sc[hl][key], 1.4426950408889634f, nm));   // exp(s - m): one fma + v_exp_f32
             sum += sc[hl][key];
           }
           const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division

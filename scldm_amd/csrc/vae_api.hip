@@ -161,7 +161,7 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   return SCLDM_OK;
 }
 
-static const int kDecTilesPerWave = (32 + kDecWaves - 1) / kDecWaves;  // kDecWaves waves x tiles x 32 genes ~ 1024 genes per workgroup
+static const int kDecTilesPerWave = getenv("SCLDM_DEC_TPW") ? atoi(getenv("SCLDM_DEC_TPW")) : (32 + kDecWaves - 1) / kDecWaves;  // kDecWaves waves x tiles x 32 genes ~ 1024 genes per workgroup
 static inline int dec_chunks(int G) { return cdiv(G, kDecWaves * kDecTilesPerWave * 32); }
 
 extern "C" size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G) {
