@@ -425,6 +425,9 @@ struct DecGeneArgs {
 constexpr int kDecWaves = SCLDM_DEC_WAVES;
 constexpr int kDecThreads = 64 * kDecWaves;
 template <bool BF>
+#ifndef SCLDM_DEC_UNROLL
+#define SCLDM_DEC_UNROLL 1   // the six SwiGLU tiles of a gene tile unrolled: the next tile's up-projection MFMAs issue under this tile's SiLU (+2 % fp32 decode)
+#endif
 #ifndef SCLDM_DEC_MINW
 #define SCLDM_DEC_MINW 4
 #endif
@@ -617,7 +620,11 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
     }
     // SwiGLU: six tiles of 16 hidden units, each consumed by the down-projection as soon as it exists
     f32x16 mo = zero16();
+#if SCLDM_DEC_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int u = 0; u < kHTiles; ++u) {
       f32x16 ht = mm8(WF, WFh, 16 + 16 * u, yn, zero16());
       ht = mm8(WF, WFh, 16 + 16 * u + 8, yn + 8, ht);
