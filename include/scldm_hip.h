@@ -193,6 +193,11 @@ typedef struct {
 size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n);
 /* Scratch bytes for either call (gradient temporaries, split-K partials). */
 size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n);
+/* The same for a known precision: the fused bf16 route of the base shape keeps 32 KB per cell per layer (layer inputs + the two
+ * gated branch outputs) instead of the generic route's 295 KB, and needs none of its per-token gradient temporaries; buffers
+ * sized by the two functions above (precision unknown: the larger, generic layout) are accepted by every route. */
+size_t scldm_dit_train_saved_bytes_for(const scldm_dit* h, int n, int precision);
+size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precision);
 
 /* out (n,S,Din) = DiT.forward(x (n,S,Din), t (n), labels) keeping every intermediate the backward needs in `saved`. */
 int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,

@@ -40,7 +40,9 @@ struct Carver {
   }
 };
 
-Saved carve_saved(const scldm_dit* h, int n, void* base) {
+// fused_path: the layers' activations are the record of train_fused.hpp (layer inputs + y1, y2 in tile layout) instead of the
+// twelve per-layer arrays; the per-layer pointers other than layer[0].x_in (the record's base) stay null
+Saved carve_saved(const scldm_dit* h, int n, void* base, bool fused_path) {
   const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim, kD = h->cfg.n_embed;
   Carver c{reinterpret_cast<char*>(base)};
   Saved s;
@@ -51,6 +53,10 @@ Saved carve_saved(const scldm_dit* h, int n, void* base) {
   s.sc = c.take((size_t)n * kD);
   s.mod = c.take((size_t)n * ((size_t)h->cfg.n_layer * 6 * kD + 2 * kD));
   s.layer.resize(h->cfg.n_layer);
+  if (fused_path) {
+    for (auto& l : s.layer) l = LayerSaved{};
+    s.layer[0].x_in = c.take(fused::carve_record(h, n, nullptr).bytes / sizeof(float) + 64);
+  } else
   for (auto& l : s.layer) {
     l.x_in = c.take(T * kD);
     l.st1 = c.take(T * 2);
@@ -66,26 +72,35 @@ Saved carve_saved(const scldm_dit* h, int n, void* base) {
     l.hid = c.take(T * H);
     l.y2 = c.take(T * kD);
   }
-  s.x_last = c.take(T * kD);
-  s.st_f = c.take(T * 2);
-  s.h_f = c.take(T * kD);
+  if (fused_path && fused::edge_kernels_available(h)) {   // the final layer's backward is one kernel on the record's tile layout
+    s.x_last = s.st_f = s.h_f = nullptr;
+  } else {
+    s.x_last = c.take(T * kD);
+    s.st_f = c.take(T * 2);
+    s.h_f = c.take(T * kD);
+  }
   s.bytes = c.off;
   return s;
 }
 
 constexpr int kMaxSplit = 32;
-Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
+// fused_path: the per-token gradient arrays of the layers (dy, dao, dqkv, dhid, da, db) are not used
+Scratch carve_scratch(const scldm_dit* h, int n, void* base, bool fused_path) {
   const size_t T = (size_t)n * kS, H = h->cfg.hidden_dim, kD = h->cfg.n_embed;
   Carver c{reinterpret_cast<char*>(base)};
   Scratch s;
   s.dx = c.take(T * kD);
   s.dh = c.take(T * kD);
-  s.dy = c.take(T * kD);
-  s.dao = c.take(T * kD);
-  s.dqkv = c.take(T * 3 * kD);
-  s.dhid = c.take(T * H);
-  s.da = c.take(T * H);
-  s.db = c.take(T * H);
+  if (fused_path) {
+    s.dy = s.dao = s.dqkv = s.dhid = s.da = s.db = nullptr;
+  } else {
+    s.dy = c.take(T * kD);
+    s.dao = c.take(T * kD);
+    s.dqkv = c.take(T * 3 * kD);
+    s.dhid = c.take(T * H);
+    s.da = c.take(T * H);
+    s.db = c.take(T * H);
+  }
   s.dmod = c.take((size_t)n * ((size_t)h->cfg.n_layer * 6 * kD + 2 * kD));
   s.dsc = c.take((size_t)n * kD);
   s.dc = c.take((size_t)n * kD);
@@ -261,12 +276,21 @@ int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int prec
 
 extern "C" size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n) {
   if (!h || n < 1) return 0;
-  return carve_saved(h, n, nullptr).bytes;
+  return carve_saved(h, n, nullptr, false).bytes;   // (precision unknown here: the larger, generic layout)
+}
+extern "C" size_t scldm_dit_train_saved_bytes_for(const scldm_dit* h, int n, int precision) {
+  if (!h || n < 1) return 0;
+  return carve_saved(h, n, nullptr, fused::eligible(h, n, precision)).bytes;
+}
+extern "C" size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precision) {
+  if (!h || n < 1) return 0;
+  const bool f = fused::eligible(h, n, precision);
+  return carve_scratch(h, n, nullptr, f).bytes + (f ? fused::carve_scratch(h, n, nullptr).bytes : 0);
 }
 extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
   if (!h || n < 1) return 0;
   // the fused bf16 path (train_fused.hpp) carves its own scratch behind the generic one
-  return carve_scratch(h, n, nullptr).bytes + (h->fused ? fused::carve_scratch(h, (n + 3) / 4 * 4, nullptr).bytes : 0);
+  return carve_scratch(h, n, nullptr, false).bytes + (h->fused ? fused::carve_scratch(h, n, nullptr).bytes : 0);
 }
 
 extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
@@ -279,10 +303,10 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, kD = cfg.n_embed, kNH = cfg.n_head;
   const int mw = L * 6 * kD + 2 * kD;
   const long T = (long)n * kS;
-  Saved s = carve_saved(h, n, saved_);
-  Scratch k = carve_scratch(h, n, ws);
-
   const bool use_fused = fused::eligible(h, n, precision);
+  Saved s = carve_saved(h, n, saved_, use_fused);
+  Scratch k = carve_scratch(h, n, ws, use_fused);
+
   if (use_fused) TRY(fused::prepare(h, w, st));   // weight re-pack on a side stream, next to the conditioning below
   // conditioning: c = t_embedder(t) + sum class embeddings; every adaLN vector (layers.py:351-364,206-216,395-398)
   hipLaunchKernelGGL(t_freq_kernel, dim3(n), dim3(256), 0, st, t, n, s.freq);
@@ -366,8 +390,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   const int L = cfg.n_layer, din = cfg.n_embed_input, H = cfg.hidden_dim, kD = cfg.n_embed, kNH = cfg.n_head;
   const int mw = L * 6 * kD + 2 * kD;
   const long T = (long)n * kS;
-  Saved s = carve_saved(h, n, saved_);
-  Scratch k = carve_scratch(h, n, ws);
+  Saved s = carve_saved(h, n, saved_, fused::eligible(h, n, precision));
+  Scratch k = carve_scratch(h, n, ws, fused::eligible(h, n, precision));
 
   const bool use_fused = fused::eligible(h, n, precision);
   const long T_pad = (long)((n + 3) / 4 * 4) * kS;   // tokens incl. the padding of the last 64-token tile (tile layouts)

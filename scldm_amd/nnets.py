@@ -97,11 +97,11 @@ class _DiTTrainFn(torch.autograd.Function):
         n = x.shape[0]
         dev = x.device
         x = x.detach().contiguous()
-        saved = torch.empty(L.scldm_dit_train_saved_bytes(h, n), dtype=torch.uint8, device=dev)
-        ws = torch.empty(L.scldm_dit_train_workspace_bytes(h, n), dtype=torch.uint8, device=dev)
+        prec = module._prec()
+        saved = torch.empty(L.scldm_dit_train_saved_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.scldm_dit_train_workspace_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
         w, _ = module._weights_struct(params)
         out = torch.empty_like(x)
-        prec = module._prec()
         with torch.cuda.device(dev):
             _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
                                                  out.data_ptr(), prec, saved.data_ptr(), ws.data_ptr(), _stream_ptr()),

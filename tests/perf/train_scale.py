@@ -23,3 +23,11 @@ for B in (256, 512, 1024, 2048, 4096):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     print(f"B={B:5d}  {1e3 * dt:.3f} ms/step  {B / dt / 1e3:.1f} k cells/s")
+
+# activation record actually allocated per cell per layer (fused bf16 vs generic)
+from scldm_amd import _lib
+m = bench.make_model(dict(bench.TRAIN_WORKLOADS["replogle_train_b1024"]), "bf16", dev).train()
+L_, h_ = m._native_handle()
+for prec, name in ((1, "bf16 (fused)"), (0, "fp32 (generic)")):
+    sb, wb = L_.scldm_dit_train_saved_bytes_for(h_, 1024, prec), L_.scldm_dit_train_workspace_bytes_for(h_, 1024, prec)
+    print(f"{name}: saved {sb / 2**20:.0f} MiB = {sb / 1024 / 8 / 1024:.1f} KiB per cell per layer, workspace {wb / 2**20:.0f} MiB")

@@ -390,3 +390,17 @@ def test_fused_training_other_latent_widths(din, monkeypatch):
         if not e < 3e-2:
             bad[name] = e
     assert not bad, bad
+
+
+def test_fused_training_buffers_are_the_small_ones():
+    """What the autograd binding allocates for the fused bf16 route: layer inputs + the two gated branch outputs (34 KiB per cell
+    per layer incl. the final layer's input) + the conditioning block - not the generic route's 295 KiB of per-layer activations."""
+    from scldm_amd import _lib
+    m, sd, cfg = build({"cell_line": 4, "gene": 2024}, "joint", 8, 83)
+    L, h = m._native_handle()
+    n, n_layer = 1024, 8
+    fused = L.scldm_dit_train_saved_bytes_for(h, n, _lib.PRECISIONS["bf16"])
+    generic = L.scldm_dit_train_saved_bytes_for(h, n, _lib.PRECISIONS["fp32"])
+    assert generic == L.scldm_dit_train_saved_bytes(h, n)
+    assert fused / (n * n_layer) < 42 * 1024 < 290 * 1024 < generic / (n * n_layer)
+    assert L.scldm_dit_train_workspace_bytes_for(h, n, _lib.PRECISIONS["bf16"]) <= L.scldm_dit_train_workspace_bytes(h, n)
