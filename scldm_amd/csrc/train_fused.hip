@@ -464,7 +464,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
 
 bool eligible(const scldm_dit* h, int n, int precision) {
   // h->train_fused: SCLDM_TRAIN_FUSED=0 at handle creation keeps the base shape on the generic GEMM-based path (A/B runs, tests)
-  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 1 && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
+  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 1 && n <= 65536 /* operand arrays stay under the 2 GB a buffer descriptor addresses */ && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
