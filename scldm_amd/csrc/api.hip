@@ -74,6 +74,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->fused = fused;
   h->mod_w = cfg->n_layer * 6 * cfg->n_embed + 2 * cfg->n_embed;
   for (int c = 0; c < cfg->n_classes; ++c) h->tab_rows[c] = cfg->class_vocab[c] + cfg->has_null_row;
+  h->bf16_sources = true;   // (a knob of the generic training path: read for every shape)
+  if (const char* e = getenv("SCLDM_TRAIN_BF16_SOURCES")) h->bf16_sources = atoi(e) != 0;
   if (!fused) {
     *out = h;
     return SCLDM_OK;
@@ -160,7 +162,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota};
+                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);

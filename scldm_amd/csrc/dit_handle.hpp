@@ -54,6 +54,13 @@ struct scldm_dit {
   void* d_tjobs;            // device PackJob table of the training step's subset
   int n_tjobs, tjob_blocks;
   bool partial_pack;        // the last pack refreshed only some precisions' streams: the next inference refresh is unconditional
+  // generic training path with bf16 operands (train_api.hip, bgemm.hpp): per-step bf16 copies of the layers' five weight matrices
+  void* w16;                // [layer][attn_w | proj_w | w1 | w2 | cproj] bf16, allocated on first use
+  size_t w16_layer_elems;
+  void* d_cast_jobs;        // device CastJob table (rebuilt when the weights' device pointers change)
+  int n_cast_jobs;
+  std::vector<const void*> w16_key;
+  bool bf16_sources;        // SCLDM_TRAIN_BF16_SOURCES (read once at create; 0 keeps fp32 activations + hgemm_kernel)
 };
 
 // api.hip internals shared with train_fused.hip

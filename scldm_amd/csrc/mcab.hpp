@@ -754,8 +754,11 @@ struct EncPoolArgs {
 
 // BF: bf16 operands for the four contractions of a gene tile (see dec_gene_kernel); LayerNorm, the online softmax and the
 // output accumulators stay fp32.
+#ifndef SCLDM_ENC_MINW
+#define SCLDM_ENC_MINW 3
+#endif
 template <bool BF>
-__global__ __launch_bounds__(256) void enc_pool_kernel(const EncPoolArgs a) {
+__global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const EncPoolArgs a) {
   __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
   __shared__ float VEC[2 * kE];
   __shared__ float MRG[4][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]

@@ -597,11 +597,26 @@ __global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) x[i] += pos[i % period];
 }
 
+// Arrays that only ever feed GEMMs (h1, ao, h2, hid and dy, dqkv, da, db) are written as bf16 when the step runs the
+// bf16-source GEMM (bgemm.hpp): TO = float or __bf16 on their producers.
+template <typename TO>
+__device__ __forceinline__ void put4(TO* __restrict__ p, const f32x4& v) {
+  if constexpr (sizeof(TO) == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+  }
+}
+
 // h = LN(x) * (1 + scale[b]) + shift[b], LayerNorm without affine (nnets.py:257-258), one wave per token.
 // stats[t] = (mean, rstd).  mod row of sample b at mod + b*mod_stride; scale/shift at column offsets.
-template <int NQ>
+template <int NQ, typename TO = float>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mod, long mod_stride,
-                                                         int sc_off, int sh_off, float eps, long tokens, float* __restrict__ h,
+                                                         int sc_off, int sh_off, float eps, long tokens, TO* __restrict__ h,
                                                          float* __restrict__ stats) {
   constexpr int D = NQ * 256, nq = NQ, kMaxDQ = NQ;
   const int lane = threadIdx.x & 63;
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
       f32x4 o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = v[q][i] * rstd * (1.0f + sc[i]) + sh[i];
-      *reinterpret_cast<f32x4*>(h + t * D + q * 256 + lane * 4) = o;
+      put4(h + t * D + q * 256 + lane * 4, o);
     }
   if (lane == 0) {
     stats[t * 2] = mean;
@@ -738,9 +753,10 @@ __global__ void gate_res_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 // dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (grid (samples, D/256), thread = feature)
+template <typename TO = float>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y,
                                                        const float* __restrict__ mod, long mod_stride, int g_off, int D,
-                                                       float* __restrict__ dy, float* __restrict__ dmod) {
+                                                       TO* __restrict__ dy, float* __restrict__ dmod) {
   const long b = blockIdx.x;
   const int f = blockIdx.y * 256 + threadIdx.x;
   const float g = mod[b * mod_stride + g_off + f];
@@ -749,25 +765,37 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   for (int t = 0; t < kS; ++t) {
     const long i = (b * kS + t) * D + f;
     const float d = dx[i];
-    dy[i] = g * d;
+    dy[i] = (TO)(g * d);
     s += d * y[i];
   }
   dmod[b * mod_stride + g_off + f] = s;
 }
 
-// hid = silu(a) * b   (MLP.forward, layers.py:172-174)
-__global__ void swiglu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ hid, long count) {
+// hid = silu(a) * b   (MLP.forward, layers.py:172-174).  a, b: [tokens][H]; the output rows have ldo >= H elements, and the
+// thread of a row's last element also zeroes the row's padding (bf16 rows are padded to 16-byte multiples for bgemm_kernel,
+// whose last k chunk reads the padding of both operands)
+template <typename TO = float>
+__global__ void swiglu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, TO* __restrict__ hid, long count, int H, int ldo) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
     const float v = a[i];
-    hid[i] = v * sigmoid_f(v) * b[i];
+    const long t = i / H;
+    const int c = (int)(i - t * H);
+    hid[t * ldo + c] = (TO)(v * sigmoid_f(v) * b[i]);
+    if (c == H - 1)
+      for (int p = H; p < ldo; ++p) hid[t * ldo + p] = (TO)0.f;
   }
 }
+template <typename TO = float>
 __global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const float* __restrict__ a, const float* __restrict__ b,
-                                  float* __restrict__ da, float* __restrict__ db, long count) {
+                                  TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
     const float v = a[i], s = sigmoid_f(v), d = dhid[i];
-    da[i] = d * b[i] * s * (1.0f + v * (1.0f - s));
-    db[i] = d * v * s;
+    const long t = i / H;
+    const int c = (int)(i - t * H);
+    da[t * ldo + c] = (TO)(d * b[i] * s * (1.0f + v * (1.0f - s)));
+    db[t * ldo + c] = (TO)(d * v * s);
+    if (c == H - 1)
+      for (int p = H; p < ldo; ++p) da[t * ldo + p] = db[t * ldo + p] = (TO)0.f;
   }
 }
 
@@ -824,9 +852,9 @@ __device__ __forceinline__ void attn_probs(const AttnTile<HD>& s, int lane, floa
 template <int HD>
 constexpr int attn_waves() { return HD == 32 ? 4 : 2; }   // waves (= (sample, head) units) per workgroup: LDS-limited for HD 64
 
-template <int HD>
+template <int HD, typename TO = float>
 __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, int n_head, int D,
-                                                                         float* __restrict__ ao) {
+                                                                         TO* __restrict__ ao) {
   __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
   constexpr int CW = HD / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -853,15 +881,15 @@ __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const f
 #pragma unroll
     for (int d = 0; d < CW; ++d) o[d] += pj * s.v[j][d0 + d];
   }
-  float* out = ao + (sample * kS + i) * (long)D + head * HD + d0;
+  TO* out = ao + (sample * kS + i) * (long)D + head * HD + d0;
 #pragma unroll
-  for (int d = 0; d < CW; ++d) out[d] = o[d];
+  for (int d = 0; d < CW; d += 4) put4(out + d, f32x4{o[d], o[d + 1], o[d + 2], o[d + 3]});
 }
 
 // dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP));  dq = scale dS k;  dk = scale dS^T q;  dv = P^T dao
-template <int HD>
+template <int HD, typename TO = float>
 __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao,
-                                                                         long n_samples, int n_head, int D, float* __restrict__ dqkv) {
+                                                                         long n_samples, int n_head, int D, TO* __restrict__ dqkv) {
   __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
   __shared__ float dos[attn_waves<HD>()][kS][HD + 1];
   __shared__ float dss[attn_waves<HD>()][kS][kS + 1];
@@ -914,12 +942,12 @@ __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const f
       dv[d] += p_ji * dos[wave][j][c0 + d];
     }
   }
-  float* dst = dqkv + (sample * kS + i) * (3L * D) + head * HD + c0;
+  TO* dst = dqkv + (sample * kS + i) * (3L * D) + head * HD + c0;
 #pragma unroll
-  for (int d = 0; d < CW; ++d) {
-    dst[d] = dq[d];
-    dst[D + d] = dk[d];
-    dst[2 * D + d] = dv[d];
+  for (int d = 0; d < CW; d += 4) {
+    put4(dst + d, f32x4{dq[d], dq[d + 1], dq[d + 2], dq[d + 3]});
+    put4(dst + D + d, f32x4{dk[d], dk[d + 1], dk[d + 2], dk[d + 3]});
+    put4(dst + 2 * D + d, f32x4{dv[d], dv[d + 1], dv[d + 2], dv[d + 3]});
   }
 }
 

@@ -7,6 +7,7 @@
 #include "api_common.hpp"
 #include "dit_handle.hpp"
 #include "train.hpp"
+#include "bgemm.hpp"
 #include "train_fused.hpp"
 
 using namespace scldm;
@@ -181,6 +182,134 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
   return SCLDM_OK;
 }
 
+// ---- bf16-source GEMM (bgemm.hpp) -------------------------------------------------------------------------------
+thread_local bool g_src16 = false;   // the call in progress keeps the layers' GEMM operands as bf16 arrays
+
+template <bool A_KC, bool B_KC>
+int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = bgemm_kernel<A_KC, B_KC>;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemmLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kBGemmLds, st, g);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+// C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
+// orientations in use: (KC, KC) forward, (KC, MC) data gradient, (MC, MC) weight gradient.
+int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, int ldb, bool b_kc, float* C, long ldc, int M, int N,
+          int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr) {
+  if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
+  if (lda % 8 || ldb % 8 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+    return fail(SCLDM_ERR_SHAPE, "bgemm: operands need 16-byte aligned rows");
+  if (rowsum_out && a_kc) return fail(SCLDM_ERR_SHAPE, "bgemm: row sums need the A operand contiguous along m");
+  if (!a_kc && b_kc) return fail(SCLDM_ERR_SHAPE, "bgemm: operand orientation (MC, KC) is not instantiated");
+  BGemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.M = M; g.N = N; g.K = K;
+  g.tiles_m = cdiv(M, 128);
+  g.tiles_n = cdiv(N, 128);
+  const long tiles = (long)g.tiles_m * g.tiles_n;
+  // split K when the output tiles leave most of the 512 workgroup slots (2 per CU) empty and the partials are small (weight
+  // gradients: K = all tokens); an activation-sized output pays more for the partials round trip than it gains
+  int splits = 1;
+  if (tiles < 256 && (long)M * N <= (4L << 20)) splits = (int)std::max<long>(1, std::min<long>(std::min<long>(512 / tiles, K / 512), kMaxSplit));
+  while (splits > 1 && (size_t)splits * M * (N + 1) > part_floats) --splits;
+  g.kchunk = cdiv(cdiv(K, splits), kGK) * kGK;
+  splits = cdiv(K, g.kchunk);
+  g.splits = splits;
+  g.accumulate = accumulate ? 1 : 0;
+  g.rowsum = rowsum_out;
+  g.per_xcd = (int)cdiv(tiles, 8);
+  int blocks = splits > 1 ? (int)tiles * splits : 8 * g.per_xcd;
+  if (splits > 1) {
+    g.C = part;
+    g.ldc = N;
+    g.bias = nullptr;
+    g.accumulate = 0;
+    if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
+  }
+  int rc = a_kc ? (b_kc ? launch_bgemm<true, true>(g, blocks, st) : launch_bgemm<true, false>(g, blocks, st))
+                : launch_bgemm<false, false>(g, blocks, st);
+  if (rc != SCLDM_OK) return rc;
+  if (splits > 1) {
+    const long total = (long)M * N;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, part,
+                       splits, M, N, C, ldc, bias, accumulate ? 1 : 0);
+    LAUNCH_CHECK();
+    if (rowsum_out) {
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, part + (size_t)splits * M * N, splits, M, rowsum_out);
+      LAUNCH_CHECK();
+    }
+  }
+  return SCLDM_OK;
+}
+
+// The generic path keeps bf16 arrays (and runs bgemm) when the step asks for bf16 operands.  Rows of `hidden` elements
+// (hid, da, db, c_proj's weight) are padded with zeros to hidden16 = the next multiple of 8 (DiT-L: 2 732 -> 2 736).
+inline int hidden16(const scldm_dit* h) { return (h->cfg.hidden_dim + 7) / 8 * 8; }
+bool src16_eligible(const scldm_dit* h, int n, int precision) {
+  return h->bf16_sources && precision == SCLDM_PREC_BF16 && !fused::eligible(h, n, precision) && (long)n * kS >= 128 &&
+         (long)n * kS * std::max(3 * h->cfg.n_embed, hidden16(h)) < (1L << 30);   // buffer descriptors address 2 GB
+}
+
+// per-step bf16 copies of the layers' weight matrices: [layer][attn_w | proj_w | w1 | w2 | cproj (D x hidden16)]
+struct W16 {
+  const __bf16 *attn_w, *proj_w, *w1, *w2, *cproj;
+};
+W16 w16_layer(const scldm_dit* h, int l) {
+  const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim;
+  const __bf16* base = reinterpret_cast<const __bf16*>(h->w16) + (size_t)l * h->w16_layer_elems;
+  return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + H * D, base + 4 * D * D + 2 * H * D};
+}
+int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+  const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
+  const int L = h->cfg.n_layer;
+  if (L == 0) return SCLDM_OK;
+  h->w16_layer_elems = 4 * D * D + 2 * H * D + Hp * D;
+  if (!h->w16) HIP_TRY(hipMalloc(&h->w16, (size_t)L * h->w16_layer_elems * sizeof(__bf16)));
+  std::vector<const void*> key;
+  for (int l = 0; l < L; ++l)
+    for (const float* p : {w->attn_w[l], w->proj_w[l], w->w1[l], w->w2[l], w->cproj[l]}) key.push_back(p);
+  if (key != h->w16_key || !h->d_cast_jobs) {
+    std::vector<CastJob> jobs;
+    for (int l = 0; l < L; ++l) {
+      const W16 d = w16_layer(h, l);
+      jobs.push_back(CastJob{w->attn_w[l], const_cast<__bf16*>(d.attn_w), (int)(3 * D), (int)D, (int)D});
+      jobs.push_back(CastJob{w->proj_w[l], const_cast<__bf16*>(d.proj_w), (int)D, (int)D, (int)D});
+      jobs.push_back(CastJob{w->w1[l], const_cast<__bf16*>(d.w1), (int)H, (int)D, (int)D});
+      jobs.push_back(CastJob{w->w2[l], const_cast<__bf16*>(d.w2), (int)H, (int)D, (int)D});
+      jobs.push_back(CastJob{w->cproj[l], const_cast<__bf16*>(d.cproj), (int)D, (int)H, (int)Hp});
+    }
+    if (!h->d_cast_jobs) HIP_TRY(hipMalloc(&h->d_cast_jobs, jobs.size() * sizeof(CastJob)));
+    // (synchronous copy of a pageable vector: only when the parameters' device pointers changed)
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(h->d_cast_jobs, jobs.data(), jobs.size() * sizeof(CastJob), hipMemcpyHostToDevice));
+    h->n_cast_jobs = (int)jobs.size();
+    h->w16_key = key;
+  }
+  hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, h->n_cast_jobs), dim3(256), 0, st, (const CastJob*)h->d_cast_jobs, h->n_cast_jobs);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+// (ldw: elements per row of the bf16 weight copy = `in` rounded up to a multiple of 8)
+int linear_fwd16(hipStream_t st, const __bf16* x, int ldx, const __bf16* W, int rows, int out, int in, const float* b, float* y, long ldy,
+                 Scratch& s) {
+  return bgemm(st, x, ldx, true, W, (in + 7) / 8 * 8, true, y, ldy, rows, out, in, b, false, s.part, s.part_floats);
+}
+int linear_dgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* W, int rows, int out, int in, float* dx, long lddx,
+                   bool accumulate, Scratch& s) {
+  return bgemm(st, dy, lddy, true, W, (in + 7) / 8 * 8, false, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats);
+}
+int linear_wgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* x, int ldx, int rows, int out, int in, float* dW, Scratch& s,
+                   float* db = nullptr) {
+  return bgemm(st, dy, lddy, false, x, ldx, false, dW, in, out, in, rows, nullptr, false, s.part, s.part_floats, db);
+}
+
 // y[rows, out] = x[rows, in] W[out, in]^T + b   (nn.Linear forward)
 int linear_fwd(hipStream_t st, const float* x, long ldx, const float* W, int rows, int out, int in, const float* b, float* y,
                long ldy, Scratch& s) {
@@ -222,9 +351,10 @@ inline unsigned ew_grid(long count) { return (unsigned)std::max<long>(1, std::mi
     default: { CALL(8); break; }   \
   }
 
-int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int sc_off, int sh_off, float eps, long T, float* h,
+template <typename TO>
+int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int sc_off, int sh_off, float eps, long T, TO* h,
            float* stats) {
-#define CALL(NQ) hipLaunchKernelGGL(ln_mod_fwd_kernel<NQ>, dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats)
+#define CALL(NQ) hipLaunchKernelGGL((ln_mod_fwd_kernel<NQ, TO>), dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats)
   SCLDM_NQ_SWITCH(D / 256, CALL)
 #undef CALL
   LAUNCH_CHECK();
@@ -238,15 +368,17 @@ int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const 
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-int attn_fwd(hipStream_t st, int D, int n_head, long n, const float* qkv, float* ao) {
-  if (D / n_head == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
-  else hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
+template <typename TO>
+int attn_fwd(hipStream_t st, int D, int n_head, long n, const float* qkv, TO* ao) {
+  if (D / n_head == 32) hipLaunchKernelGGL((attn_fwd_kernel<32, TO>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
+  else hipLaunchKernelGGL((attn_fwd_kernel<64, TO>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const float* dao, float* dqkv) {
-  if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_kernel<32>, dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
-  else hipLaunchKernelGGL(attn_bwd_kernel<64>, dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
+template <typename TO>
+int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const float* dao, TO* dqkv) {
+  if (D / n_head == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, TO>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
+  else hipLaunchKernelGGL((attn_bwd_kernel<64, TO>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -354,22 +486,36 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T, kD);
   LAUNCH_CHECK();
 
+  // bf16-source route (bgemm.hpp): h1, ao, h2, hid live as bf16 arrays in their (fp32-sized) slots of the saved block, the
+  // weights as per-step bf16 copies; same sequence of kernels otherwise
+  const bool src16 = g_src16 = src16_eligible(h, n, precision);
+  const int Hp = hidden16(h);
+  if (src16) TRY(refresh_w16(h, w, st));
+  auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y) {
+    return src16 ? linear_fwd16(st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, k)
+                 : linear_fwd(st, xin, ldx, W, (int)T, out_f, in_f, b, y, out_f, k);
+  };
   for (int l = 0; l < L; ++l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;   // a0..a5 at o + i*D (layers.py:214-216)
+    const W16 wh = src16 ? w16_layer(h, l) : W16{};
     float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
-    TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
-    TRY(linear_fwd(st, a.h1, kD, w->attn_w[l], (int)T, 3 * kD, kD, w->attn_b[l], a.qkv, 3 * kD, k));
-    TRY(attn_fwd(st, kD, kNH, n, a.qkv, a.ao));
-    TRY(linear_fwd(st, a.ao, kD, w->proj_w[l], (int)T, kD, kD, w->proj_b[l], a.y1, kD, k));
+    if (src16) TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h1), a.st1));
+    else TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
+    TRY(lin(a.h1, kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, w->attn_b[l], a.qkv));
+    if (src16) TRY(attn_fwd(st, kD, kNH, n, a.qkv, reinterpret_cast<__bf16*>(a.ao)));
+    else TRY(attn_fwd(st, kD, kNH, n, a.qkv, a.ao));
+    TRY(lin(a.ao, kD, w->proj_w[l], wh.proj_w, kD, kD, w->proj_b[l], a.y1));
     hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
     LAUNCH_CHECK();
-    TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
-    TRY(linear_fwd(st, a.h2, kD, w->w1[l], (int)T, H, kD, nullptr, a.a, H, k));
-    TRY(linear_fwd(st, a.h2, kD, w->w2[l], (int)T, H, kD, nullptr, a.b, H, k));
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H);
+    if (src16) TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h2), a.st2));
+    else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
+    TRY(lin(a.h2, kD, w->w1[l], wh.w1, H, kD, nullptr, a.a));
+    TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b));
+    if (src16) hipLaunchKernelGGL(swiglu_fwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, reinterpret_cast<__bf16*>(a.hid), T * H, H, Hp);
+    else hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H, H, H);
     LAUNCH_CHECK();
-    TRY(linear_fwd(st, a.hid, H, w->cproj[l], (int)T, kD, H, nullptr, a.y2, kD, k));
+    TRY(lin(a.hid, src16 ? Hp : H, w->cproj[l], wh.cproj, kD, H, nullptr, a.y2));
     hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
     LAUNCH_CHECK();
   }
@@ -416,29 +562,48 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st));
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
+  // bf16-source route: dy, dqkv, da, db (consumed only by GEMMs) are bf16 arrays in their slots of the scratch block
+  const bool src16 = g_src16 = src16_eligible(h, n, precision);
+  if (src16 && !h->w16) return fail(SCLDM_ERR_SHAPE, "training backward without the forward of the same step");
+  const int Hl = src16 ? hidden16(h) : H;   // elements per row of hid / da / db
+  auto wgrad = [&](const float* dyp, int lddy, const float* xs, int ldx, int out_f, int in_f, float* dW, float* db) {
+    return src16 ? linear_wgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, (int)T, out_f, in_f, dW, k, db)
+                 : linear_wgrad(st, dyp, lddy, xs, ldx, (int)T, out_f, in_f, dW, k, db);
+  };
+  auto dgrad = [&](const float* dyp, int lddy, const float* W, const __bf16* Wh, int out_f, int in_f, float* dxp, bool acc) {
+    return src16 ? linear_dgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, Wh, (int)T, out_f, in_f, dxp, in_f, acc, k)
+                 : linear_dgrad(st, dyp, lddy, W, (int)T, out_f, in_f, dxp, in_f, acc, k);
+  };
+  auto gate_bwd = [&](const float* yv, int g_off) {
+    if (src16) hipLaunchKernelGGL(gate_bwd_kernel<__bf16>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(k.dy), k.dmod);
+    else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, k.dy, k.dmod);
+  };
   for (int l = use_fused ? -1 : L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
+    const W16 wh = src16 ? w16_layer(h, l) : W16{};
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dx, a.y2, s.mod, (long)mw, o + 5 * kD, kD, k.dy, k.dmod);
+    gate_bwd(a.y2, o + 5 * kD);
     LAUNCH_CHECK();
-    TRY(linear_wgrad(st, k.dy, kD, a.hid, H, (int)T, kD, H, g->cproj[l], k));
-    TRY(linear_dgrad(st, k.dy, kD, w->cproj[l], (int)T, kD, H, k.dhid, H, false, k));
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, k.da, k.db, T * H);
+    TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
+    TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, kD, H, k.dhid, false));
+    if (src16) hipLaunchKernelGGL(swiglu_bwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
+    else hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, k.da, k.db, T * H, H, H);
     LAUNCH_CHECK();
-    TRY(linear_wgrad(st, k.da, H, a.h2, kD, (int)T, H, kD, g->w1[l], k));
-    TRY(linear_wgrad(st, k.db, H, a.h2, kD, (int)T, H, kD, g->w2[l], k));
-    TRY(linear_dgrad(st, k.da, H, w->w1[l], (int)T, H, kD, k.dh, kD, false, k));
-    TRY(linear_dgrad(st, k.db, H, w->w2[l], (int)T, H, kD, k.dh, kD, true, k));
+    TRY(wgrad(k.da, Hl, a.h2, kD, H, kD, g->w1[l], nullptr));
+    TRY(wgrad(k.db, Hl, a.h2, kD, H, kD, g->w2[l], nullptr));
+    TRY(dgrad(k.da, Hl, w->w1[l], wh.w1, H, kD, k.dh, false));
+    TRY(dgrad(k.db, Hl, w->w2[l], wh.w2, H, kD, k.dh, true));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dx, a.y1, s.mod, (long)mw, o + 2 * kD, kD, k.dy, k.dmod);
+    gate_bwd(a.y1, o + 2 * kD);
     LAUNCH_CHECK();
-    TRY(linear_wgrad(st, k.dy, kD, a.ao, kD, (int)T, kD, kD, g->proj_w[l], k, g->proj_b[l]));
-    TRY(linear_dgrad(st, k.dy, kD, w->proj_w[l], (int)T, kD, kD, k.dao, kD, false, k));
-    TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
-    TRY(linear_wgrad(st, k.dqkv, 3 * kD, a.h1, kD, (int)T, 3 * kD, kD, g->attn_w[l], k, g->attn_b[l]));
-    TRY(linear_dgrad(st, k.dqkv, 3 * kD, w->attn_w[l], (int)T, 3 * kD, kD, k.dh, kD, false, k));
+    TRY(wgrad(k.dy, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
+    TRY(dgrad(k.dy, kD, w->proj_w[l], wh.proj_w, kD, kD, k.dao, false));
+    if (src16) TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
+    else TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
+    TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
+    TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, k.dh, false));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
   }
 
