@@ -53,6 +53,9 @@ TRAIN_WORKLOADS = {
     # outside the fused family, so it runs on the generic GEMM-based HIP path
     "replogle_train_ditl_b256": dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=256,
                                      shape=dict(n_embed=1024, n_layer=24, n_head=16)),
+    # same, 1 024 cells per GPU (29 GB of saved activations): the batch at which the 256 x 256-tile GEMM fills the chip
+    "replogle_train_ditl_b1024": dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=1024,
+                                      shape=dict(n_embed=1024, n_layer=24, n_head=16)),
 }
 
 
@@ -552,6 +555,17 @@ def main():
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
                                                 "per layer (DESIGN 4.4a)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.4)"}
             note("training step done")
+            if tprec == "bf16":   # BASELINE configs[4] names a DiT-L denoiser: the same step on that shape (generic path, bf16 arrays + bgemm)
+                try:
+                    torch.cuda.empty_cache()
+                    tl = dict(TRAIN_WORKLOADS["replogle_train_ditl_b256"])
+                    dtl, _ = time_training(tl, "bf16", device, 4, 2, False, 1)
+                    result["training_step_ditl"] = {"workload": "replogle_train_ditl_b256", "cells_per_s": tl["B"] / (dtl / 4), "ms_per_step": 1e3 * dtl / 4,
+                                                    "tflops": 3 * dit_flops(n_embed=1024, n_layer=24) * tl["B"] / (dtl / 4) / 1e12, "dtype": "bf16",
+                                                    "path": "generic: bf16 operand arrays + bgemm_kernel / bgemm256_kernel (DESIGN 4.4b)"}
+                except Exception as e:   # an extra: never takes the headline line down
+                    result["training_step_ditl"] = {"error": repr(e)}
+                note("DiT-L training step done")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
             note("cpu baseline done")

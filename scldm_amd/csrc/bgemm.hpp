@@ -231,6 +231,192 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BGemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 output tile, eight waves (2 along m x 4 along n, 128 x 64 each: 8 MFMAs per 6 fragment reads instead of 4 per 4),
+// one workgroup per CU.  Timing proxies of the 128 x 128 kernel on the DiT-L products (45 us per call): without MFMAs -8 %,
+// without fragment reads 0...-14 %, without global loads -15 %, without the LDS write pass -31 % - no pipe is the limit, the
+// 16-MFMA-per-barrier lockstep of two workgroups is.  Here a stage is 32 MFMAs per wave, and the staging is the one-register-set
+// scheme: stage t+1 sits in registers while stage t is multiplied, is written to the other LDS buffer behind the MFMAs, and
+// the loads of stage t+2 are issued right after - one barrier per stage.  Used when the 256-tiles (x k splits) fill the chip.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kG2LdMC = 256 + 32;                      // [k][m] image: 576 B rows (64 mod 256, like 320)
+constexpr int kG2OperandBytes = 256 * kGLdKC * 2;      // = 64 * kG2LdMC * 2 = 36 864
+static_assert(64 * kG2LdMC * 2 == kG2OperandBytes, "both images of a 256-wide operand stage have the same size");
+constexpr int kBGemm2Lds = 4 * kG2OperandBytes;        // 147 456 B
+
+struct LoaderKC2 {   // 256 (m) x 64 (k): pass p: row 64 p + 8 wave + lane / 8, k chunk lane % 8
+  bg_u32x4 d[4];
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int m0, int rows, int k0, int kend) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool k_ok = k0 + (lane & 7) * 8 < kend;
+    const unsigned voff = (unsigned)(lane >> 3) * (unsigned)ld * 2u + (unsigned)(lane & 7) * 16u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = m0 + 64 * p + 8 * wave;
+      const bool ok = k_ok && r + (lane >> 3) < rows;
+      d[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? voff : kOob, ((unsigned)r * (unsigned)ld + (unsigned)k0) * 2u, 0);
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<bg_u32x4*>(S + (64 * p + 8 * wave + (lane >> 3)) * kGLdKC + (lane & 7) * 8) = d[p];
+  }
+  __device__ __forceinline__ void add_rowsum(float (&)[8]) const {}
+  static __device__ __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int f0, int kk, int lane) { return LoaderKC::frag(S, f0, kk, lane); }
+};
+struct LoaderMC2 {   // 64 (k) x 256 (m): pass p: k row 16 p + 2 wave + lane / 32, m chunk lane % 32
+  bg_u32x4 d[4];
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int m0, int rows, int k0, int kend) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool m_ok = m0 + (lane & 31) * 8 < rows;
+    const unsigned voff = (unsigned)(lane >> 5) * (unsigned)ld * 2u + (unsigned)(lane & 31) * 16u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = k0 + 16 * p + 2 * wave;
+      const bool ok = m_ok && k + (lane >> 5) < kend;
+      d[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? voff : kOob, ((unsigned)k * (unsigned)ld + (unsigned)m0) * 2u, 0);
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<bg_u32x4*>(S + (16 * p + 2 * wave + (lane >> 5)) * kG2LdMC + (lane & 31) * 8) = d[p];
+  }
+  __device__ __forceinline__ void add_rowsum(float (&rs)[8]) const {   // m = 8 (lane % 32) + e
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rs[2 * i] += __uint_as_float(d[p][i] << 16);
+        rs[2 * i + 1] += __uint_as_float(d[p][i] & 0xffff0000u);
+      }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const __bf16* __restrict__ S, int f0, int kk, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const int g = lane >> 4, i = lane & 15;
+    const __bf16* p = S + (kk + 8 * (g >> 1) + (i >> 2)) * kG2LdMC + f0 + 16 * (g & 1) + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kG2LdMC));
+    union { s16x4 s[2]; bf16x8 f; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.f;
+  }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
+  using LA = typename std::conditional<A_KC, LoaderKC2, LoaderMC2>::type;
+  using LB = typename std::conditional<B_KC, LoaderKC2, LoaderMC2>::type;
+  extern __shared__ __attribute__((aligned(16))) char bgemm_smem[];
+  auto As = [&](int b) { return reinterpret_cast<__bf16*>(bgemm_smem + b * kG2OperandBytes); };
+  auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(bgemm_smem + (2 + b) * kG2OperandBytes); };
+  int z = 0, tile_id;   // (same workgroup numbering as bgemm_kernel; tiles_m / tiles_n count 256-tiles)
+  if (g.splits > 1) {
+    z = blockIdx.x % g.splits;
+    tile_id = blockIdx.x / g.splits;
+  } else {
+    tile_id = (blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= g.per_xcd) return;
+  }
+  if (tile_id >= g.tiles_m * g.tiles_n) return;
+  const int tm = tile_id / g.tiles_n, tn = tile_id % g.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int k_beg = z * g.kchunk, k_end = min(g.K, k_beg + g.kchunk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 2, wn = wave & 3;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
+
+  auto make_rsrc = [](const __bf16* p) {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(g.A), rb = make_rsrc(g.B);
+  const bool want_rs = !A_KC && g.rowsum != nullptr && tn == 0;
+  float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int n_it = (k_end - k_beg + kGK - 1) / kGK;
+  if (n_it <= 0) return;
+  LA la;
+  LB lb;
+  la.load(ra, g.lda, m0, g.M, k_beg, k_end);
+  lb.load(rb, g.ldb, n0, g.N, k_beg, k_end);
+  if (want_rs) la.add_rowsum(rs);
+  la.store(As(0));
+  lb.store(Bs(0));
+  la.load(ra, g.lda, m0, g.M, k_beg + min(1, n_it - 1) * kGK, k_end);
+  lb.load(rb, g.ldb, n0, g.N, k_beg + min(1, n_it - 1) * kGK, k_end);
+  lds_barrier();
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+#pragma unroll
+    for (int kk = 0; kk < kGK; kk += 16) {
+      bf16x8 af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = LA::frag(As(buf), wm * 128 + i * 32, kk, lane);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) bf[k] = LB::frag(Bs(buf), wn * 64 + k * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[k], acc[i][k], 0, 0, 0);
+    }
+    // stage it+1 (in registers since the previous iteration) -> the other buffer, whose readers passed the last barrier; then
+    // re-request: stage it+2 (unconditional, see bgemm_kernel)
+    if (it + 1 < n_it) {
+      if (want_rs) la.add_rowsum(rs);
+      la.store(As(buf ^ 1));
+      lb.store(Bs(buf ^ 1));
+    }
+    const int ahead = k_beg + min(it + 2, n_it - 1) * kGK;
+    la.load(ra, g.lda, m0, g.M, ahead, k_end);
+    lb.load(rb, g.ldb, n0, g.N, ahead, k_end);
+    lds_barrier();
+  }
+  if constexpr (!A_KC) {
+    if (want_rs) {   // the 16 threads (tid / 32) that share an m chunk hold partial sums of the same eight rows
+      float* red = reinterpret_cast<float*>(bgemm_smem);   // [16][256]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(threadIdx.x >> 5) * 256 + (threadIdx.x & 31) * 8 + e] = rs[e];
+      lds_barrier();
+      if (threadIdx.x < 256 && m0 + (int)threadIdx.x < g.M) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q * 256 + threadIdx.x];
+        g.rowsum[(long)z * g.M + m0 + threadIdx.x] = t;
+      }
+    }
+  }
+  float* __restrict__ C = g.C + (long)z * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int n = n0 + wn * 64 + k * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + i * 32 + acc_row(r, lane >> 5);
+        if (m < g.M) {
+          float* p = C + (long)m * g.ldc + n;
+          float v = acc[i][k][r] + bv;
+          if (g.accumulate) v += *p;
+          *p = v;
+        }
+      }
+    }
+}
+
 // dst[r][c] = bf16(src[r][c]), rows of the copy padded with zeros to ldd elements, one job per blockIdx.y (the per-step bf16
 // copies of the layers' weight matrices).  cols % 4 == 0.
 struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd; };

@@ -184,16 +184,20 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 
 // ---- bf16-source GEMM (bgemm.hpp) -------------------------------------------------------------------------------
 thread_local bool g_src16 = false;   // the call in progress keeps the layers' GEMM operands as bf16 arrays
+// SCLDM_BGEMM256 (read when the library is loaded): 0 = 128-tile kernel only, 1 = pick by fill (default), 2 = the 256-tile kernel
+// whenever both extents reach 256 (tests: ragged tiles at small sizes)
+const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
 
-template <bool A_KC, bool B_KC>
+template <bool BIG, bool A_KC, bool B_KC>
 int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = bgemm_kernel<A_KC, B_KC>;
+  constexpr int smem = BIG ? kBGemm2Lds : kBGemmLds;
+  auto kern = BIG ? bgemm256_kernel<A_KC, B_KC> : bgemm_kernel<A_KC, B_KC>;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemmLds));
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), kBGemmLds, st, g);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(BIG ? 512 : 256), smem, st, g);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -210,14 +214,27 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
   BGemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
   g.M = M; g.N = N; g.K = K;
-  g.tiles_m = cdiv(M, 128);
-  g.tiles_n = cdiv(N, 128);
+  // split K when the output tiles leave most of the workgroup slots empty and the partials are small (weight gradients:
+  // K = all tokens); an activation-sized output pays more for the partials round trip than it gains
+  const bool may_split = (long)M * N <= (4L << 20);
+  auto pick_splits = [&](long tiles, long slots) {
+    int sp = 1;
+    if (tiles < slots / 2 && may_split) sp = (int)std::max<long>(1, std::min<long>(std::min<long>(slots / tiles, K / 512), kMaxSplit));
+    while (sp > 1 && (size_t)sp * M * (N + 1) > part_floats) --sp;
+    return sp;
+  };
+  // 256 x 256 tiles (one workgroup per CU, 8 MFMAs per 6 fragment reads: 700-820 TFLOP/s on long products against ~470) when
+  // they fill the chip, else 128 x 128 (two per CU).  Measured on the DiT-L step (tests/perf/bgemm_check.py): with fewer than
+  // ~224 workgroups (192 / 176 at 256 cells) or short k ranges per split (832 at 256 cells) the big tile is 0-4 % slower.
+  const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
+  const int splits256 = pick_splits(tiles256, 256);
+  const bool fills = splits256 == 1 ? tiles256 >= 224 : (tiles256 * splits256 >= 200 && K / splits256 >= 1536);
+  const bool big = g_bgemm256 && M >= 256 && N >= 256 && (fills || g_bgemm256 == 2);
+  const int tile = big ? 256 : 128;
+  g.tiles_m = cdiv(M, tile);
+  g.tiles_n = cdiv(N, tile);
   const long tiles = (long)g.tiles_m * g.tiles_n;
-  // split K when the output tiles leave most of the 512 workgroup slots (2 per CU) empty and the partials are small (weight
-  // gradients: K = all tokens); an activation-sized output pays more for the partials round trip than it gains
-  int splits = 1;
-  if (tiles < 256 && (long)M * N <= (4L << 20)) splits = (int)std::max<long>(1, std::min<long>(std::min<long>(512 / tiles, K / 512), kMaxSplit));
-  while (splits > 1 && (size_t)splits * M * (N + 1) > part_floats) --splits;
+  int splits = big ? splits256 : pick_splits(tiles, 512);
   g.kchunk = cdiv(cdiv(K, splits), kGK) * kGK;
   splits = cdiv(K, g.kchunk);
   g.splits = splits;
@@ -232,8 +249,11 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     g.accumulate = 0;
     if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
   }
-  int rc = a_kc ? (b_kc ? launch_bgemm<true, true>(g, blocks, st) : launch_bgemm<true, false>(g, blocks, st))
-                : launch_bgemm<false, false>(g, blocks, st);
+  int rc;
+  if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
+                     : launch_bgemm<true, false, false>(g, blocks, st);
+  else rc = a_kc ? (b_kc ? launch_bgemm<false, true, true>(g, blocks, st) : launch_bgemm<false, true, false>(g, blocks, st))
+                 : launch_bgemm<false, false, false>(g, blocks, st);
   if (rc != SCLDM_OK) return rc;
   if (splits > 1) {
     const long total = (long)M * N;

@@ -297,8 +297,9 @@ def test_wider_shapes_forward_backward_match_oracle(n_embed, n_head, n_layer, n)
     assert not bad, bad
 
 
-@pytest.mark.parametrize("n_embed,n_head,n_layer,n", [(512, 8, 2, 9), (1024, 16, 2, 21), (512, 16, 3, 40)])   # 144 / 336 / 640 tokens: ragged 128-row tiles
-def test_wider_shapes_bf16_sources_close_to_fp32_oracle(n_embed, n_head, n_layer, n, monkeypatch):
+@pytest.mark.parametrize("n_embed,n_head,n_layer,n,big", [(512, 8, 2, 9, 1), (1024, 16, 2, 21, 1), (512, 16, 3, 40, 1),   # 144 / 336 / 640 tokens: ragged 128-row tiles
+                                                          (1024, 16, 2, 21, 2), (512, 8, 2, 40, 2)])                          # the 256 x 256-tile kernel, ragged
+def test_wider_shapes_bf16_sources_close_to_fp32_oracle(n_embed, n_head, n_layer, n, big, monkeypatch):
     """bf16 training of shapes outside the fused family keeps the GEMM operands as bf16 ARRAYS (written by the LayerNorm /
     attention / SwiGLU / gate kernels and a per-step weight cast) and multiplies them with bgemm_kernel (16-byte tile loads,
     transposing LDS reads for the operands that are contiguous along m).  Gradients stay at bf16 rounding level of the fp32
@@ -309,6 +310,14 @@ def test_wider_shapes_bf16_sources_close_to_fp32_oracle(n_embed, n_head, n_layer
     t = torch.rand(n, generator=gen)
     cond = {k: torch.randint(0, v + 1, (n,), generator=gen) for k, v in vocab.items()}
     got = {}
+    if big == 2:   # the tile-size knob is read when the library is loaded: the forced 256-tile cases run in a child process
+        import os, subprocess, sys
+        if os.environ.get("SCLDM_BGEMM256") != "2":
+            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k",
+                                f"test_wider_shapes_bf16_sources_close_to_fp32_oracle and {n_embed}-{n_head}-{n_layer}-{n}-2"],
+                               env=dict(os.environ, SCLDM_BGEMM256="2"), capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout[-3000:]
+            return
     for src16 in (True, False):
         monkeypatch.setenv("SCLDM_TRAIN_BF16_SOURCES", "1" if src16 else "0")
         m, sd, cfg = build(vocab, "joint", n_layer, 90 + n_head, n_embed=n_embed, n_head=n_head)
