@@ -79,21 +79,22 @@ __global__ void pack_frag32_pad_kernel(const float* __restrict__ W, int ld, int 
 
 // ------------------------------------------------------------------------------------------------
 // The 16-token trunk: n_layer non-adaLN Blocks (affine LN, 8 heads x 4, SwiGLU, no biases; layers.py:222-226) on the
-// (16, 32) state of a cell.  One wave carries TWO cells as one 32-token MFMA tile through the whole network, a workgroup
-// of four waves eight cells (round 1 ran one cell per 64-thread workgroup on the VALU with an LDS read per FMA: a flat
-// 0.5 ms per call, 10-25 % of decode).  The state lives in registers in accumulator layout - lane = token (cell = token >> 4),
+// (16, 32) state of a cell.  TWO cells travel as one 32-token MFMA tile through the whole network, carried by the two waves
+// of a workgroup (trunk_blocks below says how they share a layer; round 1 ran one cell per 64-thread workgroup on the VALU with
+// an LDS read per FMA: a flat 0.5 ms per call, 10-25 % of decode).  The state lives in registers in accumulator layout - lane = token (cell = token >> 4),
 // register r <-> feature acc_row(r, lane >> 5) - which is directly the B operand of the next Linear, so every Linear is a
 // chain of exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) whose A operands are pre-packed weight fragments read straight from
-// L2 (53 KB per layer, shared by every wave).  Only the 16 x 16 attention of the 8 four-dimensional heads goes through LDS
-// (per wave, no workgroup barrier): on the matrix pipe its block-sparse P V would cost 8x the useful work.
+// L2 (53 KB per layer, shared by every wave).  Only the 16 x 16 attention of the 8 four-dimensional heads goes through LDS:
+// on the matrix pipe its block-sparse P V would cost 8x the useful work.
 // Packed per-layer weights (floats): ln1_w 32 | ln1_b 32 | ln2_w 32 | ln2_b 32 | qkv 3 tiles x 1024 | proj 1024 |
 //                                    w12 6 tiles x 1024 | c_proj 6 tiles x 512
 // ------------------------------------------------------------------------------------------------
 enum : int { T_LN1W = 0, T_LN1B = 32, T_LN2W = 64, T_LN2B = 96, T_QKV = 128, T_PROJ = T_QKV + 3 * 1024, T_W12 = T_PROJ + 1024,
              T_WC = T_W12 + kHTiles * 1024, kTrunkLayerFloats = T_WC + kHTiles * 512 };
 constexpr int kTrunkLd = 100;                    // floats per token row of the per-wave attention scratch (q | k | v, 16-byte aligned rows)
-constexpr int kTrunkWaves = 4;
-constexpr int kTrunkSmemFloats = kTrunkWaves * 32 * kTrunkLd;
+constexpr int kTrunkWaves = 2;                   // the two waves that share ONE cell pair (see trunk_blocks)
+constexpr int kTrunkXchg = 16 * 64;              // floats of one wave's partial MLP output in the exchange area
+constexpr int kTrunkSmemFloats = 32 * kTrunkLd + 2 * kTrunkXchg;
 
 // LDS traffic of ONE wave needs no workgroup barrier; the fence keeps the compiler from moving the reads above the writes
 __device__ __forceinline__ void wave_lds_sync() {
@@ -200,32 +201,46 @@ __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const
   for (int r = 0; r < 16; ++r) x[r] += mo[r];
 }
 
-// n_layer plain Blocks on the wave's 32-token tile x (in place); S = this wave's LDS scratch [32][kTrunkLd]
-__device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, const float* __restrict__ wts, int n_layer,
-                                             float eps, int lane) {
+// n_layer plain Blocks on a 32-token tile x (in place).  The tile (two cells) is carried by the TWO waves of the workgroup: a
+// single wave walks 13 dependent MFMA chains per layer (3 q|k|v + 1 proj + 6 x 1.5 SwiGLU) at one wave per SIMD - 0.155 ms per
+// call whatever the batch, with half the SIMDs idle at 1 024 cells.  Both waves hold the state x and run the LayerNorms and
+// the output projection redundantly (bit-identical); wave 0 computes the q and k tiles, wave 1 the v tile; each wave runs the
+// attention of ONE of the two cells and three of the six SwiGLU hidden tiles, and the two partial down-projections are
+// exchanged through LDS and added in a fixed order (partial of wave 0 + partial of wave 1 in both waves): 7.5 chains per layer.
+// S = the pair's scratch [32][kTrunkLd], X = the exchange area [2][16][64]; four workgroup barriers per layer.
+__device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, float* __restrict__ X, const float* __restrict__ wts,
+                                             int n_layer, float eps, int lane, int hw) {
   const int c32 = lane & 31, hh = lane >> 5;
   if (n_layer <= 0) return;
-  Frag16 nxt = load16(wts + T_QKV, lane);   // fragments of the next chain, always one chain ahead
+  Frag16 nxt = load16(wts + T_QKV + (hw ? 2 * 1024 : 0), lane);   // fragments of the wave's next chain, always one chain ahead
   for (int layer = 0; layer < n_layer; ++layer) {
     const float* w = wts + (size_t)layer * kTrunkLayerFloats;
     float yn[16];
     tile_ln(x, yn, w + T_LN1W, w + T_LN1B, kE, eps, hh);
     // q | k | v (split order of layers.py:147) -> scratch rows [token][q 32 | k 32 | v 32]
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const Frag16 cur = nxt;
-      nxt = load16(t < 2 ? w + T_QKV + (t + 1) * 1024 : w + T_PROJ, lane);
-      const f32x16 o = chain16(cur, yn, zero16());
+    auto put_tile = [&](const f32x16& o, int t) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
+    };
+    if (hw == 0) {
+      Frag16 cur = nxt;
+      nxt = load16(w + T_QKV + 1024, lane);
+      put_tile(chain16(cur, yn, zero16()), 0);
+      cur = nxt;
+      nxt = load16(w + T_PROJ, lane);
+      put_tile(chain16(cur, yn, zero16()), 1);
+    } else {
+      const Frag16 cur = nxt;
+      nxt = load16(w + T_PROJ, lane);
+      put_tile(chain16(cur, yn, zero16()), 2);
     }
-    wave_lds_sync();
-    // attention: 2 cells x 8 heads x 16 queries = 256 (cell, head, query) triples, four per lane; the output replaces q in place
+    __syncthreads();
+    // attention: 8 heads x 16 queries of cell `hw` = 128 (head, query) pairs, two per lane; the output replaces q in place
 #pragma unroll 1
-    for (int rep = 0; rep < 4; ++rep) {
-      const int p = lane + 64 * rep, cell = p >> 7, hd = (p >> 4) & 7, qi = p & 15;
-      const float* base = S + (cell * 16) * kTrunkLd + hd * 4;
+    for (int rep = 0; rep < 2; ++rep) {
+      const int p = lane + 64 * rep, hd = (p >> 4) & 7, qi = p & 15;
+      const float* base = S + (hw * 16) * kTrunkLd + hd * 4;
       const f32x4 qv = *reinterpret_cast<const f32x4*>(base + qi * kTrunkLd);
       float sc[16], m = -3.0e38f;
 #pragma unroll
@@ -245,9 +260,9 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
         for (int d = 0; d < 4; ++d) o[d] += pj * vv[d];
       }
       const float inv = __builtin_amdgcn_rcpf(sum);
-      *reinterpret_cast<f32x4*>(S + (cell * 16 + qi) * kTrunkLd + hd * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+      *reinterpret_cast<f32x4*>(S + (hw * 16 + qi) * kTrunkLd + hd * 4) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
     }
-    wave_lds_sync();
+    __syncthreads();
     float ao[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -255,24 +270,25 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
 #pragma unroll
       for (int i = 0; i < 4; ++i) ao[q * 4 + i] = t4[i];
     }
-    wave_lds_sync();   // the scratch is rewritten by the next layer's q | k | v
+    __syncthreads();   // the scratch is rewritten by the next layer's q | k | v
     {
-      const Frag16 cur = nxt;                     // proj
-      nxt = load16(w + T_W12, lane);
+      const Frag16 cur = nxt;                     // proj (both waves: each needs the new state)
+      nxt = load16(w + T_W12 + hw * 1024, lane);
       const f32x16 po = chain16(cur, ao, zero16());
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[r] += po[r];
     }
     tile_ln(x, yn, w + T_LN2W, w + T_LN2B, kE, eps, hh);
-    // SwiGLU: six 16-unit hidden tiles, each consumed by the down-projection as soon as it exists
+    // SwiGLU: hidden tiles hw, hw + 2, hw + 4, each consumed by the down-projection as soon as it exists
     f32x16 mo = zero16();
     const bool last = layer + 1 == n_layer;
 #pragma unroll
-    for (int u = 0; u < kHTiles; ++u) {
+    for (int uu = 0; uu < kHTiles / 2; ++uu) {
+      const int u = 2 * uu + hw;
       const Frag16 cur = nxt;
       const Frag8 wcf = load8(w + T_WC + u * 512, lane);
-      if (u + 1 < kHTiles) nxt = load16(w + T_W12 + (u + 1) * 1024, lane);
-      else if (!last) nxt = load16(w + kTrunkLayerFloats + T_QKV, lane);
+      if (uu + 1 < kHTiles / 2) nxt = load16(w + T_W12 + (u + 2) * 1024, lane);
+      else if (!last) nxt = load16(w + kTrunkLayerFloats + T_QKV + (hw ? 2 * 1024 : 0), lane);
       const f32x16 ht = chain16(cur, yn, zero16());   // rows 0-15 = w1 units, 16-31 = the matching w2 units
       float hv[8];
 #pragma unroll
@@ -280,12 +296,18 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
       mo = chain8(wcf, hv, mo);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] += mo[r];
+    for (int r = 0; r < 16; ++r) X[hw * kTrunkXchg + r * 64 + lane] = mo[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float other = X[(hw ^ 1) * kTrunkXchg + r * 64 + lane];
+      x[r] += hw ? other + mo[r] : mo[r] + other;   // partial of wave 0 + partial of wave 1, in both waves
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Decoder, per cell pair (one wave): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
+// Decoder, per cell pair (one workgroup of two waves, trunk_blocks): LN(z) -> Linear 16->32 -> trunk -> LN1 (cross block) -> c_attn -> K | V,
 // PLAIN (fp32 per-gene kernel, whose attention runs on the VALU): written per cell as [key 16][K 32 | V 32] fp32 (4 KiB);
 // otherwise packed as MFMA A-operand fragments for the bf16-operand per-gene kernel (48 fragments = 12 KiB per cell):
 //   K tile t (heads 2t, 2t+1), step jj < 8:  lane(row = hl*16 + key, hh): K[key][k] if head(k) == 2t + hl else 0,
@@ -305,11 +327,11 @@ struct DecCellArgs {
 template <bool PLAIN>
 __global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
   const int c32 = lane & 31, hh = lane >> 5;
-  const int pair = blockIdx.x * kTrunkWaves + wave;
-  if (pair * 2 >= a.B) return;   // wave-uniform; no workgroup barrier anywhere in this kernel
-  float* S = SM + wave * 32 * kTrunkLd;
+  const int pair = blockIdx.x;
+  float* S = SM;
+  float* X = SM + 32 * kTrunkLd;
   const int cell = min(pair * 2 + (c32 >> 4), a.B - 1);   // an odd batch pads its last tile with a copy of the last cell
   // LN (no affine) over the n_lat latent channels of every token, then Linear n_lat -> 32 (no bias)
   float zr[16], zn[16], x[16];
@@ -325,7 +347,8 @@ __global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCel
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = h0[r];
   }
-  trunk_blocks(x, S, a.trunk, a.n_layer, a.eps, lane);
+  trunk_blocks(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
+  if (hw) return;   // the tail (no workgroup barrier below) is wave 0's
   float yn[16];
   tile_ln(x, yn, a.ca_ln1_w, a.ca_ln1_b, kE, a.eps, hh);
 #pragma unroll
@@ -896,7 +919,7 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
   }
 }
 
-// Encoder tail, per cell pair (one wave): c_proj + inducing-point residual -> LN2 -> SwiGLU -> (+pos_embed) -> trunk ->
+// Encoder tail, per cell pair (one workgroup of two waves, trunk_blocks): c_proj + inducing-point residual -> LN2 -> SwiGLU -> (+pos_embed) -> trunk ->
 // Linear 32 -> n_lat -> LN (no affine)  (layers.py:326-330, nnets.py:139-144); same register-resident tile as the trunk
 struct EncCellArgs {
   const float* pooled;     // (B, 16, 32)
@@ -913,11 +936,11 @@ struct EncCellArgs {
 };
 __global__ __launch_bounds__(64 * kTrunkWaves) void enc_cell_kernel(const EncCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
   const int c32 = lane & 31, hh = lane >> 5;
-  const int pair = blockIdx.x * kTrunkWaves + wave;
-  if (pair * 2 >= a.B) return;
-  float* S = SM + wave * 32 * kTrunkLd;
+  const int pair = blockIdx.x;
+  float* S = SM;
+  float* X = SM + 32 * kTrunkLd;
   const int cell_raw = pair * 2 + (c32 >> 4), cell = min(cell_raw, a.B - 1), tok = c32 & 15;
   float att[16], x[16], yn[16];
 #pragma unroll
@@ -942,7 +965,8 @@ __global__ __launch_bounds__(64 * kTrunkWaves) void enc_cell_kernel(const EncCel
       for (int i = 0; i < 4; ++i) x[q * 4 + i] += p4[i];
     }
   }
-  trunk_blocks(x, S, a.trunk, a.n_layer, a.eps, lane);
+  trunk_blocks(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
+  if (hw) return;
   // latent head: Linear 32 -> n_lat (no bias; fragment rows >= n_lat are zero), LN without affine over the n_lat channels
   const f32x16 lt = chain16(a.lat_frag, x, zero16(), lane);
   float lv[16], ln[16];

@@ -202,7 +202,7 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
   e.pos = c.positional_encoding ? h->small + S_ENC_POS : nullptr;
   e.trunk = h->enc_trunk; e.lat_frag = h->frag_cell + F_ENC_LAT; e.z = z;
   e.B = B; e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.eps = c.layernorm_eps;
-  enc_cell_kernel<<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(e);
+  enc_cell_kernel<<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -221,8 +221,8 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   d.z = z; d.lat_frag = h->frag_cell + F_DEC_LAT; d.trunk = h->dec_trunk;
   d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.kv_frag = h->frag_cell + F_DEC_KV;
   d.kvfrag = kv; d.B = B; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.eps = c.layernorm_eps;
-  if (precision == SCLDM_PREC_BF16) dec_cell_kernel<false><<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
-  else dec_cell_kernel<true><<<cdiv(B, 2 * kTrunkWaves), 64 * kTrunkWaves, 0, st>>>(d);
+  if (precision == SCLDM_PREC_BF16) dec_cell_kernel<false><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+  else dec_cell_kernel<true><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
   LAUNCH_CHECK();
   const int nch = dec_chunks(G);
   DecGeneArgs g;
