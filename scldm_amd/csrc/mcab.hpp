@@ -777,11 +777,14 @@ struct EncPoolArgs {
 
 // BF: bf16 operands for the four contractions of a gene tile (see dec_gene_kernel); LayerNorm, the online softmax and the
 // output accumulators stay fp32.
+// Waves per SIMD (same-box A/B, 1 024 cells x 6 147 genes): the bf16-operand kernel is VALU / latency bound and gains 11 % from
+// three waves (168 VGPRs, 24 B of scratch) over two; the fp32 kernel is half matrix-pipe bound and is 7 % faster at two waves
+// without spills (218 VGPRs) once the gather is software-pipelined.
 #ifndef SCLDM_ENC_MINW
 #define SCLDM_ENC_MINW 3
 #endif
 template <bool BF>
-__global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const EncPoolArgs a) {
+__global__ __launch_bounds__(256, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(const EncPoolArgs a) {
   __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
   __shared__ float VEC[2 * kE];
   __shared__ float MRG[4][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]
@@ -798,17 +801,63 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
   float m[2] = {-3.0e38f, -3.0e38f}, l[2] = {0.f, 0.f};
   f32x16 O[2] = {zero16(), zero16()};
   const int n_tiles = (a.S + 31) / 32;
+  // bf16 operands: the weight / query fragments are the same for every tile - packed once (eight consecutive fp32 steps = the
+  // 16 k-values of one bf16 MFMA in the same order: fragment of steps [s0, s0+8))
+  bf16x8 kf16[2], vf16[2], qf16[2];
+  if constexpr (BF) {
+    auto frag8 = [&](const f32x4* F, int s0) {
+      const f32x4 lo = F[(s0 >> 2) * 64 + lane], hi = F[((s0 >> 2) + 1) * 64 + lane];
+      float t8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return OpBF16::pack8(t8);
+    };
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) { kf16[h8] = frag8(KF, 8 * h8); vf16[h8] = frag8(VF, 8 * h8); qf16[h8] = frag8(QF, 8 * h8); }
+  }
+  // Software pipeline of the gather (fp32 kernel, two waves per SIMD; the bf16 kernel's three waves hide it and need the
+  // registers): a tile's inputs are two dependent round trips (gene id, then its table row).  The table rows of the NEXT tile
+  // and the gene ids / counts of the tile after it are requested before this tile's arithmetic; indices are clamped to the
+  // cell's last gene so that every request is unconditional (padding lanes are neutralised by lc = 0 below).
+  constexpr bool PF = !BF;
+  auto idx_of = [&](int tile) { return (size_t)cell * a.S + max(min(min(tile, n_tiles - 1) * 32 + c32, a.S - 1), 0); };
+  long long g_nxt = 0;
+  float c_cur = 0.f, c_nxt = 0.f;
+  f32x4 e_cur[4];
+  if constexpr (PF) {
+    g_nxt = a.genes[idx_of(wave + 4)];
+    c_cur = a.counts[idx_of(wave)];
+    c_nxt = a.counts[idx_of(wave + 4)];
+    const long long g0 = a.genes[idx_of(wave)];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) e_cur[qd] = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g0 * kE + qd * 8 + hh * 4);
+  }
   for (int tile = wave; tile < n_tiles; tile += 4) {
-    const int gi = tile * 32 + c32;
-    const bool valid = gi < a.S;
-    const long long g = valid ? a.genes[(size_t)cell * a.S + gi] : 0;
-    const float lc = valid ? log1pf(a.counts[(size_t)cell * a.S + gi]) : 0.f;
+    const bool valid = tile * 32 + c32 < a.S;
     float x[16], s = 0.f;
+    if constexpr (PF) {
+      f32x4 e_nxt[4];
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+      for (int qd = 0; qd < 4; ++qd) e_nxt[qd] = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g_nxt * kE + qd * 8 + hh * 4);
+      const long long g_n2 = a.genes[idx_of(tile + 8)];
+      const float c_n2 = a.counts[idx_of(tile + 8)];
+      const float lc = valid ? log1pf(c_cur) : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { x[qd * 4 + i] = e4[i] * lc; s += x[qd * 4 + i]; }
+      for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[qd * 4 + i] = e_cur[qd][i] * lc; s += x[qd * 4 + i]; }
+        e_cur[qd] = e_nxt[qd];
+      }
+      g_nxt = g_n2;
+      c_cur = c_nxt;
+      c_nxt = c_n2;
+    } else {
+      const long long g = a.genes[idx_of(tile)];
+      const float lc = valid ? log1pf(a.counts[idx_of(tile)]) : 0.f;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[qd * 4 + i] = e4[i] * lc; s += x[qd * 4 + i]; }
+      }
     }
     const float mean = xor32_sum(s) * (1.0f / kE);
     float ss = 0.f;
@@ -817,19 +866,13 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
     const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) * (1.0f / kE) + a.eps);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { const int f = acc_row(r, hh); x[r] = x[r] * rstd * VEC[f] + VEC[kE + f]; }
-    // eight consecutive fp32 steps = the 16 k-values of one bf16 MFMA in the same order: fragment of steps [s0, s0+8)
-    auto frag8 = [&](const f32x4* F, int s0) {
-      const f32x4 lo = F[(s0 >> 2) * 64 + lane], hi = F[((s0 >> 2) + 1) * 64 + lane];
-      float t8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      return OpBF16::pack8(t8);
-    };
     f32x16 kt = zero16(), vt = zero16();
     if constexpr (BF) {
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {
         const bf16x8 xf = OpBF16::pack8(x + 8 * h8);
-        kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag8(KF, 8 * h8), xf, kt, 0, 0, 0);   // K^T[feature][gene]
-        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, frag8(VF, 8 * h8), vt, 0, 0, 0);   // V[gene][d]
+        kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf16[h8], xf, kt, 0, 0, 0);   // K^T[feature][gene]
+        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, vf16[h8], vt, 0, 0, 0);   // V[gene][d]
       }
     } else {
 #pragma unroll
@@ -849,7 +892,7 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
     for (int t = 0; t < 2; ++t) {
       f32x16 sc = zero16();
       if constexpr (BF) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(ktv + 8 * t), frag8(QF, 8 * t), sc, 0, 0, 0);  // S[gene][(hl, q)]
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(ktv + 8 * t), qf16[t], sc, 0, 0, 0);  // S[gene][(hl, q)]
       } else {
 #pragma unroll
         for (int g4 = 0; g4 < 2; ++g4) {
@@ -859,16 +902,19 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
         }
       }
       float tm = -3.0e38f;
+      if (tile == n_tiles - 1) {   // (wave-uniform) tile padding
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (tile * 32 + acc_row(r, hh) >= a.S) sc[r] = -3.0e38f;  // tile padding
-        tm = fmaxf(tm, sc[r]);
+        for (int r = 0; r < 16; ++r)
+          if (tile * 32 + acc_row(r, hh) >= a.S) sc[r] = -3.0e38f;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[r]);
       tm = xor32_max(tm);
-      const float nm = fmaxf(m[t], tm), alpha = __expf(m[t] - nm);
+      // scores are in log2 units (Qblk carries log2(e) / sqrt(8), enc_qfrag_kernel): softmax through v_exp_f32 without a multiply
+      const float nm = fmaxf(m[t], tm), alpha = __builtin_amdgcn_exp2f(m[t] - nm);
       float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { sc[r] = __expf(sc[r] - nm); ps += sc[r]; }
+      for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - nm); ps += sc[r]; }
       l[t] = l[t] * alpha + xor32_sum(ps);
       m[t] = nm;
 #pragma unroll
@@ -902,7 +948,7 @@ __global__ __launch_bounds__(256, SCLDM_ENC_MINW) void enc_pool_kernel(const Enc
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
       for (int w = 0; w < 4; ++w) {
-        const float sc = __expf(MRG[w][t][lane][0] - M);
+        const float sc = __builtin_amdgcn_exp2f(MRG[w][t][lane][0] - M);
         L += MRG[w][t][lane][1] * sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] += MRG[w][t][lane][2 + r] * sc;
@@ -984,7 +1030,7 @@ __global__ __launch_bounds__(64 * kTrunkWaves) void enc_cell_kernel(const EncCel
 }
 
 // Qblk^T fragments for the encoder scores (run once per weight load): tile t, step jj < 8:
-//   lane(col = hl*16 + q, hh): c_attn_q(LN_1q(inducing[q]))[k] / sqrt(8) if head(k) == 2t + hl else 0, k = acc_row(8t + jj, hh)
+//   lane(col = hl*16 + q, hh): c_attn_q(LN_1q(inducing[q]))[k] log2(e) / sqrt(8) if head(k) == 2t + hl else 0, k = acc_row(8t + jj, hh)
 __global__ __launch_bounds__(64) void enc_qfrag_kernel(const float* __restrict__ ind, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, const float* __restrict__ wq,
                                                        float* __restrict__ out, float eps) {
@@ -1001,7 +1047,7 @@ __global__ __launch_bounds__(64) void enc_qfrag_kernel(const float* __restrict__
     for (int n = 0; n < kE; ++n) {
       float acc = 0.f;
       for (int k = 0; k < kE; ++k) acc += v[k] * wq[n * kE + k];
-      qp[lane][n] = acc * 0.35355339059327373f;
+      qp[lane][n] = acc * (0.35355339059327373f * 1.4426950408889634f);   // log2(e) / sqrt(8): enc_pool_kernel's softmax runs on exp2
     }
   }
   __syncthreads();
