@@ -419,7 +419,8 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
 
 // dst[r][c] = bf16(src[r][c]), rows of the copy padded with zeros to ldd elements, one job per blockIdx.y (the per-step bf16
 // copies of the layers' weight matrices).  cols % 4 == 0.
-struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd; };
+// raw != 0: plain fp32 copy of rows * cols floats to (float*)dst (the stacked adaLN bias).
+struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd, raw; };
 __global__ void cast_jobs_kernel(const CastJob* __restrict__ jobs, int n_jobs) {
   const CastJob j = jobs[blockIdx.y];
   const int cq = j.cols / 4;
@@ -429,6 +430,10 @@ __global__ void cast_jobs_kernel(const CastJob* __restrict__ jobs, int n_jobs) {
     const long r = i / cq;
     const int c = (int)(i - r * cq) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(j.src + r * j.cols + c);
+    if (j.raw) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(j.dst) + r * j.cols + c) = v;
+      continue;
+    }
     bf16x4_t o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];

@@ -57,6 +57,8 @@ struct scldm_dit {
   // generic training path with bf16 operands (train_api.hip, bgemm.hpp): per-step bf16 copies of the layers' five weight matrices
   void* w16;                // [layer][attn_w | proj_w | w1 | w2 | cproj] bf16, allocated on first use
   size_t w16_layer_elems;
+  void* ada16;              // [mod_w][D] bf16: every adaLN Linear's weight stacked (one GEMM for all layers' modulation vectors)
+  float* ada_ball;          // [mod_w] fp32: their biases, stacked
   void* d_cast_jobs;        // device CastJob table (rebuilt when the weights' device pointers change)
   int n_cast_jobs;
   std::vector<const void*> w16_key;

@@ -404,10 +404,22 @@ __global__ void t_freq_kernel(const float* __restrict__ t, int n, float* __restr
   out[(long)i * 256 + threadIdx.x] = threadIdx.x < 128 ? cosf(a) : sinf(a);
 }
 
-__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+template <typename TO = float>
+__global__ void silu_kernel(const float* __restrict__ x, TO* __restrict__ y, long count) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
     const float v = x[i];
-    y[i] = v * sigmoid_f(v);
+    y[i] = (TO)(v * sigmoid_f(v));
+  }
+}
+// dst = bf16(src), count % 4 == 0 (the adaLN vectors' gradient before the stacked bf16-source GEMMs)
+__global__ void cast_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long count) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4; i < count; i += (long)gridDim.x * blockDim.x * 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x4_t*>(dst + i) = o;
   }
 }
 // dx = dy * silu'(x)

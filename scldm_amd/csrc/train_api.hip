@@ -276,6 +276,12 @@ bool src16_eligible(const scldm_dit* h, int n, int precision) {
          (long)n * kS * std::max(3 * h->cfg.n_embed, hidden16(h)) < (1L << 30);   // buffer descriptors address 2 GB
 }
 
+// the stacked adaLN products also run on bf16 sources when the bf16 copy of dmod (n x mod_w) fits the scratch it borrows
+// (dhid | da | db, free once the layers' backward is done): up to ~42 layers
+bool ada16_eligible(const scldm_dit* h, int n, int precision) {
+  return src16_eligible(h, n, precision) && (size_t)h->mod_w * sizeof(__bf16) <= 3 * (size_t)kS * h->cfg.hidden_dim * sizeof(float);
+}
+
 // per-step bf16 copies of the layers' weight matrices: [layer][attn_w | proj_w | w1 | w2 | cproj (D x hidden16)]
 struct W16 {
   const __bf16 *attn_w, *proj_w, *w1, *w2, *cproj;
@@ -291,18 +297,29 @@ int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   if (L == 0) return SCLDM_OK;
   h->w16_layer_elems = 4 * D * D + 2 * H * D + Hp * D;
   if (!h->w16) HIP_TRY(hipMalloc(&h->w16, (size_t)L * h->w16_layer_elems * sizeof(__bf16)));
+  if (!h->ada16) HIP_TRY(hipMalloc(&h->ada16, (size_t)h->mod_w * D * sizeof(__bf16)));
+  if (!h->ada_ball) HIP_TRY(hipMalloc(&h->ada_ball, (size_t)h->mod_w * sizeof(float)));
   std::vector<const void*> key;
   for (int l = 0; l < L; ++l)
-    for (const float* p : {w->attn_w[l], w->proj_w[l], w->w1[l], w->w2[l], w->cproj[l]}) key.push_back(p);
+    for (const float* p : {w->attn_w[l], w->proj_w[l], w->w1[l], w->w2[l], w->cproj[l], w->ada_w[l], w->ada_b[l]}) key.push_back(p);
+  key.push_back(w->fin_ada_w);
+  key.push_back(w->fin_ada_b);
   if (key != h->w16_key || !h->d_cast_jobs) {
     std::vector<CastJob> jobs;
     for (int l = 0; l < L; ++l) {
       const W16 d = w16_layer(h, l);
-      jobs.push_back(CastJob{w->attn_w[l], const_cast<__bf16*>(d.attn_w), (int)(3 * D), (int)D, (int)D});
-      jobs.push_back(CastJob{w->proj_w[l], const_cast<__bf16*>(d.proj_w), (int)D, (int)D, (int)D});
-      jobs.push_back(CastJob{w->w1[l], const_cast<__bf16*>(d.w1), (int)H, (int)D, (int)D});
-      jobs.push_back(CastJob{w->w2[l], const_cast<__bf16*>(d.w2), (int)H, (int)D, (int)D});
-      jobs.push_back(CastJob{w->cproj[l], const_cast<__bf16*>(d.cproj), (int)D, (int)H, (int)Hp});
+      jobs.push_back(CastJob{w->attn_w[l], const_cast<__bf16*>(d.attn_w), (int)(3 * D), (int)D, (int)D, 0});
+      jobs.push_back(CastJob{w->proj_w[l], const_cast<__bf16*>(d.proj_w), (int)D, (int)D, (int)D, 0});
+      jobs.push_back(CastJob{w->w1[l], const_cast<__bf16*>(d.w1), (int)H, (int)D, (int)D, 0});
+      jobs.push_back(CastJob{w->w2[l], const_cast<__bf16*>(d.w2), (int)H, (int)D, (int)D, 0});
+      jobs.push_back(CastJob{w->cproj[l], const_cast<__bf16*>(d.cproj), (int)D, (int)H, (int)Hp, 0});
+    }
+    // every adaLN Linear stacked in the order of the modulation vector's columns: layer l rows [6 D l, 6 D (l+1)), then the final layer's 2 D
+    __bf16* a16 = reinterpret_cast<__bf16*>(h->ada16);
+    for (int l = 0; l <= L; ++l) {
+      const int rows = (int)(l < L ? 6 * D : 2 * D);
+      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0});
+      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1});
     }
     if (!h->d_cast_jobs) HIP_TRY(hipMalloc(&h->d_cast_jobs, jobs.size() * sizeof(CastJob)));
     // (synchronous copy of a pageable vector: only when the parameters' device pointers changed)
@@ -460,11 +477,17 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   Scratch k = carve_scratch(h, n, ws, use_fused);
 
   if (use_fused) TRY(fused::prepare(h, w, st));   // weight re-pack on a side stream, next to the conditioning below
+  // bf16-source route (bgemm.hpp): h1, ao, h2, hid and SiLU(c) live as bf16 arrays in their (fp32-sized) slots of the saved block,
+  // the weights as per-step bf16 copies; same sequence of kernels otherwise
+  const bool src16 = g_src16 = src16_eligible(h, n, precision);
+  const int Hp = hidden16(h);
+  const bool ada16 = ada16_eligible(h, n, precision);
+  if (src16) TRY(refresh_w16(h, w, st));
   // conditioning: c = t_embedder(t) + sum class embeddings; every adaLN vector (layers.py:351-364,206-216,395-398)
   hipLaunchKernelGGL(t_freq_kernel, dim3(n), dim3(256), 0, st, t, n, s.freq);
   LAUNCH_CHECK();
   TRY(linear_fwd(st, s.freq, 256, w->t_w0, n, kD, 256, w->t_b0, s.th, kD, k));
-  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.th, s.sth, (long)n * kD);
+  hipLaunchKernelGGL(silu_kernel<float>, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.th, s.sth, (long)n * kD);
   LAUNCH_CHECK();
   TRY(linear_fwd(st, s.sth, kD, w->t_w2, n, kD, kD, w->t_b2, k.temb, kD, k));
   if (!cfg.has_null_row)
@@ -480,13 +503,19 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   }
   hipLaunchKernelGGL(cond_sum_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.temb, e, n, kD, s.c);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
+  if (ada16) hipLaunchKernelGGL(silu_kernel<__bf16>, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, reinterpret_cast<__bf16*>(s.sc), (long)n * kD);
+  else hipLaunchKernelGGL(silu_kernel<float>, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, s.c, s.sc, (long)n * kD);
   LAUNCH_CHECK();
   if (use_fused) {
     // every adaLN Linear of the network in ONE GEMM over the handle's all-layer transposed copy (ada_t is (D, mod_w), refreshed
     // from the live parameters by prepare()): mod = SiLU(c) W_all^T + b_all
     TRY(fused::prepare_join(h, st));
     TRY(gemm(st, s.sc, kD, 1, h->ada_t, 1, mw, s.mod, mw, n, mw, kD, h->ada_b, false, k.part, k.part_floats));
+  } else if (ada16) {
+    // every adaLN Linear of the network in ONE bf16-source GEMM over the stacked weight copy (refresh_w16): 2 336 tiles instead of
+    // 25 launches of 96
+    TRY(bgemm(st, reinterpret_cast<const __bf16*>(s.sc), kD, true, reinterpret_cast<const __bf16*>(h->ada16), kD, true, s.mod, mw, n, mw, kD,
+              h->ada_ball, false, k.part, k.part_floats));
   } else {
     for (int l = 0; l < L; ++l)
       TRY(linear_fwd(st, s.sc, kD, w->ada_w[l], n, 6 * kD, kD, w->ada_b[l], s.mod + (long)l * 6 * kD, mw, k));
@@ -506,11 +535,6 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T, kD);
   LAUNCH_CHECK();
 
-  // bf16-source route (bgemm.hpp): h1, ao, h2, hid live as bf16 arrays in their (fp32-sized) slots of the saved block, the
-  // weights as per-step bf16 copies; same sequence of kernels otherwise
-  const bool src16 = g_src16 = src16_eligible(h, n, precision);
-  const int Hp = hidden16(h);
-  if (src16) TRY(refresh_w16(h, w, st));
   auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y) {
     return src16 ? linear_fwd16(st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, k)
                  : linear_fwd(st, xin, ldx, W, (int)T, out_f, in_f, b, y, out_f, k);
@@ -653,7 +677,20 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, s_ada));
     TRY(gemm(st, k.dmod, mw, 1, h->ada_t, mw, 1, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
   }
-  for (int l = use_fused ? L + 1 : 0; l <= L; ++l) {
+  // bf16-source route: one cast of dmod, then d SiLU(c) = dmod W_all as ONE split-K product and the per-layer weight
+  // gradients straight into their tensors (column slices of dmod as the m-contiguous A operand, row sums = bias gradients).
+  // The bf16 copy of dmod (n x mod_w) borrows the dhid | da | db scratch, which is free once the layers are done.
+  const bool ada16 = ada16_eligible(h, n, precision);
+  if (ada16) {
+    __bf16* dmod16 = reinterpret_cast<__bf16*>(k.dhid);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid((long)n * mw / 4)), dim3(256), 0, st, k.dmod, dmod16, (long)n * mw);
+    LAUNCH_CHECK();
+    TRY(bgemm(st, dmod16, mw, true, reinterpret_cast<const __bf16*>(h->ada16), kD, false, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
+    for (int l = 0; l <= L; ++l)
+      TRY(bgemm(st, dmod16 + (size_t)l * 6 * kD, mw, false, reinterpret_cast<const __bf16*>(s.sc), kD, false, l < L ? g->ada_w[l] : g->fin_ada_w, kD,
+                l < L ? 6 * kD : 2 * kD, kD, n, nullptr, false, k.part, k.part_floats, l < L ? g->ada_b[l] : g->fin_ada_b));
+  }
+  for (int l = (use_fused || ada16) ? L + 1 : 0; l <= L; ++l) {
     const int width = l < L ? 6 * kD : 2 * kD;
     const float* dm = k.dmod + (long)l * 6 * kD;
     float* gw = l < L ? g->ada_w[l] : g->fin_ada_w;
