@@ -16,6 +16,10 @@ for g in "17002 6147" "27997 10186"; do set -- $g
   ROCPROF_ROWS=9 bash tools/rocprof_stats.sh ${tag}_stats_vae_$1 tests/perf/vae_profile.py $1 $2 1024 fp32 > ${o}_vae_G$1_fp32_kernel_stats.txt 2>&1
   ROCPROF_ROWS=9 bash tools/rocprof_stats.sh ${tag}_stats_vae_$1b tests/perf/vae_profile.py $1 $2 1024 bf16 > ${o}_vae_G$1_bf16_kernel_stats.txt 2>&1
 done
+ROCPROF_ROWS=14 bash tools/rocprof_stats.sh ${tag}_stats_ditl256 tests/perf/train_ditl_profile.py 256 > ${o}_train_ditl_b256_kernel_stats.txt 2>&1
+ROCPROF_ROWS=14 bash tools/rocprof_stats.sh ${tag}_stats_ditl1024 tests/perf/train_ditl_profile.py 1024 > ${o}_train_ditl_b1024_kernel_stats.txt 2>&1
+timeout 300 python tests/perf/bgemm_check.py 256 > ${o}_train_ditl_ab.txt 2>&1
+timeout 300 python tests/perf/vae_bench.py > ${o}_vae_bench.txt 2>&1
 K=dit_forward
 bash tools/rocprof_pmc.sh ${tag}_pmc1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" $K tests/perf/dit_profile.py bf16 6 > ${o}_pmc_sq.txt 2>&1
 bash tools/rocprof_pmc.sh ${tag}_pmc2 "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE" $K tests/perf/dit_profile.py bf16 6 > ${o}_pmc_sq2.txt 2>&1
