@@ -186,6 +186,7 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 thread_local bool g_src16 = false;   // the call in progress keeps the layers' GEMM operands as bf16 arrays
 // SCLDM_BGEMM256 (read when the library is loaded): 0 = 128-tile kernel only, 1 = pick by fill (default), 2 = the 256-tile kernel
 // whenever both extents reach 256 (tests: ragged tiles at small sizes)
+const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
 
 template <bool BIG, bool A_KC, bool B_KC>
@@ -535,8 +536,17 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   hipLaunchKernelGGL(add_pos_kernel, dim3(ew_grid(T * kD)), dim3(256), 0, st, x0, w->pos_embed, T, kD);
   LAUNCH_CHECK();
 
-  auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y) {
-    return src16 ? linear_fwd16(st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, k)
+  const bool overlap = src16 && g_overlap;   // the two up-projections of the MLP (same input, 1.4 rounds of tiles each) side by side
+  Scratch k2 = k;                            // the side stream's half of the split-K scratch (small batches split the forward products too)
+  if (overlap) {
+    const size_t half = (k.part_floats / 2) & ~(size_t)63;
+    k2.part = k.part + half;
+    k2.part_floats = k.part_floats - half;
+    k.part_floats = half;
+  }
+  auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y,
+                 hipStream_t sx = nullptr) {
+    return src16 ? linear_fwd16(sx ? sx : st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, sx ? k2 : k)
                  : linear_fwd(st, xin, ldx, W, (int)T, out_f, in_f, b, y, out_f, k);
   };
   for (int l = 0; l < L; ++l) {
@@ -554,8 +564,11 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     LAUNCH_CHECK();
     if (src16) TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h2), a.st2));
     else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
+    hipStream_t s2 = nullptr;
+    if (overlap) TRY(fused::fork_side(h, st, 2, &s2));
+    TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b, s2));
     TRY(lin(a.h2, kD, w->w1[l], wh.w1, H, kD, nullptr, a.a));
-    TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b));
+    if (overlap) TRY(fused::join_side(h, st, 2));
     if (src16) hipLaunchKernelGGL(swiglu_fwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, reinterpret_cast<__bf16*>(a.hid), T * H, H, Hp);
     else hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H, H, H);
     LAUNCH_CHECK();
@@ -610,8 +623,33 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   const bool src16 = g_src16 = src16_eligible(h, n, precision);
   if (src16 && !h->w16) return fail(SCLDM_ERR_SHAPE, "training backward without the forward of the same step");
   const int Hl = src16 ? hidden16(h) : H;   // elements per row of hid / da / db
+  // bf16-source route: the weight gradients of a layer run on a side stream next to the data-gradient chain.  Each of the two
+  // is a few hundred workgroups (240-workgroup split-K products, 256-tile activation-sized ones at 256 cells) that leave half of
+  // the chip's workgroup slots empty on their own.  fork = the side stream waits for what the main stream holds (the operand a
+  // weight gradient reads is ready); join = the main stream waits for the side stream before it overwrites such an operand.
+  // The two streams split the split-K scratch.
+  const bool overlap = src16 && g_overlap;
+  Scratch kw = k;
+  if (overlap) {
+    const size_t half = (k.part_floats / 2) & ~(size_t)63;
+    kw.part = k.part + half;
+    kw.part_floats = k.part_floats - half;
+    k.part_floats = half;
+  }
+  hipStream_t sw = st;
+  bool side_busy = false;
+  auto fork = [&]() -> int {
+    if (!overlap) return SCLDM_OK;
+    side_busy = true;
+    return fused::fork_side(h, st, 2, &sw);
+  };
+  auto join = [&]() -> int {
+    if (!side_busy) return SCLDM_OK;
+    side_busy = false;
+    return fused::join_side(h, st, 2);
+  };
   auto wgrad = [&](const float* dyp, int lddy, const float* xs, int ldx, int out_f, int in_f, float* dW, float* db) {
-    return src16 ? linear_wgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, (int)T, out_f, in_f, dW, k, db)
+    return src16 ? linear_wgrad16(sw, reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, (int)T, out_f, in_f, dW, kw, db)
                  : linear_wgrad(st, dyp, lddy, xs, ldx, (int)T, out_f, in_f, dW, k, db);
   };
   auto dgrad = [&](const float* dyp, int lddy, const float* W, const __bf16* Wh, int out_f, int in_f, float* dxp, bool acc) {
@@ -627,29 +665,36 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     const int o = l * 6 * kD;
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
+    TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
     gate_bwd(a.y2, o + 5 * kD);
     LAUNCH_CHECK();
+    TRY(fork());
     TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
     TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, kD, H, k.dhid, false));
     if (src16) hipLaunchKernelGGL(swiglu_bwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
     else hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, k.da, k.db, T * H, H, H);
     LAUNCH_CHECK();
+    TRY(fork());
     TRY(wgrad(k.da, Hl, a.h2, kD, H, kD, g->w1[l], nullptr));
     TRY(wgrad(k.db, Hl, a.h2, kD, H, kD, g->w2[l], nullptr));
     TRY(dgrad(k.da, Hl, w->w1[l], wh.w1, H, kD, k.dh, false));
     TRY(dgrad(k.db, Hl, w->w2[l], wh.w2, H, kD, k.dh, true));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
+    TRY(join());   // (c_proj's weight gradient read dy)
     gate_bwd(a.y1, o + 2 * kD);
     LAUNCH_CHECK();
+    TRY(fork());
     TRY(wgrad(k.dy, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
     TRY(dgrad(k.dy, kD, w->proj_w[l], wh.proj_w, kD, kD, k.dao, false));
     if (src16) TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
     else TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
+    TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
     TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, k.dh, false));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
   }
+  TRY(join());
 
   // ---- input projection + pos_embed ----
   // Fused route: three independent tails follow the layers - the input projection (reads d x0), the stacked adaLN weight
