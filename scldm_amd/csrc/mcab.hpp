@@ -185,6 +185,37 @@ __device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], co
   }
 }
 
+// The same with the affine vectors already in registers (LnVec: this lane's 16 weights and 16 biases): inside the trunk they are
+// requested one LayerNorm ahead - read at the point of use, each LayerNorm started with an exposed L2 round trip
+struct LnVec { f32x4 w[4], b[4]; };
+__device__ __forceinline__ LnVec load_ln(const float* __restrict__ w, const float* __restrict__ b, int hh) {
+  LnVec v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v.w[q] = *reinterpret_cast<const f32x4*>(w + q * 8 + hh * 4);
+    v.b[q] = *reinterpret_cast<const f32x4*>(b + q * 8 + hh * 4);
+  }
+  return v;
+}
+__device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], const LnVec& v, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += x[r];
+  const float mean = xor32_sum(s) / (float)kE;
+  float ss = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float d = x[r] - mean;
+    y[r] = d;
+    ss += d * d;
+  }
+  const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) / (float)kE + eps);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[q * 4 + i] = y[q * 4 + i] * rstd * v.w[q][i] + v.b[q][i];
+}
+
 // SwiGLU MLP on a normalised tile: x += c_proj( silu(w1 yn) * (w2 yn) ), six 16-unit hidden tiles (88 padded to 96 with zeros)
 __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const float* __restrict__ wc, const float (&yn)[16],
                                             float (&x)[16], int lane) {
@@ -208,15 +239,22 @@ __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const
 // attention of ONE of the two cells and three of the six SwiGLU hidden tiles, and the two partial down-projections are
 // exchanged through LDS and added in a fixed order (partial of wave 0 + partial of wave 1 in both waves): 7.5 chains per layer.
 // S = the pair's scratch [32][kTrunkLd], X = the exchange area [2][16][64]; four workgroup barriers per layer.
+// The LayerNorm vectors are requested one LayerNorm ahead (LnVec); the kernels are bounded to two waves per SIMD (256 registers):
+// same-box A/B at 1 024 / 2 048 / 4 096 cells: decoder trunk 110 / 139 / 259 -> 108 / 126 / 225 us, encoder tail 114 / 143 / 281
+// -> 113 / 136 / 260 us (three waves per SIMD spill and lose 10 %; unbounded - 305 registers, one wave - is 22 % faster at
+// 1 024 cells and 10 % slower at 4 096).
 __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, float* __restrict__ X, const float* __restrict__ wts,
                                              int n_layer, float eps, int lane, int hw) {
   const int c32 = lane & 31, hh = lane >> 5;
   if (n_layer <= 0) return;
   Frag16 nxt = load16(wts + T_QKV + (hw ? 2 * 1024 : 0), lane);   // fragments of the wave's next chain, always one chain ahead
+  LnVec ln1 = load_ln(wts + T_LN1W, wts + T_LN1B, hh);
   for (int layer = 0; layer < n_layer; ++layer) {
     const float* w = wts + (size_t)layer * kTrunkLayerFloats;
+    const LnVec ln2 = load_ln(w + T_LN2W, w + T_LN2B, hh);   // used after the attention
     float yn[16];
-    tile_ln(x, yn, w + T_LN1W, w + T_LN1B, kE, eps, hh);
+    tile_ln(x, yn, ln1, eps);
+    if (layer + 1 < n_layer) ln1 = load_ln(w + kTrunkLayerFloats + T_LN1W, w + kTrunkLayerFloats + T_LN1B, hh);   // the next layer's
     // q | k | v (split order of layers.py:147) -> scratch rows [token][q 32 | k 32 | v 32]
     auto put_tile = [&](const f32x16& o, int t) {
 #pragma unroll
@@ -278,7 +316,7 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[r] += po[r];
     }
-    tile_ln(x, yn, w + T_LN2W, w + T_LN2B, kE, eps, hh);
+    tile_ln(x, yn, ln2, eps);
     // SwiGLU: hidden tiles hw, hw + 2, hw + 4, each consumed by the down-projection as soon as it exists
     f32x16 mo = zero16();
     const bool last = layer + 1 == n_layer;
@@ -325,7 +363,7 @@ struct DecCellArgs {
   float eps;
 };
 template <bool PLAIN>
-__global__ __launch_bounds__(64 * kTrunkWaves) void dec_cell_kernel(const DecCellArgs a) {
+__global__ __launch_bounds__(64 * kTrunkWaves, 2) void dec_cell_kernel(const DecCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
   const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
   const int c32 = lane & 31, hh = lane >> 5;
@@ -980,7 +1018,7 @@ struct EncCellArgs {
   int B, n_lat, n_layer;
   float eps;
 };
-__global__ __launch_bounds__(64 * kTrunkWaves) void enc_cell_kernel(const EncCellArgs a) {
+__global__ __launch_bounds__(64 * kTrunkWaves, 2) void enc_cell_kernel(const EncCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
   const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
   const int c32 = lane & 31, hh = lane >> 5;
