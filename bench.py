@@ -558,11 +558,13 @@ def main():
             if tprec == "bf16":   # BASELINE configs[4] names a DiT-L denoiser: the same step on that shape (generic path, bf16 arrays + bgemm)
                 try:
                     torch.cuda.empty_cache()
-                    tl = dict(TRAIN_WORKLOADS["replogle_train_ditl_b256"])
-                    dtl, _ = time_training(tl, "bf16", device, 4, 2, False, 1)
-                    result["training_step_ditl"] = {"workload": "replogle_train_ditl_b256", "cells_per_s": tl["B"] / (dtl / 4), "ms_per_step": 1e3 * dtl / 4,
-                                                    "tflops": 3 * dit_flops(n_embed=1024, n_layer=24) * tl["B"] / (dtl / 4) / 1e12, "dtype": "bf16",
-                                                    "path": "generic: bf16 operand arrays + bgemm_kernel / bgemm256_kernel (DESIGN 4.4b)"}
+                    for key, name in (("training_step_ditl", "replogle_train_ditl_b256"), ("training_step_ditl_b1024", "replogle_train_ditl_b1024")):
+                        tl = dict(TRAIN_WORKLOADS[name])
+                        dtl, _ = time_training(tl, "bf16", device, 4, 2, False, 1)
+                        result[key] = {"workload": name, "cells_per_s": tl["B"] / (dtl / 4), "ms_per_step": 1e3 * dtl / 4,
+                                       "tflops": 3 * dit_flops(n_embed=1024, n_layer=24) * tl["B"] / (dtl / 4) / 1e12, "dtype": "bf16",
+                                       "path": "generic: bf16 operand arrays + bgemm_kernel / bgemm256_kernel, side streams (DESIGN 4.4b)"}
+                        torch.cuda.empty_cache()
                 except Exception as e:   # an extra: never takes the headline line down
                     result["training_step_ditl"] = {"error": repr(e)}
                 note("DiT-L training step done")
