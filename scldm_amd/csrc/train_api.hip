@@ -183,7 +183,6 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 }
 
 // ---- bf16-source GEMM (bgemm.hpp) -------------------------------------------------------------------------------
-thread_local bool g_src16 = false;   // the call in progress keeps the layers' GEMM operands as bf16 arrays
 // SCLDM_BGEMM256 (read when the library is loaded): 0 = 128-tile kernel only, 1 = pick by fill (default), 2 = the 256-tile kernel
 // whenever both extents reach 256 (tests: ragged tiles at small sizes)
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
@@ -480,7 +479,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   if (use_fused) TRY(fused::prepare(h, w, st));   // weight re-pack on a side stream, next to the conditioning below
   // bf16-source route (bgemm.hpp): h1, ao, h2, hid and SiLU(c) live as bf16 arrays in their (fp32-sized) slots of the saved block,
   // the weights as per-step bf16 copies; same sequence of kernels otherwise
-  const bool src16 = g_src16 = src16_eligible(h, n, precision);
+  const bool src16 = src16_eligible(h, n, precision);
   const int Hp = hidden16(h);
   const bool ada16 = ada16_eligible(h, n, precision);
   if (src16) TRY(refresh_w16(h, w, st));
@@ -620,7 +619,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
   // bf16-source route: dy, dqkv, da, db (consumed only by GEMMs) are bf16 arrays in their slots of the scratch block
-  const bool src16 = g_src16 = src16_eligible(h, n, precision);
+  const bool src16 = src16_eligible(h, n, precision);
   if (src16 && !h->w16) return fail(SCLDM_ERR_SHAPE, "training backward without the forward of the same step");
   const int Hl = src16 ? hidden16(h) : H;   // elements per row of hid / da / db
   // bf16-source route: the weight gradients of a layer run on a side stream next to the data-gradient chain.  Each of the two
