@@ -70,3 +70,123 @@ def training_losses(model_fn, x1: torch.Tensor, x0: torch.Tensor, t: torch.Tenso
     pred = model_fn(xt, t)
     loss = ((pred - ut) ** 2).mean(dim=list(range(1, pred.dim())))
     return {"pred": pred, "loss": loss, "xt": xt, "ut": ut}
+
+
+# ---- adaptive Dormand-Prince 5(4): the reference's DEFAULT sampler -----------------------------------------------------------
+# `Sampler.sample_ode()` with no arguments (src/scldm/models.py:793) -> sampling_method="dopri5", num_steps=50, atol=rtol=1e-5
+# (src/scldm/transport/transport.py:324-331) -> `torchdiffeq.odeint(_fn, x, t, method="dopri5", atol=[atol], rtol=[rtol])`
+# (src/scldm/transport/integrators.py:100-112).  torchdiffeq is un-vendored and unpinned: PARITY UNPINNED at the
+# stepping arithmetic.  What follows restates torchdiffeq's documented adaptive Runge-Kutta driver (README "Keyword arguments" /
+# the 0.2.x `rk_common` scheme) in float64:
+#   * Dormand & Prince (1980) 5(4) tableau with FSAL; the 5th-order solution is the last stage point; error estimate
+#     dt * sum_i (b_i - b*_i) k_i;
+#   * mixed error norm: ratio = rms( err / (atol + rtol * max(|y0|, |y1|)) ) over the WHOLE state (one step size for all cells);
+#     accept iff ratio <= 1;
+#   * next step dt * min(ifactor, max(safety / ratio^(1/5), dfactor)) with safety 0.9, ifactor 10, dfactor 0.2 - and dfactor
+#     replaced by 1 after an accepted step (a step never shrinks when it was accepted); ratio == 0 -> dt * ifactor;
+#   * initial step by Hairer-Norsett-Wanner II.4 with the rms norm and exponent 1/5 (the driver passes order - 1);
+#   * steps are NOT clipped to the requested times: the solver steps past each save point (past t = 1 as well) and evaluates
+#     the quartic interpolant fitted through (y0, y_mid, y1, f0, f1) of the last accepted step, x = (t - t0) / (t1 - t0);
+#   * the save times are float32 `linspace(0, 1, num_steps)` values cast to float64; the drift sees float(t) broadcast to (B,).
+import numpy as _np
+
+_DP_ALPHA = _np.array([1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0])
+_DP_BETA = [
+    _np.array([1 / 5]),
+    _np.array([3 / 40, 9 / 40]),
+    _np.array([44 / 45, -56 / 15, 32 / 9]),
+    _np.array([19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729]),
+    _np.array([9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]),
+    _np.array([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]),
+]
+_DP_C_ERROR = _np.array([35 / 384 - 1951 / 21600, 0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+                         -2187 / 6784 - -12231 / 42400, 11 / 84 - 649 / 6300, -1. / 60.])
+_DP_C_MID = _np.array([6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+                       187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2])
+
+
+def _rms64(a: "_np.ndarray") -> float:
+    return float(_np.sqrt(_np.mean(_np.square(_np.abs(a)))))
+
+
+def sample_ode_dopri5(x: torch.Tensor, model_fn, num_steps: int = 50, atol: float = 1e-5, rtol: float = 1e-5,
+                      safety: float = 0.9, ifactor: float = 10.0, dfactor: float = 0.2, max_num_steps: int = 100000,
+                      return_stats: bool = False):
+    """`Sampler.sample_ode(sampling_method="dopri5", num_steps=N, atol=, rtol=)(x, model)` restated in float64.
+
+    `model_fn(x64, t_vec)` is the drift on a float64 state tensor and a (B,) float32 time vector (integrators.py:103-104).
+    Returns the (num_steps, *x.shape) float64 trajectory (callers index [-1], models.py:812); with return_stats also
+    {"accepted": [(t0, dt), ...], "rejected": [(t0, dt), ...], "evaluations": n}."""
+    shape = tuple(x.shape)
+    nb = shape[0]
+    n_eval = 0
+
+    def f(t: float, y: "_np.ndarray") -> "_np.ndarray":
+        nonlocal n_eval
+        n_eval += 1
+        tv = torch.ones(nb, dtype=torch.float32) * float(t)
+        out = model_fn(torch.from_numpy(y.reshape(shape).copy()), tv)
+        assert tuple(out.shape) == shape, "Output shape from ODE solver must match input shape"     # transport.py:180
+        return out.detach().to(torch.float64).numpy().reshape(-1)
+
+    ts = torch.linspace(0.0, 1.0, num_steps).to(torch.float64).numpy()     # integrators.py:95, cast as the solver does
+    y0 = x.detach().to(torch.float64).numpy().reshape(-1).copy()
+    f0 = f(ts[0], y0)
+    # initial step
+    scale = atol + _np.abs(y0) * rtol
+    d0, d1 = _rms64(y0 / scale), _rms64(f0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = f(ts[0] + h0, y0 + h0 * f0)
+    d2 = _rms64((f1 - f0) / scale) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    dt = min(100 * h0, h1)
+
+    t0 = t1 = float(ts[0])
+    coeff = [y0] * 5
+    accepted, rejected = [], []
+    out = [y0.copy()]
+    for next_t in ts[1:]:
+        n_steps = 0
+        while next_t > t1:                                   # advance until the save point lies inside the last accepted step
+            assert n_steps < max_num_steps, "max_num_steps exceeded"
+            assert t1 + dt > t1, "underflow in dt"
+            ta, tb = t1, t1 + dt
+            k = _np.empty((7, y0.size))
+            k[0] = f0
+            yi = y0
+            for i, (alpha, beta) in enumerate(zip(_DP_ALPHA, _DP_BETA)):
+                ti = tb if alpha == 1.0 else ta + alpha * dt
+                yi = y0 + (beta * dt) @ k[:i + 1]
+                k[i + 1] = f(ti, yi)
+            y1 = yi                                           # c_sol == beta[-1] and c_sol[-1] == 0: the last stage point IS y1
+            err = (dt * _DP_C_ERROR) @ k
+            ratio = _rms64(err / (atol + rtol * _np.maximum(_np.abs(y0), _np.abs(y1))))
+            ok = ratio <= 1
+            if ok:
+                accepted.append((ta, dt))
+                y_mid = y0 + (dt * _DP_C_MID) @ k
+                fa, fb = k[0], k[6]
+                coeff = [y0,
+                         dt * fa,
+                         dt * (fb - 4 * fa) - 11 * y0 - 5 * y1 + 16 * y_mid,
+                         dt * (5 * fa - 3 * fb) + 18 * y0 + 14 * y1 - 32 * y_mid,
+                         2 * dt * (fb - fa) - 8 * (y1 + y0) + 16 * y_mid]
+                t0, t1, y0, f0 = ta, tb, y1, k[6]
+            else:
+                rejected.append((ta, dt))
+            if ratio == 0:
+                dt = dt * ifactor
+            else:
+                dt = dt * min(ifactor, max(safety / ratio ** (1.0 / 5.0), 1.0 if ratio < 1 else dfactor))
+            n_steps += 1
+        xs = (next_t - t0) / (t1 - t0)
+        total = coeff[0] + xs * coeff[1]
+        xp = xs
+        for c in coeff[2:]:
+            xp = xp * xs
+            total = total + xp * c
+        out.append(total)
+    traj = torch.from_numpy(_np.stack(out).reshape((num_steps,) + shape))
+    if return_stats:
+        return traj, {"accepted": accepted, "rejected": rejected, "evaluations": n_eval}
+    return traj

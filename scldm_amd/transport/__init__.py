@@ -158,73 +158,81 @@ class Sampler:
         self.drift = transport.get_drift()
 
     def _sample_dopri5(self, num_steps: int, atol: float, rtol: float):
-        """Adaptive Dormand-Prince 5(4) from t=0 to 1 with the published step controller (Hairer/Norsett/Wanner II.4: mixed
-        RMS error norm, safety 0.9, growth <= 10, shrink >= 0.2, automatic initial step) and quartic dense output at the
-        `num_steps` requested times - what `torchdiffeq.odeint(method="dopri5")` computes for the reference
-        (integrators.py:100-112).  PARITY UNPINNED: torchdiffeq is un-vendored and unpinned, so the accepted-step sequence
-        is not reproduced bit for bit; results agree to the tolerances (tests compare with the analytic solution and with a
-        fine fixed-grid Heun solve).  The whole state (all cells) shares one step size, as in torchdiffeq."""
+        """Adaptive Dormand-Prince 5(4) - what `torchdiffeq.odeint(method="dopri5")` computes for the reference's default
+        `sample_ode()` (integrators.py:100-112; models.py:793).  The driver follows torchdiffeq's documented scheme step for
+        step (oracle/transport.py: sample_ode_dopri5 is its float64 restatement and the checker): FSAL tableau, mixed rms error
+        ratio over the whole state (all cells share one step size), accept iff ratio <= 1, next step
+        dt * min(10, max(0.9 / ratio^(1/5), 0.2 - or 1 after an accepted step)), automatic initial step, steps never clipped to
+        the save times (the solver steps past them, past t = 1 too) and the quartic interpolant of the last accepted step
+        evaluated at the float32 `linspace(0, 1, num_steps)` save times.  PARITY UNPINNED at torchdiffeq itself (un-vendored,
+        unpinned).  State arithmetic in the state's dtype on its device; times and step sizes are host float64; every step
+        costs one host read of the error ratio.  `fn.last_stats` = evaluations, accepted / rejected (t0, dt) lists."""
         drift = self.drift
 
         @torch.no_grad()
         def _sample(x, model, **model_kwargs):
+            n_eval = 0
+
             def f(xc, tval):
                 # one scalar broadcast to (B,) as a stride-0 view: any model reads it as the reference's `ones(B) * t`
                 # (integrators.py:103-104), and a scldm_amd DiT can tell without a device round trip that t is uniform
+                nonlocal n_eval
+                n_eval += 1
                 tv = torch.full((), float(tval), device=xc.device, dtype=torch.float32).expand(xc.shape[0])
                 return drift(xc, tv, model, **model_kwargs)
 
-            ts = [i / (num_steps - 1) for i in range(num_steps)] if num_steps > 1 else [0.0]
-            out = [x]
-            t0, y0 = 0.0, x
-            f0 = f(y0, t0)
-            # initial step (Hairer et al., II.4 "starting step size")
+            def comb(base, w, ks, h):       # base + h * sum_i w_i k_i, skipping structural zeros
+                for wi, k in zip(w, ks):
+                    if wi != 0.0:
+                        base = base + (h * wi) * k
+                return base
+
+            ts = [float(v) for v in torch.linspace(0.0, 1.0, num_steps).double()]   # integrators.py:95, cast as the solver does
+            y0 = x
+            f0 = f(y0, ts[0])
+            # initial step (Hairer / Norsett / Wanner II.4, rms norm, exponent 1 / 5)
             scale = atol + rtol * y0.abs()
             d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
             h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-            d2 = _rms((f(y0 + h0 * f0, t0 + h0) - f0) / scale) / h0
-            h1 = max(1e-6, h0 * 1e-3) if max(d1, d2) <= 1e-15 else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+            d2 = _rms((f(y0 + h0 * f0, ts[0] + h0) - f0) / scale) / h0
+            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
             h = min(100.0 * h0, h1)
-            nxt = 1
-            n_eval, n_reject = 2, 0
-            while nxt < len(ts):
-                ks = [f0]
-                for a_row, c in zip(_DP_A, _DP_C):
-                    yi = y0
-                    for a, k in zip(a_row, ks):
-                        if a != 0.0:
-                            yi = yi + (h * a) * k
-                    ks.append(f(yi, t0 + c * h))
-                n_eval += 6
-                y1 = yi                      # the last stage point is the 5th-order solution (FSAL: ks[6] = f(t0 + h, y1))
-                err = sum((h * e) * k for e, k in zip(_DP_E, ks) if e != 0.0)
-                tol = atol + rtol * torch.maximum(y0.abs(), y1.abs())
-                ratio = _rms(err / tol)
-                if ratio <= 1.0:
-                    t1 = t0 + h
-                    if nxt < len(ts) and ts[nxt] <= t1 + 1e-12:   # dense output for every requested time inside this step
-                        ymid = y0 + sum((h * m) * k for m, k in zip(_DP_MID, ks) if m != 0.0)
-                        f1 = ks[6]
-                        ca = 2 * h * (f1 - f0) - 8 * (y1 + y0) + 16 * ymid
-                        cb = h * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * ymid
-                        cc = h * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * ymid
-                        cd = h * f0
-                        while nxt < len(ts) and ts[nxt] <= t1 + 1e-12:
-                            s_ = min(1.0, (ts[nxt] - t0) / h)
-                            out.append((((ca * s_ + cb) * s_ + cc) * s_ + cd) * s_ + y0)
-                            nxt += 1
-                    t0, y0, f0 = t1, y1, ks[6]
-                else:
-                    n_reject += 1
-                # step-size controller
-                if ratio == 0.0:
-                    factor = 10.0
-                else:
-                    factor = min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
-                h = h * factor
-                if n_eval > 100000:
-                    raise RuntimeError("dopri5: step size underflow / too many evaluations")
-            _sample.last_stats = {"evaluations": n_eval, "rejected": n_reject}
+            t0 = t1 = ts[0]
+            coeff = None
+            out = [x]
+            accepted, rejected = [], []
+            for next_t in ts[1:]:
+                while next_t > t1:            # advance until the save time lies inside the last accepted step
+                    if not (t1 + h > t1) or n_eval > 100000:
+                        raise RuntimeError("dopri5: step size underflow / too many evaluations")
+                    ta = t1
+                    ks = [f0]
+                    for a_row, c in zip(_DP_A, _DP_C):
+                        yi = comb(y0, a_row, ks, h)
+                        ks.append(f(yi, ta + h if c == 1.0 else ta + c * h))
+                    y1 = yi                   # the last stage point is the 5th-order solution (FSAL: ks[6] = f(ta + h, y1))
+                    err = sum((h * e) * k for e, k in zip(_DP_E, ks) if e != 0.0)
+                    ratio = _rms(err / (atol + rtol * torch.maximum(y0.abs(), y1.abs())))
+                    if ratio <= 1.0:
+                        accepted.append((ta, h))
+                        ymid = comb(y0, _DP_MID, ks, h)
+                        fa, fb = ks[0], ks[6]
+                        coeff = (y0, h * fa, h * (fb - 4 * fa) - 11 * y0 - 5 * y1 + 16 * ymid,
+                                 h * (5 * fa - 3 * fb) + 18 * y0 + 14 * y1 - 32 * ymid, 2 * h * (fb - fa) - 8 * (y1 + y0) + 16 * ymid)
+                        t0, t1, y0, f0 = ta, ta + h, y1, ks[6]
+                    else:
+                        rejected.append((ta, h))
+                    if ratio == 0.0:
+                        h = h * 10.0
+                    else:
+                        h = h * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
+                s_ = (next_t - t0) / (t1 - t0)
+                total, sp = coeff[0] + s_ * coeff[1], s_
+                for cf in coeff[2:]:
+                    sp = sp * s_
+                    total = total + sp * cf
+                out.append(total)
+            _sample.last_stats = {"evaluations": n_eval, "rejected": len(rejected), "accepted_steps": accepted, "rejected_steps": rejected}
             return torch.stack(out)
 
         return _sample

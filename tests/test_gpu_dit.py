@@ -235,26 +235,56 @@ def test_fused_sampler_full_size_properties(vocab, strategy, B, method, steps, s
     assert max_abs_rel(got, ref) < TOL_BF16
 
 
-def test_adaptive_dopri5_sampling_agrees_with_fine_heun():
-    """The reference's default sampler (sample_ode() -> dopri5, transport.py:324-332; parity unpinned, see oracle/transport.py):
-    adaptive solve over the fused forward_with_cfg agrees with a 400-evaluation fused Heun solve, both through
-    DiT.sample_ode_cfg and through the reference-style Sampler call (models.py:793-812)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_dopri5_sampler_matches_float64_oracle(precision):
+    """The reference's DEFAULT sampler (`sample_ode()` -> dopri5, 50 save points, atol = rtol = 1e-5: transport.py:324-331,
+    models.py:793-812): the host-driven stepper over the fused forward_with_cfg against oracle/transport.py's float64
+    restatement of torchdiffeq's driver running oracle.dit in float64, 4 cells (8 rows), whole 50-point trajectories.
+
+    What can be asserted at which tolerance (measured on the CPU with bit-faithful fp32 arithmetic too):
+      * at atol = rtol <= 1e-6 the solver's own global error is below the parity gate, and product == oracle at the SAME
+        tolerance within 1e-4 (measured 3e-5 at 1e-6, 2e-6 at 1e-7);
+      * at the default 1e-5 the float64 oracle itself is 2.0e-4 away from the converged solution (oracle at 1e-10) and so is
+        any fp32 run of the same algorithm: the first step's error estimate (h0 ~ 0.045, true error ~1e-9) is below fp32
+        rounding noise, the controller's growth factor after it is anywhere in [5, 10], and the 4-5 large steps that follow
+        land 1-2e-4 apart.  There the assertion is 5e-4 against the oracle AND against the converged solution - the solver's
+        tolerance, not an arithmetic difference."""
+    from oracle.transport import sample_ode_dopri5
     from scldm_amd.transport import Sampler, create_transport
-    g, m, cfg, sd = build("dit_base")
-    gen = torch.Generator(device="cuda").manual_seed(4)
-    B = 6
-    z0 = torch.randn(B, 16, 16, device="cuda", generator=gen)
+    g, m, cfg, sd = build("dit_base", precision)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    gen = torch.Generator().manual_seed(4)
+    B = 4
+    z0 = torch.randn(B, 16, 16, generator=gen)
     z2 = torch.cat([z0, z0])
-    cond = {"clusters": torch.randint(0, 14, (B,), device="cuda", generator=gen).repeat(2)}
+    cond = {"clusters": torch.randint(0, 14, (B,), generator=gen).repeat(2)}
     scales = {"clusters": 2.0}
-    ref = m.sample_ode_cfg(z2, cond, scales, 201, "heun")
-    out = m.sample_ode_cfg(z2, cond, scales, 2, "dopri5", atol=1e-6, rtol=1e-6)
-    assert max_abs_rel(out.cpu(), ref.cpu()) < 1e-3
-    fn = Sampler(create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)).sample_ode()      # the reference's default call
-    traj = fn(z2, m.forward_with_cfg, condition=cond, cfg_scale=scales)
-    assert traj.shape == (50, 2 * B, 16, 16) and torch.equal(traj[0], z2)
-    assert max_abs_rel(traj[-1].cpu(), ref.cpu()) < 1e-3
-    assert 20 < fn.last_stats["evaluations"] < 2000
+    f64 = lambda x, t: dit_forward_with_cfg(sd64, cfg, x, t, cond, scales)
+    condg = {k: v.cuda() for k, v in cond.items()}
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    for tol in (1e-6, 1e-7):
+        ref, st = sample_ode_dopri5(z2, f64, 50, tol, tol, return_stats=True)
+        fn = Sampler(tr).sample_ode(sampling_method="dopri5", num_steps=50, atol=tol, rtol=tol)
+        traj = fn(z2.cuda(), m.forward_with_cfg, condition=condg, cfg_scale=scales)
+        ls = fn.last_stats
+        print(f"[dopri5 tol {tol:g}] oracle {len(st['accepted'])} accepted / {len(st['rejected'])} rejected, {st['evaluations']} evaluations; "
+              f"product [{precision}] {len(ls['accepted_steps'])} / {len(ls['rejected_steps'])}, {ls['evaluations']}")
+        assert traj.shape == (50, 2 * B, 16, 16) and torch.equal(traj[0].cpu(), z2)
+        check_err(traj.cpu(), ref.float(), TOL_FP32, f"dopri5 trajectory, atol = rtol = {tol:g} [{precision}] vs float64 oracle", FLOOR_TOL[precision])
+        end = m.sample_ode_cfg(z2.cuda(), condg, scales, 2, "dopri5", atol=tol, rtol=tol)     # same steps; only the save times differ
+        check_err(end.cpu(), ref[-1].float(), TOL_FP32, f"sample_ode_cfg dopri5, atol = rtol = {tol:g} [{precision}] vs float64 oracle", FLOOR_TOL[precision])
+    truth = sample_ode_dopri5(z2, f64, 50, 1e-10, 1e-10)
+    ref, st = sample_ode_dopri5(z2, f64, return_stats=True)
+    fn = Sampler(tr).sample_ode()                                                          # the reference's default call
+    traj = fn(z2.cuda(), m.forward_with_cfg, condition=condg, cfg_scale=scales)
+    ls = fn.last_stats
+    print(f"[dopri5 default] oracle {len(st['accepted'])} / {len(st['rejected'])}, product [{precision}] {len(ls['accepted_steps'])} / "
+          f"{len(ls['rejected_steps'])}; oracle vs converged {max_abs_rel(ref.float(), truth.float()):.2e}")
+    assert traj.shape == (50, 2 * B, 16, 16) and 20 <= ls["evaluations"] <= 80
+    (ta, ha), (tb, hb) = ls["accepted_steps"][0], st["accepted"][0]
+    assert ta == tb == 0.0 and abs(ha - hb) < 1e-3 * hb                                  # same automatic initial step
+    check_err(traj.cpu(), ref.float(), 5e-4, f"dopri5 default call [{precision}] vs float64 oracle (solver tolerance)")
+    check_err(traj.cpu(), truth.float(), 5e-4, f"dopri5 default call [{precision}] vs converged solution (solver tolerance)")
 
 
 def test_forward_with_cfg_joint_mirror():

@@ -91,3 +91,62 @@ def test_dopri5_rejects_steps_on_a_stiff_transient_and_matches_fine_heun():
     ref = sample_ode_fixed(x0, lambda x, t: f(x, t), 20001, "heun")
     assert float((out[-1] - ref).abs().max()) < 1e-5
     assert fn.last_stats["rejected"] >= 1
+
+
+# ---- the float64 dopri5 oracle (oracle/transport.py: sample_ode_dopri5) and the product's host stepper against it -------------
+def test_dopri5_oracle_analytic_and_controller_constants():
+    from oracle.transport import sample_ode_dopri5
+    x0 = torch.ones(2, 3, dtype=torch.float64)
+    traj, st = sample_ode_dopri5(x0, lambda x, t: -x, 50, 1e-5, 1e-5, return_stats=True)       # the reference's default call shape
+    ts = torch.linspace(0.0, 1.0, 50).double()
+    assert traj.shape == (50, 2, 3) and torch.equal(traj[0], x0)
+    assert float((traj[:, 0, 0] - torch.exp(-ts)).abs().max()) < 3e-5                            # within a few tolerances at all 50 save points
+    assert st["evaluations"] == 2 + 6 * (len(st["accepted"]) + len(st["rejected"]))              # FSAL: 6 new stages per attempted step
+    # documented controller: no accepted step is followed by a smaller one; growth <= ifactor = 10; steps are contiguous
+    acc = st["accepted"]
+    for (ta, ha), (tb, hb) in zip(acc, acc[1:]):
+        assert abs(ta + ha - tb) < 1e-15 and hb <= 10.0 * ha * (1 + 1e-12)
+    assert acc[0][0] == 0.0 and acc[-1][0] + acc[-1][1] >= 1.0                                  # the last step is not clipped to t = 1
+    # tolerance is honoured (the end point is INTERPOLATED inside an unclipped last step, so the quartic interpolant's own
+    # O(h^5) error floors the gain at tight tolerances)
+    e = []
+    for tol in (1e-4, 1e-7, 1e-10):
+        out = sample_ode_dopri5(x0, lambda x, t: 3.0 * t.view(-1, 1).double() * x, 2, tol, tol)
+        e.append(abs(float(out[-1, 0, 0]) - 4.4816890703380645))
+    assert e[0] > 50 * e[1] and e[1] > 10 * e[2] and e[2] < 1e-7
+    # a rejected step shrinks by at least 0.2 and re-starts from the same point
+    f = lambda x, t: -50.0 * (x - torch.cos(6.0 * t.view(-1, 1).double()))
+    _, st = sample_ode_dopri5(torch.tensor([[0.0], [2.0]], dtype=torch.float64), f, 3, 1e-7, 1e-7, return_stats=True)
+    assert len(st["rejected"]) >= 1
+    steps = sorted(st["accepted"] + st["rejected"], key=lambda p: (p[0], -p[1]))
+    for tr, hr in st["rejected"]:
+        nxt = [h for (t, h) in steps if t == tr and h < hr]
+        assert nxt and 0.2 * hr * (1 - 1e-12) <= max(nxt) < hr
+
+
+def test_host_dopri5_reproduces_the_oracle_step_sequence():
+    """The product's host-driven stepper (scldm_amd.transport.Sampler, float64 state here) takes exactly the oracle's accepted and
+    rejected steps and returns its trajectory, on a smooth field, one with rejections, and a nonlinear coupled one."""
+    from oracle.transport import sample_ode_dopri5
+    A = torch.tensor([[0.0, 2.0, -1.0], [-2.0, 0.0, 0.5], [1.0, -0.5, -0.3]], dtype=torch.float64)
+    fields = [
+        (lambda x, t: -x, torch.ones(3, 2, 3, dtype=torch.float64), 50, 1e-5),
+        # a narrow source term at t = 0.5: the controller runs into it with a large step and has to reject (a stiffness-limited
+        # field is no use here: its step sequence amplifies the last-bit differences of the two summation orders)
+        (lambda x, t: -x + 10.0 * torch.exp(-((t.view(-1, 1, 1).double() - 0.5) / 0.02) ** 2), torch.tensor([[[0.0]], [[2.0]]], dtype=torch.float64), 7, 1e-7),
+        (lambda x, t: torch.tanh(x @ A) * (1.0 + t.view(-1, 1, 1).double()) - 0.1 * x ** 3,
+         torch.linspace(-1.5, 1.5, 24, dtype=torch.float64).view(2, 4, 3), 50, 1e-5),
+    ]
+    for fn_, x0, n, tol in fields:
+        ref, st = sample_ode_dopri5(x0, fn_, n, tol, tol, return_stats=True)
+        m = _Model(fn_)
+        fn = _dopri5(n, tol, tol)
+        out = fn(x0, m)
+        ls = fn.last_stats
+        assert ls["evaluations"] == st["evaluations"] == m.calls
+        if "exp" in fn_.__code__.co_names:
+            assert len(st["rejected"]) >= 2
+        assert len(ls["accepted_steps"]) == len(st["accepted"]) and len(ls["rejected_steps"]) == len(st["rejected"])
+        for (ta, ha), (tb, hb) in zip(ls["accepted_steps"] + ls["rejected_steps"], st["accepted"] + st["rejected"]):
+            assert abs(ta - tb) <= 1e-6 * max(1.0, abs(tb)) and abs(ha - hb) <= 1e-6 * hb
+        assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-9 * max(1.0, float(ref.abs().max()))
