@@ -39,7 +39,8 @@ extern "C" {
 #define SCLDM_PREC_BF16X3 2 /* split-bf16: every GEMM operand as hi + lo bf16, three v_mfma_f32_32x32x16_bf16 per k-step (hi*hi, hi*lo,
                              * lo*hi), fp32 accumulate - the arithmetic class of the reference's
                              * torch.set_float32_matmul_precision("high") (experiments/scripts/inference.py:26); ~1e-5 vs fp32,
-                             * inside the 1e-4 parity gate at 5x the exact-fp32 MFMA rate.  DiT inference entry points only. */
+                             * inside the 1e-4 parity gate at 5x the exact-fp32 MFMA rate.  Fused DiT inference kernels; the training /
+                             * generic entry points serve it with the exact-fp32 GEMM route (same parity class). */
 
 #define SCLDM_METHOD_EULER 0
 #define SCLDM_METHOD_HEUN 1
@@ -96,7 +97,7 @@ int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* strea
 /* Cheap staleness guard for callers that cannot know whether the parameter tensors were modified in place
  * (e.g. ema_pytorch updates through `.data`, which does not bump torch's version counter; reference
  * src/scldm/models.py:446,690): fingerprints the tensors given to the last scldm_dit_load_weights ON DEVICE (every
- * element of small tensors, 4096 evenly spaced elements of large ones) and re-packs, in the same stream and without a
+ * element of every tensor: one read of the parameters, ~10 us for the base DiT) and re-packs, in the same stream and without a
  * host synchronisation, only if the fingerprint changed.  Three small launches when nothing changed. */
 int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
 
@@ -140,7 +141,11 @@ int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, const int64_
  *   mutually_exclusive: one pass per cfg_scale entry, mask = that class, scale = its value (:372-376)
  * Conditional labels are given for n_urows UNIQUE label rows (ulabels[c]: device (n_urows) int64) and
  * cell_row (device (B) int32, or NULL when n_urows == B) maps each cell of the second half to its row.
- * With t_stride 1 the rows must be per-cell (n_urows == B, cell_row NULL). */
+ * With t_stride 1 the rows must be per-cell (n_urows == B, cell_row NULL).
+ * t_stride 2: t is a dense (2B) vector whose uniformity is decided ON DEVICE (what torchdiffeq's `ones(B) * t` looks like
+ * to a callee, integrators.py:103-104): a one-workgroup kernel compares the entries, the conditioning kernels of both plans
+ * are enqueued and the ones of the plan that does not apply exit at once - no host synchronisation; the workspace must be
+ * sized for the dense plan (n_rows = 2B + n_pass * B); de-duplicated label rows + cell_row are accepted. */
 int scldm_dit_forward_cfg(scldm_dit* h, const float* x, const float* t, int t_stride, const int64_t* const* ulabels,
                           int n_urows, const int32_t* cell_row, int B, int n_pass, const uint32_t* pass_mask,
                           const float* pass_scale, float* out, int precision, void* ws, void* stream);
@@ -198,6 +203,14 @@ size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n);
  * sized by the two functions above (precision unknown: the larger, generic layout) are accepted by every route. */
 size_t scldm_dit_train_saved_bytes_for(const scldm_dit* h, int n, int precision);
 size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precision);
+
+/* One-time set-up for training on the parameter tensors `w` at batch size n and `precision`: everything the two calls below
+ * would otherwise create on first use - the bf16 weight mirror of the bf16-source route (DiT-L: 0.9 GB) with its cast-job
+ * table, or the fused route's pack-job tables, side streams and events.  May allocate and synchronise `stream`; after it,
+ * train_forward / train_backward on the same parameter pointers issue kernel launches and event records only.  Optional: a
+ * forward on parameters it was not prepared for prepares itself (scldm_amd.nnets calls this whenever the parameters' storage
+ * moved).  SCLDM_PREC_BF16X3 is accepted on the training entry points and served by the exact-fp32 GEMM route. */
+int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w, int n, int precision, void* stream);
 
 /* out (n,S,Din) = DiT.forward(x (n,S,Din), t (n), labels) keeping every intermediate the backward needs in `saved`. */
 int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,

@@ -139,6 +139,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->d_plan, 8);
   if (e == hipSuccess) e = alloc((void**)&h->label_err, 4);
   if (e == hipSuccess) e = hipMemset(h->label_err, 0, 4);
   if (e == hipSuccess) e = alloc((void**)&h->d_fp_state, 16);
@@ -162,7 +163,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs, h->ada16, h->ada_ball};
+                  h->b_proj, h->label_err, h->d_plan, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs, h->ada16, h->ada_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -195,7 +196,7 @@ int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st)
     return SCLDM_OK;
   }
   if (force) set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);   // (not a memcpy from a host stack variable: it must stay stream-ordered and asynchronous)
-  fingerprint_kernel<<<h->n_fp, 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
+  fingerprint_kernel<<<dim3(h->n_fp, kFpSplit), 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
   fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
   pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty, prec_mask);
   LAUNCH_CHECK();
@@ -390,7 +391,7 @@ extern "C" size_t scldm_dit_workspace_bytes(const scldm_dit* h, int n_fwd, int n
 
 // conditioning rows -> silu_c rows [row0, row0+rows)
 static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t* const* labels, uint32_t mask, int rows,
-                       float* silu_c, hipStream_t st) {
+                       float* silu_c, hipStream_t st, const int* gate = nullptr, int gate_want = 0, const int32_t* row_map = nullptr) {
   if (rows <= 0) return SCLDM_OK;
   if (!h->cfg.has_null_row)
     for (int c = 0; c < h->cfg.n_classes; ++c)
@@ -411,13 +412,16 @@ static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t
   a.silu_c = silu_c;
   a.rows = rows;
   a.label_err = h->label_err;
+  a.gate = gate;
+  a.gate_want = gate_want;
+  a.row_map = row_map;
   cond_embed_kernel<<<rows, 256, 0, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st) {
+static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st, const int* rows_dev = nullptr) {
   dim3 grid(cdiv(h->mod_w, 64), cdiv(rows, kAdaRU));
-  adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w);
+  adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w, rows_dev);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -595,10 +599,17 @@ struct CfgPlan {
   float scale[SCLDM_MAX_CLASSES];
 };
 
+// plan (optional, device): plan[0] == 0 selects the dense plan (one row per sample-forward: uncond_rows = n_direct, U = B, no
+// cell_row) over the uniform one given by the arguments
 __global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_t* __restrict__ cell_row, int n_direct,
-                                          int uncond_rows, int B, int U, int P) {
+                                          int uncond_rows, int B, int U, int P, const int* __restrict__ plan = nullptr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_direct + P * B) return;
+  if (plan && plan[0] == 0) {
+    uncond_rows = n_direct;
+    U = B;
+    cell_row = nullptr;
+  }
   if (s < n_direct) { ri[s] = (uncond_rows == 1) ? 0 : s; return; }
   const int p = (s - n_direct) / B, i = (s - n_direct) % B;
   ri[s] = uncond_rows + p * U + (cell_row ? cell_row[i] : i);
@@ -608,7 +619,9 @@ __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
                     float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr) {
   int rc;
-  if (t_stride == 0) {
+  const int* gate = t_stride == 2 ? h->d_plan : nullptr;   // dense t, uniformity decided on device: both plans are enqueued, one runs
+  const int rows_u = 1 + pl.P * pl.U, rows_d = 2 * pl.B + pl.P * pl.B;
+  if (t_stride == 0 || t_stride == 2) {
     // scalar t: one timestep-MLP evaluation per step, then all rows (unconditional + every pass) in one launch
     const float* temb = temb_pre;
     if (!temb) {
@@ -630,18 +643,23 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
     }
     ca.silu_c = w.silu;
     ca.label_err = h->label_err;
-    cond_rows_kernel<<<pl.n_rows, 256, 0, st>>>(ca);
+    ca.gate = gate;
+    cond_rows_kernel<<<t_stride == 2 ? rows_u : pl.n_rows, 256, 0, st>>>(ca);
     LAUNCH_CHECK();
-  } else {
-    // per-sample t: unconditional rows (every class null), then one launch per conditional pass
-    if ((rc = launch_cond(h, t_dev, t_stride, nullptr, 0u, pl.uncond_rows, w.silu, st))) return rc;
+  }
+  if (t_stride == 1 || t_stride == 2) {
+    // per-sample t: unconditional rows (every class null), then one launch per conditional pass (per-cell labels; under the
+    // device-decided plan they are read through cell_row out of the de-duplicated rows)
+    const int ur = t_stride == 2 ? 2 * pl.B : pl.uncond_rows, U = t_stride == 2 ? pl.B : pl.U;
+    if ((rc = launch_cond(h, t_dev, 1, nullptr, 0u, ur, w.silu, st, gate, 0))) return rc;
     for (int p = 0; p < pl.P; ++p) {
       const float* tp = t_dev + pl.B;  // second half of t
-      if ((rc = launch_cond(h, tp, t_stride, pl.ulabels, pl.mask[p], pl.U, w.silu + (size_t)(pl.uncond_rows + p * pl.U) * 256, st)))
+      if ((rc = launch_cond(h, tp, 1, pl.ulabels, pl.mask[p], U, w.silu + (size_t)(ur + p * U) * 256, st, gate, 0,
+                            t_stride == 2 ? pl.cell_row : nullptr)))
         return rc;
     }
   }
-  if ((rc = launch_adaln(h, w.silu, w.mod, pl.n_rows, st))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr))) return rc;
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;
   CfgArgs ca;
   ca.v = w.v;
@@ -664,14 +682,14 @@ static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, i
   if (n_pass < 0 || n_pass > SCLDM_MAX_CLASSES) return fail(SCLDM_ERR_SHAPE, "n_pass out of range");
   if (n_pass > 0 && (!ulabels || !pass_mask || !pass_scale || n_urows <= 0)) return fail(SCLDM_ERR_SHAPE, "conditional passes need labels/masks/scales");
   if (n_pass > 0 && !cell_row && n_urows != B) return fail(SCLDM_ERR_SHAPE, "cell_row is NULL but n_urows (%d) != B (%d)", n_urows, B);
-  if (t_stride != 0 && n_pass > 0 && (cell_row || n_urows != B))
+  if (t_stride == 1 && n_pass > 0 && (cell_row || n_urows != B))
     return fail(SCLDM_ERR_SHAPE, "per-sample t (t_stride=1) requires per-cell label rows (n_urows == B, cell_row NULL)");
   pl.B = B;
   pl.P = n_pass;
   pl.U = n_pass > 0 ? n_urows : 0;
   pl.uncond_rows = (t_stride == 0) ? 1 : 2 * B;
   pl.n_fwd = 2 * B + n_pass * B;
-  pl.n_rows = pl.uncond_rows + pl.P * pl.U;
+  pl.n_rows = (t_stride == 2) ? 2 * B + n_pass * B /* the larger, dense plan sizes the workspace */ : pl.uncond_rows + pl.P * pl.U;
   pl.ulabels = ulabels;
   pl.cell_row = cell_row;
   for (int p = 0; p < n_pass; ++p) {
@@ -687,12 +705,17 @@ extern "C" int scldm_dit_forward_cfg(scldm_dit* h, const float* x, const float* 
   int rc = check_ready(h, precision);
   if (rc) return rc;
   if (!x || !t || !out || !ws_) return fail(SCLDM_ERR_SHAPE, "null pointer argument");
-  if (t_stride != 0 && t_stride != 1) return fail(SCLDM_ERR_SHAPE, "t_stride must be 0 or 1");
+  if (t_stride < 0 || t_stride > 2) return fail(SCLDM_ERR_SHAPE, "t_stride must be 0 (scalar), 1 (per sample) or 2 (dense, uniformity decided on device)");
   CfgPlan pl;
   if ((rc = make_plan(h, pl, ulabels, n_urows, cell_row, B, n_pass, pass_mask, pass_scale, t_stride))) return rc;
   hipStream_t st = (hipStream_t)stream_;
   Ws w = carve(h, ws_, pl.n_fwd, pl.n_rows, 0);
-  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, pl.uncond_rows, B, pl.U, pl.P);
+  if (t_stride == 2) {
+    uniform_t_kernel<<<1, 256, 0, st>>>(t, 2 * B, 1 + pl.P * pl.U, 2 * B + pl.P * B, h->d_plan);
+    LAUNCH_CHECK();
+  }
+  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, t_stride == 2 ? 1 : pl.uncond_rows, B, pl.U, pl.P,
+                                                                   t_stride == 2 ? h->d_plan : nullptr);
   LAUNCH_CHECK();
   return cfg_eval(h, pl, x, t, t_stride, w, out, precision, st);
 }

@@ -181,8 +181,11 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   }
 }
 
-// Fingerprint of the parameter tensors (scldm_dit_refresh_weights): block b hashes tensor b - every element if it has at
-// most 4096, else 4096 evenly spaced ones plus the last - into one 64-bit order-independent sum.
+// Fingerprint of the parameter tensors (scldm_dit_refresh_weights): EVERY element of every tensor enters one 64-bit
+// position-dependent, order-independent (wrapping) sum - tensor blockIdx.x is split over kFpSplit workgroups.  A partial
+// `.data` write (a few rows of a class table, a masked update) therefore always moves it; the pass reads the parameters once
+// (39 MB for the base DiT: ~10 us, against >= 300 us for the smallest forward).
+constexpr int kFpSplit = 8;
 struct FpSrc {
   const uint32_t* p;
   long long n;
@@ -190,15 +193,14 @@ struct FpSrc {
 __global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
   const FpSrc s = src[blockIdx.x];
   if (s.n <= 0) return;
-  const long long cnt = s.n < 4096 ? s.n : 4096;
-  const long long step = s.n / cnt;
+  const long long chunk = ((s.n + kFpSplit - 1) / kFpSplit + 255) / 256 * 256;
+  const long long lo = (long long)blockIdx.y * chunk, hi = lo + chunk < s.n ? lo + chunk : s.n;
+  if (lo >= s.n) return;
   unsigned long long hsum = 0;
-  for (long long i = threadIdx.x; i < cnt; i += 256) {
-    const long long pos = i * step;
+  for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) {
     const unsigned long long v = s.p[pos];
     hsum += (v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1 + blockIdx.x * 7919ll)) * 0xBF58476D1CE4E5B9ull ^ (v << 29);
   }
-  if (threadIdx.x == 0 && s.n > 0) hsum += (unsigned long long)s.p[s.n - 1] * 0x94D049BB133111EBull;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
   if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
@@ -234,6 +236,9 @@ struct CondArgs {
   float* silu_c;           // (rows,256)
   int rows;
   int* label_err;          // sticky count of out-of-range labels (clamped instead of reading another class's table)
+  const int* gate;         // device-decided plan (scldm_dit_forward_cfg, t_stride 2): run only if gate == nullptr or *gate == gate_want
+  int gate_want;
+  const int32_t* row_map;  // optional: the label of row u is labels[c][row_map[u]] (per-cell rows out of de-duplicated label rows)
 };
 
 // label -> table row; out-of-range labels are clamped and counted (the reference's nn.Embedding raises, nnets.py:420,453)
@@ -249,6 +254,7 @@ __device__ __forceinline__ int checked_label(const int64_t* lab, int i, int tab_
 __global__ __launch_bounds__(256) void cond_embed_kernel(const CondArgs a) {
   __shared__ float te[256];
   __shared__ float h1[256];
+  if (a.gate && *a.gate != a.gate_want) return;
   const int u = blockIdx.x, n = threadIdx.x;
   const float t = a.t[(size_t)u * a.t_stride];
   {
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(256) void cond_embed_kernel(const CondArgs a) {
   for (int k = 0; k < 256; ++k) c += a.w2t[k * 256 + n] * h1[k];
   for (int ci = 0; ci < a.n_classes; ++ci) {
     int tok = a.null_tok[ci];
-    if (a.labels[ci] != nullptr) tok = checked_label(a.labels[ci], u, a.tab_rows[ci], a.label_err, n == 0);
+    if (a.labels[ci] != nullptr) tok = checked_label(a.labels[ci], a.row_map ? a.row_map[u] : u, a.tab_rows[ci], a.label_err, n == 0);
     c += a.emb[(size_t)(a.emb_row0[ci] + tok) * 256 + n];
   }
   a.silu_c[(size_t)u * 256 + n] = silu_f(c);
@@ -343,8 +349,10 @@ struct CondRowsArgs {
   uint32_t mask[kMaxClasses];   // per pass: which classes keep their labels
   float* silu_c;
   int* label_err;
+  const int* gate;              // device-decided plan: run only if gate == nullptr or *gate == 1 (t is uniform)
 };
 __global__ __launch_bounds__(256) void cond_rows_kernel(const CondRowsArgs a) {
+  if (a.gate && *a.gate != 1) return;
   const int r = blockIdx.x, n = threadIdx.x;
   float c = a.temb[n];
   const int p = r > 0 ? (r - 1) / a.U : 0, u = r > 0 ? (r - 1) % a.U : 0;
@@ -360,14 +368,20 @@ __global__ __launch_bounds__(256) void cond_rows_kernel(const CondRowsArgs a) {
 // Workgroup = 64 columns x 4 k-quarters (split-K, combined through LDS), kAdaRU rows share each weight read;
 // grid = (mod_w / 64, rows / kAdaRU): 400 workgroups for the sampler's 15 rows instead of 100.
 constexpr int kAdaRU = 8;
+// rows_dev (optional): the number of rows is decided on device (scldm_dit_forward_cfg with t_stride 2): row groups at or beyond
+// it exit at once, so the grid may be sized for the larger plan.
 __global__ __launch_bounds__(256) void adaln_all_kernel(const float* __restrict__ silu_c, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ mod,
-                                                        int rows, int mod_w) {
+                                                        int rows, int mod_w, const int* __restrict__ rows_dev = nullptr) {
   __shared__ float sc[kAdaRU][256];
   __shared__ float part[4][kAdaRU][64];
   const int col = threadIdx.x & 63, kq = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + col;
   const int u0 = blockIdx.y * kAdaRU;
+  if (rows_dev) {
+    rows = *rows_dev;
+    if (u0 >= rows) return;
+  }
   for (int i = threadIdx.x; i < kAdaRU * 256; i += 256) {
     const int u = u0 + (i >> 8);
     sc[i >> 8][i & 255] = (u < rows) ? silu_c[(size_t)u * 256 + (i & 255)] : 0.f;
@@ -391,6 +405,24 @@ __global__ __launch_bounds__(256) void adaln_all_kernel(const float* __restrict_
   if (n < mod_w) {
     for (int r = kq; r < kAdaRU; r += 4)
       if (u0 + r < rows) mod[(size_t)(u0 + r) * mod_w + n] = bias[n] + part[0][r][col] + part[1][r][col] + part[2][r][col] + part[3][r][col];
+  }
+}
+
+// plan[0] = 1 if every t[i] == t[0] (the scalar an ODE solver broadcasts, integrators.py:103-104) else 0; plan[1] = the number of
+// conditioning rows of the plan that follows (rows_uniform or rows_dense).  One workgroup; NaNs compare unequal (dense plan).
+__global__ __launch_bounds__(256) void uniform_t_kernel(const float* __restrict__ t, int n, int rows_uniform, int rows_dense,
+                                                        int* __restrict__ plan) {
+  __shared__ int diff;
+  if (threadIdx.x == 0) diff = 0;
+  __syncthreads();
+  const float t0 = t[0];
+  int d = 0;
+  for (int i = threadIdx.x; i < n; i += 256) d |= !(t[i] == t0);
+  if (d) diff = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    plan[0] = diff ? 0 : 1;
+    plan[1] = diff ? rows_dense : rows_uniform;
   }
 }
 

@@ -31,6 +31,7 @@ struct scldm_dit {
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
   int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)
   int* label_err;  // device: sticky count of clamped out-of-range labels
+  int* d_plan;     // device: [0] t is uniform, [1] conditioning rows of the chosen plan (scldm_dit_forward_cfg, t_stride 2)
   // packing job table + fingerprint state (scldm_dit_load_weights / scldm_dit_refresh_weights)
   void* d_jobs;    // device PackJob[n_jobs]
   int n_jobs, job_blocks, jobs_cap;

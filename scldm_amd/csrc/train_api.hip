@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "api_common.hpp"
 #include "dit_handle.hpp"
@@ -14,6 +15,8 @@ using namespace scldm;
 using namespace scldm::train;
 
 namespace {
+
+constexpr int kMaxDevices = 64;
 
 // ---- activation record ---------------------------------------------------------------------------------------
 struct LayerSaved {
@@ -118,12 +121,14 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base, bool fused_path) {
 // ---- GEMM dispatch --------------------------------------------------------------------------------------------
 template <bool BF, int WTM, int WTN, bool A_KC, bool B_KC>
 int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set[kMaxDevices];   // the attribute is per device (and per function): one flag each
   constexpr int smem = BF ? hgemm_smem_bytes<WTM, WTN>() : gemm_smem_bytes<WTM, WTN>();
   auto kern = BF ? hgemm_kernel<WTM, WTN, A_KC, B_KC> : sgemm_kernel<WTM, WTN, A_KC, B_KC>;
-  if (!attr_set) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
   }
   dim3 grid(cdiv(g.N, 64 * WTN), cdiv(g.M, 64 * WTM), splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g);
@@ -190,12 +195,14 @@ const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ?
 
 template <bool BIG, bool A_KC, bool B_KC>
 int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set[kMaxDevices];
   constexpr int smem = BIG ? kBGemm2Lds : kBGemmLds;
   auto kern = BIG ? bgemm256_kernel<A_KC, B_KC> : bgemm_kernel<A_KC, B_KC>;
-  if (!attr_set) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BIG ? 512 : 256), smem, st, g);
   LAUNCH_CHECK();
@@ -291,7 +298,10 @@ W16 w16_layer(const scldm_dit* h, int l) {
   const __bf16* base = reinterpret_cast<const __bf16*>(h->w16) + (size_t)l * h->w16_layer_elems;
   return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + H * D, base + 4 * D * D + 2 * H * D};
 }
-int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+// allocations and the cast-job table of the bf16 weight mirror (synchronises `st` when the table is re-uploaded): everything
+// that is not a kernel launch.  scldm_dit_train_prepare runs it ahead of the first step; refresh_w16 falls back to it when
+// the parameters' device pointers are not the ones it was prepared for.
+int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
   const int L = h->cfg.n_layer;
   if (L == 0) return SCLDM_OK;
@@ -328,6 +338,12 @@ int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
     h->n_cast_jobs = (int)jobs.size();
     h->w16_key = key;
   }
+  return SCLDM_OK;
+}
+int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+  if (h->cfg.n_layer == 0) return SCLDM_OK;
+  int rc = prepare_w16(h, w, st);   // no-op (a pointer-list compare) once prepared for these parameters
+  if (rc != SCLDM_OK) return rc;
   hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, h->n_cast_jobs), dim3(256), 0, st, (const CastJob*)h->d_cast_jobs, h->n_cast_jobs);
   LAUNCH_CHECK();
   return SCLDM_OK;
@@ -420,6 +436,10 @@ int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const 
   return SCLDM_OK;
 }
 
+// The split-bf16 policy exists in the fused inference kernel only; on the training / generic entry points a request for it is
+// served by the exact-fp32 GEMM route (same parity class: fp32 products are a superset of bf16x3's accuracy).
+inline int train_precision(int precision) { return precision == SCLDM_PREC_BF16X3 ? SCLDM_PREC_FP32 : precision; }
+
 int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
@@ -449,10 +469,12 @@ extern "C" size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n) {
 }
 extern "C" size_t scldm_dit_train_saved_bytes_for(const scldm_dit* h, int n, int precision) {
   if (!h || n < 1) return 0;
+  precision = train_precision(precision);
   return carve_saved(h, n, nullptr, fused::eligible(h, n, precision)).bytes;
 }
 extern "C" size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precision) {
   if (!h || n < 1) return 0;
+  precision = train_precision(precision);
   const bool f = fused::eligible(h, n, precision);
   return carve_scratch(h, n, nullptr, f).bytes + (f ? fused::carve_scratch(h, n, nullptr).bytes : 0);
 }
@@ -462,9 +484,20 @@ extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
   return carve_scratch(h, n, nullptr, false).bytes + (h->fused ? fused::carve_scratch(h, n, nullptr).bytes : 0);
 }
 
+extern "C" int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w, int n, int precision, void* stream_) {
+  if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
+  precision = train_precision(precision);
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  hipStream_t st = (hipStream_t)stream_;
+  if (fused::eligible(h, n, precision)) return fused::prepare_tables(h, w, st);
+  if (src16_eligible(h, n, precision)) return prepare_w16(h, w, st);
+  return SCLDM_OK;
+}
+
 extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
                                        const int64_t* const* labels, int n, float* out, int precision, void* saved_, void* ws,
                                        void* stream_) {
+  precision = train_precision(precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!x || !t || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
@@ -585,6 +618,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
 extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* g, const float* x,
                                         const int64_t* const* labels, const float* dout, int n, float* dx_out, int precision,
                                         void* saved_, void* ws, void* stream_) {
+  precision = train_precision(precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;

@@ -468,16 +468,24 @@ bool eligible(const scldm_dit* h, int n, int precision) {
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
-int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+// everything of a step that is not a kernel launch or an event: the pack-job tables of the live parameters, the side streams
+// and their events (scldm_dit_train_prepare calls it ahead of the first step; prepare() re-checks it per step for free)
+int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   int rc = scldm_build_pack_tables(h, w, st);   // (the backward stream itself is allocated with the handle)
+  if (rc) return rc;
+  for (int k = 0; k < 3; ++k)
+    if (!h->side[k]) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming));
+    }
+  if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  return SCLDM_OK;
+}
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+  int rc = prepare_tables(h, w, st);
   if (rc) return rc;
   // The re-pack (90 us, memory bound) runs on a side stream next to the conditioning MLP, which reads the live parameters:
   // forked here, joined by prepare_join() before the first consumer of a packed copy.
-  if (!h->side[0]) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->side[0], hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->join_ev[0], hipEventDisableTiming));
-  }
-  if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(h->fork_ev, st));            // everything queued so far (the previous step's optimizer update) comes first
   HIP_TRY(hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
   rc = scldm_run_pack(h, true, (1u << SCLDM_PREC_BF16) | 0x100u, h->side[0]);

@@ -36,6 +36,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base);
 bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision and batch served by the fused path
 
 // refresh the packed forward (bf16) and backward weight streams from the live parameters
+int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // pack-job tables, side streams, events (no kernel work)
 int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // forks the re-pack onto a side stream
 int prepare_join(scldm_dit* h, hipStream_t st);                           // `st` waits for it (before the first packed copy is read)
 // trunk forward (input projection .. final layer) with the record; mod = (n, mod_w) adaLN vectors

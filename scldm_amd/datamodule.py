@@ -126,10 +126,10 @@ def tokenize_cells(counts: torch.Tensor, gene_idx: torch.Tensor, genes_seq_len: 
                 "library_size": lib}
     if sample_genes == "random_expressed":
         order = ((~expressed).to(counts.dtype) * 2 + rand()).argsort(dim=1)[:, :S]   # expressed genes first, random order
+        if S > G:   # the reference accepts genes_seq_len > G and pads with the mask token (np.pad, :759-768): pad the gather index
+            order = torch.cat([order, order.new_zeros((N, S - G))], dim=1)
         take = torch.arange(S, device=counts.device).unsqueeze(0) < expressed.sum(1, keepdim=True)
         g = torch.where(take, genes.gather(1, order), torch.full_like(order, int(mask_token_idx)))
         c = torch.where(take, counts.gather(1, order), torch.zeros((), dtype=counts.dtype, device=counts.device))
-        if S > G:
-            raise ValueError("genes_seq_len exceeds the number of genes")
         return {"genes": g, "counts": c, "library_size": lib}
     raise ValueError(f"Invalid sample_genes value: {sample_genes}")

@@ -101,6 +101,13 @@ class _DiTTrainFn(torch.autograd.Function):
         saved = torch.empty(L.scldm_dit_train_saved_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
         ws = torch.empty(L.scldm_dit_train_workspace_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
         w, _ = module._weights_struct(params)
+        pkey = (id(w), n, prec)
+        if module.__dict__.get("_prepared_key") != pkey:
+            # one-time set-up for these parameter tensors (weight mirrors, job tables, side streams): the calls below then only
+            # launch kernels.  Re-run when the parameters' storage moved (a new pointer struct), the batch size or precision changes.
+            with torch.cuda.device(dev):
+                _lib.check(L.scldm_dit_train_prepare(h, C.byref(w), n, prec, _stream_ptr()), "scldm_dit_train_prepare")
+            module.__dict__["_prepared_key"] = pkey
         out = torch.empty_like(x)
         with torch.cuda.device(dev):
             _lib.check(L.scldm_dit_train_forward(h, C.byref(w), x.data_ptr(), t.data_ptr(), C.cast(labels, _lib.c_void_pp), n,
@@ -201,7 +208,7 @@ class DiT(nn.Module):
         self.input_proj = nn.Linear(n_embed_input, n_embed, bias=bias)
         self.final_layer = FinalLayerDit(n_embed, n_embed_input, bias, layernorm_eps)
         self.precision = os.environ.get("SCLDM_PRECISION", "fp32")
-        self.detect_uniform_t = True   # forward_with_cfg: test a dense t for uniformity (one host sync per call); see there
+        self.detect_uniform_t = True   # forward_with_cfg: test a dense t for uniformity on device (no host sync); see there
         self._handle = None
         self._weights_key = None
         self._ws = None
@@ -303,7 +310,7 @@ class DiT(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
-        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_pos_idx", "_param_list"):
+        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_pos_idx", "_param_list", "_prepared_key"):
             state.pop(k, None)
         return state
 
@@ -595,17 +602,17 @@ class DiT(nn.Module):
             raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(x.shape)}, {tuple(t.shape)}")
         # An ODE solver broadcasts ONE scalar t over the batch (integrators.py:103-104): the unconditional pass then needs one
         # conditioning row and the conditional passes one per unique label tuple.  A stride-0 / one-element t proves it for
-        # free (scldm_amd.transport passes such a view); for a dense t (the reference's `ones(B) * t` under torchdiffeq) one
-        # device comparison per call decides - costing a host synchronisation, which the shared conditioning work repays.
+        # free (scldm_amd.transport passes such a view).  For a dense t (the reference's `ones(B) * t` under torchdiffeq) the
+        # decision is taken ON DEVICE (t_stride 2): one small kernel compares the entries, both plans' conditioning kernels are
+        # enqueued and the one that does not apply exits at once - no host synchronisation per evaluation.
         if t.stride(0) == 0 or n == 1:
-            uniform_t = True
+            t_stride = 0
         else:
-            uniform_t = bool((t == t[0]).all().item()) if self.detect_uniform_t else False
-        tt = _require_cuda_f32("t", t[:1] if uniform_t else t)
-        ul, n_u, cell_row, n_pass, masks, scales, keep = self._cfg_plan(condition, cfg_scale, B, dedup=uniform_t)
+            t_stride = 2 if self.detect_uniform_t else 1
+        tt = _require_cuda_f32("t", t[:1] if t_stride == 0 else t)
+        ul, n_u, cell_row, n_pass, masks, scales, keep = self._cfg_plan(condition, cfg_scale, B, dedup=t_stride != 1)
         out = torch.empty_like(x)
-        t_stride = 0 if uniform_t else 1
-        n_rows = (1 if uniform_t else 2 * B) + n_pass * n_u
+        n_rows = (1 + n_pass * n_u) if t_stride == 0 else (2 * B + n_pass * B)
         ws = self._workspace(L, 2 * B + n_pass * B, n_rows, 0)
         with torch.cuda.device(x.device):
             _lib.check(L.scldm_dit_forward_cfg(h, x.data_ptr(), tt.data_ptr(), t_stride,

@@ -163,3 +163,10 @@ def test_tokenize_expressed_zero_and_random_expressed():
         assert bool((out2["counts"][i, :k] > 0).all()) and bool((out2["counts"][i, k:] == 0).all())
         assert bool((out2["genes"][i, k:] == 1).all())
         assert len(set(out2["genes"][i, :k].tolist())) == k
+    # genes_seq_len > G: the reference pads with the mask token (np.pad, datamodule.py:759-768) - so does this
+    out3 = tokenize_cells(counts, gene_idx, 340, "random_expressed", mask_token_idx=1)
+    assert out3["genes"].shape == (256, 340) and out3["counts"].shape == (256, 340)
+    for i in (0, 17, 255):
+        k = int(n_exp[i])
+        assert bool((out3["counts"][i, :k] > 0).all()) and bool((out3["counts"][i, k:] == 0).all()) and bool((out3["genes"][i, k:] == 1).all())
+        assert sorted(out3["genes"][i, :k].tolist()) == gene_idx[counts[i] > 0].tolist()     # every expressed gene, once
