@@ -9,6 +9,7 @@ roofline = the fused DiT block kernel (dominant): algorithmic FLOPs per launch /
            with HIP events on the launch stream inside the timed region, against the dense MFMA peak.
 parity_path = the same workload at precision "bf16x3" (split-bf16, <= 1e-4 vs the reference): cells/s, roofline against
            its own peak (three bf16 MFMAs per product sum: 2.5 PF / 3), error measured against the exact-fp32 path.
+reference_class_path = the same at precision "fp16" (10 mantissa bits = the TF32 arithmetic the reference itself computes in).
 cpu_baseline = the CPU oracle ("port" of the reference algorithm) on this box's host cores, bounded sample.
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (one process per
@@ -73,7 +74,7 @@ FLOPS_TRUNK_PER_SAMPLE_FWD = 8 * FLOPS_PER_SAMPLE_BLOCK + 16 * 2 * 16 * 256 + 16
 FLOPS_ADALN_PER_ROW = 2 * 256 * (8 * 1536 + 512)
 FLOPS_TMLP = 2 * 256 * 256 * 2
 # dense MFMA peaks, MI355X_MICROARCH.md:41-42; bf16x3 issues three bf16 MFMAs per algorithmic product sum
-PEAK = {"bf16": 2.5e15, "fp32": 157.3e12, "bf16x3": 2.5e15 / 3}
+PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 157.3e12, "bf16x3": 2.5e15 / 3}
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -245,7 +246,7 @@ def fused_kernel_roofline(m, blocks, n_fwd, precision, wl, evals_per_step):
     # to launch (written by every launch but the last, read by every launch but the first), every layer's packed weights once
     n_l = 8
     launches_per_eval = (n_l + lpl - 1) // lpl
-    wbytes = {"bf16": 2, "bf16x3": 4, "fp32": 4}[precision] * (768 * 256 + 256 * 256 + 3 * 256 * 704)
+    wbytes = {"bf16": 2, "fp16": 2, "bf16x3": 4, "fp32": 4}[precision] * (768 * 256 + 256 * 256 + 3 * 256 * 704)
     per_eval = 2 * n_fwd * 16 * 16 * 4 + (launches_per_eval - 1) * 2 * n_fwd * 16 * 256 * 4 + n_l * wbytes
     return {"bound": "mfma", "kernel": "dit_forward_kernel", "achieved": ach, "peak": PEAK[precision] / 1e12, "unit": "TFLOP/s",
             "frac": ach / (PEAK[precision] / 1e12), "launches": n_launch, "avg_launch_us": avg_s * 1e6, "layers_per_launch": lpl,
@@ -277,7 +278,7 @@ def decode_inclusive(m, wl, device, n_genes=17002):
     """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count), and the
     decode alone at both VAE precisions with its roofline (fp32-MFMA peak for the parity path, bf16 peak for the bf16 one)."""
     vae = make_vae(n_genes, device)
-    vae.precision = "bf16" if m.precision == "bf16" else "fp32"   # bf16 run: bf16-operand decode as well
+    vae.precision = "bf16" if m.precision in ("bf16", "fp16") else "fp32"   # bf16 run: bf16-operand decode as well
     B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
     w2 = dict(wl); w2["B"] = B
     z2, cond2, scales = make_inputs(w2, B, device, seed=7)
@@ -307,32 +308,41 @@ def decode_inclusive(m, wl, device, n_genes=17002):
                                       "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK[prec] / 1e12, "unit": "TFLOP/s",
                                                    "frac": ach / (PEAK[prec] / 1e12),
                                                    "hbm_out_GBps": 2 * B * n_genes * 8 / dd / 1e9}}
-    rec["decode_only_cells_per_s"] = rec[f"decode_only_{'bf16' if m.precision == 'bf16' else 'fp32'}"]["rows_per_s"]
+    rec["decode_only_cells_per_s"] = rec[f"decode_only_{'bf16' if m.precision in ('bf16', 'fp16') else 'fp32'}"]["rows_per_s"]
     return rec
 
 
-def parity_path(wl, device, ref_cells=64):
-    """The <= 1e-4 path of the same workload: precision 'bf16x3' - throughput, fused-kernel roofline against ITS peak, and its
-    error against the exact-fp32 path (itself pinned to the reference's golden vectors at ~6e-7 by tests/) on `ref_cells`
-    cells x 8 Euler evaluations: scale-relative max error and the elementwise relative error floored at 1 % of max|ref|."""
-    m3 = make_model(wl, "bf16x3", device)
+ARITH = {
+    "bf16x3": "operands split into hi + lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate / LN / softmax / residual",
+    "fp16": "fp16 operands (10 mantissa bits = TF32, the reference's set_float32_matmul_precision('high') class), v_mfma_f32_32x32x16_f16, "
+            "fp32 accumulate / LN / softmax / residual",
+}
+
+
+def precision_path(wl, device, prec, ref_cells=64):
+    """The same workload at another operand precision: throughput, fused-kernel roofline against ITS peak, and the error of every
+    fast precision against the exact-fp32 path (itself pinned to the reference's golden vectors at ~6e-7 by tests/) on `ref_cells`
+    cells x 8 Euler evaluations: scale-relative max error and the elementwise relative error floored at 1 % of max|ref|.
+      parity_path          = 'bf16x3' (<= 1e-4 vs exact fp32)
+      reference_class_path = 'fp16'   (TF32's mantissa: the arithmetic the reference itself computes in; ~1e-3 vs exact fp32, as
+                                       the reference's own TF32 mode is - tests/test_gpu_dit.py asserts <= 1.5 x a TF32-operand oracle)"""
+    m3 = make_model(wl, prec, device)
     dt, blocks, _, (z2, cond2, scales, B) = time_workload(m3, wl, device, 1, 1, False, 1, 0, time_blocks=True)
     n_fwd = (2 + n_passes(wl)) * B
-    rec = {"precision": "bf16x3", "cells_per_s": B / dt, "ms_per_step": 1e3 * dt,
-           "arithmetic": "operands split into hi + lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate / LN / softmax / residual",
-           "dit_fwd_mfma_frac": executed_flops_per_eval(wl, B, cond2) * wl["evals"] / dt / PEAK["bf16x3"]}
+    rec = {"precision": prec, "cells_per_s": B / dt, "ms_per_step": 1e3 * dt, "arithmetic": ARITH[prec],
+           "dit_fwd_mfma_frac": executed_flops_per_eval(wl, B, cond2) * wl["evals"] / dt / PEAK[prec]}
     if blocks and blocks[0] > 0:
-        rec["roofline"] = fused_kernel_roofline(m3, blocks, n_fwd, "bf16x3", wl, wl["evals"])
+        rec["roofline"] = fused_kernel_roofline(m3, blocks, n_fwd, prec, wl, wl["evals"])
     zs, cs, ss = make_inputs(wl, ref_cells, device, seed=31)
     outs = {}
-    for prec in ("fp32", "bf16x3", "bf16"):
-        m3.precision = prec
-        outs[prec] = m3.sample_ode_cfg(zs, cs, ss, 9, "euler").double()
+    for pr in ("fp32", "bf16x3", "fp16", "bf16"):
+        m3.precision = pr
+        outs[pr] = m3.sample_ode_cfg(zs, cs, ss, 9, "euler").double()
     ref = outs["fp32"]
-    for prec in ("bf16x3", "bf16"):
-        d = (outs[prec] - ref).abs()
-        rec[f"err_{prec}_vs_fp32"] = {"max_abs_over_max_ref": float(d.max() / ref.abs().max()),
-                                      "max_rel_floor_1pct": float((d / ref.abs().clamp_min(0.01 * float(ref.abs().max()))).max())}
+    for pr in ("bf16x3", "fp16", "bf16"):
+        d = (outs[pr] - ref).abs()
+        rec[f"err_{pr}_vs_fp32"] = {"max_abs_over_max_ref": float(d.max() / ref.abs().max()),
+                                    "max_rel_floor_1pct": float((d / ref.abs().clamp_min(0.01 * float(ref.abs().max()))).max())}
     rec["err_note"] = f"{ref_cells} cells x 8 Euler CFG evaluations, against the exact-fp32 path on the same device"
     return rec
 
@@ -412,7 +422,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--evals", type=int, default=0, help="override the number of CFG evaluations (profiling only; not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -530,8 +540,11 @@ def main():
     if rank == 0 and not dist_on and not fake:
         if not args.no_extra:
             if args.precision != "bf16x3":
-                result["parity_path"] = parity_path(wl, device)
+                result["parity_path"] = precision_path(wl, device, "bf16x3")
                 note("parity path done")
+            if args.precision != "fp16":
+                result["reference_class_path"] = precision_path(wl, device, "fp16")
+                note("reference-class (fp16) path done")
             extra = []
             for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100", "parse1m_b8192_euler100_strong"):
                 if name == args.workload:
@@ -548,7 +561,7 @@ def main():
             note("decode done")
             tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
             torch.cuda.empty_cache()
-            tprec = "bf16" if args.precision == "bf16" else "fp32"
+            tprec = "bf16" if args.precision in ("bf16", "fp16") else "fp32"   # (fp16 is an inference policy: training runs bf16 beside it)
             dtt, _ = time_training(tw, tprec, device, 10, 5, False, 1)
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,

@@ -42,6 +42,11 @@ extern "C" {
                              * inside the 1e-4 parity gate at 5x the exact-fp32 MFMA rate.  Fused DiT inference kernels; the training /
                              * generic entry points serve it with the exact-fp32 GEMM route (same parity class). */
 
+#define SCLDM_PREC_FP16 3  /* fp16 operands (v_mfma_f32_32x32x16_f16), fp32 accumulate / LN / softmax / residual: 10 mantissa bits = the
+                            * TF32 arithmetic the reference runs under set_float32_matmul_precision("high") (inference.py:26,
+                            * train_ldm.py:18) at the bf16 MFMA rate.  Fused DiT inference kernels; range |w| <= 65 504 checked at
+                            * pack time (scldm_dit_fp16_stats).  Training / generic entry points: exact-fp32 route. */
+
 #define SCLDM_METHOD_EULER 0
 #define SCLDM_METHOD_HEUN 1
 
@@ -100,6 +105,11 @@ int scldm_dit_load_weights(scldm_dit* h, const scldm_dit_weights* w, void* strea
  * element of every tensor: one read of the parameters, ~10 us for the base DiT) and re-packs, in the same stream and without a
  * host synchronisation, only if the fingerprint changed.  Three small launches when nothing changed. */
 int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
+
+/* Range report of the fp16 weight stream packed by the last load / refresh (synchronises `stream`): values beyond +-65 504
+ * (stored as inf: SCLDM_PREC_FP16 must not be used), non-zero values below the smallest fp16 normal 6.1e-5 (stored with fewer
+ * than 10 mantissa bits) and the non-zero values packed. */
+int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream);
 
 /* Labels outside [0, vocab] (or == vocab without a null row) are clamped by the conditioning kernels and counted in a
  * device-side sticky counter instead of reading another class's table (the reference's nn.Embedding raises).  This call

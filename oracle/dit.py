@@ -56,8 +56,48 @@ def layer_norm(x: torch.Tensor, eps: float, weight=None, bias=None) -> torch.Ten
     return y
 
 
+# ---- matmul operand precision (the reference's `torch.set_float32_matmul_precision("high")`) ---------------------------------
+# experiments/scripts/inference.py:26, train_ldm.py:18, train.py:18 select "high": every fp32 matmul (nn.Linear, the q k^T and
+# p v products of eager flex_attention) rounds its OPERANDS to TF32 - 10 explicit mantissa bits, fp32 exponent - and accumulates
+# exact products in fp32.  `matmul_operand_bits(10)` restates that arithmetic class here (round-to-nearest-even on the 13 dropped
+# bits) so that tests can state a reduced-precision tolerance in terms of the REFERENCE's own arithmetic:
+# err(product path) <= 1.5 x err(this mode), both measured against the exact-fp32 oracle on the same inputs.
+_OPERAND_BITS: int | None = None
+
+
+class matmul_operand_bits:
+    """Context manager: round both operands of every matmul in this module to `bits` explicit mantissa bits (None = exact)."""
+
+    def __init__(self, bits: int | None):
+        self.bits = bits
+
+    def __enter__(self):
+        global _OPERAND_BITS
+        self.prev, _OPERAND_BITS = _OPERAND_BITS, self.bits
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_BITS
+        _OPERAND_BITS = self.prev
+        return False
+
+
+def round_operand(x: torch.Tensor) -> torch.Tensor:
+    if _OPERAND_BITS is None:
+        return x
+    assert x.dtype == torch.float32, "operand rounding is defined on fp32 tensors"
+    drop = 23 - _OPERAND_BITS
+    i = x.contiguous().view(torch.int32)
+    i = (i + ((1 << (drop - 1)) - 1) + ((i >> drop) & 1)) & ~((1 << drop) - 1)      # round to nearest, ties to even
+    return i.view(torch.float32)
+
+
+def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return round_operand(a) @ round_operand(b)
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, b=None) -> torch.Tensor:
-    y = x @ w.transpose(-1, -2)
+    y = matmul(x, w.transpose(-1, -2))
     return y if b is None else y + b
 
 
@@ -122,9 +162,9 @@ def self_attention(sd: dict, prefix: str, x: torch.Tensor, n_head: int, bias: bo
     q = q.view(B, S, n_head, hd).transpose(1, 2)
     k = k.view(B, S, n_head, hd).transpose(1, 2)
     v = v.view(B, S, n_head, hd).transpose(1, 2)
-    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    s = matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
     p = torch.softmax(s, dim=-1)
-    y = (p @ v).transpose(1, 2).reshape(B, S, D)
+    y = matmul(p, v).transpose(1, 2).reshape(B, S, D)
     return linear(y, sd[f"{prefix}.c_proj.weight"], sd.get(f"{prefix}.c_proj.bias"))
 
 

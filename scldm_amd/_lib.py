@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCLDM_LIB", os.path.join(_HERE, "libscldm_hip.so"))  # SCLDM_LIB: debug-build override
 
 MAX_CLASSES = 8
-PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
 METHOD_EULER, METHOD_HEUN = 0, 1
-PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16}
 METHODS = {"euler": METHOD_EULER, "heun": METHOD_HEUN}
 
 c_float_p = C.POINTER(C.c_float)
@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
     L.scldm_dit_destroy.restype = None
     L.scldm_dit_load_weights.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p]
     L.scldm_dit_refresh_weights.argtypes = [C.c_void_p, C.c_void_p]
+    L.scldm_dit_fp16_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]
     L.scldm_dit_label_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
     L.scldm_dit_mod_width.argtypes = [C.c_void_p]
     L.scldm_dit_layers_per_launch.argtypes = [C.c_void_p]
@@ -140,7 +141,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
-           "scldm_dit_refresh_weights", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
+           "scldm_dit_refresh_weights", "scldm_dit_fp16_stats", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
            "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes", "scldm_dit_train_saved_bytes_for", "scldm_dit_train_workspace_bytes_for",
            "scldm_dit_train_prepare", "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_fm_mix", "scldm_fm_loss", "scldm_fm_loss_bwd", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights",

@@ -27,10 +27,11 @@ static inline int pad8(int n) { return (n + 7) & ~7; }  // sample-forwards per 1
 
 
 extern "C" const char* scldm_last_error(void) { return g_err; }
-extern "C" int scldm_version(void) { return 2; }   // 2: has_null_row in scldm_dit_config, SCLDM_PREC_BF16X3, refresh_weights / label_errors
+extern "C" int scldm_version(void) { return 3; }   // 3: SCLDM_PREC_FP16, scldm_dit_fp16_stats, scldm_dit_train_prepare, forward_cfg t_stride 2
+//   // 2: has_null_row in scldm_dit_config, SCLDM_PREC_BF16X3, refresh_weights / label_errors
 
-static size_t esize(int prec) { return prec == SCLDM_PREC_BF16 ? 2 : 4; }  // bytes per packed weight element (split-bf16: hi + lo)
-static const int kNPrec = 3;
+static size_t esize(int prec) { return (prec == SCLDM_PREC_BF16 || prec == SCLDM_PREC_FP16) ? 2 : 4; }  // bytes per packed weight element (split-bf16: hi + lo)
+static const int kNPrec = 4;
 
 // Kernel shape: (token tiles of 32*NTT, FT feature tiles per wave => 8/FT waves per workgroup).
 //   fp32   : NTT=2, FT=2 (4 waves, one per SIMD, 512-register budget)
@@ -42,7 +43,7 @@ static const int kNPrec = 3;
 static void pick_shape(const scldm_dit* h, int prec, int* ntt, int* ft) {
   *ntt = 2;
   *ft = 2;
-  if (prec == SCLDM_PREC_BF16) {
+  if (prec == SCLDM_PREC_BF16 || prec == SCLDM_PREC_FP16) {   // fp16: the bf16 kernel's shape, layout and schedule
     if (h->force_ft == 1 || h->force_ft == 2) *ft = h->force_ft;
   } else if (prec == SCLDM_PREC_BF16X3) {
     if (h->force_x3_ft == 1) *ft = 1;
@@ -140,6 +141,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->pos, 16 * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->fin_b, (size_t)din * 4);
   if (e == hipSuccess) e = alloc((void**)&h->d_plan, 8);
+  if (e == hipSuccess) e = alloc((void**)&h->d_fp16_stats, 16);
+  if (e == hipSuccess) e = hipMemset(h->d_fp16_stats, 0, 16);
   if (e == hipSuccess) e = alloc((void**)&h->label_err, 4);
   if (e == hipSuccess) e = hipMemset(h->label_err, 0, 4);
   if (e == hipSuccess) e = alloc((void**)&h->d_fp_state, 16);
@@ -163,7 +166,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_plan, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs, h->ada16, h->ada_ball};
+                  h->b_proj, h->label_err, h->d_plan, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs, h->ada16, h->ada_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -182,7 +185,7 @@ extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h-
 // device, in stream order; `force` makes the first pack after scldm_dit_load_weights unconditional)
 // prec_mask: which streams to refresh (bit p: precision p's forward stream; 0x100: the backward stream); anything but "all"
 // leaves the other streams stale, so the next full refresh is forced
-static const unsigned kPackAll = 0x1ffu;
+static const unsigned kPackAll = 0x1ffu;   // bits 0..3: the four precisions' forward streams, bit 8: the backward stream
 int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st) {
   if (prec_mask == kPackAll && h->partial_pack) {
     force = true;
@@ -197,8 +200,8 @@ int scldm_run_pack(scldm_dit* h, bool force, unsigned prec_mask, hipStream_t st)
   }
   if (force) set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);   // (not a memcpy from a host stack variable: it must stay stream-ordered and asynchronous)
   fingerprint_kernel<<<dim3(h->n_fp, kFpSplit), 256, 0, st>>>((const FpSrc*)h->d_fp_src, h->d_fp_state);
-  fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
-  pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty, prec_mask);
+  fingerprint_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty, h->d_fp16_stats);
+  pack_jobs_kernel<<<h->job_blocks, 256, 0, st>>>((const PackJob*)h->d_jobs, h->n_jobs, h->d_dirty, prec_mask, h->d_fp16_stats);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -341,6 +344,20 @@ extern "C" int scldm_dit_refresh_weights(scldm_dit* h, void* stream_) {
   return run_pack(h, false, (hipStream_t)stream_);
 }
 
+extern "C" int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream_) {
+  if (!h || !overflow || !subnormal || !nonzero) return fail(SCLDM_ERR_SHAPE, "null argument");
+  *overflow = *subnormal = *nonzero = 0;
+  if (!h->d_fp16_stats) return SCLDM_OK;
+  hipStream_t st = (hipStream_t)stream_;
+  int v[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(v, h->d_fp16_stats, 12, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *overflow = v[0];
+  *subnormal = v[1];
+  *nonzero = v[2];
+  return SCLDM_OK;
+}
+
 extern "C" int scldm_dit_label_errors(scldm_dit* h, int* count, void* stream_) {
   if (!h || !count) return fail(SCLDM_ERR_SHAPE, "null argument");
   *count = 0;
@@ -447,6 +464,7 @@ static int launch_fwd(int prec, int ntt, int ft, const FwdArgs& a, hipStream_t s
   if (prec == SCLDM_PREC_FP32) return launch_fwd_t<OpF32, 2, 2>(a, st);
   if (prec == SCLDM_PREC_BF16X3)
     return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : ntt == 1 ? launch_fwd_t<OpBF16x3, 1, 2>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
+  if (prec == SCLDM_PREC_FP16) return ft == 1 ? launch_fwd_t<OpFP16, 2, 1>(a, st) : launch_fwd_t<OpFP16, 2, 2>(a, st);
   if (ft == 1) return launch_fwd_t<OpBF16, 2, 1>(a, st);
   return launch_fwd_t<OpBF16, 2, 2>(a, st);
 }
@@ -549,7 +567,7 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
 static int check_ready(const scldm_dit* h, int prec) {
   if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
   if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_dit_load_weights has not been called");
-  if (prec != SCLDM_PREC_FP32 && prec != SCLDM_PREC_BF16 && prec != SCLDM_PREC_BF16X3) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", prec);
+  if (prec != SCLDM_PREC_FP32 && prec != SCLDM_PREC_BF16 && prec != SCLDM_PREC_BF16X3 && prec != SCLDM_PREC_FP16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", prec);
   if (!h->fused) return fail(SCLDM_ERR_SHAPE, "this handle's shape is outside the fused family (scldm_dit_train_* only)");
   return SCLDM_OK;
 }

@@ -66,6 +66,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Frag = one lane's 8 k-values.  `mma` accumulates a 32x32 tile over 16 k-values.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 struct OpBF16 {
   using E = __bf16;
@@ -114,6 +115,62 @@ struct OpBF16 {
   static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
     Quad q;
     q[0] = (__bf16)a; q[1] = (__bf16)b; q[2] = (__bf16)c; q[3] = (__bf16)d;
+    return q;
+  }
+};
+
+// fp16 operands (v_mfma_f32_32x32x16_f16, fp32 accumulate): 10 explicit mantissa bits - exactly TF32's, the arithmetic the
+// reference computes in under torch.set_float32_matmul_precision("high") (experiments/scripts/inference.py:26, train_ldm.py:18) -
+// at the bf16 MFMA rate.  Same fragment layout, LDS image, weight stream and schedule as OpBF16; what it gives up against TF32
+// is exponent range (|v| <= 65 504, gradual underflow below 6.1e-5): weights are range-checked when packed (scldm_dit_fp16_stats),
+// activations of a LayerNorm-ed network are O(1-100).
+struct OpFP16 {
+  using E = _Float16;
+  using ModE = _Float16;   // LDS copy of the adaLN vectors in the operand precision (they multiply values that are rounded to it next)
+  static __device__ __forceinline__ f32x4 load_mod4(const ModE* p) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+  }
+  static __device__ __forceinline__ void store_mod4(ModE* p, const f32x4 v) {
+    *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  }
+  using Frag = f16x8;
+  using Quad = f16x4;  // 4 consecutive elements (one accumulator register group)
+  static constexpr bool kIsBF16 = true;   // (= "16-bit throughput policy": selects the weight-ring depth knob)
+  static constexpr bool kTwoPassLN = false;  // sum / sum-of-squares in one sweep (fp32 accumulation)
+  static constexpr bool kPin = true;         // pin the per-k-step issue order of a GEMM pass (sched_group_barrier)
+  static constexpr bool kMfmaIn = true;      // input projection on the matrix pipe
+  static constexpr bool kTwoWG = true;       // two workgroups per CU (LDS and registers allow it for 64-token tiles)
+  static constexpr int kRing = 4;            // k-steps of weight-ring run-ahead
+  static constexpr int kFragLoads = 1;       // 16-byte loads per fragment
+  static constexpr int kMmaOps = 1;          // MFMA instructions per mma()
+  static __device__ __forceinline__ f32x16 mma(const Frag& a, const Frag& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  // SwiGLU with the w1 rows packed times -log2(e) and the w2 rows times -1/log2(e) (kW1Scale / kW2Scale, applied by the weight
+  // packer): the up-projection delivers a' = -log2(e) a and b' = -b / log2(e), so silu(a) b = a' b' / (1 + 2^a') - one multiply less
+  static constexpr float kW1Scale = -1.4426950408889634f, kW2Scale = -0.6931471805599453f;
+  static __device__ __forceinline__ float swiglu(float a, float b) { return (a * b) * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
+  // 4 consecutive features starting at feature f (multiple of 4) of an activation row
+  static __device__ __forceinline__ void store_quad(E* row, int f, const Quad& q) { *reinterpret_cast<Quad*>(row + f) = q; }
+  // quads q (q0) and q + 1 (q1) of a feature tile, f8 = first feature of quad q's 8-feature group: one 16-byte store per lane
+  static __device__ __forceinline__ void store_quad_pair(E* row, int f8, int hh, const Quad& q0, const Quad& q1) {
+    union { Quad q; unsigned u[2]; } a, b;
+    a.q = q0; b.q = q1;
+    halfwave_pair(a.u[0], b.u[0]);
+    halfwave_pair(a.u[1], b.u[1]);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    *reinterpret_cast<u32x4*>(row + f8 + 8 * hh) = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+  }
+  static __device__ __forceinline__ Frag pack8(const float* v) {
+    Frag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (_Float16)v[i];
+    return f;
+  }
+  static __device__ __forceinline__ Quad pack4(float a, float b, float c, float d) {
+    Quad q;
+    q[0] = (_Float16)a; q[1] = (_Float16)b; q[2] = (_Float16)c; q[3] = (_Float16)d;
     return q;
   }
 };

@@ -108,12 +108,25 @@ __device__ __forceinline__ float pack_bwd_val(const float* __restrict__ Wqkv, co
 }
 
 // Store packed element `idx` (fragment-major: 8 consecutive indices = one lane's 8 k-values) in the stream's precision.
-//   prec 0: fp32   1: bf16   2: split-bf16 (the 8 hi values then the 8 lo values of a lane: 32 bytes per lane-fragment)
-__device__ __forceinline__ void pack_store(void* out, long long idx, float val, int prec) {
+//   prec 0: fp32   1: bf16   2: split-bf16 (the 8 hi values then the 8 lo values of a lane: 32 bytes per lane-fragment)   3: fp16
+// fp16_stats (prec 3): [0] += values beyond the fp16 range (stored as +-inf), [1] += non-zero values below the smallest normal
+// (6.1e-5: stored with fewer than 10 mantissa bits), [2] += non-zero values packed
+__device__ __forceinline__ void pack_store(void* out, long long idx, float val, int prec, int* fp16_stats = nullptr) {
   if (prec == 0) {
     reinterpret_cast<float*>(out)[idx] = val;
   } else if (prec == 1) {
     reinterpret_cast<__bf16*>(out)[idx] = (__bf16)val;
+  } else if (prec == 3) {
+    reinterpret_cast<_Float16*>(out)[idx] = (_Float16)val;
+    if (fp16_stats && val != 0.f) {
+      const float av = fabsf(val);
+      // wave-aggregated counters: one atomic per wave and counter
+      const unsigned long long over = __ballot(av > 65504.f), sub = __ballot(av < 6.103515625e-05f), nz = __ballot(true);
+      const int lane = threadIdx.x & 63;
+      if (over && lane == __ffsll((long long)over) - 1) atomicAdd(fp16_stats + 0, __popcll(over));
+      if (sub && lane == __ffsll((long long)sub) - 1) atomicAdd(fp16_stats + 1, __popcll(sub));
+      if (lane == __ffsll((long long)nz) - 1) atomicAdd(fp16_stats + 2, __popcll(nz));
+    }
   } else {
     __bf16 hi, lo;
     OpBF16x3::split(val, hi, lo);
@@ -140,7 +153,7 @@ struct PackJob {
 // prec_mask: bit p set = pack the streams of precision p (kPackLayer / kPackFinal jobs of other precisions are skipped - the
 // training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set.
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty,
-                                                        unsigned prec_mask) {
+                                                        unsigned prec_mask, int* __restrict__ fp16_stats = nullptr) {
   if (dirty && *dirty == 0) return;
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {
@@ -168,14 +181,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       if (!((prec_mask >> j.p[4]) & 1u)) return;
       pack_store(j.d, j.d_off + idx,
                  pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3],
-                                j.p[4] == 1 ? OpBF16::kW1Scale : 1.0f, j.p[4] == 1 ? OpBF16::kW2Scale : 1.0f),
-                 j.p[4]);
+                                (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW1Scale : 1.0f, (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW2Scale : 1.0f),
+                 j.p[4], fp16_stats);
       break;
     case kPackFinal: {  // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
       if (!((prec_mask >> j.p[1]) & 1u)) return;
       const int jj = idx & 7, l = (idx >> 3) & 63, ks = (int)(idx >> 9);
       const int row = l & 31, k = ks * 16 + (l >> 5) * 8 + jj;
-      pack_store(j.d, idx, (row < j.p[0]) ? j.s[0][row * 256 + k] : 0.f, j.p[1]);
+      pack_store(j.d, idx, (row < j.p[0]) ? j.s[0][row * 256 + k] : 0.f, j.p[1], fp16_stats);
       break;
     }
   }
@@ -207,8 +220,9 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restric
 }
 // state[0] = accumulator of the current pass, state[1] = fingerprint of the packed weights; dirty[0] = re-pack?, dirty[1] = force
 __global__ void set_word_kernel(int* p, int v) { *p = v; }
-__global__ void fingerprint_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty) {
+__global__ void fingerprint_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty, int* __restrict__ fp16_stats = nullptr) {
   dirty[0] = (state[0] != state[1]) || dirty[1];
+  if (dirty[0] && fp16_stats) fp16_stats[0] = fp16_stats[1] = fp16_stats[2] = 0;   // the pack that follows recounts
   dirty[1] = 0;
   state[1] = state[0];
   state[0] = 0;

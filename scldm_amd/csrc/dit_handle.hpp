@@ -12,8 +12,8 @@ struct scldm_dit {
   int mod_w;
   bool loaded;
   bool fused;   // shape served by the fused inference kernels (otherwise only the scldm_dit_train_* path)
-  void* stream[3][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack); NULL = shape unused
-  void* wfinal[3];   // [precision] packed final_layer.linear
+  void* stream[4][2];  // [precision][FT-1] packed weight streams, [layer][wave][unit][tile] (+ ring over-read slack); NULL = shape unused
+  void* wfinal[4];   // [precision] packed final_layer.linear
   float *b_qkv, *b_proj;  // (n_layer,768), (n_layer,256)
   float *w0t, *b0, *w2t, *b2;      // timestep MLP (transposed weights)
   float* emb;                      // concatenated class tables
@@ -31,6 +31,7 @@ struct scldm_dit {
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
   int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)
   int* label_err;  // device: sticky count of clamped out-of-range labels
+  int* d_fp16_stats;  // device: [0] packed fp16 weights beyond +-65504, [1] below the smallest normal, [2] non-zero values packed
   int* d_plan;     // device: [0] t is uniform, [1] conditioning rows of the chosen plan (scldm_dit_forward_cfg, t_stride 2)
   // packing job table + fingerprint state (scldm_dit_load_weights / scldm_dit_refresh_weights)
   void* d_jobs;    // device PackJob[n_jobs]

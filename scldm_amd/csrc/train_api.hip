@@ -436,9 +436,9 @@ int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const 
   return SCLDM_OK;
 }
 
-// The split-bf16 policy exists in the fused inference kernel only; on the training / generic entry points a request for it is
+// The split-bf16 and fp16 policies exist in the fused inference kernel only; on the training / generic entry points a request for it is
 // served by the exact-fp32 GEMM route (same parity class: fp32 products are a superset of bf16x3's accuracy).
-inline int train_precision(int precision) { return precision == SCLDM_PREC_BF16X3 ? SCLDM_PREC_FP32 : precision; }
+inline int train_precision(int precision) { return (precision == SCLDM_PREC_BF16X3 || precision == SCLDM_PREC_FP16) ? SCLDM_PREC_FP32 : precision; }
 
 int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");

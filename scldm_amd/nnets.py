@@ -160,8 +160,11 @@ class DiT(nn.Module):
     """Diffusion Transformer (adaLN-Zero) - drop-in for scldm.nnets.DiT.
 
     Extra (non-reference) knobs: `precision` - "fp32" (exact-fp32 MFMA), "bf16x3" (split-bf16, three bf16 MFMAs per
-    product sum: the arithmetic class of the reference's `set_float32_matmul_precision("high")`, inference.py:26; both
-    inside the 1e-4 parity gate) or "bf16" (throughput path); default from $SCLDM_PRECISION, else "fp32".
+    product sum; both inside the 1e-4 parity gate vs exact fp32), "fp16" (fp16 operands = TF32's 10 mantissa bits, the
+    arithmetic the reference itself runs under `set_float32_matmul_precision("high")`, inference.py:26 - ~1e-3 vs exact fp32,
+    like the reference; weights are range-checked against +-65 504 when packed) or "bf16" (8 bits: throughput path); default
+    from $SCLDM_PRECISION, else "fp32".  "bf16x3" and "fp16" are policies of the fused inference kernels: in training mode and
+    on shapes outside the fused family (e.g. a DiT-L) they are served by the exact-fp32 GEMM route.
 
     The fused inference kernels read PACKED copies of the parameters.  They are refreshed automatically when a parameter's
     storage or torch version counter changes, and an on-device fingerprint of the parameters is re-checked at every call so
@@ -288,7 +291,31 @@ class DiT(nn.Module):
             # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation)
             with torch.cuda.device(self.pos_embed.device):
                 _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
+        if self.precision == "fp16" and self.__dict__.get("_fp16_checked") != self._weights_key:
+            # once per (re)load: the fp16 stream's range report (one stream synchronisation).  `.data` updates that are picked up
+            # by the fingerprint re-pack are not re-checked: call fp16_weight_report() after such an update if in doubt.
+            self.fp16_weight_report(strict=True)
+            self.__dict__["_fp16_checked"] = self._weights_key
         return L, self._handle
+
+    def fp16_weight_report(self, strict: bool = False) -> dict:
+        """Range report of the packed fp16 weight stream (precision "fp16"): `overflow` values beyond +-65 504 (stored as inf),
+        `subnormal` non-zero values below 6.1e-5 (fewer than 10 mantissa bits), `nonzero` values packed.  strict: raise on any
+        overflow, warn when more than 1 % of the non-zero weights are subnormal.  Synchronises the stream."""
+        if self._handle is None:
+            self._native_handle()
+        o, sn, nz = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        with torch.cuda.device(self.pos_embed.device):
+            _lib.check(_lib.lib().scldm_dit_fp16_stats(self._handle, C.byref(o), C.byref(sn), C.byref(nz), _stream_ptr()), "scldm_dit_fp16_stats")
+        rep = {"overflow": o.value, "subnormal": sn.value, "nonzero": nz.value}
+        if strict:
+            if rep["overflow"]:
+                raise ValueError(f"precision='fp16': {rep['overflow']} weight(s) exceed the fp16 range (|w| > 65504); use 'bf16x3' or 'fp32'")
+            if rep["nonzero"] and rep["subnormal"] > 0.01 * rep["nonzero"]:
+                import warnings
+                warnings.warn(f"precision='fp16': {rep['subnormal']} of {rep['nonzero']} weights are below the smallest fp16 normal (6.1e-5) "
+                              "and lose mantissa bits", RuntimeWarning, stacklevel=3)
+        return rep
 
     def invalidate_weights(self) -> None:
         """Force the next call to re-pack the fused kernels' weight copies from the parameters."""
