@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build libscldm_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.  The four translation units are
+# Build libscldm_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.  The five translation units are
 # compiled in parallel (objects under build/, git-ignored) and linked into one shared library.
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -15,10 +15,10 @@ esac
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize ${SCLDM_HIPCC_FLAGS:-}"
 mkdir -p "$OBJ"
 pids=()
-for tu in api vae_api train_api train_fused; do
+for tu in api vae_api vae_train_api train_api train_fused; do
   hipcc $FLAGS -c "scldm_amd/csrc/$tu.hip" -o "$OBJ/$tu.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/vae_train_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o"
 echo "built $OUT"

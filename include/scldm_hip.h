@@ -326,6 +326,35 @@ int scldm_vae_decode_sample(scldm_vae* h, const float* z, const int64_t* genes, 
 int scldm_nb_sample(const float* mu, const float* theta, float* out, size_t n, unsigned long long seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * TransformerVAE TRAINING step (BASELINE configs[0]; the reference trains through torch autograd over
+ * TransformerVAE.forward, src/scldm/vae.py:29-56, inside VAE.training_step, src/scldm/models.py:249-290, with the loss
+ * -log_nb_positive(counts, mu, theta), models.py:243, src/scldm/distributions.py:6-42).  fp32.
+ *   forward : (mu, theta, z) = TransformerVAE.forward(counts, genes, library_size, counts_subset, genes_subset) - the inference
+ *             kernels - and leaves in `saved` what the backward cannot recompute cheaply (the pooling's attention output and
+ *             log-sum-exp); uses the packed weights of the last scldm_vae_load_weights (call it after every optimiser step).
+ *   backward: given d loss / d mu, d theta (B, G; either may be NULL) and optionally d loss / d z (B, 16, n_lat), writes d loss / d
+ *             parameter for EVERY tensor named in `g` (same struct and layouts as scldm_vae_weights, pointers writable; overwritten,
+ *             not accumulated; enc_pos_embed is ignored: frozen in the reference, nnets.py:103-106).  Parameters are read LIVE from
+ *             `w`.  The two embedding tables' gradients (gene_embedding, theta) are scatter-added with float atomics (like torch's
+ *             embedding backward); every other gradient is a deterministic two-stage sum.
+ * mu / theta / z passed to the backward are the forward's outputs.  Buffers: scldm_vae_train_saved_bytes / _workspace_bytes. */
+size_t scldm_vae_train_saved_bytes(const scldm_vae* h, int B);
+size_t scldm_vae_train_workspace_bytes(const scldm_vae* h, int B, int S, int G);
+int scldm_vae_train_forward(scldm_vae* h, const float* counts_subset, const int64_t* genes_subset, int B, int S, const int64_t* genes,
+                            const float* library_size, int G, float* mu, float* theta, float* z, void* saved, void* ws, void* stream);
+int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w, const scldm_vae_weights* g, const float* counts_subset,
+                             const int64_t* genes_subset, int B, int S, const int64_t* genes, const float* library_size, int G,
+                             const float* mu, const float* theta, const float* z, const float* dmu, const float* dtheta, const float* dz,
+                             void* saved, void* ws, void* stream);
+
+/* log_nb_positive (src/scldm/distributions.py:6-42) elementwise over n values, and its gradient w.r.t. mu and theta given the
+ * upstream gradient of the log-likelihood (either output may be NULL):
+ *   res = theta (log(theta + eps) - L) + x (log(mu + eps) - L) + lgamma(x + theta) - lgamma(theta) - lgamma(x + 1),  L = log(theta + mu + eps) */
+int scldm_nb_loglik(const float* x, const float* mu, const float* theta, float eps, float* out, size_t n, void* stream);
+int scldm_nb_loglik_bwd(const float* x, const float* mu, const float* theta, const float* gout, float eps, float* dmu, float* dtheta,
+                        size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Encoder input path: tokenize_cells(sample_genes="expressed"),
  * reference src/scldm/datamodule.py:660-731.  counts: device (N,G) fp32; gene_idx: device int64 token ids,
  * one shared row (gene_row_stride 0) or per cell (gene_row_stride G) - the reference tiles one row N times (:691).

@@ -809,6 +809,7 @@ struct EncPoolArgs {
   const float* vfrag;     // Wv (rows 32-63 of c_attn) fragments, 16 steps
   const float* qfrag;     // Qblk^T fragments: 2 tiles x 8 steps (built from the inducing points at weight load)
   float* pooled;          // (B, 16, 32): softmax(QK^T/sqrt(8)) V, heads concatenated
+  float* lse2;            // optional (B, 4, 16): log2-domain log-sum-exp of the scaled scores (m + log2 l), for the training backward
   int S;
   float eps;
 };
@@ -994,6 +995,7 @@ __global__ __launch_bounds__(256, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(
       // lane = column (hl, q) of tile t; rows d = acc_row(r, hh); only d in head 2t + hl carry this head's output
       const int hl = c32 >> 4, qi = c32 & 15, head = 2 * t + hl;
       const float inv = 1.0f / L;
+      if (a.lse2 && hh == 0) a.lse2[((size_t)cell * 4 + head) * kNI + qi] = M + __log2f(L);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = acc_row(r, hh);

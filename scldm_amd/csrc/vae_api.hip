@@ -3,29 +3,10 @@
 #include <cstring>
 #include <vector>
 
-#include "api_common.hpp"
+#include "vae_handle.hpp"
 #include "mcab.hpp"
 
 using namespace scldm;
-
-struct scldm_vae {
-  scldm_vae_config cfg;
-  bool loaded;
-  // owned device buffers
-  float* enc_trunk;   // n_layer * kTrunkLayerFloats (LayerNorm vectors + MFMA fragments of every Linear)
-  float* dec_trunk;
-  float* frag_cell;   // fragments of the per-cell Linears around the trunks (layout: F_* below)
-  float* frag_dec;    // c_proj 16 | w12 96 | wc 48 fragments (160*64 floats)
-  float* frag_dec_halves;   // the 16 c_proj fragments with k in lane-half order (fp32 per-gene kernel)
-  float* frag_enc_k;  // 16*64
-  float* frag_enc_v;  // 16*64
-  float* frag_enc_q;  // 16*64
-  float* qtab;        // (n_genes+1, 32)
-  float* small;       // copies of the small vectors / matrices (layout below)
-  // borrowed (caller-owned, must stay alive): the big tables
-  const float* emb;
-  const float* theta;
-};
 
 // offsets (floats) into `frag_cell`
 enum : int {
@@ -47,6 +28,8 @@ enum : int {
   S_DEC_KV = S_DEC_LN1B + 32, S_DEC_LN2W = S_DEC_KV + 64 * 32, S_DEC_LN2B = S_DEC_LN2W + 32,
   S_HEAD_W = S_DEC_LN2B + 32, S_HEAD_B = S_HEAD_W + 32, S_TOTAL = S_HEAD_B + 32
 };
+
+
 
 extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
   if (!cfg || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
@@ -161,6 +144,12 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   return SCLDM_OK;
 }
 
+static int vae_ready(const scldm_vae* h) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_vae_load_weights has not been called");
+  return SCLDM_OK;
+}
+
 static const int kDecTilesPerWave = getenv("SCLDM_DEC_TPW") ? atoi(getenv("SCLDM_DEC_TPW")) : (32 + kDecWaves - 1) / kDecWaves;  // kDecWaves waves x tiles x 32 genes ~ 1024 genes per workgroup
 static inline int dec_chunks(int G) { return cdiv(G, kDecWaves * kDecTilesPerWave * 32); }
 
@@ -172,26 +161,18 @@ extern "C" size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G) {
   return kv + part + pooled;
 }
 
-static int vae_ready(const scldm_vae* h) {
-  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
-  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_vae_load_weights has not been called");
-  return SCLDM_OK;
-}
-
-extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision,
-                                void* ws_, void* stream_) {
+int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision, float* pooled,
+                        float* lse2, hipStream_t st) {
   int rc = vae_ready(h);
   if (rc) return rc;
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
-  if (B <= 0 || S <= 0 || !counts || !genes || !z || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
-  hipStream_t st = (hipStream_t)stream_;
+  if (B <= 0 || S <= 0 || !counts || !genes || !z || !pooled) return fail(SCLDM_ERR_SHAPE, "bad argument");
   const scldm_vae_config& c = h->cfg;
-  float* pooled = (float*)ws_;  // (B,16,32); encode and decode calls are stream-ordered, so they may share the workspace
   EncPoolArgs p;
   p.counts = counts; p.genes = genes; p.emb = h->emb;
   p.ln1_w = h->small + S_ENC_LN1W; p.ln1_b = h->small + S_ENC_LN1B;
   p.kfrag = h->frag_enc_k; p.vfrag = h->frag_enc_v; p.qfrag = h->frag_enc_q;
-  p.pooled = pooled; p.S = S; p.eps = c.layernorm_eps;
+  p.pooled = pooled; p.lse2 = lse2; p.S = S; p.eps = c.layernorm_eps;
   if (precision == SCLDM_PREC_BF16) enc_pool_kernel<true><<<B, 256, 0, st>>>(p);
   else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
   LAUNCH_CHECK();
@@ -205,6 +186,13 @@ extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t
   enc_cell_kernel<<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
   LAUNCH_CHECK();
   return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision,
+                                void* ws_, void* stream_) {
+  if (!ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  // (B,16,32) pooled attention output; encode and decode calls are stream-ordered, so they may share the workspace
+  return scldm_vae_encode_ex(h, counts, genes, B, S, z, precision, (float*)ws_, nullptr, (hipStream_t)stream_);
 }
 
 static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,

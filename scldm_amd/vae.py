@@ -12,6 +12,76 @@ from .nnets import Decoder, Encoder, _require_cuda_f32, _stream_ptr
 from .stochastic_layers import NegativeBinomial, NegativeBinomialTransformerLayer
 
 
+class _VAETrainFn(torch.autograd.Function):
+    """TransformerVAE.forward with a HIP backward (scldm_vae_train_forward / _backward, include/scldm_hip.h): replaces torch
+    autograd over the reference's module tree (vae.py:29-56) inside VAE.training_step (models.py:249-290).  Outputs mu, theta
+    (B, G) and z (B, 16, n_lat) are ordinary differentiable tensors: the reference's own `-log_nb_positive(counts, mu, theta)`
+    (models.py:243) - or scldm_amd.distributions.log_nb_positive, the fused form - sits on top of them unchanged."""
+
+    @staticmethod
+    def forward(ctx, module, counts_subset, genes_subset, genes, lib, *params):
+        L, h = module._native()
+        B, S = counts_subset.shape
+        G = genes.shape[1]
+        dev = counts_subset.device
+        mu = torch.empty(B, G, device=dev, dtype=torch.float32)
+        theta = torch.empty(B, G, device=dev, dtype=torch.float32)
+        z = torch.empty(B, module.encoder.latent_dim, module.encoder.latent_embedding, device=dev, dtype=torch.float32)
+        saved = torch.empty(L.scldm_vae_train_saved_bytes(h, B), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.scldm_vae_train_workspace_bytes(h, B, S, G), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.scldm_vae_train_forward(h, counts_subset.data_ptr(), genes_subset.data_ptr(), B, S, genes.data_ptr(), lib.data_ptr(), G,
+                                                 mu.data_ptr(), theta.data_ptr(), z.data_ptr(), saved.data_ptr(), ws.data_ptr(), _stream_ptr()),
+                       "scldm_vae_train_forward")
+        ctx.module, ctx.saved, ctx.ws = module, saved, ws
+        ctx.inputs = (counts_subset, genes_subset, genes, lib)
+        ctx.outs = (mu, theta, z)
+        ctx.params = params
+        ctx.param_versions = [p._version for p in params]
+        return mu, theta, z
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dmu, dtheta, dz):
+        module, params = ctx.module, ctx.params
+        L, h = _lib.lib(), module._handle
+        if [p._version for p in params] != ctx.param_versions:
+            raise RuntimeError("TransformerVAE parameters were modified between forward and backward (the HIP backward reads them live)")
+        counts_subset, genes_subset, genes, lib = ctx.inputs
+        mu, theta, z = ctx.outs
+        B, S = counts_subset.shape
+        G = genes.shape[1]
+        dev = mu.device
+        prep = lambda t: None if t is None else t.contiguous().float()
+        dmu, dtheta, dz = prep(dmu), prep(dtheta), prep(dz)
+        # every gradient is a view of ONE zero-initialised buffer (parameters the kernels do not write, e.g. a frozen table, stay 0)
+        offs, total = {}, 0
+        for p in params:
+            offs[id(p)] = total
+            total += (p.numel() + 63) // 64 * 64
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        base = flat.data_ptr()
+        gptr = lambda t: base + 4 * offs[id(t)]
+        w, keep_w = module._weights_struct(lambda t: t.data_ptr())
+        g, keep_g = module._weights_struct(gptr)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            _lib.check(L.scldm_vae_train_backward(h, C.byref(w), C.byref(g), counts_subset.data_ptr(), genes_subset.data_ptr(), B, S,
+                                                  genes.data_ptr(), lib.data_ptr(), G, mu.data_ptr(), theta.data_ptr(), z.data_ptr(),
+                                                  ptr(dmu), ptr(dtheta), ptr(dz), ctx.saved.data_ptr(), ctx.ws.data_ptr(), _stream_ptr()),
+                       "scldm_vae_train_backward")
+        del keep_w, keep_g
+        ctx.saved = ctx.ws = None
+        out = []
+        for i, p in enumerate(params):
+            if not ctx.needs_input_grad[5 + i]:
+                out.append(None)
+            else:
+                o = offs[id(p)]
+                out.append(flat[o:o + p.numel()].view(p.shape))
+        return (None, None, None, None, None, *out)
+
+
 class TransformerVAE(nn.Module):
     def __init__(self, encoder: Encoder, decoder: Decoder, decoder_head: NegativeBinomialTransformerLayer,
                  input_layer: InputTransformerVAE):
@@ -70,37 +140,39 @@ class TransformerVAE(nn.Module):
         for k in ("_handle", "_weights_key", "_weights_fp", "_ws", "_keep"):
             self.__dict__.setdefault(k, None)
 
-    @staticmethod
-    def _block(b):
-        dp = lambda t: t.data_ptr()
-        return _lib.VaeBlock(ln1_w=dp(b.ln_1.weight), ln1_b=dp(b.ln_1.bias), attn_w=dp(b.attn.c_attn.weight),
-                             proj_w=dp(b.attn.c_proj.weight), ln2_w=dp(b.ln_2.weight), ln2_b=dp(b.ln_2.bias), w1=dp(b.mlp.w1.weight),
-                             w2=dp(b.mlp.w2.weight), cproj=dp(b.mlp.c_proj.weight))
+    def _weights_struct(self, dp):
+        """scldm_vae_weights filled with dp(parameter) -> device pointer (the same struct, with writable pointers, receives the
+        gradients in scldm_vae_train_backward).  Returns (struct, keepalive)."""
+        enc, dec = self.encoder, self.decoder
+        n = enc.n_layer
 
-    @staticmethod
-    def _cross(c):
-        dp = lambda t: t.data_ptr()
-        return _lib.VaeCross(ln1_w=dp(c.ln_1.weight), ln1_b=dp(c.ln_1.bias), ln1q_w=dp(c.ln_1q.weight), ln1q_b=dp(c.ln_1q.bias),
-                             attn_kv=dp(c.attn.c_attn.weight), attn_q=dp(c.attn.c_attn_q.weight), attn_proj=dp(c.attn.c_proj.weight),
-                             ln2_w=dp(c.ln_2.weight), ln2_b=dp(c.ln_2.bias), w1=dp(c.mlp.w1.weight), w2=dp(c.mlp.w2.weight),
-                             cproj=dp(c.mlp.c_proj.weight))
+        def block(b):
+            return _lib.VaeBlock(ln1_w=dp(b.ln_1.weight), ln1_b=dp(b.ln_1.bias), attn_w=dp(b.attn.c_attn.weight),
+                                 proj_w=dp(b.attn.c_proj.weight), ln2_w=dp(b.ln_2.weight), ln2_b=dp(b.ln_2.bias), w1=dp(b.mlp.w1.weight),
+                                 w2=dp(b.mlp.w2.weight), cproj=dp(b.mlp.c_proj.weight))
+
+        def cross(c):
+            return _lib.VaeCross(ln1_w=dp(c.ln_1.weight), ln1_b=dp(c.ln_1.bias), ln1q_w=dp(c.ln_1q.weight), ln1q_b=dp(c.ln_1q.bias),
+                                 attn_kv=dp(c.attn.c_attn.weight), attn_q=dp(c.attn.c_attn_q.weight), attn_proj=dp(c.attn.c_proj.weight),
+                                 ln2_w=dp(c.ln_2.weight), ln2_b=dp(c.ln_2.bias), w1=dp(c.mlp.w1.weight), w2=dp(c.mlp.w2.weight),
+                                 cproj=dp(c.mlp.c_proj.weight))
+
+        eb = (_lib.VaeBlock * max(n, 1))(*[block(b) for b in enc.encoder_layers])
+        db = (_lib.VaeBlock * max(n, 1))(*[block(b) for b in dec.decoder_layers])
+        w = _lib.VaeWeights(gene_embedding=dp(self.input_layer.gene_embedding.weight), inducing_points=dp(enc.ca_layer.inducing_points),
+                            enc_pos_embed=dp(enc.pos_embed) if enc.pos_embed is not None else None,
+                            enc_latent_w=dp(enc.encoder_latent_input[0].weight), dec_latent_w=dp(dec.decoder_latent_input[1].weight),
+                            theta=dp(self.decoder_head.theta.weight), head_w=dp(self.decoder_head.params.weight),
+                            head_b=dp(self.decoder_head.params.bias), enc_cross=cross(enc.ca_layer),
+                            dec_cross=cross(dec.decoder_cross_attention), enc_blocks=eb, dec_blocks=db)
+        return w, (eb, db)
 
     def _load_weights(self, L):
         for p in self.parameters():
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("TransformerVAE parameters must be contiguous fp32")
-        enc, dec = self.encoder, self.decoder
-        n = enc.n_layer
-        eb = (_lib.VaeBlock * max(n, 1))(*[self._block(b) for b in enc.encoder_layers])
-        db = (_lib.VaeBlock * max(n, 1))(*[self._block(b) for b in dec.decoder_layers])
-        dp = lambda t: t.data_ptr()
-        w = _lib.VaeWeights(gene_embedding=dp(self.input_layer.gene_embedding.weight), inducing_points=dp(enc.ca_layer.inducing_points),
-                            enc_pos_embed=dp(enc.pos_embed) if enc.pos_embed is not None else None,
-                            enc_latent_w=dp(enc.encoder_latent_input[0].weight), dec_latent_w=dp(dec.decoder_latent_input[1].weight),
-                            theta=dp(self.decoder_head.theta.weight), head_w=dp(self.decoder_head.params.weight),
-                            head_b=dp(self.decoder_head.params.bias), enc_cross=self._cross(enc.ca_layer),
-                            dec_cross=self._cross(dec.decoder_cross_attention), enc_blocks=eb, dec_blocks=db)
-        self._keep = (eb, db)
+        w, keep = self._weights_struct(lambda t: t.data_ptr())
+        self._keep = keep
         with torch.cuda.device(self.input_layer.gene_embedding.weight.device):
             _lib.check(L.scldm_vae_load_weights(self._handle, C.byref(w), _stream_ptr()), "scldm_vae_load_weights")
 
@@ -183,9 +255,28 @@ class TransformerVAE(nn.Module):
                                                  _lib.PRECISIONS[self.precision], ws, _stream_ptr()), "scldm_vae_decode_sample")
         return counts
 
-    @torch.no_grad()
     def forward(self, counts, genes, library_size, counts_subset=None, genes_subset=None):
-        """(params, z) with params = {"mu", "theta"} (vae.py:29-56).  Inference only: VAE training is out of scope."""
-        z = self.encode(counts, genes, counts_subset, genes_subset)
-        nb = self.decode(z, genes, library_size)
-        return {"mu": nb.mu, "theta": nb.theta}, z
+        """(params, z) with params = {"mu", "theta"} (vae.py:29-56).  With gradients enabled and trainable parameters the outputs
+        are differentiable: forward on the inference kernels + a hand-derived HIP backward (`_VAETrainFn`), fp32.  As in the
+        reference, the encoder reads counts_subset / genes_subset (vae.py:37-40: no fallback to the full vectors in forward)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if counts_subset is None or genes_subset is None:
+                raise ValueError("TransformerVAE.forward needs counts_subset / genes_subset (the reference passes them to the input layer, vae.py:37-40)")
+            cs = _require_cuda_f32("counts_subset", counts_subset)
+            if not genes_subset.is_cuda or not genes.is_cuda:
+                raise RuntimeError("genes / genes_subset must be CUDA (ROCm) tensors")
+            gs = genes_subset.to(torch.long).contiguous()
+            g = genes.to(torch.long).contiguous()
+            lib = _require_cuda_f32("library_size", library_size).reshape(-1)
+            if cs.dim() != 2 or gs.shape != cs.shape or g.dim() != 2 or g.shape[0] != cs.shape[0] or lib.shape[0] != cs.shape[0]:
+                raise ValueError(f"expected counts_subset / genes_subset (B,S), genes (B,G), library_size (B,1); got {tuple(cs.shape)}, "
+                                 f"{tuple(gs.shape)}, {tuple(g.shape)}, {tuple(library_size.shape)}")
+            if self.precision != "fp32":
+                raise NotImplementedError("TransformerVAE training runs in fp32 (precision='fp32')")
+            params = tuple(self.parameters())
+            mu, theta, z = _VAETrainFn.apply(self, cs, gs, g, lib, *params)
+            return {"mu": mu, "theta": theta}, z
+        with torch.no_grad():
+            z = self.encode(counts, genes, counts_subset, genes_subset)
+            nb = self.decode(z, genes, library_size)
+            return {"mu": nb.mu, "theta": nb.theta}, z

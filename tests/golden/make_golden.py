@@ -416,6 +416,53 @@ def gen_vae(name, n_genes, G, S, B, seed):
     print(name, "z absmax", float(z.abs().max()), "mu rowsum", nb.mu.sum(1).numpy(), "lib", lib[:, 0])
 
 
+def gen_vae_train(name, n_genes, G, S, B, seed):
+    """TransformerVAE.forward + VAE.loss (-log_nb_positive(counts, mu, theta).sum(1).mean(): src/scldm/vae.py:29-56,
+    src/scldm/models.py:231-249, src/scldm/distributions.py:6-42) and the reference's own autograd gradient of every parameter
+    (digests), on the inputs of gen_vae's case of the same size.  BASELINE configs[0] / VERDICT r2 row V1."""
+    from scldm.distributions import log_nb_positive
+    enc = Encoder(n_layer=8, n_inducing_points=16, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, dropout=0.0,
+                  bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", positional_encoding=True)
+    dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, n_inducing_points=16,
+                  dropout=0.0, bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
+                  use_adaln=False)
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm",
+                                            layernorm_eps=1e-8)
+    inp = InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p")
+    vae = TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=inp)
+    shapes = shapes_of(vae)
+    vae.load_state_dict(make_state_dict(shapes, seed), strict=True)
+    vae.train()
+    rng = np.random.default_rng(seed + 1000)
+    genes = np.stack([rng.permutation(n_genes)[:G] for _ in range(B)]).astype(np.int64)
+    counts = rng.poisson(0.7, (B, G)).astype(np.float32)
+    sub = np.stack([np.sort(rng.permutation(G)[:S]) for _ in range(B)])
+    genes_subset = np.take_along_axis(genes, sub, 1)
+    counts_subset = np.take_along_axis(counts, sub, 1)
+    lib = counts.sum(1, keepdims=True).astype(np.float32) + 1.0
+    params, z = vae(torch.from_numpy(counts), torch.from_numpy(genes), torch.from_numpy(lib), torch.from_numpy(counts_subset),
+                    torch.from_numpy(genes_subset))
+    recon = -log_nb_positive(torch.from_numpy(counts), params["mu"], params["theta"])
+    loss = recon.sum(dim=1).mean()
+    loss.backward()
+    out = {"shapes_json": np.array(json.dumps({k: list(v) for k, v in shapes.items()})), "seed": np.array(seed), "n_genes": np.array(n_genes),
+           "genes": genes, "counts": counts, "genes_subset": genes_subset, "counts_subset": counts_subset, "library_size": lib,
+           "loss": np.array(float(loss.detach())), "recon_row": recon.sum(dim=1).detach().numpy(), "z": z.detach().numpy(),
+           "mu": params["mu"].detach().numpy(), "theta": params["theta"].detach().numpy()}
+    frozen = []
+    for k, p in vae.named_parameters():
+        if p.grad is None:
+            frozen.append(k)
+            continue
+        out[f"grad_{k}"] = grad_digest(p.grad.numpy())
+    out["frozen_json"] = np.array(json.dumps(frozen))
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(name, "loss", float(loss), "frozen", frozen, "n grads", sum(k.startswith("grad_") for k in out))
+
+
+VAE_TRAIN_CASES = {"vae_train_small": (dict(n_genes=60), 50, 20, 3, 211), "vae_train_2000": (dict(n_genes=2000), 2000, 700, 2, 212)}
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     models = {}
@@ -434,3 +481,5 @@ if __name__ == "__main__":
         gen_vae(name, kw["n_genes"], G, S, B, seed)
     for name, (kw, B, seed) in LATE_DIT_CASES.items():
         gen_dit(name, kw, B, seed)
+    for name, (kw, G, S, B, seed) in VAE_TRAIN_CASES.items():     # (last: everything above stays bit-identical to earlier rounds)
+        gen_vae_train(name, kw["n_genes"], G, S, B, seed)

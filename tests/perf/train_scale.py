@@ -1,12 +1,21 @@
-"""Training step wall time vs batch size (host-bound if the time does not grow with the batch)."""
-import os, sys, time
+"""Training step wall time vs batch size (host-bound if the time does not grow with the batch).
+   python tests/perf/train_scale.py            one process, models built one after the other, the previous one released first
+   python tests/perf/train_scale.py nogc       the round-2 behaviour: no explicit release / collection between sizes (see DESIGN 4.4a:
+                                               Python's cyclic collector then frees the previous model - ~30 hipFree, each a device
+                                               synchronisation - in the middle of the next size's timed loop)"""
+import gc, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import bench
 from scldm_amd.training import train_step
 from scldm_amd.transport import create_transport
 dev = torch.device("cuda:0")
+m = opt = None
 for B in (256, 512, 1024, 2048, 4096):
+    if "nogc" not in sys.argv:
+        m = opt = None            # torch optimizers sit in reference cycles: drop the previous model + optimizer NOW, not whenever
+        gc.collect()              # the cyclic collector runs (its __del__ destroys the native handle: ~30 synchronising hipFree)
+        torch.cuda.synchronize()
     wl = dict(bench.TRAIN_WORKLOADS["replogle_train_b1024"]); wl["B"] = B
     m = bench.make_model(wl, "bf16", dev).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)

@@ -34,3 +34,35 @@ def test_state_dict_keys_pin():
               "input_layer.gene_embedding.weight", "decoder_head.theta.weight", "decoder_head.params.bias"):
         assert k in shapes, k
     assert shapes["encoder.ca_layer.mlp.w1.weight"] == [88, 32]
+
+
+# ---- VAE training step (BASELINE configs[0]): oracle autograd vs the reference's own gradients --------------------------------
+@pytest.mark.parametrize("name", ["vae_train_small", "vae_train_2000"])
+def test_vae_training_gradients_match_reference_digests(name):
+    """oracle/vae_train.py (autograd over the restated TransformerVAE.forward + log_nb_positive) against digests of the reference's
+    autograd gradient of EVERY parameter (tests/golden/make_golden.py: gen_vae_train)."""
+    import numpy as np
+    from oracle.train import grad_digest
+    from oracle.vae_train import FROZEN, vae_training_grads
+    g, cfg, sd = setup(name)
+    t = lambda k: torch.from_numpy(g[k])
+    loss, (mu, theta, z), grads = vae_training_grads(sd, cfg, t("counts"), t("genes"), t("library_size"), t("counts_subset"), t("genes_subset"))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert max_abs_rel(mu, g["mu"]) < 5e-5 and max_abs_rel(z, g["z"]) < 5e-5
+    assert golden_json(g, "frozen_json") == list(FROZEN)
+    n = 0
+    for k, v in grads.items():
+        ref = g[f"grad_{k}"]
+        ours = grad_digest(v)
+        if k == "decoder_head.params.bias":
+            # mathematically ZERO: the logits enter through a softmax over genes, which is invariant to a common shift - both
+            # autograd results are rounding noise of a sum of O(1) terms; pinned as "negligible next to the weight's gradient"
+            wn = g["grad_decoder_head.params.weight"][1]
+            assert abs(ours[0]) <= 1e-4 * wn and abs(ref[0]) <= 1e-4 * wn
+            n += 1
+            continue
+        scale = max(np.abs(ref[2:]).max(), ref[1] / np.sqrt(v.numel()))
+        assert np.abs(ours[2:] - ref[2:]).max() <= 1e-4 * scale, k
+        assert abs(ours[1] - ref[1]) <= 1e-4 * ref[1] + 1e-12, k
+        n += 1
+    assert n == sum(k.startswith("grad_") for k in g) == 175
