@@ -106,7 +106,8 @@ class FakeSampler(torch.nn.Module):
 
     def sample_ode_cfg(self, z2, cond2, scales, num_steps, method):
         lab = sum(v.float() for v in cond2.values()).view(-1, 1, 1)
-        return z2 * 2.0 + lab
+        bad = os.environ.get("BENCH_FAKE_CORRUPT_RANK")     # test hook: this rank computes something else (the self-check must catch it)
+        return z2 * 2.0 + lab + (1e-3 if bad is not None and bad == os.environ.get("RANK") else 0.0)
 
     def block_timing(self, enable=None):
         return None if enable is not None else (0, 0.0)
@@ -198,10 +199,54 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
     if time_blocks:
         m.block_timing(False)
     if dist_on:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = torch.empty(world, device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, mine)
+        time_workload.per_rank_s = [float(v) for v in every.tolist()]
+        dt = max(time_workload.per_rank_s)
     return dt, blocks, out, (z2, cond2, scales, B)
+
+
+def cross_rank_check(m, wl, out, B, device, world, rank, n_check=8):
+    """Self-validation of the sharded run (no curve can be measured on a 1-GPU lease: this makes the first N-GPU run its own test):
+    rank 0 regenerates `n_check` cells of ANOTHER rank's shard from that rank's seed, integrates them locally with its own copy of
+    the weights and requires BIT equality with the rows that came back through the all-gather - both CFG halves.  Proves the
+    gathered tensor is ordered [rank][2B rows], that every rank ran the same model on its own inputs, and that a cell's result
+    does not depend on its batch (the property the sharding relies on).  Returns a record for the JSON line."""
+    if world < 2 or out is None:
+        return None
+    rec = {"checked_rank": None, "cells": 0, "bit_equal": None}
+    if rank == 0:
+        r = world - 1 if world > 1 else 0
+        n = min(n_check, B)
+        z2, cond2, scales = make_inputs(wl, B, device, seed=1234 + r)
+        idx = torch.cat([torch.arange(n), torch.arange(B, B + n)]).to(device)
+        zs, cs = z2[idx], {k: v[idx] for k, v in cond2.items()}
+        steps = wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1
+        local = m.sample_ode_cfg(zs, cs, scales, steps, wl["method"])
+        block = out[r * 2 * B:(r + 1) * 2 * B]
+        got = torch.cat([block[:n], block[B:B + n]])
+        rec = {"checked_rank": r, "cells": n, "bit_equal": bool(torch.equal(local, got)),
+               "max_abs_diff": float((local - got).abs().max())}
+        if not rec["bit_equal"]:
+            raise SystemExit(f"bench.py: cross-rank self-check FAILED: rank {r}'s first {n} cells, recomputed on rank 0, differ from the "
+                             f"gathered rows (max |diff| {rec['max_abs_diff']:.3e})")
+    return rec
+
+
+def time_allgather(out, B, device, world, reps=5):
+    """The path's single collective on its own: mean seconds of an all-gather of one rank's (2B, 16, 16) latents."""
+    import torch.distributed as dist
+    mine = out[:2 * B].contiguous()
+    gathered = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), device=device, dtype=mine.dtype)
+    dist.all_gather_into_tensor(gathered, mine)
+    sync(device)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(gathered, mine)
+    sync(device)
+    return (time.perf_counter() - t0) / reps
 
 
 def time_training(wl, precision, device, steps, warmup, dist_on, world):
@@ -228,10 +273,22 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sync_obj = m.__dict__.get("_train_step_sync")
+    time_training.info = {"gradient_collectives_per_step": sync_obj.collectives if sync_obj is not None else 0,
+                          "gradient_buckets": len(m.grad_bucket_plan()) if hasattr(m, "grad_bucket_plan") else None,
+                          "overlapped_with_backward": bool(sync_obj is not None and sync_obj.handled)}
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # every rank must hold the same parameters after the same number of averaged steps
+        chk = torch.stack([p.detach().double().sum() for p in m.parameters()]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        time_training.info["replicas_in_sync"] = bool(float(hi - lo) <= 1e-6 * max(1.0, abs(float(hi))))
+        if not time_training.info["replicas_in_sync"]:
+            raise SystemExit("bench.py: data-parallel replicas diverged (parameter checksums differ across ranks)")
     return dt, float(loss)
 
 
@@ -480,9 +537,9 @@ def main():
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                   "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": world * wl["B"],
                              "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "AdamW (fused)",
-                             "parallelism": f"data-parallel x{world}, one flat-bucket all-reduce of gradients" if dist_on else "single GPU"},
+                             "parallelism": f"data-parallel x{world}, bucketed in-place gradient all-reduce overlapped with the backward" if dist_on else "single GPU"},
                   "train_tflops_per_gpu": 3 * dit_flops(**{k: v for k, v in wl.get("shape", {}).items() if k != "n_head"}) * wl["B"]
-                  / (dt / args.steps) / 1e12, "final_loss": loss}
+                  / (dt / args.steps) / 1e12, "final_loss": loss, "data_parallel": time_training.info}
         if "shape" in wl:
             result["config"]["dit_shape"] = wl["shape"]
         if dist_on:
@@ -584,13 +641,29 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(m, wl)
             note("cpu baseline done")
-    elif dist_on and not args.no_extra and args.workload == "dentate_b4096_euler100":
+    if dist_on:
+        result["per_rank_ms_per_step"] = [1e3 * v / args.steps for v in getattr(time_workload, "per_rank_s", [])]
+        result["allgather_ms"] = 1e3 * time_allgather(out, B, device, world)
+        result["cross_rank_check"] = cross_rank_check(m, wl, out, B, device, world, rank)
+    if dist_on and not args.no_extra and args.workload == "dentate_b4096_euler100":
         # N > 1: the strong-scaling leg north_star names (parse1m, 8192 cells global = 8192 / N per GPU), every rank takes part
         w2 = dict(WORKLOADS["parse1m_b8192_euler100_strong"])
         m2 = make_model(w2, args.precision, device)
         d2, _, _, (_, _, _, B2) = time_workload(m2, w2, device, 1, 1, dist_on, world, rank, time_blocks=False)
         result["strong_scaling"] = {"workload": "parse1m_b8192_euler100_strong", "global_cells": w2["B"], "cells_per_gpu": B2,
                                     "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2, "scaling": "strong"}
+        if not fake:
+            # BASELINE configs[4] under the same launch: the data-parallel training step (bucketed gradient all-reduce overlapped with
+            # the backward) on the base shape and on the DiT-L shape, 1 024 / 256 cells per GPU
+            del m2
+            torch.cuda.empty_cache()
+            for key, name, st_, wu_ in (("training_step", "replogle_train_b1024", 10, 5), ("training_step_ditl", "replogle_train_ditl_b256", 4, 2)):
+                tw = dict(TRAIN_WORKLOADS[name])
+                dtt, _ = time_training(tw, "bf16", device, st_, wu_, dist_on, world)
+                fl = 3 * dit_flops(**{k: v for k, v in tw.get("shape", {}).items() if k != "n_head"})
+                result[key] = {"workload": name, "cells_per_s": world * tw["B"] / (dtt / st_), "ms_per_step": 1e3 * dtt / st_,
+                               "tflops_per_gpu": fl * tw["B"] / (dtt / st_) / 1e12, "dtype": "bf16", "data_parallel": time_training.info}
+                torch.cuda.empty_cache()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

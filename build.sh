@@ -14,10 +14,27 @@ case " ${SCLDM_HIPCC_FLAGS:-} " in
 esac
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize ${SCLDM_HIPCC_FLAGS:-}"
 mkdir -p "$OBJ"
+# incremental: a translation unit is recompiled when its object is older than any file it included (dependency lists written by
+# the compiler next to the objects), when the flags changed, or when SCLDM_REBUILD=1
+echo "$FLAGS" > "$OBJ/.flags.new"
+if [ "${SCLDM_REBUILD:-0}" = 1 ] || ! cmp -s "$OBJ/.flags.new" "$OBJ/.flags" 2>/dev/null; then rm -f "$OBJ"/*.o "$OBJ"/*.d; fi
+mv "$OBJ/.flags.new" "$OBJ/.flags"
+stale() {  # $1 = tu
+  local o="$OBJ/$1.o" d="$OBJ/$1.d"
+  [ -f "$o" ] && [ -f "$d" ] || return 0
+  local f
+  for f in $(sed -e 's/^[^:]*://' -e 's/\\$//' "$d"); do
+    [ -f "$f" ] || return 0
+    [ "$f" -nt "$o" ] && return 0
+  done
+  return 1
+}
 pids=()
 for tu in api vae_api vae_train_api train_api train_fused; do
-  hipcc $FLAGS -c "scldm_amd/csrc/$tu.hip" -o "$OBJ/$tu.o" &
-  pids+=($!)
+  if stale "$tu"; then
+    hipcc $FLAGS -MD -MF "$OBJ/$tu.d" -c "scldm_amd/csrc/$tu.hip" -o "$OBJ/$tu.o" &
+    pids+=($!)
+  fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/vae_train_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o"

@@ -222,6 +222,20 @@ size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precis
  * moved).  SCLDM_PREC_BF16X3 is accepted on the training entry points and served by the exact-fp32 GEMM route. */
 int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w, int n, int precision, void* stream);
 
+/* Gradient-ready events for the NEXT scldm_dit_train_backward on this handle - what a data-parallel caller needs to start
+ * all-reducing a bucket of gradients while the rest of the backward still runs (the reference gets this from DDP's autograd
+ * hooks, experiments/scripts/train_ldm.py:101).  events[i] is a hipEvent_t the call records on its stream once the gradients it
+ * stands for are complete:
+ *   SCLDM_GRAD_LAYER, l : attn / proj / w1 / w2 / cproj gradients (weights and biases) of every layer >= l
+ *   SCLDM_GRAD_ADA,   l : adaLN weight / bias gradients of every layer <= l (l == n_layer: the final layer's adaLN as well)
+ *   SCLDM_GRAD_END      : every gradient
+ * The backward walks the layers from last to first and computes the adaLN gradients afterwards, first layer first.  Routes that
+ * produce everything at once (the fused base-shape route) record all events at the end.  The list is consumed by that call. */
+#define SCLDM_GRAD_LAYER 0
+#define SCLDM_GRAD_ADA 1
+#define SCLDM_GRAD_END 2
+int scldm_dit_train_set_grad_events(scldm_dit* h, void* const* events, const int* kinds, const int* layers, int n);
+
 /* out (n,S,Din) = DiT.forward(x (n,S,Din), t (n), labels) keeping every intermediate the backward needs in `saved`. */
 int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
                             const int64_t* const* labels, int n, float* out, int precision, void* saved, void* ws,

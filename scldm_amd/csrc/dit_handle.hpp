@@ -64,6 +64,9 @@ struct scldm_dit {
   void* d_cast_jobs;        // device CastJob table (rebuilt when the weights' device pointers change)
   int n_cast_jobs;
   std::vector<const void*> w16_key;
+  // gradient-ready events of the NEXT scldm_dit_train_backward (scldm_dit_train_set_grad_events): recorded on the call's stream
+  struct GradEvent { hipEvent_t ev; int kind, layer; bool fired; };
+  std::vector<GradEvent> grad_events;
   bool bf16_sources;        // SCLDM_TRAIN_BF16_SOURCES (read once at create; 0 keeps fp32 activations + hgemm_kernel)
 };
 

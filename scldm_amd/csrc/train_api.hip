@@ -615,6 +615,16 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   return SCLDM_OK;
 }
 
+extern "C" int scldm_dit_train_set_grad_events(scldm_dit* h, void* const* events, const int* kinds, const int* layers, int n) {
+  if (!h || n < 0 || (n > 0 && (!events || !kinds || !layers))) return fail(SCLDM_ERR_SHAPE, "bad argument");
+  h->grad_events.clear();
+  for (int i = 0; i < n; ++i) {
+    if (kinds[i] < SCLDM_GRAD_LAYER || kinds[i] > SCLDM_GRAD_END || !events[i]) return fail(SCLDM_ERR_SHAPE, "bad gradient event %d", i);
+    h->grad_events.push_back(scldm_dit::GradEvent{(hipEvent_t)events[i], kinds[i], layers[i], false});
+  }
+  return SCLDM_OK;
+}
+
 extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* g, const float* x,
                                         const int64_t* const* labels, const float* dout, int n, float* dx_out, int precision,
                                         void* saved_, void* ws, void* stream_) {
@@ -693,12 +703,23 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     if (src16) hipLaunchKernelGGL(gate_bwd_kernel<__bf16>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(k.dy), k.dmod);
     else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, k.dy, k.dmod);
   };
+  // gradient-ready events (scldm_dit_train_set_grad_events): `st` is ordered after every kernel that writes the gradients an event
+  // stands for when it is recorded.  Events the route cannot time individually fire at the end of the call.
+  auto fire = [&](int kind, int layer) -> int {
+    for (auto& e : h->grad_events)
+      if (!e.fired && (kind == SCLDM_GRAD_END || (e.kind == kind && (kind == SCLDM_GRAD_LAYER ? e.layer >= layer : e.layer <= layer)))) {
+        HIP_TRY(hipEventRecord(e.ev, st));
+        e.fired = true;
+      }
+    return SCLDM_OK;
+  };
   for (int l = use_fused ? -1 : L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
+    if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
     gate_bwd(a.y2, o + 5 * kD);
     LAUNCH_CHECK();
     TRY(fork());
@@ -728,6 +749,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
   }
   TRY(join());
+  if (!use_fused) TRY(fire(SCLDM_GRAD_LAYER, 0));
 
   // ---- input projection + pos_embed ----
   // Fused route: three independent tails follow the layers - the input projection (reads d x0), the stacked adaLN weight
@@ -764,9 +786,11 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid((long)n * mw / 4)), dim3(256), 0, st, k.dmod, dmod16, (long)n * mw);
     LAUNCH_CHECK();
     TRY(bgemm(st, dmod16, mw, true, reinterpret_cast<const __bf16*>(h->ada16), kD, false, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
-    for (int l = 0; l <= L; ++l)
+    for (int l = 0; l <= L; ++l) {
       TRY(bgemm(st, dmod16 + (size_t)l * 6 * kD, mw, false, reinterpret_cast<const __bf16*>(s.sc), kD, false, l < L ? g->ada_w[l] : g->fin_ada_w, kD,
                 l < L ? 6 * kD : 2 * kD, kD, n, nullptr, false, k.part, k.part_floats, l < L ? g->ada_b[l] : g->fin_ada_b));
+      TRY(fire(SCLDM_GRAD_ADA, l));   // (one stream: issue order is completion order)
+    }
   }
   for (int l = (use_fused || ada16) ? L + 1 : 0; l <= L; ++l) {
     const int width = l < L ? 6 * kD : 2 * kD;
@@ -775,6 +799,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     float* gb = l < L ? g->ada_b[l] : g->fin_ada_b;
     const float* wl = l < L ? w->ada_w[l] : w->fin_ada_w;
     TRY(linear_wgrad(st, dm, mw, s.sc, kD, n, width, kD, gw, k, gb));
+    TRY(fire(SCLDM_GRAD_ADA, l));
     TRY(linear_dgrad(st, dm, mw, wl, n, width, kD, k.dsc, kD, l > 0, k));
   }
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsc, s.c, k.dc, (long)n * kD);
@@ -803,6 +828,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
   if (s_in != st) TRY(fused::join_side(h, st, 0));
   if (s_ada != st) TRY(fused::join_side(h, st, 1));
+  TRY(fire(SCLDM_GRAD_END, 0));
+  h->grad_events.clear();
   return SCLDM_OK;
 }
 

@@ -137,6 +137,9 @@ class _DiTTrainFn(torch.autograd.Function):
         g, keep_g = module._param_struct(lambda p: (gpos.data_ptr() if gpos is not None else None) if p is module.pos_embed
                                          else base + 4 * offs[id(p)])
         dx = torch.empty_like(ctx.x) if ctx.needs_input_grad[1] else None
+        sync = module.__dict__.get("_grad_sync")      # scldm_amd.training.OverlappedGradSync while a data-parallel step runs
+        if sync is not None:
+            sync.before_backward(module, L, h)
         with torch.cuda.device(dout.device):
             _lib.check(L.scldm_dit_train_backward(h, C.byref(w), C.byref(g), ctx.x.data_ptr(), C.cast(ctx.labels, _lib.c_void_pp),
                                                   dout.data_ptr(), n, dx.data_ptr() if dx is not None else None,
@@ -144,6 +147,8 @@ class _DiTTrainFn(torch.autograd.Function):
                        "scldm_dit_train_backward")
         del keep_g
         ctx.saved = ctx.ws = None
+        if sync is not None:
+            sync.after_backward(flat)        # the call above only ENQUEUED the kernels: the bucket all-reduces are queued behind their events
         out = []
         for i, p in enumerate(params):
             if not ctx.needs_input_grad[5 + i]:
@@ -337,7 +342,7 @@ class DiT(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
-        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_pos_idx", "_param_list", "_prepared_key"):
+        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_grad_segs", "_pos_idx", "_param_list", "_prepared_key", "_grad_sync"):
             state.pop(k, None)
         return state
 
@@ -376,15 +381,59 @@ class DiT(nn.Module):
         if c is None or c[0] != key:
             self._check_params()
             w, keep = self._param_struct(lambda t: t.data_ptr())
+            # the flat gradient buffer is laid out in the order the backward COMPLETES the gradients (grad_segments()), so that a
+            # data-parallel caller can all-reduce contiguous slices of it in place while later slices are still being computed
             offs, total = {}, 0
-            for p in params:
-                if p is not self.pos_embed:
+            segs = []
+            for kind, layer, plist in self.grad_segments():
+                start = total
+                for p in plist:
                     offs[id(p)] = total
                     total += (p.numel() + 63) // 64 * 64       # 256-byte aligned views
+                segs.append((kind, layer, start, total))
+            missing = [p for p in params if p is not self.pos_embed and id(p) not in offs]
+            assert not missing, "grad_segments() must cover every parameter"
             self.__dict__["_wstruct_cache"] = c = (key, w, keep)
-            self.__dict__["_grad_offsets"], self.__dict__["_grad_numel"] = offs, total
+            self.__dict__["_grad_offsets"], self.__dict__["_grad_numel"], self.__dict__["_grad_segs"] = offs, total, segs
             self.__dict__["_pos_idx"] = next(i for i, p in enumerate(params) if p is self.pos_embed)
         return c[1], c[2]
+
+    def grad_segments(self):
+        """[(kind, layer, [parameters])] in the order scldm_dit_train_backward completes their gradients (include/scldm_hip.h,
+        SCLDM_GRAD_*): the main weights of the layers from LAST to first ("layer", l), then the adaLN projections first layer
+        first ("ada", l; l == n_layer: the final layer's), then everything else ("end")."""
+        segs = []
+        for l in range(self.n_layer - 1, -1, -1):
+            b = self.blocks[l]
+            segs.append(("layer", l, [b.attn.c_attn.weight, b.attn.c_attn.bias, b.attn.c_proj.weight, b.attn.c_proj.bias,
+                                      b.mlp.w1.weight, b.mlp.w2.weight, b.mlp.c_proj.weight]))
+        for l in range(self.n_layer):
+            segs.append(("ada", l, [self.blocks[l].adaln_modulation[1].weight, self.blocks[l].adaln_modulation[1].bias]))
+        segs.append(("ada", self.n_layer, [self.final_layer.adaln_modulation[1].weight, self.final_layer.adaln_modulation[1].bias]))
+        rest = [self.class_embeddings[n].weight for n in self._class_names]
+        rest += [self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias, self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias,
+                 self.input_proj.weight, self.input_proj.bias, self.final_layer.linear.weight, self.final_layer.linear.bias]
+        segs.append(("end", 0, rest))
+        return segs
+
+    def grad_bucket_plan(self, bucket_bytes: int = 128 << 20):
+        """Contiguous slices [(start, end, kind, layer)] (element offsets into the flat gradient buffer of the HIP backward) of at
+        most ~bucket_bytes each, in completion order, each with the SCLDM_GRAD_* trigger after which the whole slice is final.
+        Slices never mix kinds; a single segment larger than bucket_bytes is its own slice."""
+        self._weights_struct(tuple(self.parameters()))
+        plan, cur = [], None
+        for kind, layer, a, b in self.__dict__["_grad_segs"]:
+            if b == a:
+                continue
+            if cur is not None and cur[2] == kind and 4 * (b - cur[0]) <= bucket_bytes:
+                cur = [cur[0], b, kind, layer]          # the trigger of the LAST segment of a run covers the earlier ones
+            else:
+                if cur is not None:
+                    plan.append(tuple(cur))
+                cur = [a, b, kind, layer]
+        if cur is not None:
+            plan.append(tuple(cur))
+        return plan
 
     def _pos_index(self, params):
         return self.__dict__["_pos_idx"]

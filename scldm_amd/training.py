@@ -1,13 +1,19 @@
 """Data-parallel flow-matching training step for the scldm_amd DiT (SURVEY.md section 8a row T1, 8e training row).
 
-The reference trains through Lightning + DDP (experiments/scripts/train_ldm.py; src/scldm/models.py:443-470): per-rank
-mini-batches, `Transport.training_losses`, `loss.mean().backward()`, gradient all-reduce, AdamW.  Here the backward is one
-C call (scldm_dit_train_backward), so every gradient exists at the same instant and there is nothing to overlap with: the
-exchange is ONE all-reduce of a flat fp32 buffer per bucket (the base DiT's 9.8 M parameters = 39 MB fit a single bucket),
-which on xGMI's point-to-point links is the efficient shape - few, large collectives.  `torch.nn.parallel.DistributedDataParallel`
-also works on the module unchanged (its hooks see ordinary .grad tensors); this helper avoids its per-bucket bookkeeping.
+The reference trains through Lightning + DDP (experiments/scripts/train_ldm.py:101; src/scldm/models.py:443-470): per-rank
+mini-batches, `Transport.training_losses`, `loss.mean().backward()`, gradient all-reduce in buckets that overlap the rest of the
+backward, AdamW.  Here the backward is one C call (scldm_dit_train_backward) that only ENQUEUES kernels; it writes every gradient
+into ONE flat fp32 buffer laid out in the order the gradients are completed (DiT.grad_segments: last layer first, then the adaLN
+projections, then the ends) and records a HIP event per bucket at the point of the stream where that bucket is final
+(scldm_dit_train_set_grad_events).  `OverlappedGradSync` queues one in-place all-reduce per bucket on a side stream behind its
+event: contiguous slices of the buffer, no gather / scatter copies, bucket sizes chosen for xGMI's point-to-point links (few,
+large collectives: 64-128 MB), overlapped with the layers still being differentiated.  The base DiT (39 MB of gradients, a fused
+backward that finishes everything at once) degenerates to one collective, the DiT-L shape (1.84 GB) to ~20.
+`torch.nn.parallel.DistributedDataParallel` also works on the module unchanged (its hooks see ordinary .grad tensors).
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -48,9 +54,12 @@ def _shared_flat_grad(params):
 
 
 @torch.no_grad()
-def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20, average: bool = True) -> int:
-    """Sum (or average) .grad over the ranks of `group` with one all_reduce per bucket.  A parameter whose .grad is None on
-    this rank contributes zeros (and receives the reduced value).  Returns the number of collectives issued."""
+def allreduce_gradients(params, group=None, bucket_bytes: int = 128 << 20, average: bool = True) -> int:
+    """Sum (or average) .grad over the ranks of `group` AFTER the backward (no overlap; `OverlappedGradSync` is the overlapped
+    form).  Gradients that are views of one flat buffer (the HIP backward's) are reduced IN PLACE, in contiguous slices of at most
+    bucket_bytes - no gather / scatter copies whatever the model size; anything else goes through per-bucket flat copies.  A
+    parameter whose .grad is None on this rank contributes zeros (and receives the reduced value).  Returns the number of
+    collectives issued."""
     if not dist.is_available() or not dist.is_initialized():
         return 0
     world = dist.get_world_size(group)
@@ -59,13 +68,16 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20, avera
     calls = 0
     params = list(params)
     flat = _shared_flat_grad(params)
-    if flat is not None and flat.numel() * flat.element_size() <= bucket_bytes:
-        # the HIP backward returns every gradient as a view of ONE buffer: reduce that buffer in place (no gather / scatter
-        # copies; the alignment gaps between the views are reduced along with them and never read)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat.div_(world)
-        return 1
+    if flat is not None:
+        # (the alignment gaps between the views are reduced along with them and never read)
+        step = max(1, bucket_bytes // flat.element_size())
+        for a in range(0, flat.numel(), step):
+            piece = flat[a:a + step]
+            dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                piece.div_(world)
+            calls += 1
+        return calls
     for bucket in grad_buckets(params, bucket_bytes):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -84,12 +96,107 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20, avera
     return calls
 
 
-def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str, torch.Tensor], group=None) -> torch.Tensor:
+class OverlappedGradSync:
+    """Bucketed, in-place gradient all-reduce overlapped with the HIP backward of one scldm_amd DiT.
+
+    attach(dit) -> the module's next backward (a) asks the C side to record one event per bucket of `dit.grad_bucket_plan()`
+    and (b) right after the backward call returned - its kernels are only queued - queues, on a side stream, one all-reduce per
+    bucket behind that bucket's event.  finish() makes the current stream wait for them (and scales by 1 / world).  Every bucket
+    is a contiguous slice of the backward's flat gradient buffer: there is no copy on either side of a collective.
+    On CPU tensors (the gloo tests) there are no streams / events: buckets are reduced in plan order at after_backward().
+    Counters: `collectives` (issued by the last step), `copies` (always 0 on this path; the tests assert it)."""
+
+    def __init__(self, group=None, bucket_bytes: int = 128 << 20, average: bool = True):
+        self.group, self.bucket_bytes, self.average = group, bucket_bytes, average
+        self.collectives = 0
+        self.copies = 0
+        self._works, self._flat, self._plan, self._events, self._side = [], None, None, None, None
+        self.handled = False
+
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def attach(self, dit) -> None:
+        dit.__dict__["_grad_sync"] = self
+        self.handled = False
+        self.collectives = 0
+
+    @staticmethod
+    def detach(dit) -> None:
+        dit.__dict__.pop("_grad_sync", None)
+
+    # ---- called by scldm_amd.nnets._DiTTrainFn.backward -----------------------------------------------------------------------
+    def before_backward(self, dit, L, h) -> None:
+        self._plan = dit.grad_bucket_plan(self.bucket_bytes)
+        dev = dit.pos_embed.device
+        if dev.type != "cuda":
+            self._events = None
+            return
+        kinds = {"layer": 0, "ada": 1, "end": 2}
+        self._events = [torch.cuda.Event() for _ in self._plan]
+        cur = torch.cuda.current_stream(dev)
+        for e in self._events:
+            e.record(cur)          # (creates the underlying hipEvent_t; re-recorded by the C side at the bucket's completion point)
+        n = len(self._plan)
+        ev = (C.c_void_p * n)(*[e.cuda_event for e in self._events])
+        kd = (C.c_int * n)(*[kinds[b[2]] for b in self._plan])
+        ly = (C.c_int * n)(*[b[3] for b in self._plan])
+        from . import _lib
+        _lib.check(L.scldm_dit_train_set_grad_events(h, C.cast(ev, _lib.c_void_pp), kd, ly, n), "scldm_dit_train_set_grad_events")
+
+    def after_backward(self, flat: torch.Tensor) -> None:
+        self._flat = flat
+        self._works = []
+        op = dist.ReduceOp.SUM
+        if flat.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(flat.device)
+            for (a, b, _, _), ev in zip(self._plan, self._events):
+                self._side.wait_event(ev)                      # the bucket is final from this point of the backward's stream on
+                with torch.cuda.stream(self._side):
+                    self._works.append(dist.all_reduce(flat[a:b], op=op, group=self.group, async_op=True))
+                self.collectives += 1
+            flat.record_stream(self._side)
+        else:
+            for a, b, _, _ in self._plan:
+                self._works.append(dist.all_reduce(flat[a:b], op=op, group=self.group, async_op=True))
+                self.collectives += 1
+        self.handled = True
+
+    def finish(self) -> None:
+        """The current stream waits for every bucket; gradients become the mean over ranks."""
+        for w in self._works:
+            w.wait()
+        if self._flat is not None and self.average:
+            self._flat.div_(dist.get_world_size(self.group))
+        self._works, self._flat, self._events = [], None, None
+
+
+def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str, torch.Tensor], group=None,
+               bucket_bytes: int = 128 << 20, sync: OverlappedGradSync | None = None) -> torch.Tensor:
     """One optimisation step on this rank's mini-batch: loss = mean_b training_losses(...)["loss"] (models.py:443-470),
-    backward through the HIP kernels, gradient all-reduce (mean over ranks), optimizer.step().  Returns the local loss."""
+    backward through the HIP kernels with the bucketed gradient all-reduce (mean over ranks) overlapped with it, then
+    optimizer.step().  Returns the local loss."""
     optimizer.zero_grad(set_to_none=True)
     loss = transport.training_losses(dit, x1, {"condition": condition})["loss"].mean()
-    loss.backward()
-    allreduce_gradients(dit.parameters(), group)
+    if sync is None:
+        sync = dit.__dict__.get("_train_step_sync")
+        if sync is None or sync.group is not group or sync.bucket_bytes != bucket_bytes:
+            sync = dit.__dict__["_train_step_sync"] = OverlappedGradSync(group, bucket_bytes)
+    overlapped = sync.active() and hasattr(dit, "grad_bucket_plan")
+    if overlapped:
+        sync.attach(dit)
+    try:
+        loss.backward()
+    finally:
+        if overlapped:
+            OverlappedGradSync.detach(dit)
+    if overlapped and sync.handled:
+        sync.finish()
+        extra = [p for p in dit.parameters() if p.requires_grad and p.grad is not None and p is getattr(dit, "pos_embed", None)]
+        if extra:          # (pos_embed is frozen in the reference; if unfrozen its gradient lives outside the flat buffer)
+            allreduce_gradients(extra, group, bucket_bytes)
+    else:
+        allreduce_gradients(dit.parameters(), group, bucket_bytes)
     optimizer.step()
     return loss.detach()

@@ -25,6 +25,17 @@ def test_gpus_2_launches_two_ranks_and_gathers():
     assert j["config"]["gathered_rows"] == 2 * 2 * 64          # both ranks' (2B) rows arrived in the all-gather
     assert j["scaling"] == "weak" and j["steps"] == 2 and j["value"] > 0
     assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1   # rank 0 only prints
+    # self-validation of the sharded run: rank 0 recomputed 8 cells of rank 1's shard and compared bit for bit
+    chk = j["cross_rank_check"]
+    assert chk["checked_rank"] == 1 and chk["cells"] == 8 and chk["bit_equal"] is True
+    assert len(j["per_rank_ms_per_step"]) == 2 and j["allgather_ms"] >= 0
+
+
+def test_cross_rank_check_catches_a_rank_that_ran_something_else():
+    """BENCH_FAKE_CORRUPT_RANK=1: rank 1's stand-in sampler is perturbed - the self-check must fail the job loudly."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "16"], {"BENCH_FAKE": "1", "BENCH_FAKE_CORRUPT_RANK": "1"})
+    assert r.returncode != 0
+    assert "cross-rank self-check FAILED" in (r.stderr + r.stdout)
 
 
 def test_strong_scaling_leg_splits_the_global_batch():

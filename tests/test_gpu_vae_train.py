@@ -128,9 +128,18 @@ def test_fused_log_nb_positive_matches_the_reference_formula_and_its_autograd():
     mg, tg = mu.cuda().requires_grad_(True), theta.cuda().requires_grad_(True)
     out = log_nb_positive(x.cuda(), mg, tg)
     (out * w.cuda()).sum().backward()
+    # fp32 arithmetic on differences of lgamma / log values of size ~1e4 (x = 3000): the yardstick is the error of the reference's
+    # own fp32 eager formula against float64 on the same inputs - the fused kernel must not be worse than twice that
     rel = lambda a, b: float(((a.double().cpu() - b).abs() / (b.abs() + 1e-3 * b.abs().max())).max())
-    assert rel(out.detach(), ref.detach()) < 2e-5
-    assert rel(mg.grad, mo.grad) < 2e-5 and rel(tg.grad, to.grad) < 1e-4
+    m32, t32 = mu.clone().requires_grad_(True), theta.clone().requires_grad_(True)
+    ref32 = log_nb_oracle(x, m32, t32)
+    (ref32 * w).sum().backward()
+    e_out, e_dmu, e_dth = rel(out.detach(), ref.detach()), rel(mg.grad, mo.grad), rel(tg.grad, to.grad)
+    r_out, r_dmu, r_dth = rel(ref32.detach(), ref.detach()), rel(m32.grad, mo.grad), rel(t32.grad, to.grad)
+    print(f"[parity] fused log_nb_positive vs float64: value {e_out:.2e} (torch fp32 eager {r_out:.2e}), d mu {e_dmu:.2e} ({r_dmu:.2e}), "
+          f"d theta {e_dth:.2e} ({r_dth:.2e})")
+    assert e_out <= 2 * r_out + 1e-5 and e_dmu <= 2 * r_dmu + 1e-5 and e_dth <= 2 * r_dth + 1e-4
+    assert e_out < 5e-4 and e_dmu < 1e-4 and e_dth < 1e-3
 
 
 def test_training_loop_at_the_dentate_shape_reduces_the_loss():
