@@ -112,50 +112,56 @@ __device__ __forceinline__ void flush_tile(float* __restrict__ dst, const f32x16
 // ---- SwiGLU MLP, forward and backward in ONE streaming pass over the hidden units ------------------------------------------
 // m = Wc (silu(W1 h2) * (W2 h2)); given dm: dh2 = W1^T da + W2^T db.  Weight-gradient tiles (3 chunks of 32 hidden units):
 // g1[c] += da_c (x) h2, g2[c] += db_c (x) h2, gc[c] += dm (x) hid_c.  WcT = Wc transposed ([H][32]).  bufX / bufD must hold the
-// staged h2 / dm tiles; bufS is scratch.  WANT_M: also return m (the forward value).
+// staged h2 / dm tiles; bufS is scratch of THREE tiles (da | db | hid of a chunk).  WANT_M: also return m (the forward value).
 struct MlpW { const float* w1; const float* w2; const float* wct; int H; };
-template <bool WANT_M>
+// FLUSH (the cell kernels: one token tile per workgroup, nothing to accumulate across tiles): every chunk's three tiles are written
+// to the partial at once (P1 / P2: [96][32] row blocks, PC: [32][96] column blocks) instead of living in 144 accumulator registers.
+template <bool WANT_M, bool FLUSH = false>
 __device__ __forceinline__ void mlp_fwd_bwd(const MlpW w, const float (&h2)[32], const float (&dm)[32], float (&m)[32], float (&dh2)[32],
                                             f32x16 (&g1)[3], f32x16 (&g2)[3], f32x16 (&gc)[3], float* __restrict__ bufX,
-                                            float* __restrict__ bufD, float* __restrict__ bufS, int lane, bool valid) {
+                                            float* __restrict__ bufD, float* __restrict__ bufS, int lane, bool valid,
+                                            float* __restrict__ P1 = nullptr, float* __restrict__ P2 = nullptr, float* __restrict__ PC = nullptr) {
 #pragma unroll
   for (int i = 0; i < 32; ++i) { dh2[i] = 0.f; if (WANT_M) m[i] = 0.f; }
   stage32(bufX, lane, h2, valid);
   stage32(bufD, lane, dm, valid);
+  float* __restrict__ S1 = bufS;                 // bufS holds THREE [64][kSL] tiles: da | db | hid of the current chunk
+  float* __restrict__ S2 = bufS + 64 * kSL;
+  float* __restrict__ S3 = bufS + 2 * 64 * kSL;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float da[32], db[32], hd[32];
-#pragma unroll
+    wsync();   // (the previous chunk's MFMAs have read the three tiles)
+#pragma unroll 2
     for (int jj = 0; jj < 32; ++jj) {
       const int j = c * 32 + jj;
+      float da = 0.f, db = 0.f, hd = 0.f;
       if (j < w.H) {   // wave-uniform
         const float a = dotw<32>(w.w1 + j * 32, h2), b = dotw<32>(w.w2 + j * 32, h2);
         const float s = sigm(a), sa = a * s;
-        hd[jj] = sa * b;
+        hd = sa * b;
         const float dh = dotw<32>(w.wct + j * 32, dm);
-        da[jj] = dh * b * (s * (1.0f + a * (1.0f - s)));
-        db[jj] = dh * sa;
+        da = dh * b * (s * (1.0f + a * (1.0f - s)));
+        db = dh * sa;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-          dh2[i] = fmaf(w.w1[j * 32 + i], da[jj], fmaf(w.w2[j * 32 + i], db[jj], dh2[i]));
-          if (WANT_M) m[i] = fmaf(w.wct[j * 32 + i], hd[jj], m[i]);
+          dh2[i] = fmaf(w.w1[j * 32 + i], da, fmaf(w.w2[j * 32 + i], db, dh2[i]));
+          if (WANT_M) m[i] = fmaf(w.wct[j * 32 + i], hd, m[i]);
         }
-      } else {
-        da[jj] = db[jj] = hd[jj] = 0.f;
       }
+      S1[lane * kSL + jj] = valid ? da : 0.f;
+      S2[lane * kSL + jj] = valid ? db : 0.f;
+      S3[lane * kSL + jj] = valid ? hd : 0.f;
     }
-    wsync();   // (the previous chunk's MFMAs have read bufS)
-    stage32(bufS, lane, da, valid);
     wsync();
-    wgrad32(g1[c], bufS, bufX, lane);
-    wsync();
-    stage32(bufS, lane, db, valid);
-    wsync();
-    wgrad32(g2[c], bufS, bufX, lane);
-    wsync();
-    stage32(bufS, lane, hd, valid);
-    wsync();
-    wgrad32(gc[c], bufD, bufS, lane);
+    if constexpr (FLUSH) {
+      f32x16 t = z16(); wgrad32(t, S1, bufX, lane); flush_tile(P1, t, lane, 32 * c, 0, 32);
+      t = z16(); wgrad32(t, S2, bufX, lane); flush_tile(P2, t, lane, 32 * c, 0, 32);
+      t = z16(); wgrad32(t, bufD, S3, lane); flush_tile(PC, t, lane, 0, 32 * c, kHP);
+    } else {
+      wgrad32(g1[c], S1, bufX, lane);
+      wgrad32(g2[c], S2, bufX, lane);
+      wgrad32(gc[c], bufD, S3, lane);
+    }
   }
   wsync();
 }
@@ -289,7 +295,7 @@ struct DecBwdArgs {
   float eps;
 };
 __global__ __launch_bounds__(64) void dec_gene_bwd_kernel(const DecBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float SA[64 * kSL], SB[64 * kSL], SC[64 * kSL];
+  __shared__ __attribute__((aligned(16))) float SA[64 * kSL], SB[64 * kSL], SC[3 * 64 * kSL];
   const int lane = threadIdx.x, chunk = blockIdx.x, cell = blockIdx.y, nch = gridDim.x;
   const float* __restrict__ KV = a.kv + (size_t)cell * (kT * 64);
   f32x16 gq = z16(), gp = z16(), g1[3] = {z16(), z16(), z16()}, g2[3] = {z16(), z16(), z16()}, gc[3] = {z16(), z16(), z16()};
@@ -510,6 +516,8 @@ __device__ __forceinline__ void block_fwd(const BlockW& w, float (&x)[32], float
   float ao[32];
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
+    __builtin_amdgcn_sched_barrier(0);   /* keep one head's LDS reads from being hoisted over the previous heads (register pressure) */
+
     float s[16], mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -563,30 +571,31 @@ __device__ __forceinline__ void block_bwd(const BlockW& w, const float (&x)[32],
   for (int i = 0; i < 64; ++i) EX[lane * kXL + i] = qkv[32 + i];
   wsync();
   const float* KVc = EX + (lane & ~15) * kXL;
-  float p[8][16], lse[8], ao[32];
+  float lse[8], ao[32];      // (the probabilities are recomputed from lse in the backward: 128 registers less across the MLP)
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
-    float mx = -3.0e38f;
+    __builtin_amdgcn_sched_barrier(0);   /* keep one head's LDS reads from being hoisted over the previous heads (register pressure) */
+
+    float pj[16], mx = -3.0e38f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       float t = 0.f;
 #pragma unroll
       for (int d = 0; d < 4; ++d) t = fmaf(qkv[h * 4 + d], KVc[j * kXL + h * 4 + d], t);
-      p[h][j] = t * kTScale;
-      mx = fmaxf(mx, p[h][j]);
+      pj[j] = t * kTScale;
+      mx = fmaxf(mx, pj[j]);
     }
     float l = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { p[h][j] = __expf(p[h][j] - mx); l += p[h][j]; }
+    for (int j = 0; j < 16; ++j) l += __expf(pj[j] - mx);
     lse[h] = mx + __logf(l);
-    const float inv = 1.0f / l;
 #pragma unroll
     for (int d = 0; d < 4; ++d) ao[h * 4 + d] = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      p[h][j] *= inv;
+      const float pp = __expf(pj[j] - lse[h]);
 #pragma unroll
-      for (int d = 0; d < 4; ++d) ao[h * 4 + d] = fmaf(p[h][j], KVc[j * kXL + 32 + h * 4 + d], ao[h * 4 + d]);
+      for (int d = 0; d < 4; ++d) ao[h * 4 + d] = fmaf(pp, KVc[j * kXL + 32 + h * 4 + d], ao[h * 4 + d]);
     }
   }
   float x1[32], xh2[32], h2[32], r2;
@@ -597,14 +606,10 @@ __device__ __forceinline__ void block_bwd(const BlockW& w, const float (&x)[32],
 #pragma unroll
   for (int i = 0; i < 32; ++i) h2[i] = fmaf(xh2[i], w.ln2_w[i], w.ln2_b[i]);
   // ---- MLP + LN_2 backward
-  f32x16 g1[3] = {z16(), z16(), z16()}, g2[3] = {z16(), z16(), z16()}, gc[3] = {z16(), z16(), z16()};
   float dh2[32], dummy[32];
-  mlp_fwd_bwd<false>(w.mlp, h2, dx, dummy, dh2, g1, g2, gc, SA, SB, SC, lane, valid);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    flush_tile(P + TP_W1, g1[c], lane, 32 * c, 0, 32);
-    flush_tile(P + TP_W2, g2[c], lane, 32 * c, 0, 32);
-    flush_tile(P + TP_WC, gc[c], lane, 0, 32 * c, kHP);
+  {
+    f32x16 gu[3];   // (unused in FLUSH mode)
+    mlp_fwd_bwd<false, true>(w.mlp, h2, dx, dummy, dh2, gu, gu, gu, SA, SB, SC, lane, valid, P + TP_W1, P + TP_W2, P + TP_WC);
   }
   {
     float t2[32];
@@ -639,21 +644,24 @@ __device__ __forceinline__ void block_bwd(const BlockW& w, const float (&x)[32],
   float dqkv[96], dgq[8];
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
-    float dp[16], dg = 0.f;
+    __builtin_amdgcn_sched_barrier(0);   /* keep one head's LDS reads from being hoisted over the previous heads (register pressure) */
+
+    float dp[16], pj[16], dg = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      float t = 0.f;
+      float t = 0.f, sc = 0.f;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) t = fmaf(dao[h * 4 + d], KVc[j * kXL + 32 + h * 4 + d], t);
+      for (int d = 0; d < 4; ++d) { t = fmaf(dao[h * 4 + d], KVc[j * kXL + 32 + h * 4 + d], t); sc = fmaf(qkv[h * 4 + d], KVc[j * kXL + h * 4 + d], sc); }
       dp[j] = t;
-      dg = fmaf(p[h][j], t, dg);
+      pj[j] = __expf(sc * kTScale - lse[h]);
+      dg = fmaf(pj[j], t, dg);
     }
     dgq[h] = dg;
 #pragma unroll
     for (int d = 0; d < 4; ++d) dqkv[h * 4 + d] = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float dsj = p[h][j] * (dp[j] - dg) * kTScale;
+      const float dsj = pj[j] * (dp[j] - dg) * kTScale;
 #pragma unroll
       for (int d = 0; d < 4; ++d) dqkv[h * 4 + d] = fmaf(dsj, KVc[j * kXL + h * 4 + d], dqkv[h * 4 + d]);
     }
@@ -666,14 +674,19 @@ __device__ __forceinline__ void block_bwd(const BlockW& w, const float (&x)[32],
 #pragma unroll
   for (int i = 0; i < 32; ++i) { EX[lane * kXL + i] = qkv[i]; EX[lane * kXL + 32 + i] = valid ? dao[i] : 0.f; }
 #pragma unroll
-  for (int h = 0; h < 8; ++h) { EX[lane * kXL + 64 + h] = lse[h]; EX[lane * kXL + 72 + h] = dgq[h]; }
+  for (int h = 0; h < 8; ++h) {
+    __builtin_amdgcn_sched_barrier(0);   /* keep one head's LDS reads from being hoisted over the previous heads (register pressure) */
+ EX[lane * kXL + 64 + h] = lse[h]; EX[lane * kXL + 72 + h] = dgq[h]; }
   wsync();
 #pragma unroll
   for (int i = 0; i < 64; ++i) dqkv[32 + i] = 0.f;
+#pragma unroll 1
   for (int qi = 0; qi < 16; ++qi) {
     const float* R = KVc + qi * kXL;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
+    __builtin_amdgcn_sched_barrier(0);   /* keep one head's LDS reads from being hoisted over the previous heads (register pressure) */
+
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < 4; ++d) { s = fmaf(R[h * 4 + d], kme[h * 4 + d], s); dp = fmaf(R[32 + h * 4 + d], vme[h * 4 + d], dp); }
@@ -798,7 +811,7 @@ __global__ __launch_bounds__(64) void dec_cell_fwd_kernel(const DecCellTrainArgs
 
 template <int NL>
 __global__ __launch_bounds__(64) void dec_cell_bwd_kernel(const DecCellTrainArgs a) {
-  __shared__ __attribute__((aligned(16))) float EX[64 * kXL], SA[64 * kSL], SB[64 * kSL], SC[64 * kSL];
+  __shared__ __attribute__((aligned(16))) float EX[64 * kXL], SA[64 * kSL], SB[64 * kSL], SC[3 * 64 * kSL];
   const int lane = threadIdx.x, cell_raw = blockIdx.x * 4 + (lane >> 4), tok = lane & 15;
   const bool valid = cell_raw < a.B;
   const int cell = valid ? cell_raw : a.B - 1;
@@ -964,7 +977,7 @@ __global__ __launch_bounds__(64) void enc_cell_fwd_kernel(const EncCellTrainArgs
 
 template <int NL>
 __global__ __launch_bounds__(64) void enc_cell_bwd_kernel(const EncCellTrainArgs a) {
-  __shared__ __attribute__((aligned(16))) float EX[64 * kXL], SA[64 * kSL], SB[64 * kSL], SC[64 * kSL];
+  __shared__ __attribute__((aligned(16))) float EX[64 * kXL], SA[64 * kSL], SB[64 * kSL], SC[3 * 64 * kSL];
   const int lane = threadIdx.x, cell_raw = blockIdx.x * 4 + (lane >> 4), tok = lane & 15;
   const bool valid = cell_raw < a.B;
   const int cell = valid ? cell_raw : a.B - 1;
@@ -1027,14 +1040,11 @@ __global__ __launch_bounds__(64) void enc_cell_bwd_kernel(const EncCellTrainArgs
   ln_fwd<32>(y, xh2, r2, a.eps);
 #pragma unroll
   for (int i = 0; i < 32; ++i) h2[i] = fmaf(xh2[i], a.cln2_w[i], a.cln2_b[i]);
-  f32x16 g1[3] = {z16(), z16(), z16()}, g2[3] = {z16(), z16(), z16()}, gc[3] = {z16(), z16(), z16()};
   float dh2[32], dummy[32];
-  mlp_fwd_bwd<false>(a.cmlp, h2, dx, dummy, dh2, g1, g2, gc, SA, SB, SC, lane, valid);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    flush_tile(P + ec_off_w1(a.n_layer), g1[c], lane, 32 * c, 0, 32);
-    flush_tile(P + ec_off_w2(a.n_layer), g2[c], lane, 32 * c, 0, 32);
-    flush_tile(P + ec_off_wc(a.n_layer), gc[c], lane, 0, 32 * c, kHP);
+  {
+    f32x16 gu[3];
+    mlp_fwd_bwd<false, true>(a.cmlp, h2, dx, dummy, dh2, gu, gu, gu, SA, SB, SC, lane, valid, P + ec_off_w1(a.n_layer), P + ec_off_w2(a.n_layer),
+                             P + ec_off_wc(a.n_layer));
   }
   {
     float t2[32];
@@ -1225,26 +1235,32 @@ __global__ __launch_bounds__(64) void enc_pool_bwd_kernel(const EncPoolBwdArgs a
 struct RedJob { float* dst; int off, n, accumulate; int rows, ld_src, ld_dst; };   // rows > 1: a [rows][ld_src] block copied to [rows][ld_dst] (n = cols)
 constexpr int kMaxRedJobs = 24;
 struct RedArgs { const float* part; int n_part; long stride; int n_jobs; RedJob job[kMaxRedJobs]; };
+// sum over the partials of one element, eight independent running sums (memory-level parallelism; fixed order: deterministic)
+__device__ __forceinline__ float sum_partials(const float* __restrict__ src, int n_part, long stride) {
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 8 <= n_part; p += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] += src[(size_t)(p + u) * stride];
+  for (; p < n_part; ++p) s[p & 7] += src[(size_t)p * stride];
+  return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(const RedArgs a) {
   const RedJob& j = a.job[blockIdx.y];
   const int total = j.rows * j.n;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     const int r = i / j.n, c = i % j.n;
-    const float* src = a.part + j.off + (size_t)r * j.ld_src + c;
-    float s = 0.f;
-    for (int p = 0; p < a.n_part; ++p) s += src[(size_t)p * a.stride];
+    const float s = sum_partials(a.part + j.off + (size_t)r * j.ld_src + c, a.n_part, a.stride);
     float* d = j.dst + (size_t)r * j.ld_dst + c;
     *d = j.accumulate ? *d + s : s;
   }
 }
-// dQ (16, 32) from the pooling partial's [h*16 + i][32] block-diagonal rows: dQ[i][d] = sum_h row(h, i)[d]
-__global__ __launch_bounds__(256) void fold_dq_kernel(const float* __restrict__ part, int n_part, long stride, float* __restrict__ dQ) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+// dQ (16, 32) from the pooling partial's [h*16 + i][32] block-diagonal rows: dQ[i][d] = row(head(d), i)[d]
+__global__ __launch_bounds__(64) void fold_dq_kernel(const float* __restrict__ part, int n_part, long stride, float* __restrict__ dQ) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
   if (idx >= 16 * 32) return;
   const int i = idx >> 5, d = idx & 31, h = d >> 3;
-  float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += part[(size_t)p * stride + EP_DQ + (h * 16 + i) * 32 + d];
-  dQ[idx] = s;
+  dQ[idx] = sum_partials(part + EP_DQ + (h * 16 + i) * 32 + d, n_part, stride);
 }
 
 // =================================================================================================================================

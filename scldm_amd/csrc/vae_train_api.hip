@@ -110,7 +110,7 @@ struct Jobs {
       a.part = part; a.n_part = n_part; a.stride = stride;
       a.n_jobs = (int)std::min<size_t>(kMaxRedJobs, v.size() - i);
       for (int j = 0; j < a.n_jobs; ++j) a.job[j] = v[i + j];
-      reduce_jobs_kernel<<<dim3(12, a.n_jobs), 256, 0, st>>>(a);
+      reduce_jobs_kernel<<<dim3(12, a.n_jobs), 256, 0, st>>>(a);   // (3 072 threads per job: one element each for the largest blocks)
       LAUNCH_CHECK();
     }
     return SCLDM_OK;
@@ -277,7 +277,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     j.vec(G_(g->enc_cross.ln1_w), EP_LN1W, 32);
     j.vec(G_(g->enc_cross.ln1_b), EP_LN1B, 32);
     if ((rc = j.run(k.p_pool, B * k.chunksE, EP_SIZE, st))) return rc;
-    fold_dq_kernel<<<2, 256, 0, st>>>(k.p_pool, B * k.chunksE, EP_SIZE, k.dQ);
+    fold_dq_kernel<<<8, 64, 0, st>>>(k.p_pool, B * k.chunksE, EP_SIZE, k.dQ);
     LAUNCH_CHECK();
     // (the inducing-point gradient was set by the encoder-cell reduction above; this adds the query-projection branch)
     if (!g->inducing_points || !g->enc_cross.attn_q || !g->enc_cross.ln1q_w || !g->enc_cross.ln1q_b)
