@@ -77,6 +77,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   for (int c = 0; c < cfg->n_classes; ++c) h->tab_rows[c] = cfg->class_vocab[c] + cfg->has_null_row;
   h->bf16_sources = true;   // (a knob of the generic training path: read for every shape)
   if (const char* e = getenv("SCLDM_TRAIN_BF16_SOURCES")) h->bf16_sources = atoi(e) != 0;
+  h->wgrad_batch = true;
+  if (const char* e = getenv("SCLDM_WGRAD_BATCH")) h->wgrad_batch = atoi(e) != 0;
   if (!fused) {
     *out = h;
     return SCLDM_OK;

@@ -24,6 +24,7 @@ struct BGemmArgs {
   const __bf16* A; int lda;   // KC: A(m,k) = A[m*lda + k];  MC: A(m,k) = A[k*lda + m]
   const __bf16* B; int ldb;
   float* C; long ldc;
+  __bf16* C16;       // optional: the result is stored as bf16 here (row stride N) instead of fp32 in C (no split-K, no accumulate)
   const float* bias;
   int M, N, K;
   int kchunk;        // multiple of 64; == K rounded up without split-K
@@ -222,10 +223,14 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BGemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane >> 5);
         if (m < g.M) {
-          float* p = C + (long)m * g.ldc + n;
           float v = acc[i][k][r] + bv;
-          if (g.accumulate) v += *p;
-          *p = v;
+          if (g.C16) {
+            g.C16[(long)m * g.N + n] = (__bf16)v;
+          } else {
+            float* p = C + (long)m * g.ldc + n;
+            if (g.accumulate) v += *p;
+            *p = v;
+          }
         }
       }
     }
@@ -307,8 +312,10 @@ struct LoaderMC2 {   // 64 (k) x 256 (m): pass p: k row 16 p + 2 wave + lane / 3
   }
 };
 
+// `bid`: the workgroup's index inside this product (blockIdx.x for a single launch; blockIdx.x minus the product's first block in
+// a batched launch)
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
+__device__ __forceinline__ void bgemm256_body(const BGemmArgs& g, const int bid) {
   using LA = typename std::conditional<A_KC, LoaderKC2, LoaderMC2>::type;
   using LB = typename std::conditional<B_KC, LoaderKC2, LoaderMC2>::type;
   extern __shared__ __attribute__((aligned(16))) char bgemm_smem[];
@@ -316,11 +323,11 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
   auto Bs = [&](int b) { return reinterpret_cast<__bf16*>(bgemm_smem + (2 + b) * kG2OperandBytes); };
   int z = 0, tile_id;   // (same workgroup numbering as bgemm_kernel; tiles_m / tiles_n count 256-tiles)
   if (g.splits > 1) {
-    z = blockIdx.x % g.splits;
-    tile_id = blockIdx.x / g.splits;
+    z = bid % g.splits;
+    tile_id = bid / g.splits;
   } else {
-    tile_id = (blockIdx.x & 7) * g.per_xcd + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= g.per_xcd) return;
+    tile_id = (bid & 7) * g.per_xcd + (bid >> 3);
+    if ((bid >> 3) >= g.per_xcd) return;
   }
   if (tile_id >= g.tiles_m * g.tiles_n) return;
   const int tm = tile_id / g.tiles_n, tn = tile_id % g.tiles_n;
@@ -408,13 +415,38 @@ __global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 128 + i * 32 + acc_row(r, lane >> 5);
         if (m < g.M) {
-          float* p = C + (long)m * g.ldc + n;
           float v = acc[i][k][r] + bv;
-          if (g.accumulate) v += *p;
-          *p = v;
+          if (g.C16) {
+            g.C16[(long)m * g.N + n] = (__bf16)v;
+          } else {
+            float* p = C + (long)m * g.ldc + n;
+            if (g.accumulate) v += *p;
+            *p = v;
+          }
         }
       }
     }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) { bgemm256_body<A_KC, B_KC>(g, (int)blockIdx.x); }
+
+// Several independent products in ONE launch (the five weight gradients of a DiT-L layer: 48 + 16 + 3 x 44 = 196 tiles of 256 x 256
+// fill the chip WITHOUT split-K - no partial tiles, no reduction kernels, one launch instead of twelve).  Workgroups
+// [first[j], first[j+1]) belong to product j; inside a product the numbering (and the XCD-aware tile order) is bgemm256_body's.
+constexpr int kBGemmBatchMax = 6;
+struct BGemmBatch {
+  BGemmArgs job[kBGemmBatchMax];
+  int first[kBGemmBatchMax + 1];
+  int n;
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void bgemm256_batch_kernel(const BGemmBatch b) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < kBGemmBatchMax; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first[i]) j = i;
+  bgemm256_body<A_KC, B_KC>(b.job[j], (int)blockIdx.x - b.first[j]);
 }
 
 // dst[r][c] = bf16(src[r][c]), rows of the copy padded with zeros to ldd elements, one job per blockIdx.y (the per-step bf16

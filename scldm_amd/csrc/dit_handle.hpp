@@ -67,6 +67,7 @@ struct scldm_dit {
   // gradient-ready events of the NEXT scldm_dit_train_backward (scldm_dit_train_set_grad_events): recorded on the call's stream
   struct GradEvent { hipEvent_t ev; int kind, layer; bool fired; };
   std::vector<GradEvent> grad_events;
+  bool wgrad_batch;         // SCLDM_WGRAD_BATCH (read once at create; 0: per-product weight-gradient launches with split-K, the round-2 scheme)
   bool bf16_sources;        // SCLDM_TRAIN_BF16_SOURCES (read once at create; 0 keeps fp32 activations + hgemm_kernel)
 };
 

@@ -786,25 +786,25 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // hid = silu(a) * b   (MLP.forward, layers.py:172-174).  a, b: [tokens][H]; the output rows have ldo >= H elements, and the
 // thread of a row's last element also zeroes the row's padding (bf16 rows are padded to 16-byte multiples for bgemm_kernel,
 // whose last k chunk reads the padding of both operands)
-template <typename TO = float>
-__global__ void swiglu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, TO* __restrict__ hid, long count, int H, int ldo) {
+template <typename TO = float, typename TI = float>
+__global__ void swiglu_fwd_kernel(const TI* __restrict__ a, const TI* __restrict__ b, TO* __restrict__ hid, long count, int H, int ldo) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-    const float v = a[i];
+    const float v = (float)a[i];
     const long t = i / H;
     const int c = (int)(i - t * H);
-    hid[t * ldo + c] = (TO)(v * sigmoid_f(v) * b[i]);
+    hid[t * ldo + c] = (TO)(v * sigmoid_f(v) * (float)b[i]);
     if (c == H - 1)
       for (int p = H; p < ldo; ++p) hid[t * ldo + p] = (TO)0.f;
   }
 }
-template <typename TO = float>
-__global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const float* __restrict__ a, const float* __restrict__ b,
+template <typename TO = float, typename TI = float>
+__global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const TI* __restrict__ a, const TI* __restrict__ b,
                                   TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-    const float v = a[i], s = sigmoid_f(v), d = dhid[i];
+    const float v = (float)a[i], s = sigmoid_f(v), d = dhid[i];
     const long t = i / H;
     const int c = (int)(i - t * H);
-    da[t * ldo + c] = (TO)(d * b[i] * s * (1.0f + v * (1.0f - s)));
+    da[t * ldo + c] = (TO)(d * (float)b[i] * s * (1.0f + v * (1.0f - s)));
     db[t * ldo + c] = (TO)(d * v * s);
     if (c == H - 1)
       for (int p = H; p < ldo; ++p) da[t * ldo + p] = db[t * ldo + p] = (TO)0.f;
@@ -820,16 +820,16 @@ template <int HD>
 struct AttnTile {
   float q[kS][HD + 1], k[kS][HD + 1], v[kS][HD + 1], p[kS][kS + 1];
 };
-template <int HD>
-__device__ __forceinline__ void attn_load(AttnTile<HD>& s, const float* __restrict__ qkv, long sample, int head, int D, int lane) {
+template <int HD, typename TI>
+__device__ __forceinline__ void attn_load(AttnTile<HD>& s, const TI* __restrict__ qkv, long sample, int head, int D, int lane) {
   constexpr int CW = HD / 4;
   const int tok = lane >> 2, c0 = (lane & 3) * CW;
-  const float* base = qkv + (sample * kS + tok) * (3L * D) + head * HD + c0;
+  const TI* base = qkv + (sample * kS + tok) * (3L * D) + head * HD + c0;
 #pragma unroll
   for (int i = 0; i < CW; ++i) {
-    s.q[tok][c0 + i] = base[i];
-    s.k[tok][c0 + i] = base[D + i];
-    s.v[tok][c0 + i] = base[2 * D + i];
+    s.q[tok][c0 + i] = (float)base[i];
+    s.k[tok][c0 + i] = (float)base[D + i];
+    s.v[tok][c0 + i] = (float)base[2 * D + i];
   }
 }
 // lane -> (i = lane / 4, j in {j0..j0+3}, j0 = (lane & 3) * 4): returns this lane's 4 probabilities of row i
@@ -864,8 +864,8 @@ __device__ __forceinline__ void attn_probs(const AttnTile<HD>& s, int lane, floa
 template <int HD>
 constexpr int attn_waves() { return HD == 32 ? 4 : 2; }   // waves (= (sample, head) units) per workgroup: LDS-limited for HD 64
 
-template <int HD, typename TO = float>
-__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const float* __restrict__ qkv, long n_samples, int n_head, int D,
+template <int HD, typename TO = float, typename TI = float>
+__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const TI* __restrict__ qkv, long n_samples, int n_head, int D,
                                                                          TO* __restrict__ ao) {
   __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
   constexpr int CW = HD / 4;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const f
   const long sample = unit / n_head;
   const int head = (int)(unit % n_head);
   AttnTile<HD>& s = tiles[wave];
-  attn_load<HD>(s, qkv, sample, head, D, lane);
+  attn_load<HD, TI>(s, qkv, sample, head, D, lane);
   __builtin_amdgcn_wave_barrier();
   float p4[4];
   attn_probs<HD>(s, lane, p4);
@@ -899,8 +899,8 @@ __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_fwd_kernel(const f
 }
 
 // dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP));  dq = scale dS k;  dk = scale dS^T q;  dv = P^T dao
-template <int HD, typename TO = float>
-__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dao,
+template <int HD, typename TO = float, typename TI = float>
+__global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ dao,
                                                                          long n_samples, int n_head, int D, TO* __restrict__ dqkv) {
   __shared__ AttnTile<HD> tiles[attn_waves<HD>()];
   __shared__ float dos[attn_waves<HD>()][kS][HD + 1];
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * attn_waves<HD>()) void attn_bwd_kernel(const f
   const long sample = unit / n_head;
   const int head = (int)(unit % n_head);
   AttnTile<HD>& s = tiles[wave];
-  attn_load<HD>(s, qkv, sample, head, D, lane);
+  attn_load<HD, TI>(s, qkv, sample, head, D, lane);
   const int i = lane >> 2, c0 = (lane & 3) * CW, j0 = (lane & 3) * 4;
   {
     const float* src = dao + (sample * kS + i) * (long)D + head * HD + c0;

@@ -29,7 +29,7 @@ struct Saved {
   size_t bytes;
 };
 struct Scratch {
-  float *dx, *dh, *dy, *dao, *dqkv, *dhid, *da, *db, *dmod, *dsc, *dc, *dsth, *dth, *part, *temb;
+  float *dx, *dh, *dy, *dy2, *dao, *dqkv, *dhid, *da, *db, *dmod, *dsc, *dc, *dsth, *dth, *part, *temb;
   size_t part_floats;
   size_t bytes;
 };
@@ -96,9 +96,10 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base, bool fused_path) {
   s.dx = c.take(T * kD);
   s.dh = c.take(T * kD);
   if (fused_path) {
-    s.dy = s.dao = s.dqkv = s.dhid = s.da = s.db = nullptr;
+    s.dy = s.dy2 = s.dao = s.dqkv = s.dhid = s.da = s.db = nullptr;
   } else {
     s.dy = c.take(T * kD);
+    s.dy2 = c.take(T * kD / 2);     // bf16 (T, D): the attention branch's gated gradient when a layer's weight gradients are batched
     s.dao = c.take(T * kD);
     s.dqkv = c.take(T * 3 * kD);
     s.dhid = c.take(T * H);
@@ -212,18 +213,18 @@ int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
 // orientations in use: (KC, KC) forward, (KC, MC) data gradient, (MC, MC) weight gradient.
 int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, int ldb, bool b_kc, float* C, long ldc, int M, int N,
-          int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr) {
+          int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr, __bf16* C16 = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
   if (lda % 8 || ldb % 8 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
     return fail(SCLDM_ERR_SHAPE, "bgemm: operands need 16-byte aligned rows");
   if (rowsum_out && a_kc) return fail(SCLDM_ERR_SHAPE, "bgemm: row sums need the A operand contiguous along m");
   if (!a_kc && b_kc) return fail(SCLDM_ERR_SHAPE, "bgemm: operand orientation (MC, KC) is not instantiated");
   BGemmArgs g{};
-  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias; g.C16 = C16;
   g.M = M; g.N = N; g.K = K;
   // split K when the output tiles leave most of the workgroup slots empty and the partials are small (weight gradients:
   // K = all tokens); an activation-sized output pays more for the partials round trip than it gains
-  const bool may_split = (long)M * N <= (4L << 20);
+  const bool may_split = (long)M * N <= (4L << 20) && !C16;   // (a bf16 result is written by the product's own epilogue: no partials)
   auto pick_splits = [&](long tiles, long slots) {
     int sp = 1;
     if (tiles < slots / 2 && may_split) sp = (int)std::max<long>(1, std::min<long>(std::min<long>(slots / tiles, K / 512), kMaxSplit));
@@ -272,6 +273,50 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
       LAUNCH_CHECK();
     }
   }
+  return SCLDM_OK;
+}
+
+// One launch for several weight gradients dW_j[out][in] = sum_t dy_j[t][out] x_j[t][in] (both operands m-contiguous, K = tokens),
+// 256 x 256 tiles, no split-K: see bgemm256_batch_kernel.  db_j (optional) receives the row sums of dy_j (bias gradient).
+struct WgradJobH { const __bf16* dy; int lddy; const __bf16* x; int ldx; int out_f, in_f; float* dW; float* db; };
+bool wgrad_batch_eligible(const WgradJobH* j, int n, long T) {
+  if (!g_bgemm256 || n < 1 || n > kBGemmBatchMax || T < 2048) return false;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (j[i].out_f < 256 || j[i].in_f < 256 || j[i].lddy % 8 || j[i].ldx % 8) return false;
+    tiles += (long)cdiv(j[i].out_f, 256) * cdiv(j[i].in_f, 256);
+  }
+  return tiles >= 128;   // (fewer: the per-product split-K launches fill the chip better)
+}
+int wgrad_batch(hipStream_t st, const WgradJobH* j, int n, long T) {
+  static std::atomic<bool> attr_set[kMaxDevices];
+  auto kern = bgemm256_batch_kernel<false, false>;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm2Lds));
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
+  }
+  BGemmBatch b{};
+  b.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    BGemmArgs& g = b.job[i];
+    g.A = j[i].dy; g.lda = j[i].lddy; g.B = j[i].x; g.ldb = j[i].ldx; g.C = j[i].dW; g.ldc = j[i].in_f; g.bias = nullptr;
+    g.M = j[i].out_f; g.N = j[i].in_f; g.K = (int)T;
+    g.kchunk = cdiv(T, kGK) * kGK;
+    g.splits = 1;
+    g.accumulate = 0;
+    g.rowsum = j[i].db;
+    g.tiles_m = cdiv(g.M, 256);
+    g.tiles_n = cdiv(g.N, 256);
+    g.per_xcd = cdiv((long)g.tiles_m * g.tiles_n, 8);
+    b.first[i] = blocks;
+    blocks += 8 * g.per_xcd;
+  }
+  for (int i = n; i <= kBGemmBatchMax; ++i) b.first[i] = blocks;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), kBGemm2Lds, st, b);
+  LAUNCH_CHECK();
   return SCLDM_OK;
 }
 
@@ -350,9 +395,12 @@ int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
 }
 
 // (ldw: elements per row of the bf16 weight copy = `in` rounded up to a multiple of 8)
+// y16: the result is stored as a dense bf16 array (rows, out) at y instead of fp32 (arrays that only attention / SwiGLU kernels read:
+// qkv, a, b - half the bytes written here, half the bytes read by the forward and the backward consumer)
 int linear_fwd16(hipStream_t st, const __bf16* x, int ldx, const __bf16* W, int rows, int out, int in, const float* b, float* y, long ldy,
-                 Scratch& s) {
-  return bgemm(st, x, ldx, true, W, (in + 7) / 8 * 8, true, y, ldy, rows, out, in, b, false, s.part, s.part_floats);
+                 Scratch& s, bool y16 = false) {
+  return bgemm(st, x, ldx, true, W, (in + 7) / 8 * 8, true, y, ldy, rows, out, in, b, false, s.part, s.part_floats, nullptr,
+               y16 ? reinterpret_cast<__bf16*>(y) : nullptr);
 }
 int linear_dgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* W, int rows, int out, int in, float* dx, long lddx,
                    bool accumulate, Scratch& s) {
@@ -421,17 +469,17 @@ int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const 
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-template <typename TO>
-int attn_fwd(hipStream_t st, int D, int n_head, long n, const float* qkv, TO* ao) {
-  if (D / n_head == 32) hipLaunchKernelGGL((attn_fwd_kernel<32, TO>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
-  else hipLaunchKernelGGL((attn_fwd_kernel<64, TO>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
+template <typename TO, typename TI>
+int attn_fwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, TO* ao) {
+  if (D / n_head == 32) hipLaunchKernelGGL((attn_fwd_kernel<32, TO, TI>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
+  else hipLaunchKernelGGL((attn_fwd_kernel<64, TO, TI>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-template <typename TO>
-int attn_bwd(hipStream_t st, int D, int n_head, long n, const float* qkv, const float* dao, TO* dqkv) {
-  if (D / n_head == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, TO>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
-  else hipLaunchKernelGGL((attn_bwd_kernel<64, TO>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
+template <typename TO, typename TI>
+int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const float* dao, TO* dqkv) {
+  if (D / n_head == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, TO, TI>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
+  else hipLaunchKernelGGL((attn_bwd_kernel<64, TO, TI>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -577,8 +625,8 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     k.part_floats = half;
   }
   auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y,
-                 hipStream_t sx = nullptr) {
-    return src16 ? linear_fwd16(sx ? sx : st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, sx ? k2 : k)
+                 hipStream_t sx = nullptr, bool y16 = false) {
+    return src16 ? linear_fwd16(sx ? sx : st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, sx ? k2 : k, y16)
                  : linear_fwd(st, xin, ldx, W, (int)T, out_f, in_f, b, y, out_f, k);
   };
   for (int l = 0; l < L; ++l) {
@@ -588,9 +636,9 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
     if (src16) TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h1), a.st1));
     else TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
-    TRY(lin(a.h1, kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, w->attn_b[l], a.qkv));
-    if (src16) TRY(attn_fwd(st, kD, kNH, n, a.qkv, reinterpret_cast<__bf16*>(a.ao)));
-    else TRY(attn_fwd(st, kD, kNH, n, a.qkv, a.ao));
+    TRY(lin(a.h1, kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, w->attn_b[l], a.qkv, nullptr, src16));   // (bf16 route: qkv itself is a bf16 array)
+    if (src16) TRY(attn_fwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), reinterpret_cast<__bf16*>(a.ao)));
+    else TRY(attn_fwd(st, kD, kNH, n, (const float*)a.qkv, a.ao));
     TRY(lin(a.ao, kD, w->proj_w[l], wh.proj_w, kD, kD, w->proj_b[l], a.y1));
     hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
     LAUNCH_CHECK();
@@ -598,11 +646,12 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
     hipStream_t s2 = nullptr;
     if (overlap) TRY(fused::fork_side(h, st, 2, &s2));
-    TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b, s2));
-    TRY(lin(a.h2, kD, w->w1[l], wh.w1, H, kD, nullptr, a.a));
+    TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b, s2, src16));   // (bf16 route: the pre-activations a, b are bf16 arrays)
+    TRY(lin(a.h2, kD, w->w1[l], wh.w1, H, kD, nullptr, a.a, nullptr, src16));
     if (overlap) TRY(fused::join_side(h, st, 2));
-    if (src16) hipLaunchKernelGGL(swiglu_fwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, reinterpret_cast<__bf16*>(a.hid), T * H, H, Hp);
-    else hipLaunchKernelGGL(swiglu_fwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, a.a, a.b, a.hid, T * H, H, H);
+    if (src16) hipLaunchKernelGGL((swiglu_fwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(a.a),
+                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(a.hid), T * H, H, Hp);
+    else hipLaunchKernelGGL((swiglu_fwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, (const float*)a.a, (const float*)a.b, a.hid, T * H, H, H);
     LAUNCH_CHECK();
     TRY(lin(a.hid, src16 ? Hp : H, w->cproj[l], wh.cproj, kD, H, nullptr, a.y2));
     hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
@@ -671,7 +720,20 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // the chip's workgroup slots empty on their own.  fork = the side stream waits for what the main stream holds (the operand a
   // weight gradient reads is ready); join = the main stream waits for the side stream before it overwrites such an operand.
   // The two streams split the split-K scratch.
-  const bool overlap = src16 && g_overlap;
+  // Batched weight gradients (bf16-source route, every product of a layer at least 256 x 256: the DiT-L of configs[4]): the five
+  // weight gradients of a layer are ONE launch of 256 x 256 tiles at the end of the layer - 196 tiles for the DiT-L shape fill the
+  // chip without split-K, so there are no partial tiles and no reduction kernels (7 % of the step at 1 024 cells before).  The
+  // attention branch's gated gradient then gets its own array (dy2): both dy arrays must live until the launch.
+  WgradJobH wj[kBGemmBatchMax];
+  int n_wj = 0;
+  bool batched = false;
+  if (src16 && L > 0 && h->wgrad_batch) {
+    const WgradJobH probe[5] = {{nullptr, kD, nullptr, Hl, kD, H, nullptr, nullptr}, {nullptr, Hl, nullptr, kD, H, kD, nullptr, nullptr},
+                                {nullptr, Hl, nullptr, kD, H, kD, nullptr, nullptr}, {nullptr, kD, nullptr, kD, kD, kD, nullptr, nullptr},
+                                {nullptr, 3 * kD, nullptr, kD, 3 * kD, kD, nullptr, nullptr}};
+    batched = wgrad_batch_eligible(probe, 5, T);
+  }
+  const bool overlap = src16 && g_overlap && !batched;
   Scratch kw = k;
   if (overlap) {
     const size_t half = (k.part_floats / 2) & ~(size_t)63;
@@ -692,6 +754,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     return fused::join_side(h, st, 2);
   };
   auto wgrad = [&](const float* dyp, int lddy, const float* xs, int ldx, int out_f, int in_f, float* dW, float* db) {
+    if (batched) {   // recorded; launched with the layer's other weight gradients (wgrad_batch below)
+      wj[n_wj++] = WgradJobH{reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, out_f, in_f, dW, db};
+      return (int)SCLDM_OK;
+    }
     return src16 ? linear_wgrad16(sw, reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, (int)T, out_f, in_f, dW, kw, db)
                  : linear_wgrad(st, dyp, lddy, xs, ldx, (int)T, out_f, in_f, dW, k, db);
   };
@@ -699,10 +765,11 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     return src16 ? linear_dgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, Wh, (int)T, out_f, in_f, dxp, in_f, acc, k)
                  : linear_dgrad(st, dyp, lddy, W, (int)T, out_f, in_f, dxp, in_f, acc, k);
   };
-  auto gate_bwd = [&](const float* yv, int g_off) {
-    if (src16) hipLaunchKernelGGL(gate_bwd_kernel<__bf16>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(k.dy), k.dmod);
-    else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, k.dy, k.dmod);
+  auto gate_bwd = [&](const float* yv, int g_off, float* dst) {
+    if (src16) hipLaunchKernelGGL(gate_bwd_kernel<__bf16>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(dst), k.dmod);
+    else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, dst, k.dmod);
   };
+  float* const dy_attn = batched ? k.dy2 : k.dy;
   // gradient-ready events (scldm_dit_train_set_grad_events): `st` is ordered after every kernel that writes the gradients an event
   // stands for when it is recorded.  Events the route cannot time individually fire at the end of the call.
   auto fire = [&](int kind, int layer) -> int {
@@ -720,13 +787,14 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
     if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
-    gate_bwd(a.y2, o + 5 * kD);
+    gate_bwd(a.y2, o + 5 * kD, k.dy);
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
     TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, kD, H, k.dhid, false));
-    if (src16) hipLaunchKernelGGL(swiglu_bwd_kernel<__bf16>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
-    else hipLaunchKernelGGL(swiglu_bwd_kernel<float>, dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, a.a, a.b, k.da, k.db, T * H, H, H);
+    if (src16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, reinterpret_cast<const __bf16*>(a.a),
+                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
+    else hipLaunchKernelGGL((swiglu_bwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, (const float*)a.a, (const float*)a.b, k.da, k.db, T * H, H, H);
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(k.da, Hl, a.h2, kD, H, kD, g->w1[l], nullptr));
@@ -736,17 +804,21 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
     TRY(join());   // (c_proj's weight gradient read dy)
-    gate_bwd(a.y1, o + 2 * kD);
+    gate_bwd(a.y1, o + 2 * kD, dy_attn);
     LAUNCH_CHECK();
     TRY(fork());
-    TRY(wgrad(k.dy, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
-    TRY(dgrad(k.dy, kD, w->proj_w[l], wh.proj_w, kD, kD, k.dao, false));
-    if (src16) TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
-    else TRY(attn_bwd(st, kD, kNH, n, a.qkv, k.dao, k.dqkv));
+    TRY(wgrad(dy_attn, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
+    TRY(dgrad(dy_attn, kD, w->proj_w[l], wh.proj_w, kD, kD, k.dao, false));
+    if (src16) TRY(attn_bwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
+    else TRY(attn_bwd(st, kD, kNH, n, (const float*)a.qkv, k.dao, k.dqkv));
     TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
     TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, k.dh, false));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
+    if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
+      TRY(wgrad_batch(st, wj, n_wj, T));
+      n_wj = 0;
+    }
   }
   TRY(join());
   if (!use_fused) TRY(fire(SCLDM_GRAD_LAYER, 0));

@@ -514,3 +514,37 @@ def test_full_depth_bf16_training_gradients_close_to_fp32_oracle(n_embed, n_head
             bad[name] = e
     print(f"[parity] 24-layer bf16 training, n_embed {n_embed}, {n} cells: pred rel-L2 {e_pred:.2e}, worst gradient rel-L2 {worst:.2e}")
     assert e_pred < 3e-2 and not bad, (e_pred, bad)
+
+
+def test_batched_weight_gradients_of_a_dit_l_layer(monkeypatch):
+    """DiT-L width, 2 layers, 130 cells (2 080 tokens: the batched route needs >= 2 048): the five weight gradients of a layer
+    as ONE launch of 256 x 256 tiles without split-K (bgemm256_batch_kernel) against the per-product split-K launches
+    (SCLDM_WGRAD_BATCH=0) - same operands, different summation order - and against autograd over the fp32 oracle."""
+    vocab = {"cell_line": 4, "gene": 2024}
+    n = 130
+    gen = torch.Generator().manual_seed(77)
+    x1, x0 = torch.randn(n, 16, 16, generator=gen), torch.randn(n, 16, 16, generator=gen)
+    t = torch.rand(n, generator=gen)
+    cond = {k: torch.randint(0, v + 1, (n,), generator=gen) for k, v in vocab.items()}
+    got = {}
+    for batch in (True, False):
+        monkeypatch.setenv("SCLDM_WGRAD_BATCH", "1" if batch else "0")
+        m, sd, cfg = build(vocab, "joint", 2, 96, n_embed=1024, n_head=16)
+        sc = 0.5
+        sd = {k: (v * sc if v.dim() == 2 and v.shape[1] == 1024 else v) for k, v in sd.items()}
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda()
+        m.precision = "bf16"
+        hip_training_step(m, x1, x0, t, cond)
+        got[batch] = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters() if p.grad is not None}
+    loss, pred, grads, _ = training_grads(sd, cfg, x1, x0, t, cond)
+    bad = {}
+    for name, g in got[True].items():
+        ref = grads[name].double()
+        e = float((g - ref).norm() / ref.norm())
+        e2 = float((g - got[False][name]).norm() / got[False][name].norm())
+        if not (e < 3e-2 and e2 < 1e-3):
+            bad[name] = (e, e2)
+    assert not bad, bad
+    main = [k for k in got[True] if k.endswith(("attn.c_attn.weight", "attn.c_proj.weight", "mlp.w1.weight", "mlp.w2.weight", "mlp.c_proj.weight"))]
+    assert any(not torch.equal(got[True][k], got[False][k]) for k in main)       # the switch selects a different code path
