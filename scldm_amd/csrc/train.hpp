@@ -671,81 +671,86 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   }
 }
 
-// Backward of ln_mod_fwd for one sample per workgroup (4 waves x 4 tokens):
+// Backward of ln_mod_fwd for one sample per workgroup (8 waves x 2 tokens):
 //   g = dh * (1 + scale);  dx (+)= rstd * (g - mean_f(g) - xhat * mean_f(g * xhat))
 //   dscale[b] = sum_t dh * xhat;  dshift[b] = sum_t dh      (written to dmod row b at the same column offsets)
+// Round 3: HBM-bound by design (reads dh, x, dx; writes dx: 16 B per element) but it ran at 1.9 TB/s - four waves walking four
+// tokens each, every token's loads issued only after the previous token's wave reductions.  Now eight waves, and a wave requests
+// BOTH its tokens' rows (and the old dx when accumulating) before any arithmetic.
+constexpr int kLnBwdWaves = 8, kLnBwdTok = kS / kLnBwdWaves;
 template <int NQ>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+__global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ stats, const float* __restrict__ mod,
                                                          long mod_stride, int sc_off, int sh_off, float* __restrict__ dx,
                                                          int accumulate_dx, float* __restrict__ dmod) {
-  __shared__ f32x4 red[2][4][64];
-  constexpr int D = NQ * 256, nq = NQ, kMaxDQ = NQ;
+  __shared__ f32x4 red[2][kLnBwdWaves][64];
+  constexpr int D = NQ * 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long b = blockIdx.x;
-  f32x4 sc[kMaxDQ], dsc[kMaxDQ], dsh[kMaxDQ];
+  f32x4 sc[NQ], dsc[NQ], dsh[NQ];
 #pragma unroll
-  for (int q = 0; q < kMaxDQ; ++q)
-    if (q < nq) {
-      sc[q] = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + sc_off + q * 256 + lane * 4);
-      dsc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      dsh[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < NQ; ++q) {
+    sc[q] = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + sc_off + q * 256 + lane * 4);
+    dsc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dsh[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 xv[kLnBwdTok][NQ], dv[kLnBwdTok][NQ], ov[kLnBwdTok][NQ];
+  float mean[kLnBwdTok], rstd[kLnBwdTok];
+#pragma unroll
+  for (int tt = 0; tt < kLnBwdTok; ++tt) {
+    const long t = b * kS + wave * kLnBwdTok + tt;
+    mean[tt] = stats[t * 2];
+    rstd[tt] = stats[t * 2 + 1];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      xv[tt][q] = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
+      dv[tt][q] = *reinterpret_cast<const f32x4*>(dh + t * D + q * 256 + lane * 4);
+      if (accumulate_dx) ov[tt][q] = *reinterpret_cast<const f32x4*>(dx + t * D + q * 256 + lane * 4);
     }
-  for (int tt = 0; tt < 4; ++tt) {
-    const long t = b * kS + wave * 4 + tt;
-    const float mean = stats[t * 2], rstd = stats[t * 2 + 1];
-    f32x4 xh[kMaxDQ], g[kMaxDQ];
+  }
+#pragma unroll
+  for (int tt = 0; tt < kLnBwdTok; ++tt) {
+    const long t = b * kS + wave * kLnBwdTok + tt;
+    f32x4 xh[NQ], g[NQ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < kMaxDQ; ++q)
-      if (q < nq) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(dh + t * D + q * 256 + lane * 4);
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          xh[q][i] = (v[i] - mean) * rstd;
-          g[q][i] = d[i] * (1.0f + sc[q][i]);
-          s1 += g[q][i];
-          s2 += g[q][i] * xh[q][i];
-          dsc[q][i] += d[i] * xh[q][i];
-          dsh[q][i] += d[i];
-        }
+      for (int i = 0; i < 4; ++i) {
+        xh[q][i] = (xv[tt][q][i] - mean[tt]) * rstd[tt];
+        g[q][i] = dv[tt][q][i] * (1.0f + sc[q][i]);
+        s1 += g[q][i];
+        s2 += g[q][i] * xh[q][i];
+        dsc[q][i] += dv[tt][q][i] * xh[q][i];
+        dsh[q][i] += dv[tt][q][i];
       }
     s1 = wave_sum(s1) / (float)D;
     s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int q = 0; q < kMaxDQ; ++q)
-      if (q < nq) {
-        f32x4 o;
+    for (int q = 0; q < NQ; ++q) {
+      f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = rstd * (g[q][i] - s1 - xh[q][i] * s2);
-        float* p = dx + t * D + q * 256 + lane * 4;
-        if (accumulate_dx) {
-          const f32x4 old = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] += old[i];
-        }
-        *reinterpret_cast<f32x4*>(p) = o;
-      }
+      for (int i = 0; i < 4; ++i) o[i] = rstd[tt] * (g[q][i] - s1 - xh[q][i] * s2) + (accumulate_dx ? ov[tt][q][i] : 0.f);
+      *reinterpret_cast<f32x4*>(dx + t * D + q * 256 + lane * 4) = o;
+    }
   }
 #pragma unroll
-  for (int q = 0; q < kMaxDQ; ++q)
-    if (q < nq) {   // nq is workgroup-uniform: the barriers are reached by every thread
-      red[0][wave][lane] = dsc[q];
-      red[1][wave][lane] = dsh[q];
-      __syncthreads();
-      if (wave < 2) {
-        f32x4 s = red[wave][0][lane];
+  for (int q = 0; q < NQ; ++q) {
+    red[0][wave][lane] = dsc[q];
+    red[1][wave][lane] = dsh[q];
+    __syncthreads();
+    if (wave < 2) {
+      f32x4 s = red[wave][0][lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-          const f32x4 o = red[wave][w][lane];
+      for (int w = 1; w < kLnBwdWaves; ++w) {
+        const f32x4 o = red[wave][w][lane];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) s[i] += o[i];
-        }
-        *reinterpret_cast<f32x4*>(dmod + b * mod_stride + (wave == 0 ? sc_off : sh_off) + q * 256 + lane * 4) = s;
+        for (int i = 0; i < 4; ++i) s[i] += o[i];
       }
-      __syncthreads();
+      *reinterpret_cast<f32x4*>(dmod + b * mod_stride + (wave == 0 ? sc_off : sh_off) + q * 256 + lane * 4) = s;
     }
+    __syncthreads();
+  }
 }
 
 // x_out = x + gate[b] * y
@@ -786,28 +791,60 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // hid = silu(a) * b   (MLP.forward, layers.py:172-174).  a, b: [tokens][H]; the output rows have ldo >= H elements, and the
 // thread of a row's last element also zeroes the row's padding (bf16 rows are padded to 16-byte multiples for bgemm_kernel,
 // whose last k chunk reads the padding of both operands)
+// (round 3: FOUR consecutive hidden units per thread - H % 4 == 0 is a requirement of the training path - so one 8- / 16-byte load
+// and store per array and one 32-bit index division per four elements; the scalar form spent its time in a 64-bit division per element)
+template <typename T>
+__device__ __forceinline__ f32x4 load4f(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4f(T* p, const f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+}
 template <typename TO = float, typename TI = float>
 __global__ void swiglu_fwd_kernel(const TI* __restrict__ a, const TI* __restrict__ b, TO* __restrict__ hid, long count, int H, int ldo) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-    const float v = (float)a[i];
-    const long t = i / H;
-    const int c = (int)(i - t * H);
-    hid[t * ldo + c] = (TO)(v * sigmoid_f(v) * (float)b[i]);
-    if (c == H - 1)
-      for (int p = H; p < ldo; ++p) hid[t * ldo + p] = (TO)0.f;
+  const unsigned H4 = (unsigned)H / 4u, n4 = (unsigned)(count / 4);
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+    const unsigned t = i4 / H4, c = (i4 - t * H4) * 4u;
+    const f32x4 av = load4f(a + (size_t)i4 * 4), bv = load4f(b + (size_t)i4 * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = av[e] * sigmoid_f(av[e]) * bv[e];
+    store4f(hid + (size_t)t * ldo + c, o);
+    if (c + 4 == (unsigned)H)
+      for (int p = H; p < ldo; ++p) hid[(size_t)t * ldo + p] = (TO)0.f;
   }
 }
 template <typename TO = float, typename TI = float>
 __global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const TI* __restrict__ a, const TI* __restrict__ b,
                                   TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
-    const float v = (float)a[i], s = sigmoid_f(v), d = dhid[i];
-    const long t = i / H;
-    const int c = (int)(i - t * H);
-    da[t * ldo + c] = (TO)(d * (float)b[i] * s * (1.0f + v * (1.0f - s)));
-    db[t * ldo + c] = (TO)(d * v * s);
-    if (c == H - 1)
-      for (int p = H; p < ldo; ++p) da[t * ldo + p] = db[t * ldo + p] = (TO)0.f;
+  const unsigned H4 = (unsigned)H / 4u, n4 = (unsigned)(count / 4);
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
+    const unsigned t = i4 / H4, c = (i4 - t * H4) * 4u;
+    const f32x4 av = load4f(a + (size_t)i4 * 4), bv = load4f(b + (size_t)i4 * 4), dv = load4f(dhid + (size_t)i4 * 4);
+    f32x4 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float s = sigmoid_f(av[e]);
+      oa[e] = dv[e] * bv[e] * s * (1.0f + av[e] * (1.0f - s));
+      ob[e] = dv[e] * av[e] * s;
+    }
+    store4f(da + (size_t)t * ldo + c, oa);
+    store4f(db + (size_t)t * ldo + c, ob);
+    if (c + 4 == (unsigned)H)
+      for (int p = H; p < ldo; ++p) da[(size_t)t * ldo + p] = db[(size_t)t * ldo + p] = (TO)0.f;
   }
 }
 

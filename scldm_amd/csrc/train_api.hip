@@ -463,7 +463,7 @@ int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int
 }
 int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const float* stats, const float* mod, long mw, int sc_off,
            int sh_off, float* dx, int accumulate, float* dmod) {
-#define CALL(NQ) hipLaunchKernelGGL(ln_mod_bwd_kernel<NQ>, dim3(n), dim3(256), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
+#define CALL(NQ) hipLaunchKernelGGL(ln_mod_bwd_kernel<NQ>, dim3(n), dim3(64 * kLnBwdWaves), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
   SCLDM_NQ_SWITCH(D / 256, CALL)
 #undef CALL
   LAUNCH_CHECK();
