@@ -32,6 +32,7 @@ struct BGemmArgs {
   int accumulate;    // C += (only without split-K)
   float* rowsum;     // optional, MC A only: rowsum[z*M + m] = sum_k A(m,k) of this split (first column of tiles)
   int tiles_m, tiles_n, per_xcd;
+  int n_blocks;      // logical workgroups of this product (a persistent launch walks them with a grid stride; 0: one per launched workgroup)
 };
 
 constexpr int kGK = 64;              // k per stage
@@ -428,8 +429,20 @@ __device__ __forceinline__ void bgemm256_body(const BGemmArgs& g, const int bid)
     }
 }
 
+// Persistent form (n_blocks > 0): the launch has one workgroup per CU (a multiple of 8, so a workgroup keeps its XCD) and each walks
+// the logical workgroups bid = blockIdx.x, blockIdx.x + gridDim.x, ... - a 256 x 256 tile of a K = 1 024 product is only 16 stages, and
+// a fresh workgroup per tile pays launch + first-load latency + store drain each time with nothing else resident on the CU to hide it.
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) { bgemm256_body<A_KC, B_KC>(g, (int)blockIdx.x); }
+__global__ __launch_bounds__(512) void bgemm256_kernel(const BGemmArgs g) {
+  if (g.n_blocks <= 0) {
+    bgemm256_body<A_KC, B_KC>(g, (int)blockIdx.x);
+    return;
+  }
+  for (int bid = blockIdx.x; bid < g.n_blocks; bid += gridDim.x) {
+    bgemm256_body<A_KC, B_KC>(g, bid);
+    lds_barrier();   // the next tile's first stage overwrites the LDS buffers (and the row-sum scratch) this one read last
+  }
+}
 
 // Several independent products in ONE launch (the five weight gradients of a DiT-L layer: 48 + 16 + 3 x 44 = 196 tiles of 256 x 256
 // fill the chip WITHOUT split-K - no partial tiles, no reduction kernels, one launch instead of twelve).  Workgroups

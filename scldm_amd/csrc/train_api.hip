@@ -193,6 +193,7 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 // whenever both extents reach 256 (tests: ragged tiles at small sizes)
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
+const bool g_bgemm_persist = [] { const char* e = getenv("SCLDM_BGEMM_PERSIST"); return e && atoi(e) != 0; }();   // A/B switch (read at load)
 
 template <bool BIG, bool A_KC, bool B_KC>
 int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
@@ -258,6 +259,10 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
   }
   int rc;
+  if (big && g_bgemm_persist && splits == 1 && blocks > 256) {   // persistent: one workgroup per CU walks the tiles (see bgemm256_kernel)
+    g.n_blocks = blocks;
+    blocks = 256;
+  }
   if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
                      : launch_bgemm<true, false, false>(g, blocks, st);
   else rc = a_kc ? (b_kc ? launch_bgemm<false, true, true>(g, blocks, st) : launch_bgemm<false, true, false>(g, blocks, st))
