@@ -168,7 +168,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_plan, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->d_cast_jobs, h->ada16, h->ada_ball};
+                  h->b_proj, h->label_err, h->d_plan, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->wt16, h->d_cast_jobs, h->ada16, h->ada_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);

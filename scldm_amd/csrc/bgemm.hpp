@@ -465,12 +465,55 @@ __global__ __launch_bounds__(512) void bgemm256_batch_kernel(const BGemmBatch b)
 // dst[r][c] = bf16(src[r][c]), rows of the copy padded with zeros to ldd elements, one job per blockIdx.y (the per-step bf16
 // copies of the layers' weight matrices).  cols % 4 == 0.
 // raw != 0: plain fp32 copy of rows * cols floats to (float*)dst (the stacked adaLN bias).
-struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd, raw; };
-__global__ void cast_jobs_kernel(const CastJob* __restrict__ jobs, int n_jobs) {
+// dst_t (optional): ALSO the transposed copy dst_t[c][r] = bf16(src[r][c]), rows padded with zeros to ldt elements - the operand of
+// a data gradient dY W as a k-contiguous B (W^T[in][out]), so that it runs on the same (KC, KC) kernels as the forward.  The source
+// is read once: 64 x 64 tiles through LDS, both copies written in 8-byte pieces along their own contiguous dimension.
+struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd, raw; __bf16* dst_t; int ldt; };
+__global__ __launch_bounds__(256) void cast_jobs_kernel(const CastJob* __restrict__ jobs, int n_jobs) {
   const CastJob j = jobs[blockIdx.y];
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  if (j.dst_t) {
+    __shared__ __bf16 tile[64][64 + 4];   // 136-byte rows: the 8-byte pieces of a transposed read walk 4 rows
+    const int tr = (j.rows + 63) / 64, tc = (j.cols + 63) / 64;
+    const int t = threadIdx.x;
+    for (int id = blockIdx.x; id < tr * tc; id += gridDim.x) {
+      const int r0 = (id / tc) * 64, c0 = (id % tc) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + (t >> 4) + 16 * i, c = c0 + (t & 15) * 4;
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)0.f;
+        if (r < j.rows && c < j.cols) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(j.src + (long)r * j.cols + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4_t*>(j.dst + (long)r * j.ldd + c) = o;
+          if (c + 4 == j.cols)
+            for (int p = j.cols; p < j.ldd; ++p) j.dst[(long)r * j.ldd + p] = (__bf16)0.f;
+        }
+        *reinterpret_cast<bf16x4_t*>(&tile[(t >> 4) + 16 * i][(t & 15) * 4]) = o;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = (t >> 4) + 16 * i, r = (t & 15) * 4;   // dst_t row c0 + c, elements r0 + r .. + 3
+        if (c0 + c < j.cols) {
+          __bf16* d = j.dst_t + (long)(c0 + c) * j.ldt + r0 + r;
+          if (r0 + r + 3 < j.ldt) {   // (ldt % 4 == 0: a piece is either inside the padded row or outside it)
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = tile[r + e][c];   // (rows beyond j.rows hold zeros: the padding of the transposed rows)
+            *reinterpret_cast<bf16x4_t*>(d) = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int cq = j.cols / 4;
   const long total = (long)j.rows * cq;
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / cq;
     const int c = (int)(i - r * cq) * 4;

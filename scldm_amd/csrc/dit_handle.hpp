@@ -59,6 +59,9 @@ struct scldm_dit {
   // generic training path with bf16 operands (train_api.hip, bgemm.hpp): per-step bf16 copies of the layers' five weight matrices
   void* w16;                // [layer][attn_w | proj_w | w1 | w2 | cproj] bf16, allocated on first use
   size_t w16_layer_elems;
+  void* wt16;               // the same matrices transposed ([in][out], rows padded to a multiple of 8): k-contiguous operands of the data gradients
+  size_t wt16_layer_elems;
+  bool wt16_live;           // the current step's forward refreshed the transposed copies (large batches only)
   void* ada16;              // [mod_w][D] bf16: every adaLN Linear's weight stacked (one GEMM for all layers' modulation vectors)
   float* ada_ball;          // [mod_w] fp32: their biases, stacked
   void* d_cast_jobs;        // device CastJob table (rebuilt when the weights' device pointers change)

@@ -827,8 +827,8 @@ __global__ void swiglu_fwd_kernel(const TI* __restrict__ a, const TI* __restrict
       for (int p = H; p < ldo; ++p) hid[(size_t)t * ldo + p] = (TO)0.f;
   }
 }
-template <typename TO = float, typename TI = float>
-__global__ void swiglu_bwd_kernel(const float* __restrict__ dhid, const TI* __restrict__ a, const TI* __restrict__ b,
+template <typename TO = float, typename TI = float, typename TD = float>
+__global__ void swiglu_bwd_kernel(const TD* __restrict__ dhid, const TI* __restrict__ a, const TI* __restrict__ b,
                                   TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo) {
   const unsigned H4 = (unsigned)H / 4u, n4 = (unsigned)(count / 4);
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {

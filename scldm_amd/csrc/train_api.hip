@@ -9,6 +9,7 @@
 #include "dit_handle.hpp"
 #include "train.hpp"
 #include "bgemm.hpp"
+#include "bgemm8.hpp"
 #include "train_fused.hpp"
 
 using namespace scldm;
@@ -193,6 +194,7 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 // whenever both extents reach 256 (tests: ragged tiles at small sizes)
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
+const bool g_bgemm8 = [] { const char* e = getenv("SCLDM_BGEMM8"); return !e || atoi(e) != 0; }();   // LDS-DMA phase-split kernel for (KC, KC) (A/B switch)
 const bool g_bgemm_persist = [] { const char* e = getenv("SCLDM_BGEMM_PERSIST"); return e && atoi(e) != 0; }();   // A/B switch (read at load)
 
 template <bool BIG, bool A_KC, bool B_KC>
@@ -209,6 +211,27 @@ int launch_bgemm(const BGemmArgs& g, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(BIG ? 512 : 256), smem, st, g);
   LAUNCH_CHECK();
   return SCLDM_OK;
+}
+
+template <int EPI>
+int launch_bgemm8_t(const BGemmArgs& g, int blocks, hipStream_t st) {
+  static std::atomic<bool> attr_set[kMaxDevices];
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm8Lds));
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(bgemm8_kernel<EPI>, dim3(blocks), dim3(512), kBGemm8Lds, st, g);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+// vector epilogue (transposed accumulator blocks) unless the 32 rows of a store would all fall on one memory channel (fp32 rows
+// that are a multiple of 4 KB apart) or the output is not aligned for 16-byte stores; bf16 results: rows of N % 4 == 0 elements (8-byte stores)
+int launch_bgemm8(const BGemmArgs& g, int blocks, hipStream_t st) {
+  const bool vec_ok = g.C16 ? (g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 7) == 0)
+                            : (g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.ldc * 4) % 4096 != 0);
+  return vec_ok ? launch_bgemm8_t<0>(g, blocks, st) : launch_bgemm8_t<1024>(g, blocks, st);
 }
 
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
@@ -259,11 +282,13 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
   }
   int rc;
-  if (big && g_bgemm_persist && splits == 1 && blocks > 256) {   // persistent: one workgroup per CU walks the tiles (see bgemm256_kernel)
+  const bool use8 = big && a_kc && b_kc && splits == 1 && g_bgemm8;   // LDS-DMA kernel (bgemm8.hpp)
+  if (big && !use8 && g_bgemm_persist && splits == 1 && blocks > 256) {   // persistent: one workgroup per CU walks the tiles (see bgemm256_kernel)
     g.n_blocks = blocks;
     blocks = 256;
   }
-  if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
+  if (use8) rc = launch_bgemm8(g, blocks, st);
+  else if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
                      : launch_bgemm<true, false, false>(g, blocks, st);
   else rc = a_kc ? (b_kc ? launch_bgemm<false, true, true>(g, blocks, st) : launch_bgemm<false, true, false>(g, blocks, st))
                  : launch_bgemm<false, false, false>(g, blocks, st);
@@ -348,15 +373,33 @@ W16 w16_layer(const scldm_dit* h, int l) {
   const __bf16* base = reinterpret_cast<const __bf16*>(h->w16) + (size_t)l * h->w16_layer_elems;
   return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + H * D, base + 4 * D * D + 2 * H * D};
 }
+// transposed copies W^T[in][out] (row = input feature, `out` rounded up to a multiple of 8 elements per row, zero padded):
+// [layer][attn_w^T (D x 3D) | proj_w^T (D x D) | w1^T (D x hidden16) | w2^T (D x hidden16) | cproj^T (hidden x D)]
+const bool g_dhid16 = [] { const char* e = getenv("SCLDM_DHID16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_dgrad_wt = [] { const char* e = getenv("SCLDM_DGRAD_WT"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+W16 wt16_layer(const scldm_dit* h, int l) {
+  const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = (H + 7) / 8 * 8;
+  const __bf16* base = reinterpret_cast<const __bf16*>(h->wt16) + (size_t)l * h->wt16_layer_elems;
+  return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + D * Hp, base + 4 * D * D + 2 * D * Hp};
+}
 // allocations and the cast-job table of the bf16 weight mirror (synchronises `st` when the table is re-uploaded): everything
 // that is not a kernel launch.  scldm_dit_train_prepare runs it ahead of the first step; refresh_w16 falls back to it when
 // the parameters' device pointers are not the ones it was prepared for.
-int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+// transposed copies only where the data gradients run on 256-tiles (>= 224 tiles for a 1 024-wide output: ~900 cells): below that the
+// (KC, MC) 128-tile products are as fast and the extra 0.2 ms of the transposing cast is a loss (24.6 -> 25.0 ms at 256 cells)
+bool want_wt(const scldm_dit* h, int n) {
+  return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= 224);   // (2: the tests force 256-tiles)
+}
+int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
   const int L = h->cfg.n_layer;
   if (L == 0) return SCLDM_OK;
   h->w16_layer_elems = 4 * D * D + 2 * H * D + Hp * D;
   if (!h->w16) HIP_TRY(hipMalloc(&h->w16, (size_t)L * h->w16_layer_elems * sizeof(__bf16)));
+  h->wt16_layer_elems = 4 * D * D + 2 * D * Hp + H * D;
+  const bool wt = want_wt(h, n);
+  if (wt && !h->wt16) HIP_TRY(hipMalloc(&h->wt16, (size_t)L * h->wt16_layer_elems * sizeof(__bf16)));
+  h->wt16_live = wt;
   if (!h->ada16) HIP_TRY(hipMalloc(&h->ada16, (size_t)h->mod_w * D * sizeof(__bf16)));
   if (!h->ada_ball) HIP_TRY(hipMalloc(&h->ada_ball, (size_t)h->mod_w * sizeof(float)));
   std::vector<const void*> key;
@@ -364,22 +407,25 @@ int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
     for (const float* p : {w->attn_w[l], w->proj_w[l], w->w1[l], w->w2[l], w->cproj[l], w->ada_w[l], w->ada_b[l]}) key.push_back(p);
   key.push_back(w->fin_ada_w);
   key.push_back(w->fin_ada_b);
+  key.push_back(wt ? h->wt16 : nullptr);
   if (key != h->w16_key || !h->d_cast_jobs) {
     std::vector<CastJob> jobs;
     for (int l = 0; l < L; ++l) {
       const W16 d = w16_layer(h, l);
-      jobs.push_back(CastJob{w->attn_w[l], const_cast<__bf16*>(d.attn_w), (int)(3 * D), (int)D, (int)D, 0});
-      jobs.push_back(CastJob{w->proj_w[l], const_cast<__bf16*>(d.proj_w), (int)D, (int)D, (int)D, 0});
-      jobs.push_back(CastJob{w->w1[l], const_cast<__bf16*>(d.w1), (int)H, (int)D, (int)D, 0});
-      jobs.push_back(CastJob{w->w2[l], const_cast<__bf16*>(d.w2), (int)H, (int)D, (int)D, 0});
-      jobs.push_back(CastJob{w->cproj[l], const_cast<__bf16*>(d.cproj), (int)D, (int)H, (int)Hp, 0});
+      const W16 dt = wt ? wt16_layer(h, l) : W16{};
+      auto tp = [](const __bf16* p) { return const_cast<__bf16*>(p); };
+      jobs.push_back(CastJob{w->attn_w[l], tp(d.attn_w), (int)(3 * D), (int)D, (int)D, 0, tp(dt.attn_w), (int)(3 * D)});
+      jobs.push_back(CastJob{w->proj_w[l], tp(d.proj_w), (int)D, (int)D, (int)D, 0, tp(dt.proj_w), (int)D});
+      jobs.push_back(CastJob{w->w1[l], tp(d.w1), (int)H, (int)D, (int)D, 0, tp(dt.w1), (int)Hp});
+      jobs.push_back(CastJob{w->w2[l], tp(d.w2), (int)H, (int)D, (int)D, 0, tp(dt.w2), (int)Hp});
+      jobs.push_back(CastJob{w->cproj[l], tp(d.cproj), (int)D, (int)H, (int)Hp, 0, tp(dt.cproj), (int)D});
     }
     // every adaLN Linear stacked in the order of the modulation vector's columns: layer l rows [6 D l, 6 D (l+1)), then the final layer's 2 D
     __bf16* a16 = reinterpret_cast<__bf16*>(h->ada16);
     for (int l = 0; l <= L; ++l) {
       const int rows = (int)(l < L ? 6 * D : 2 * D);
-      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0});
-      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1});
+      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0, nullptr, 0});
+      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1, nullptr, 0});
     }
     if (!h->d_cast_jobs) HIP_TRY(hipMalloc(&h->d_cast_jobs, jobs.size() * sizeof(CastJob)));
     // (synchronous copy of a pageable vector: only when the parameters' device pointers changed)
@@ -390,9 +436,9 @@ int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   }
   return SCLDM_OK;
 }
-int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st) {
   if (h->cfg.n_layer == 0) return SCLDM_OK;
-  int rc = prepare_w16(h, w, st);   // no-op (a pointer-list compare) once prepared for these parameters
+  int rc = prepare_w16(h, w, n, st);   // no-op (a pointer-list compare) once prepared for these parameters
   if (rc != SCLDM_OK) return rc;
   hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, h->n_cast_jobs), dim3(256), 0, st, (const CastJob*)h->d_cast_jobs, h->n_cast_jobs);
   LAUNCH_CHECK();
@@ -408,8 +454,11 @@ int linear_fwd16(hipStream_t st, const __bf16* x, int ldx, const __bf16* W, int 
                y16 ? reinterpret_cast<__bf16*>(y) : nullptr);
 }
 int linear_dgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* W, int rows, int out, int in, float* dx, long lddx,
-                   bool accumulate, Scratch& s) {
-  return bgemm(st, dy, lddy, true, W, (in + 7) / 8 * 8, false, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats);
+                   bool accumulate, Scratch& s, const __bf16* WT = nullptr, __bf16* dx16 = nullptr) {
+  // dx16: the gradient is stored as a dense bf16 array (rows, in) instead of fp32 (dhid: only the SwiGLU backward reads it)
+  // with the transposed copy W^T[in][out] the product is (KC, KC) like a forward one: dx[t][i] = sum_o dy[t][o] W^T[i][o]
+  if (WT) return bgemm(st, dy, lddy, true, WT, (out + 7) / 8 * 8, true, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats, nullptr, dx16);
+  return bgemm(st, dy, lddy, true, W, (in + 7) / 8 * 8, false, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats, nullptr, dx16);
 }
 int linear_wgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* x, int ldx, int rows, int out, int in, float* dW, Scratch& s,
                    float* db = nullptr) {
@@ -543,7 +592,7 @@ extern "C" int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w,
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
   hipStream_t st = (hipStream_t)stream_;
   if (fused::eligible(h, n, precision)) return fused::prepare_tables(h, w, st);
-  if (src16_eligible(h, n, precision)) return prepare_w16(h, w, st);
+  if (src16_eligible(h, n, precision)) return prepare_w16(h, w, n, st);
   return SCLDM_OK;
 }
 
@@ -568,7 +617,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   const bool src16 = src16_eligible(h, n, precision);
   const int Hp = hidden16(h);
   const bool ada16 = ada16_eligible(h, n, precision);
-  if (src16) TRY(refresh_w16(h, w, st));
+  if (src16) TRY(refresh_w16(h, w, n, st));
   // conditioning: c = t_embedder(t) + sum class embeddings; every adaLN vector (layers.py:351-364,206-216,395-398)
   hipLaunchKernelGGL(t_freq_kernel, dim3(n), dim3(256), 0, st, t, n, s.freq);
   LAUNCH_CHECK();
@@ -766,8 +815,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     return src16 ? linear_wgrad16(sw, reinterpret_cast<const __bf16*>(dyp), lddy, reinterpret_cast<const __bf16*>(xs), ldx, (int)T, out_f, in_f, dW, kw, db)
                  : linear_wgrad(st, dyp, lddy, xs, ldx, (int)T, out_f, in_f, dW, k, db);
   };
-  auto dgrad = [&](const float* dyp, int lddy, const float* W, const __bf16* Wh, int out_f, int in_f, float* dxp, bool acc) {
-    return src16 ? linear_dgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, Wh, (int)T, out_f, in_f, dxp, in_f, acc, k)
+  auto dgrad = [&](const float* dyp, int lddy, const float* W, const __bf16* Wh, const __bf16* WhT, int out_f, int in_f, float* dxp, bool acc,
+                   bool out16 = false) {
+    return src16 ? linear_dgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, Wh, (int)T, out_f, in_f, dxp, in_f, acc, k, WhT,
+                                  out16 ? reinterpret_cast<__bf16*>(dxp) : nullptr)
                  : linear_dgrad(st, dyp, lddy, W, (int)T, out_f, in_f, dxp, in_f, acc, k);
   };
   auto gate_bwd = [&](const float* yv, int g_off, float* dst) {
@@ -789,6 +840,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
+    const W16 wt = (src16 && h->wt16_live) ? wt16_layer(h, l) : W16{};
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
     if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
@@ -796,16 +848,18 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
-    TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, kD, H, k.dhid, false));
-    if (src16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, reinterpret_cast<const __bf16*>(a.a),
+    TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
+    if (src16 && g_dhid16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(k.dhid), reinterpret_cast<const __bf16*>(a.a),
+                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
+    else if (src16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, reinterpret_cast<const __bf16*>(a.a),
                                   reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
     else hipLaunchKernelGGL((swiglu_bwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, (const float*)a.a, (const float*)a.b, k.da, k.db, T * H, H, H);
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(k.da, Hl, a.h2, kD, H, kD, g->w1[l], nullptr));
     TRY(wgrad(k.db, Hl, a.h2, kD, H, kD, g->w2[l], nullptr));
-    TRY(dgrad(k.da, Hl, w->w1[l], wh.w1, H, kD, k.dh, false));
-    TRY(dgrad(k.db, Hl, w->w2[l], wh.w2, H, kD, k.dh, true));
+    TRY(dgrad(k.da, Hl, w->w1[l], wh.w1, wt.w1, H, kD, k.dh, false));
+    TRY(dgrad(k.db, Hl, w->w2[l], wh.w2, wt.w2, H, kD, k.dh, true));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
     TRY(join());   // (c_proj's weight gradient read dy)
@@ -813,12 +867,12 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(dy_attn, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
-    TRY(dgrad(dy_attn, kD, w->proj_w[l], wh.proj_w, kD, kD, k.dao, false));
+    TRY(dgrad(dy_attn, kD, w->proj_w[l], wh.proj_w, wt.proj_w, kD, kD, k.dao, false));
     if (src16) TRY(attn_bwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
     else TRY(attn_bwd(st, kD, kNH, n, (const float*)a.qkv, k.dao, k.dqkv));
     TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
-    TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, k.dh, false));
+    TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
     if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
       TRY(wgrad_batch(st, wj, n_wj, T));
