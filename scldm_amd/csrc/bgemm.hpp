@@ -32,6 +32,7 @@ struct BGemmArgs {
   int accumulate;    // C += (only without split-K)
   float* rowsum;     // optional, MC A only: rowsum[z*M + m] = sum_k A(m,k) of this split (first column of tiles)
   int tiles_m, tiles_n, per_xcd;
+  int rowsum_split;  // bgemm8 only: tile column tn sums the stages t % tiles_n == tn and writes rowsum[tn * M + m] (the host adds the tiles_n partials)
   int n_blocks;      // logical workgroups of this product (a persistent launch walks them with a grid stride; 0: one per launched workgroup)
 };
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ void g8_lds_dma16(bg_u32x4 rsrc, unsigned voff, unsig
 // 64 (result stays exact): the staging unit of a phase is issued between its MFMAs instead of ahead of its fragment reads;
 // 128 (exact): two phases of 16 MFMAs per stage; 256 (exact): bf16 results stored element by element; 1024 (exact): untransposed
 // accumulator blocks with the element-wise epilogue.
-template <int PROBE = 0>
+template <int PROBE = 0, bool A_KC = true, bool B_KC = true>
 __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char bgemm_smem[];
   int tile_id = (bid & 7) * g.per_xcd + (bid >> 3);   // (no split-K on this kernel; same XCD-aware numbering as bgemm256_body)
@@ -80,33 +80,46 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   const bg_u32x4 ra = make_rsrc(g.A), rb = make_rsrc(g.B);
   const unsigned smem0 = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<unsigned long long>(bgemm_smem));
 
-  // ---- staging: thread -> (unit row j = 64 q + tid / 8, slot tid % 8); source chunk c = slot ^ ((j >> 1) & 7) ----------------
+  // ---- staging ------------------------------------------------------------------------------------------------------------------
+  // KC operand: unit image [128 operand rows][64 k] (128-byte rows).  thread -> (unit row j = 64 q + tid / 8, slot tid % 8);
+  //   source chunk c = slot ^ ((j >> 1) & 7).
+  // MC operand (contiguous along m: both operands of a weight gradient): unit image [64 k][128 operand columns] (256-byte rows).
+  //   thread -> (k row 32 q + tid / 16, slot tid % 16); the 64-byte segments of a row are XORed with (k row & 3) - the four k rows
+  //   of a ds_read_b64_tr_b16 lane group then cover all 64 banks (what the 576-byte rows of bgemm256_kernel do by padding):
+  //   source chunk c = slot ^ ((k row & 3) << 2).  Chunk c holds 8 consecutive m: A unit: wave row wm' = c / 8, m = 128 wm' + 64 sub
+  //   + 8 (c % 8); B unit: wn' = c / 4, n = 64 wn' + 32 sub + 8 (c % 4).
   const int c_src = (tid & 7) ^ ((tid >> 4) & 7);
-  const unsigned voff_a = (unsigned)(tid >> 3) * (unsigned)g.lda * 2u + (unsigned)c_src * 16u;
+  const int c_mc = (tid & 15) ^ (((tid >> 4) & 3) << 2);
   const int brow = (tid >> 8) * 64 + ((tid >> 3) & 31);
-  const unsigned voff_b = (unsigned)brow * (unsigned)g.ldb * 2u + (unsigned)c_src * 16u;
-  unsigned ok_a = 0, ok_b = 0;   // bit 2 sub + q: the row this thread stages for (sub, q) exists
+  const int a_mc_m = (c_mc >> 3) * 128 + (c_mc & 7) * 8, b_mc_n = (c_mc >> 2) * 64 + (c_mc & 3) * 8;
+  const unsigned voff_a = A_KC ? (unsigned)(tid >> 3) * (unsigned)g.lda * 2u + (unsigned)c_src * 16u
+                               : (unsigned)(tid >> 4) * (unsigned)g.lda * 2u + (unsigned)a_mc_m * 2u;
+  const unsigned voff_b = B_KC ? (unsigned)brow * (unsigned)g.ldb * 2u + (unsigned)c_src * 16u
+                               : (unsigned)(tid >> 4) * (unsigned)g.ldb * 2u + (unsigned)b_mc_n * 2u;
+  unsigned ok_a = 0, ok_b = 0;   // bit 2 sub + q: the row (KC) / 8-column chunk (MC: same for both q) this thread stages for (sub, q) exists
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      ok_a |= (unsigned)(m0 + q * 128 + sub * 64 + (tid >> 3) < g.M) << (2 * sub + q);
-      ok_b |= (unsigned)(n0 + q * 128 + sub * 32 + brow < g.N) << (2 * sub + q);
+      ok_a |= (unsigned)(A_KC ? m0 + q * 128 + sub * 64 + (tid >> 3) < g.M : m0 + sub * 64 + a_mc_m < g.M) << (2 * sub + q);
+      ok_b |= (unsigned)(B_KC ? n0 + q * 128 + sub * 32 + brow < g.N : n0 + sub * 32 + b_mc_n < g.N) << (2 * sub + q);
     }
   // unit u: 0 = B sub 0, 1 = A sub 0, 2 = B sub 1, 3 = A sub 1 (the order the phases consume them)
   auto issue = [&](auto u_tag, int tt) {
     constexpr int U = decltype(u_tag)::value;
     constexpr int IS_A = U & 1, SUB = U >> 1;
+    constexpr bool KC = IS_A ? A_KC : B_KC;
     const int stage = tt & 1;
     const int k0 = tt * kGK;
-    const bool k_ok = tt < n_tiles && k0 + c_src * 8 < g.K;
     if ((PROBE & 1) && tt >= 2) return;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+      const bool k_ok = tt < n_tiles && (KC ? k0 + c_src * 8 < g.K : k0 + q * 32 + (tid >> 4) < g.K);
       const bool ok = k_ok && (((IS_A ? ok_a : ok_b) >> (2 * SUB + q)) & 1u);
       const unsigned voff = ok ? (IS_A ? voff_a : voff_b) : kOob;
-      const unsigned row0 = IS_A ? (unsigned)(m0 + q * 128 + SUB * 64) : (unsigned)(n0 + q * 128 + SUB * 32);
-      const unsigned soff = (row0 * (unsigned)(IS_A ? g.lda : g.ldb) + (unsigned)k0) * 2u;
+      const unsigned ld = (unsigned)(IS_A ? g.lda : g.ldb);
+      const unsigned row0 = IS_A ? (unsigned)(m0 + SUB * 64) : (unsigned)(n0 + SUB * 32);
+      const unsigned soff = KC ? ((row0 + q * 128u) * ld + (unsigned)k0) * 2u : ((unsigned)(k0 + q * 32) * ld + row0) * 2u;
       const unsigned dst = smem0 + (unsigned)(((IS_A * 2 + SUB) * 2) * kG8Unit) + (unsigned)stage * kG8Unit + q * 8192u + (unsigned)wave * 1024u;
       g8_lds_dma16(IS_A ? ra : rb, voff, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane(dst));
     }
@@ -116,19 +129,73 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   using U2 = std::integral_constant<int, 2>;
   using U3 = std::integral_constant<int, 3>;
 
-  // ---- fragment reads: lane -> row lane % 32 of a 32-row block, chunk 2 ks + lane / 32, swizzled ----------------------------
+  // ---- fragment reads ---------------------------------------------------------------------------------------------------------
+  // KC: lane -> row lane % 32 of a 32-row block, chunk 2 ks + lane / 32, swizzled (ds_read_b128).
+  // MC: two ds_read_b64_tr_b16 per fragment (k rows 16 ks + 8 (g / 2) + i / 4 and + 4, g = lane / 16, i = lane % 16; 4 consecutive
+  //     columns at 16 (g % 2) + 4 (i % 4) of the block's 32): segment (block's 64-byte segment) ^ (i / 4), see the staging note.
   const char* rd[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
     rd[ks] = bgemm_smem + (lane & 31) * 128 + (((2 * ks + (lane >> 5)) ^ (((lane & 31) >> 1) & 7)) << 4);
   const int a_wave = wm * 8192, b_wave = wn * 4096;   // 64 / 32 unit rows per wave
-  auto frag = [&](int ks, int off) {
+  const int tg = lane >> 4, ti = lane & 15;
+  const int tr_row = (8 * (tg >> 1) + (ti >> 2)) * 256 + 32 * (tg & 1) + 8 * (ti & 3);
+  const char* rd_a_mc[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) rd_a_mc[blk] = bgemm_smem + tr_row + (((wm * 2 + blk) ^ (ti >> 2)) << 6);
+  const char* rd_b_mc = bgemm_smem + tr_row + ((wn ^ (ti >> 2)) << 6);
+  auto tr_frag = [&](const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 256));
+    union { s16x4 s[2]; bf16x8 f; } u;
+    u.s[0] = lo;
+    u.s[1] = hi;
+    return u.f;
+  };
+  auto frag_a = [&](int ks, int sub, int blk, int stage) {
     if constexpr ((PROBE & 2) != 0) {
       bf16x8 v;
       asm volatile("; keep" : "=v"(v));
       return v;
+    } else if constexpr (A_KC) {
+      return *reinterpret_cast<const bf16x8*>(rd[ks] + g8_base(1, sub, stage) + a_wave + blk * 4096);
     } else {
-      return *reinterpret_cast<const bf16x8*>(rd[ks] + off);
+      return tr_frag(rd_a_mc[blk] + g8_base(1, sub, stage) + ks * 4096);
+    }
+  };
+  auto frag_b = [&](int ks, int sub, int stage) {
+    if constexpr ((PROBE & 2) != 0) {
+      bf16x8 v;
+      asm volatile("; keep" : "=v"(v));
+      return v;
+    } else if constexpr (B_KC) {
+      return *reinterpret_cast<const bf16x8*>(rd[ks] + g8_base(0, sub, stage) + b_wave);
+    } else {
+      return tr_frag(rd_b_mc + g8_base(0, sub, stage) + ks * 4096);
+    }
+  };
+  // bias gradient of a weight-gradient product (A = dy, contiguous along m): rowsum[m] = sum_k A(m, k), taken from the A fragments
+  // in the tiles of the first tile column - or, with rowsum_split, by every tile column for its share of the stages (all tiles of the
+  // launch then take equally long; the host adds the partial vectors).  The four waves that share a row block (wn = 0..3) each take the k step ks == wn of
+  // every stage (one v_dot2c_f32_bf16 per pair: 16 per stage and wave), in the read sections of phases 1 and 3 - beside the other wave
+  // group's MFMAs; between the wave's own MFMAs the same 16 instructions cost the tile 40 % - and the partial sums meet in LDS after
+  // the loop.
+  const bool want_rs = !A_KC && g.rowsum != nullptr && (g.rowsum_split || tn == 0);
+  int rs_next = g.rowsum_split ? tn : 0;   // the next stage whose row sums this tile takes (rowsum_split: every tiles_n-th, else all)
+  const int rs_stride = g.rowsum_split ? g.tiles_n : 1;
+  float rs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  auto add_rs = [&](const bf16x8& f, float& r) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t one;
+    one[0] = (__bf16)1.0f;
+    one[1] = (__bf16)1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bf16x2_t a;
+      a[0] = f[2 * e];
+      a[1] = f[2 * e + 1];
+      r = __builtin_amdgcn_fdot2_f32_bf16(a, one, r, false);
     }
   };
   auto mma = [&](const bf16x8& a, const bf16x8& b, f32x16& c) {
@@ -170,16 +237,30 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   if (!(PROBE & 32)) __builtin_amdgcn_s_barrier();         \
   __builtin_amdgcn_sched_barrier(0)
 
+  auto rowsum_step = [&](int sub, int t) {
+    if constexpr (!A_KC) {
+      if (want_rs && t == rs_next) {
+        if (sub == 1) rs_next += rs_stride;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks == wn) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) add_rs(fa[blk][ks], rs[sub][blk]);
+          }
+      }
+    }
+  };
+  static_assert(A_KC || !((PROBE & 128) != 0), "the merged-phase schedule carries no row sums");
   auto tile = [&](auto st_tag, int t) {
     constexpr int ST = decltype(st_tag)::value;
     // phase 0: A sub 0 x B sub 0
     if constexpr (!LATE) issue(U2{}, t + 1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = frag(ks, g8_base(0, 0, ST) + b_wave);
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = frag_b(ks, 0, ST);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag(ks, g8_base(1, 0, ST) + a_wave + blk * 4096);
+      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag_a(ks, 0, blk, ST);
     G8_PHASE_SYNC();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -196,8 +277,9 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
     G8_PHASE_END();
     // phase 1: A sub 0 x B sub 1
     if constexpr (!LATE) issue(U3{}, t + 1);
+    rowsum_step(0, t);   // (A sub 0 is still in fa: VALU work belongs here, beside the other wave group's MFMAs, not between this wave's own)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = frag(ks, g8_base(0, 1, ST) + b_wave);
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = frag_b(ks, 1, ST);
     G8_PHASE_SYNC();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -217,7 +299,7 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag(ks, g8_base(1, 1, ST) + a_wave + blk * 4096);
+      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag_a(ks, 1, blk, ST);
     G8_PHASE_SYNC();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -234,6 +316,7 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
     G8_PHASE_END();
     // phase 3: A sub 1 x B sub 0 (both in registers)
     if constexpr (!LATE) issue(U1{}, t + 2);
+    rowsum_step(1, t);
     G8_PHASE_SYNC();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -257,13 +340,13 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   auto tile2 = [&](auto st_tag, int t) {
     constexpr int ST = decltype(st_tag)::value;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb0[ks] = frag(ks, g8_base(0, 0, ST) + b_wave);
+    for (int ks = 0; ks < 4; ++ks) fb0[ks] = frag_b(ks, 0, ST);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag(ks, g8_base(1, 0, ST) + a_wave + blk * 4096);
+      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag_a(ks, 0, blk, ST);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb1[ks] = frag(ks, g8_base(0, 1, ST) + b_wave);
+    for (int ks = 0; ks < 4; ++ks) fb1[ks] = frag_b(ks, 1, ST);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if (!(PROBE & 32)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -286,7 +369,7 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag(ks, g8_base(1, 1, ST) + a_wave + blk * 4096);
+      for (int ks = 0; ks < 4; ++ks) fa[blk][ks] = frag_a(ks, 1, blk, ST);
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (!(PROBE & 32)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -328,7 +411,22 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   if (wm == 0 && !(PROBE & 8)) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last phases' requests lie beyond K: zeros into stages nobody reads)
   __builtin_amdgcn_sched_barrier(0);
-
+  if constexpr (!A_KC) {
+    if (want_rs) {   // (uniform over the workgroup)
+      __builtin_amdgcn_s_barrier();   // every wave's LDS-DMA has landed (vmcnt(0) above): the staging area is free
+      float* red = reinterpret_cast<float*>(bgemm_smem);   // [4 k steps][256 rows]
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const float tot = xor32_sum(rs[sub][blk]);   // lanes l and l + 32 hold the two k halves of row l % 32
+          if (lane < 32) red[wn * 256 + wm * 128 + (sub * 2 + blk) * 32 + lane] = tot;
+        }
+      lds_barrier();
+      if (tid < 256 && m0 + tid < g.M)
+        g.rowsum[(g.rowsum_split ? (long)tn * g.M : 0L) + m0 + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+    }
+  }
   if constexpr ((PROBE & 512) != 0) {   // timing probe: no stores at all
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -431,9 +529,18 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
 // PROBE 0: transposed accumulator blocks + vector epilogue; PROBE 1024: element-wise epilogue (fp32 outputs whose row stride is a
 // multiple of 4 KB - the 1 024-wide activations: the 32 rows of a vector store all fall on one memory channel, 52.6 against 43.6 us
 // on [16 384 x 1 024 x 1 024]; everything else is 15 % faster with the vector epilogue).  Other values: tests/perf/gemm_probe.hip.
-template <int PROBE>
+template <int PROBE, bool A_KC = true, bool B_KC = true>
 __global__ __launch_bounds__(512) void bgemm8_kernel(const BGemmArgs g) {
-  bgemm8_body<PROBE>(g, (int)blockIdx.x);
+  bgemm8_body<PROBE, A_KC, B_KC>(g, (int)blockIdx.x);
+}
+// Several independent products in one launch (the five weight gradients of a layer, see bgemm256_batch_kernel): both operands
+// contiguous along m, element-wise epilogue (four of the five outputs have 4 KB rows).
+__global__ __launch_bounds__(512) void bgemm8_batch_kernel(const BGemmBatch b) {
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < kBGemmBatchMax; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first[i]) j = i;
+  bgemm8_body<1024, false, false>(b.job[j], (int)blockIdx.x - b.first[j]);
 }
 
 }  // namespace train

@@ -195,6 +195,7 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
 const bool g_bgemm8 = [] { const char* e = getenv("SCLDM_BGEMM8"); return !e || atoi(e) != 0; }();   // LDS-DMA phase-split kernel for (KC, KC) (A/B switch)
+const bool g_bgemm8_wgrad = [] { const char* e = getenv("SCLDM_BGEMM8_WGRAD"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_bgemm_persist = [] { const char* e = getenv("SCLDM_BGEMM_PERSIST"); return e && atoi(e) != 0; }();   // A/B switch (read at load)
 
 template <bool BIG, bool A_KC, bool B_KC>
@@ -318,18 +319,20 @@ bool wgrad_batch_eligible(const WgradJobH* j, int n, long T) {
   }
   return tiles >= 128;   // (fewer: the per-product split-K launches fill the chip better)
 }
-int wgrad_batch(hipStream_t st, const WgradJobH* j, int n, long T) {
+int wgrad_batch(hipStream_t st, const WgradJobH* j, int n, long T, float* part, size_t part_floats) {
   static std::atomic<bool> attr_set[kMaxDevices];
-  auto kern = bgemm256_batch_kernel<false, false>;
+  const bool dma = g_bgemm8 && g_bgemm8_wgrad;   // LDS-DMA form (bgemm8.hpp) of the same launch
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm2Lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm256_batch_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm2Lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm8_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm8Lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
   }
   BGemmBatch b{};
   b.n = n;
   int blocks = 0;
+  size_t part_used = 0;
   for (int i = 0; i < n; ++i) {
     BGemmArgs& g = b.job[i];
     g.A = j[i].dy; g.lda = j[i].lddy; g.B = j[i].x; g.ldb = j[i].ldx; g.C = j[i].dW; g.ldc = j[i].in_f; g.bias = nullptr;
@@ -340,13 +343,26 @@ int wgrad_batch(hipStream_t st, const WgradJobH* j, int n, long T) {
     g.rowsum = j[i].db;
     g.tiles_m = cdiv(g.M, 256);
     g.tiles_n = cdiv(g.N, 256);
+    if (dma && j[i].db && g.tiles_n > 1 && part_used + (size_t)g.tiles_n * g.M <= part_floats) {
+      // bias gradient: every tile column sums its share of the token stages into its own partial vector (all tiles of the
+      // launch take equally long); colsum_final_kernel below adds the tiles_n vectors in a fixed order
+      g.rowsum = part + part_used;
+      g.rowsum_split = 1;
+      part_used += (size_t)g.tiles_n * g.M;
+    }
     g.per_xcd = cdiv((long)g.tiles_m * g.tiles_n, 8);
     b.first[i] = blocks;
     blocks += 8 * g.per_xcd;
   }
   for (int i = n; i <= kBGemmBatchMax; ++i) b.first[i] = blocks;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), kBGemm2Lds, st, b);
+  if (dma) hipLaunchKernelGGL(bgemm8_batch_kernel, dim3(blocks), dim3(512), kBGemm8Lds, st, b);
+  else hipLaunchKernelGGL((bgemm256_batch_kernel<false, false>), dim3(blocks), dim3(512), kBGemm2Lds, st, b);
   LAUNCH_CHECK();
+  for (int i = 0; i < n; ++i)
+    if (b.job[i].rowsum_split) {
+      hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(b.job[i].M, 256)), dim3(256), 0, st, b.job[i].rowsum, b.job[i].tiles_n, b.job[i].M, j[i].db);
+      LAUNCH_CHECK();
+    }
   return SCLDM_OK;
 }
 
@@ -875,7 +891,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false));
     TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
     if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
-      TRY(wgrad_batch(st, wj, n_wj, T));
+      TRY(wgrad_batch(st, wj, n_wj, T, k.part, k.part_floats));
       n_wj = 0;
     }
   }

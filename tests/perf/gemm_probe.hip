@@ -10,6 +10,7 @@
 #include <vector>
 #include <functional>
 #include <algorithm>
+#include <cmath>
 #include <array>
 #include "../../scldm_amd/csrc/bgemm8.hpp"
 using namespace scldm;
@@ -26,6 +27,7 @@ struct Variant {
   std::function<void(int, const BGemmArgs&)> launch;
   bool exact;   // the result must equal the register-staged kernel's bit for bit
   bool c16 = false;   // bf16 output (C16) instead of fp32
+  bool split = false; // mc: row sums split over the tile columns
   std::vector<float> us;
 };
 template <typename K>
@@ -36,10 +38,27 @@ static Variant variant(const char* name, K kern, int smem, bool exact) {
 #define PROBE(name, bits, exact) variant(name, bgemm8_kernel<bits>, kBGemm8Lds, exact)
 
 int main(int argc, char** argv) {
+  const bool mc = argc > 1 && !strcmp(argv[1], "mc");   // weight-gradient orientation: both operands contiguous along m (A[k][m], B[k][n])
+  if (mc) { --argc; ++argv; }
   std::vector<std::array<int, 3>> shapes;
   for (int i = 1; i + 2 < argc; i += 3) shapes.push_back({atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2])});
+  const bool explicit_shapes = !shapes.empty();
   if (shapes.empty()) shapes = {{16384, 3072, 1024}, {16384, 1024, 1024}, {16384, 1024, 2736}, {16384, 2736, 1024}, {16384, 1024, 8192}};
   std::vector<Variant> vs;
+  if (mc) {
+    if (!explicit_shapes) shapes = {{3072, 1024, 16384}, {2732, 1024, 16384}, {1024, 2732, 16384}, {1000, 520, 4000}};
+    vs.push_back(variant("bgemm256_kernel<MC,MC> (register staging)", bgemm256_kernel<false, false>, kBGemm2Lds, true));
+    vs.push_back(variant("bgemm8_kernel<MC,MC>, element-wise epilogue", bgemm8_kernel<1024, false, false>, kBGemm8Lds, true));
+    vs.push_back(variant("bgemm8_kernel<MC,MC>, vector epilogue", bgemm8_kernel<0, false, false>, kBGemm8Lds, true));
+    vs.push_back(variant("bgemm8_kernel<MC,MC> ew, row sums split over tn", bgemm8_kernel<1024, false, false>, kBGemm8Lds, false)); vs.back().split = true;
+    vs.push_back(variant("bgemm256_kernel<MC,MC>, no row sums", bgemm256_kernel<false, false>, kBGemm2Lds, false)); vs.back().c16 = true;
+    vs.push_back(variant("bgemm8_kernel<MC,MC> vector, no row sums", bgemm8_kernel<0, false, false>, kBGemm8Lds, false)); vs.back().c16 = true;
+    vs.push_back(variant("  probe: no staging in the loop", bgemm8_kernel<1024 | 1, false, false>, kBGemm8Lds, false));
+    vs.push_back(variant("  probe: no fragment reads", bgemm8_kernel<1024 | 2, false, false>, kBGemm8Lds, false));
+    vs.push_back(variant("  probe: MFMAs + barriers only", bgemm8_kernel<1024 | 3, false, false>, kBGemm8Lds, false));
+    vs.push_back(variant("  probe: staging + barriers only", bgemm8_kernel<1024 | 6, false, false>, kBGemm8Lds, false));
+    vs.push_back(variant("  probe: reads + barriers only", bgemm8_kernel<1024 | 5, false, false>, kBGemm8Lds, false));
+  } else {
   vs.push_back(variant("bgemm256_kernel<KC,KC> (register staging)", bgemm256_kernel<true, true>, kBGemm2Lds, true));
   vs.push_back(variant("bgemm8_kernel<0> (vector epilogue)", bgemm8_kernel<0>, kBGemm8Lds, true));
   vs.push_back(PROBE("8 phases, staging ahead of the reads", 0, true));
@@ -55,20 +74,29 @@ int main(int argc, char** argv) {
   vs.push_back(PROBE("  probe: MFMAs + barriers, no stores", 512 | 3, false));
   vs.push_back(PROBE("  8ph probe: MFMAs + barriers only", 3, false));
   vs.push_back(PROBE("  8ph probe: no staging in the loop", 1, false));
+  }
   for (auto& s : shapes) {
     const int M = s[0], N = s[1], K = s[2];
-    const int lda = (K + 7) / 8 * 8, ldb = lda;
-    std::vector<unsigned short> ha((size_t)M * lda, 0), hb((size_t)N * ldb, 0);
+    const int lda = mc ? (M + 7) / 8 * 8 : (K + 7) / 8 * 8, ldb = mc ? (N + 7) / 8 * 8 : lda;
+    std::vector<unsigned short> ha((size_t)(mc ? K : M) * lda, 0), hb((size_t)(mc ? K : N) * ldb, 0);
     unsigned x = 12345u;
     auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) ha[(size_t)m * lda + k] = f2bf(rnd());
-    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) hb[(size_t)n * ldb + k] = f2bf(rnd());
+    if (mc) {   // (the padding columns M..lda stay zero, as the producers of the real arrays leave them)
+      for (int k = 0; k < K; ++k) for (int m = 0; m < M; ++m) ha[(size_t)k * lda + m] = f2bf(rnd());
+      for (int k = 0; k < K; ++k) for (int n = 0; n < N; ++n) hb[(size_t)k * ldb + n] = f2bf(rnd());
+    } else {
+      for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) ha[(size_t)m * lda + k] = f2bf(rnd());
+      for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) hb[(size_t)n * ldb + k] = f2bf(rnd());
+    }
     __bf16 *A, *B; float *C0, *C1;
     CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2));
     CK(hipMalloc(&C0, (size_t)M * N * 4)); CK(hipMalloc(&C1, (size_t)M * N * 4));
     CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    float *RS0 = nullptr, *RS1 = nullptr;
+    CK(hipMalloc(&RS0, (size_t)M * 4)); CK(hipMalloc(&RS1, (size_t)M * 4));
     BGemmArgs g{};
+    if (mc) g.rowsum = RS0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.kchunk = (K + 63) / 64 * 64; g.splits = 1;
     g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
@@ -85,10 +113,14 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
     g.C = C1;
+    if (mc) g.rowsum = RS1;
+    std::vector<float> r0(M), r1(M);
+    if (mc) CK(hipMemcpy(r0.data(), RS0, (size_t)M * 4, hipMemcpyDeviceToHost));
     std::vector<long> bad(vs.size(), -1);
     for (size_t v = 1; v < vs.size(); ++v) {
       if (!vs[v].exact) continue;
       CK(hipMemset(C1, 0xff, (size_t)M * N * 4));
+      if (mc) CK(hipMemset(RS1, 0xff, (size_t)M * 4));
       for (int rep = 0; rep < 3; ++rep) vs[v].launch(blocks, g);   // (repeated: a race that corrupts one launch in three shows)
       CK(hipDeviceSynchronize());
       CK(hipGetLastError());
@@ -96,8 +128,14 @@ int main(int argc, char** argv) {
       long b = 0;
       for (size_t i = 0; i < h0.size(); ++i) b += memcmp(&h0[i], &h1[i], 4) != 0;
       bad[v] = b;
+      if (mc) {   // row sums: other summation order than the register-staged kernel's - compared relatively
+        CK(hipMemcpy(r1.data(), RS1, (size_t)M * 4, hipMemcpyDeviceToHost));
+        double worst = 0, scale = 0;
+        for (int m = 0; m < M; ++m) { worst = std::max(worst, (double)fabsf(r0[m] - r1[m])); scale = std::max(scale, (double)fabsf(r0[m])); }
+        printf("  [%s] row sums: max |diff| %.3g against max |value| %.3g\n", vs[v].name, worst, scale);
+      }
     }
-    {   // bf16 outputs: the three kernels must agree bit for bit
+    if (!mc) {   // bf16 outputs: the three kernels must agree bit for bit
       std::vector<unsigned short> r0((size_t)M * N), r1((size_t)M * N);
       bool first = true;
       for (size_t v = 0; v < vs.size(); ++v) {
@@ -123,7 +161,9 @@ int main(int argc, char** argv) {
     for (int round = 0; round < 7; ++round)
       for (auto& v : vs) {
         BGemmArgs gv = g;
-        if (v.c16) gv.C16 = reinterpret_cast<__bf16*>(C1);
+        if (v.c16 && !mc) gv.C16 = reinterpret_cast<__bf16*>(C1);
+        if (v.c16 && mc) gv.rowsum = nullptr;
+        if (v.split) { gv.rowsum = reinterpret_cast<float*>(C0); gv.rowsum_split = 1; }   // (scratch: C0 is not read any more)
         v.launch(blocks, gv);
         CK(hipEventRecord(e0));
         for (int i = 0; i < 10; ++i) v.launch(blocks, gv);

@@ -622,6 +622,11 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
             if k.startswith("class_embeddings"):       # label tables: atomics
                 assert max_abs_rel(v, ref[k].numpy()) < 1e-5, (route, k)
                 continue
+            if route == "lds_dma" and ".attn." in k and k.endswith(".bias"):
+                # bias gradients of the batched weight-gradient launch: the LDS-DMA kernel sums the token stages per tile column
+                # (v_dot2c pairs, partial vectors added by colsum_final_kernel) - another order than the register-staged kernel's
+                assert max_abs_rel(v, ref[k].numpy()) < 1e-5, (route, k)
+                continue
             assert torch.equal(v, ref[k]), (route, k, float((v.double() - ref[k].double()).abs().max()))
     res = {"1": res["lds_dma"]}
     print(f"[parity] LDS-DMA GEMM vs register-staged GEMM, {n_embed} wide x {n_layer} layers, {16 * n} tokens: pred and "
