@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512) void bgemm256_batch_kernel(const BGemmBatch b)
 // dst_t (optional): ALSO the transposed copy dst_t[c][r] = bf16(src[r][c]), rows padded with zeros to ldt elements - the operand of
 // a data gradient dY W as a k-contiguous B (W^T[in][out]), so that it runs on the same (KC, KC) kernels as the forward.  The source
 // is read once: 64 x 64 tiles through LDS, both copies written in 8-byte pieces along their own contiguous dimension.
-struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd, raw; __bf16* dst_t; int ldt; };
+struct CastJob { const float* src; __bf16* dst; int rows, cols, ldd, raw; __bf16* dst_t; int ldt, tcols; };   // tcols: padded length of a transposed row (<= its stride ldt)
 __global__ __launch_bounds__(256) void cast_jobs_kernel(const CastJob* __restrict__ jobs, int n_jobs) {
   const CastJob j = jobs[blockIdx.y];
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void cast_jobs_kernel(const CastJob* __restric
         const int c = (t >> 4) + 16 * i, r = (t & 15) * 4;   // dst_t row c0 + c, elements r0 + r .. + 3
         if (c0 + c < j.cols) {
           __bf16* d = j.dst_t + (long)(c0 + c) * j.ldt + r0 + r;
-          if (r0 + r + 3 < j.ldt) {   // (ldt % 4 == 0: a piece is either inside the padded row or outside it)
+          if (r0 + r + 3 < j.tcols) {   // (tcols % 4 == 0: a piece is either inside the padded row or outside it)
             bf16x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = tile[r + e][c];   // (rows beyond j.rows hold zeros: the padding of the transposed rows)

@@ -753,46 +753,6 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const floa
   }
 }
 
-// x_out = x + gate[b] * y
-__global__ void gate_res_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ mod,
-                                long mod_stride, int g_off, long tokens, int D, float* __restrict__ out) {
-  const int dq = D / 4;
-  const long total = tokens * dq;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long t = i / dq;
-    const int f = (int)(i % dq) * 4;
-    const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (t / kS) * mod_stride + g_off + f);
-    const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * D + f), b = *reinterpret_cast<const f32x4*>(y + t * D + f);
-    f32x4 o;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = a[k] + g[k] * b[k];
-    *reinterpret_cast<f32x4*>(out + t * D + f) = o;
-  }
-}
-// dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (grid (samples, D/256), thread = feature)
-template <typename TO = float>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ y,
-                                                       const float* __restrict__ mod, long mod_stride, int g_off, int D,
-                                                       TO* __restrict__ dy, float* __restrict__ dmod) {
-  const long b = blockIdx.x;
-  const int f = blockIdx.y * 256 + threadIdx.x;
-  const float g = mod[b * mod_stride + g_off + f];
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < kS; ++t) {
-    const long i = (b * kS + t) * D + f;
-    const float d = dx[i];
-    dy[i] = (TO)(g * d);
-    s += d * y[i];
-  }
-  dmod[b * mod_stride + g_off + f] = s;
-}
-
-// hid = silu(a) * b   (MLP.forward, layers.py:172-174).  a, b: [tokens][H]; the output rows have ldo >= H elements, and the
-// thread of a row's last element also zeroes the row's padding (bf16 rows are padded to 16-byte multiples for bgemm_kernel,
-// whose last k chunk reads the padding of both operands)
-// (round 3: FOUR consecutive hidden units per thread - H % 4 == 0 is a requirement of the training path - so one 8- / 16-byte load
-// and store per array and one 32-bit index division per four elements; the scalar form spent its time in a 64-bit division per element)
 template <typename T>
 __device__ __forceinline__ f32x4 load4f(const T* p) {
   if constexpr (sizeof(T) == 4) {
@@ -813,6 +773,47 @@ __device__ __forceinline__ void store4f(T* p, const f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = o;
   }
 }
+// x_out = x + gate[b] * y
+template <typename TY = float>
+__global__ void gate_res_kernel(const float* __restrict__ x, const TY* __restrict__ y, const float* __restrict__ mod,
+                                long mod_stride, int g_off, long tokens, int D, float* __restrict__ out) {
+  const int dq = D / 4;
+  const long total = tokens * dq;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long t = i / dq;
+    const int f = (int)(i % dq) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(mod + (t / kS) * mod_stride + g_off + f);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * D + f), b = load4f(y + t * D + f);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = a[k] + g[k] * b[k];
+    *reinterpret_cast<f32x4*>(out + t * D + f) = o;
+  }
+}
+// dy = gate[b] * dx;  dgate[b] = sum_t dx * y        (grid (samples, D/256), thread = feature)
+template <typename TO = float, typename TY = float>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const TY* __restrict__ y,
+                                                       const float* __restrict__ mod, long mod_stride, int g_off, int D,
+                                                       TO* __restrict__ dy, float* __restrict__ dmod) {
+  const long b = blockIdx.x;
+  const int f = blockIdx.y * 256 + threadIdx.x;
+  const float g = mod[b * mod_stride + g_off + f];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < kS; ++t) {
+    const long i = (b * kS + t) * D + f;
+    const float d = dx[i];
+    dy[i] = (TO)(g * d);
+    s += d * (float)y[i];
+  }
+  dmod[b * mod_stride + g_off + f] = s;
+}
+
+// hid = silu(a) * b   (MLP.forward, layers.py:172-174).  a, b: [tokens][H]; the output rows have ldo >= H elements, and the
+// thread of a row's last element also zeroes the row's padding (bf16 rows are padded to 16-byte multiples for bgemm_kernel,
+// whose last k chunk reads the padding of both operands)
+// (round 3: FOUR consecutive hidden units per thread - H % 4 == 0 is a requirement of the training path - so one 8- / 16-byte load
+// and store per array and one 32-bit index division per four elements; the scalar form spent its time in a 64-bit division per element)
 template <typename TO = float, typename TI = float>
 __global__ void swiglu_fwd_kernel(const TI* __restrict__ a, const TI* __restrict__ b, TO* __restrict__ hid, long count, int H, int ldo) {
   const unsigned H4 = (unsigned)H / 4u, n4 = (unsigned)(count / 4);
@@ -829,7 +830,9 @@ __global__ void swiglu_fwd_kernel(const TI* __restrict__ a, const TI* __restrict
 }
 template <typename TO = float, typename TI = float, typename TD = float>
 __global__ void swiglu_bwd_kernel(const TD* __restrict__ dhid, const TI* __restrict__ a, const TI* __restrict__ b,
-                                  TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo) {
+                                  TO* __restrict__ da, TO* __restrict__ db, long count, int H, int ldo, int lpad) {
+  // (rows of da / db are ldo apart and zero padded up to lpad elements: lpad == ldo for separate arrays, ldo == 2 lpad when the two
+  // live side by side in one row - the k-concatenated operand of the merged MLP data gradient)
   const unsigned H4 = (unsigned)H / 4u, n4 = (unsigned)(count / 4);
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += gridDim.x * blockDim.x) {
     const unsigned t = i4 / H4, c = (i4 - t * H4) * 4u;
@@ -844,7 +847,7 @@ __global__ void swiglu_bwd_kernel(const TD* __restrict__ dhid, const TI* __restr
     store4f(da + (size_t)t * ldo + c, oa);
     store4f(db + (size_t)t * ldo + c, ob);
     if (c + 4 == (unsigned)H)
-      for (int p = H; p < ldo; ++p) da[(size_t)t * ldo + p] = db[(size_t)t * ldo + p] = (TO)0.f;
+      for (int p = H; p < lpad; ++p) da[(size_t)t * ldo + p] = db[(size_t)t * ldo + p] = (TO)0.f;
   }
 }
 

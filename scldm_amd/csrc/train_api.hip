@@ -10,6 +10,7 @@
 #include "train.hpp"
 #include "bgemm.hpp"
 #include "bgemm8.hpp"
+#include "attn_mfma.hpp"
 #include "train_fused.hpp"
 
 using namespace scldm;
@@ -390,13 +391,18 @@ W16 w16_layer(const scldm_dit* h, int l) {
   return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + H * D, base + 4 * D * D + 2 * H * D};
 }
 // transposed copies W^T[in][out] (row = input feature, `out` rounded up to a multiple of 8 elements per row, zero padded):
-// [layer][attn_w^T (D x 3D) | proj_w^T (D x D) | w1^T (D x hidden16) | w2^T (D x hidden16) | cproj^T (hidden x D)]
+// [layer][attn_w^T (D x 3D) | proj_w^T (D x D) | (w1^T | w2^T) (D x 2 hidden16: side by side in one row, the k-concatenated operand
+// of the merged MLP data gradient) | cproj^T (hidden x D)]
+// the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
+// rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
+const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_mlp_merge = [] { const char* e = getenv("SCLDM_MLP_MERGE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_dhid16 = [] { const char* e = getenv("SCLDM_DHID16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_dgrad_wt = [] { const char* e = getenv("SCLDM_DGRAD_WT"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 W16 wt16_layer(const scldm_dit* h, int l) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = (H + 7) / 8 * 8;
   const __bf16* base = reinterpret_cast<const __bf16*>(h->wt16) + (size_t)l * h->wt16_layer_elems;
-  return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + D * Hp, base + 4 * D * D + 2 * D * Hp};
+  return W16{base, base + 3 * D * D, base + 4 * D * D, base + 4 * D * D + Hp, base + 4 * D * D + 2 * D * Hp};   // (w1^T / w2^T rows are 2 Hp apart)
 }
 // allocations and the cast-job table of the bf16 weight mirror (synchronises `st` when the table is re-uploaded): everything
 // that is not a kernel launch.  scldm_dit_train_prepare runs it ahead of the first step; refresh_w16 falls back to it when
@@ -430,18 +436,18 @@ int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st)
       const W16 d = w16_layer(h, l);
       const W16 dt = wt ? wt16_layer(h, l) : W16{};
       auto tp = [](const __bf16* p) { return const_cast<__bf16*>(p); };
-      jobs.push_back(CastJob{w->attn_w[l], tp(d.attn_w), (int)(3 * D), (int)D, (int)D, 0, tp(dt.attn_w), (int)(3 * D)});
-      jobs.push_back(CastJob{w->proj_w[l], tp(d.proj_w), (int)D, (int)D, (int)D, 0, tp(dt.proj_w), (int)D});
-      jobs.push_back(CastJob{w->w1[l], tp(d.w1), (int)H, (int)D, (int)D, 0, tp(dt.w1), (int)Hp});
-      jobs.push_back(CastJob{w->w2[l], tp(d.w2), (int)H, (int)D, (int)D, 0, tp(dt.w2), (int)Hp});
-      jobs.push_back(CastJob{w->cproj[l], tp(d.cproj), (int)D, (int)H, (int)Hp, 0, tp(dt.cproj), (int)D});
+      jobs.push_back(CastJob{w->attn_w[l], tp(d.attn_w), (int)(3 * D), (int)D, (int)D, 0, tp(dt.attn_w), (int)(3 * D), (int)(3 * D)});
+      jobs.push_back(CastJob{w->proj_w[l], tp(d.proj_w), (int)D, (int)D, (int)D, 0, tp(dt.proj_w), (int)D, (int)D});
+      jobs.push_back(CastJob{w->w1[l], tp(d.w1), (int)H, (int)D, (int)D, 0, tp(dt.w1), (int)(2 * Hp), (int)Hp});
+      jobs.push_back(CastJob{w->w2[l], tp(d.w2), (int)H, (int)D, (int)D, 0, tp(dt.w2), (int)(2 * Hp), (int)Hp});
+      jobs.push_back(CastJob{w->cproj[l], tp(d.cproj), (int)D, (int)H, (int)Hp, 0, tp(dt.cproj), (int)D, (int)D});
     }
     // every adaLN Linear stacked in the order of the modulation vector's columns: layer l rows [6 D l, 6 D (l+1)), then the final layer's 2 D
     __bf16* a16 = reinterpret_cast<__bf16*>(h->ada16);
     for (int l = 0; l <= L; ++l) {
       const int rows = (int)(l < L ? 6 * D : 2 * D);
-      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0, nullptr, 0});
-      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1, nullptr, 0});
+      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0, nullptr, 0, 0});
+      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1, nullptr, 0, 0});
     }
     if (!h->d_cast_jobs) HIP_TRY(hipMalloc(&h->d_cast_jobs, jobs.size() * sizeof(CastJob)));
     // (synchronous copy of a pageable vector: only when the parameters' device pointers changed)
@@ -470,10 +476,10 @@ int linear_fwd16(hipStream_t st, const __bf16* x, int ldx, const __bf16* W, int 
                y16 ? reinterpret_cast<__bf16*>(y) : nullptr);
 }
 int linear_dgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* W, int rows, int out, int in, float* dx, long lddx,
-                   bool accumulate, Scratch& s, const __bf16* WT = nullptr, __bf16* dx16 = nullptr) {
+                   bool accumulate, Scratch& s, const __bf16* WT = nullptr, __bf16* dx16 = nullptr, int ldwt = 0) {
   // dx16: the gradient is stored as a dense bf16 array (rows, in) instead of fp32 (dhid: only the SwiGLU backward reads it)
   // with the transposed copy W^T[in][out] the product is (KC, KC) like a forward one: dx[t][i] = sum_o dy[t][o] W^T[i][o]
-  if (WT) return bgemm(st, dy, lddy, true, WT, (out + 7) / 8 * 8, true, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats, nullptr, dx16);
+  if (WT) return bgemm(st, dy, lddy, true, WT, ldwt ? ldwt : (out + 7) / 8 * 8, true, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats, nullptr, dx16);
   return bgemm(st, dy, lddy, true, W, (in + 7) / 8 * 8, false, dx, lddx, rows, in, out, nullptr, accumulate, s.part, s.part_floats, nullptr, dx16);
 }
 int linear_wgrad16(hipStream_t st, const __bf16* dy, int lddy, const __bf16* x, int ldx, int rows, int out, int in, float* dW, Scratch& s,
@@ -539,8 +545,18 @@ int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const 
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
+const bool g_attn_mfma = [] { const char* e = getenv("SCLDM_ATTN_MFMA"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 template <typename TO, typename TI>
 int attn_fwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, TO* ao) {
+  if constexpr (sizeof(TO) == 2 && sizeof(TI) == 2) {   // bf16 arrays: the matrix-core kernels (attn_mfma.hpp)
+    if (g_attn_mfma) {
+      const dim3 grid(cdiv(n * n_head, kAttnMfmaWaves)), block(64 * kAttnMfmaWaves);
+      if (D / n_head == 32) hipLaunchKernelGGL(attn_fwd_mfma_kernel<32>, grid, block, 0, st, qkv, n, n_head, D, ao);
+      else hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, block, 0, st, qkv, n, n_head, D, ao);
+      LAUNCH_CHECK();
+      return SCLDM_OK;
+    }
+  }
   if (D / n_head == 32) hipLaunchKernelGGL((attn_fwd_kernel<32, TO, TI>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, n, n_head, D, ao);
   else hipLaunchKernelGGL((attn_fwd_kernel<64, TO, TI>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, n, n_head, D, ao);
   LAUNCH_CHECK();
@@ -548,6 +564,15 @@ int attn_fwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, TO* ao) {
 }
 template <typename TO, typename TI>
 int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const float* dao, TO* dqkv) {
+  if constexpr (sizeof(TO) == 2 && sizeof(TI) == 2) {
+    if (g_attn_mfma) {
+      const dim3 grid(cdiv(n * n_head, kAttnMfmaWaves)), block(64 * kAttnMfmaWaves);
+      if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_mfma_kernel<32>, grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
+      else hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
+      LAUNCH_CHECK();
+      return SCLDM_OK;
+    }
+  }
   if (D / n_head == 32) hipLaunchKernelGGL((attn_bwd_kernel<32, TO, TI>), dim3(cdiv(n * n_head, attn_waves<32>())), dim3(64 * attn_waves<32>()), 0, st, qkv, dao, n, n_head, D, dqkv);
   else hipLaunchKernelGGL((attn_bwd_kernel<64, TO, TI>), dim3(cdiv(n * n_head, attn_waves<64>())), dim3(64 * attn_waves<64>()), 0, st, qkv, dao, n, n_head, D, dqkv);
   LAUNCH_CHECK();
@@ -694,6 +719,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     k2.part_floats = k.part_floats - half;
     k.part_floats = half;
   }
+  const bool y16 = src16 && g_y16;
   auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y,
                  hipStream_t sx = nullptr, bool y16 = false) {
     return src16 ? linear_fwd16(sx ? sx : st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, sx ? k2 : k, y16)
@@ -709,8 +735,9 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     TRY(lin(a.h1, kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, w->attn_b[l], a.qkv, nullptr, src16));   // (bf16 route: qkv itself is a bf16 array)
     if (src16) TRY(attn_fwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), reinterpret_cast<__bf16*>(a.ao)));
     else TRY(attn_fwd(st, kD, kNH, n, (const float*)a.qkv, a.ao));
-    TRY(lin(a.ao, kD, w->proj_w[l], wh.proj_w, kD, kD, w->proj_b[l], a.y1));
-    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
+    TRY(lin(a.ao, kD, w->proj_w[l], wh.proj_w, kD, kD, w->proj_b[l], a.y1, nullptr, y16));
+    if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, reinterpret_cast<const __bf16*>(a.y1), s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
+    else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
     LAUNCH_CHECK();
     if (src16) TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h2), a.st2));
     else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
@@ -723,8 +750,9 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
                                   reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(a.hid), T * H, H, Hp);
     else hipLaunchKernelGGL((swiglu_fwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, (const float*)a.a, (const float*)a.b, a.hid, T * H, H, H);
     LAUNCH_CHECK();
-    TRY(lin(a.hid, src16 ? Hp : H, w->cproj[l], wh.cproj, kD, H, nullptr, a.y2));
-    hipLaunchKernelGGL(gate_res_kernel, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
+    TRY(lin(a.hid, src16 ? Hp : H, w->cproj[l], wh.cproj, kD, H, nullptr, a.y2, nullptr, y16));
+    if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, reinterpret_cast<const __bf16*>(a.y2), s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
+    else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
     LAUNCH_CHECK();
   }
   // FinalLayerDit (layers.py:397-401): [shift | scale] = adaLN(c); LN(x) * (1 + scale) + shift; Linear
@@ -832,14 +860,15 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
                  : linear_wgrad(st, dyp, lddy, xs, ldx, (int)T, out_f, in_f, dW, k, db);
   };
   auto dgrad = [&](const float* dyp, int lddy, const float* W, const __bf16* Wh, const __bf16* WhT, int out_f, int in_f, float* dxp, bool acc,
-                   bool out16 = false) {
+                   bool out16 = false, int ldwt = 0) {
     return src16 ? linear_dgrad16(st, reinterpret_cast<const __bf16*>(dyp), lddy, Wh, (int)T, out_f, in_f, dxp, in_f, acc, k, WhT,
-                                  out16 ? reinterpret_cast<__bf16*>(dxp) : nullptr)
+                                  out16 ? reinterpret_cast<__bf16*>(dxp) : nullptr, ldwt)
                  : linear_dgrad(st, dyp, lddy, W, (int)T, out_f, in_f, dxp, in_f, acc, k);
   };
   auto gate_bwd = [&](const float* yv, int g_off, float* dst) {
-    if (src16) hipLaunchKernelGGL(gate_bwd_kernel<__bf16>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(dst), k.dmod);
-    else hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, dst, k.dmod);
+    if (src16 && g_y16) hipLaunchKernelGGL((gate_bwd_kernel<__bf16, __bf16>), dim3(n, kD / 256), dim3(256), 0, st, k.dx, reinterpret_cast<const __bf16*>(yv), s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(dst), k.dmod);
+    else if (src16) hipLaunchKernelGGL((gate_bwd_kernel<__bf16, float>), dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, reinterpret_cast<__bf16*>(dst), k.dmod);
+    else hipLaunchKernelGGL((gate_bwd_kernel<float, float>), dim3(n, kD / 256), dim3(256), 0, st, k.dx, yv, s.mod, (long)mw, g_off, kD, dst, k.dmod);
   };
   float* const dy_attn = batched ? k.dy2 : k.dy;
   // gradient-ready events (scldm_dit_train_set_grad_events): `st` is ordered after every kernel that writes the gradients an event
@@ -865,17 +894,27 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(fork());
     TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
     TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
+    // bf16 route: da and db live side by side in one row (da16[t][0 .. Hl) | [Hl .. 2 Hl)): with the transposed copies (w1^T | w2^T laid
+    // out the same way) the two data gradients of the MLP are ONE product over k = 2 Hl - one epilogue instead of two and no
+    // read-modify-write of dh
+    float* const da_p = k.da;
+    float* const db_p = src16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(k.da) + Hl) : k.db;
+    const int ldab = src16 ? 2 * Hl : H;
     if (src16 && g_dhid16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(k.dhid), reinterpret_cast<const __bf16*>(a.a),
-                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
+                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(da_p), reinterpret_cast<__bf16*>(db_p), T * H, H, ldab, Hl);
     else if (src16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, reinterpret_cast<const __bf16*>(a.a),
-                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(k.da), reinterpret_cast<__bf16*>(k.db), T * H, H, Hl);
-    else hipLaunchKernelGGL((swiglu_bwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, (const float*)a.a, (const float*)a.b, k.da, k.db, T * H, H, H);
+                                  reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(da_p), reinterpret_cast<__bf16*>(db_p), T * H, H, ldab, Hl);
+    else hipLaunchKernelGGL((swiglu_bwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, (const float*)a.a, (const float*)a.b, k.da, k.db, T * H, H, H, H);
     LAUNCH_CHECK();
     TRY(fork());
-    TRY(wgrad(k.da, Hl, a.h2, kD, H, kD, g->w1[l], nullptr));
-    TRY(wgrad(k.db, Hl, a.h2, kD, H, kD, g->w2[l], nullptr));
-    TRY(dgrad(k.da, Hl, w->w1[l], wh.w1, wt.w1, H, kD, k.dh, false));
-    TRY(dgrad(k.db, Hl, w->w2[l], wh.w2, wt.w2, H, kD, k.dh, true));
+    TRY(wgrad(da_p, ldab, a.h2, kD, H, kD, g->w1[l], nullptr));
+    TRY(wgrad(db_p, ldab, a.h2, kD, H, kD, g->w2[l], nullptr));
+    if (src16 && wt.w1 && g_mlp_merge) {
+      TRY(linear_dgrad16(st, reinterpret_cast<const __bf16*>(da_p), ldab, nullptr, (int)T, 2 * Hl, kD, k.dh, kD, false, k, wt.w1));
+    } else {
+      TRY(dgrad(da_p, ldab, w->w1[l], wh.w1, wt.w1, H, kD, k.dh, false, false, 2 * Hl));
+      TRY(dgrad(db_p, ldab, w->w2[l], wh.w2, wt.w2, H, kD, k.dh, true, false, 2 * Hl));
+    }
     TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
     TRY(join());   // (c_proj's weight gradient read dy)

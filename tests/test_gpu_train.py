@@ -600,34 +600,40 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
     """bgemm8_kernel (LDS-DMA staging, swizzled 128-byte rows, phase-split schedule with four staging units in flight across the
     barriers) against bgemm256_kernel<KC, KC> (register staging, padded rows), and the data gradients against the transposed bf16
     weight copies (k-contiguous, the same two kernels) against the (KC, MC) products over the untransposed copies: same operand
-    values, same MFMA, same k order - the forward and every gradient of a bf16 training step must come out BIT-identical on the
-    three routes (child processes: the knobs are read when the library is loaded; 256-tiles forced so that ragged tiles in m and
+    values, same MFMA, same k order - the forward and every gradient of a bf16 training step must come out BIT-identical between
+    the routes that differ only in the kernel (the merged MLP data gradient - one product over k = 2 hidden - is compared with
+    the two accumulated products at 2e-3; child processes: the knobs are read when the library is loaded; 256-tiles forced so that ragged tiles in m and
     n and the 48-wide k tail of the 2 736-wide hidden layer are all exercised), and three repetitions inside each child reproduce
     each other (race screen for the hand-ordered LDS-DMA hazards)."""
     import os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gemm_route_child.py")
     res = {}
     routes = {"lds_dma": dict(SCLDM_BGEMM8="1", SCLDM_DGRAD_WT="1"), "staged": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="1"),
-              "staged_mc": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="0")}
+              "lds_dma_two": dict(SCLDM_BGEMM8="1", SCLDM_DGRAD_WT="1", SCLDM_MLP_MERGE="0"),
+              "staged_mc": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="0", SCLDM_MLP_MERGE="0")}
     for route, env in routes.items():
         out = str(tmp_path / f"route_{route}.pt")
         r = subprocess.run([sys.executable, child, out, str(n_embed), str(n_head), str(n_layer), str(n), "3"],
                            env=dict(os.environ, SCLDM_BGEMM256="2", **env), capture_output=True, text=True)
         assert r.returncode == 0, (route, r.stdout[-2000:], r.stderr[-3000:])
         res[route] = torch.load(out)
-    ref = res["staged_mc"]
-    for route in ("lds_dma", "staged"):
+
+    def same(route, ref_route, exact):
+        ref = res[ref_route]
         assert res[route].keys() == ref.keys()
         for k, v in res[route].items():
-            if k.startswith("class_embeddings"):       # label tables: atomics
-                assert max_abs_rel(v, ref[k].numpy()) < 1e-5, (route, k)
-                continue
-            if route == "lds_dma" and ".attn." in k and k.endswith(".bias"):
-                # bias gradients of the batched weight-gradient launch: the LDS-DMA kernel sums the token stages per tile column
-                # (v_dot2c pairs, partial vectors added by colsum_final_kernel) - another order than the register-staged kernel's
-                assert max_abs_rel(v, ref[k].numpy()) < 1e-5, (route, k)
-                continue
-            assert torch.equal(v, ref[k]), (route, k, float((v.double() - ref[k].double()).abs().max()))
+            loose = k.startswith("class_embeddings")        # label tables: atomics
+            # bias gradients of the batched weight-gradient launch: the LDS-DMA kernel sums the token stages per tile column
+            # (v_dot2c pairs, partial vectors added by colsum_final_kernel) - another order than the register-staged kernel's
+            loose = loose or (".attn." in k and k.endswith(".bias"))
+            if loose or not exact:
+                assert max_abs_rel(v, ref[k].numpy()) < (1e-5 if exact else 2e-3), (route, ref_route, k)
+            else:
+                assert torch.equal(v, ref[k]), (route, ref_route, k, float((v.double() - ref[k].double()).abs().max()))
+
+    same("lds_dma", "staged", True)            # LDS-DMA kernels against the register-staged ones, merged MLP data gradient in both
+    same("lds_dma_two", "staged_mc", True)     # ... and with two data gradients per MLP: transposed copies against the (KC, MC) products
+    same("lds_dma", "staged_mc", False)        # one product over k = 2 hidden against two accumulated ones: another summation order
     res = {"1": res["lds_dma"]}
     print(f"[parity] LDS-DMA GEMM vs register-staged GEMM, {n_embed} wide x {n_layer} layers, {16 * n} tokens: pred and "
           f"{len(res['1']) - 1} gradients bit-identical")
