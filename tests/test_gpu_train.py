@@ -637,3 +637,27 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
     res = {"1": res["lds_dma"]}
     print(f"[parity] LDS-DMA GEMM vs register-staged GEMM, {n_embed} wide x {n_layer} layers, {16 * n} tokens: pred and "
           f"{len(res['1']) - 1} gradients bit-identical")
+
+
+@pytest.mark.parametrize("n_embed,n_head,n_layer,n", [(1024, 16, 2, 40), (512, 16, 2, 24)])
+def test_matrix_core_attention_matches_the_vector_unit_attention(n_embed, n_head, n_layer, n, tmp_path):
+    """attn_fwd_mfma_kernel / attn_bwd_mfma_kernel (bf16 images of q, k, v, dao in LDS, scores in both orientations, P and dS taken
+    from the accumulators as MFMA operands: head_dim 64 and 32) against the fp32-tile kernels on the vector unit, inside a bf16
+    training step of the generic route (child processes: SCLDM_ATTN_MFMA is read when the library is loaded).  The two differ by
+    the bf16 rounding of P, dS and dao only: prediction within 5e-3, every gradient within 2e-2 (scale-relative)."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gemm_route_child.py")
+    res = {}
+    for route in ("1", "0"):
+        out = str(tmp_path / f"attn{route}.pt")
+        r = subprocess.run([sys.executable, child, out, str(n_embed), str(n_head), str(n_layer), str(n), "2"],
+                           env=dict(os.environ, SCLDM_ATTN_MFMA=route), capture_output=True, text=True)
+        assert r.returncode == 0, (route, r.stdout[-2000:], r.stderr[-3000:])
+        res[route] = torch.load(out)
+    worst = {}
+    for k, v in res["1"].items():
+        worst[k] = max_abs_rel(v, res["0"][k].numpy())
+    bad = {k: e for k, e in worst.items() if e > (5e-3 if k == "pred" else 2e-2)}
+    assert not bad, bad
+    print(f"[parity] matrix-core attention vs vector-unit attention, head_dim {n_embed // n_head}: pred {worst['pred']:.2e}, "
+          f"worst gradient {max(e for k, e in worst.items() if k != 'pred'):.2e}")
