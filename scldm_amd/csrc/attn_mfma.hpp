@@ -143,8 +143,8 @@ __global__ __launch_bounds__(64 * kAttnMfmaWaves) void attn_fwd_mfma_kernel(cons
 }
 
 // dqkv from (qkv, dao):  dP = dao v^T;  dS = P * (dP - rowsum(P * dP)) / sqrt(hd);  dq = dS k;  dk = dS^T q;  dv = P^T dao
-template <int HD>
-__global__ __launch_bounds__(64 * kAttnMfmaWaves) void attn_bwd_mfma_kernel(const __bf16* __restrict__ qkv, const float* __restrict__ dao,
+template <int HD, typename TD = float>
+__global__ __launch_bounds__(64 * kAttnMfmaWaves) void attn_bwd_mfma_kernel(const __bf16* __restrict__ qkv, const TD* __restrict__ dao,
                                                                             long n_samples, int n_head, int D, __bf16* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) AttnMfmaTile<HD> tiles[kAttnMfmaWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64 * kAttnMfmaWaves) void attn_bwd_mfma_kernel(cons
   am_stage_bf16<HD>(s.q, base, 3L * D, lane);
   am_stage_bf16<HD>(s.k, base + D, 3L * D, lane);
   am_stage_bf16<HD>(s.v, base + 2 * D, 3L * D, lane);
-  am_stage_f32<HD>(s.d, dao + sample * 16 * (long)D + head * HD, D, lane);
+  if constexpr (sizeof(TD) == 2) am_stage_bf16<HD>(s.d, dao + sample * 16 * (long)D + head * HD, D, lane);   // (dao written as bf16 by its data gradient)
+  else am_stage_f32<HD>(s.d, dao + sample * 16 * (long)D + head * HD, D, lane);
   __builtin_amdgcn_wave_barrier();
   const int g = lane >> 4, i = lane & 15;
   const float scale = HD == 32 ? 0.17677669529663687f : 0.125f, sl2 = scale * 1.4426950408889634f;

@@ -677,9 +677,29 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
 // Round 3: HBM-bound by design (reads dh, x, dx; writes dx: 16 B per element) but it ran at 1.9 TB/s - four waves walking four
 // tokens each, every token's loads issued only after the previous token's wave reductions.  Now eight waves, and a wave requests
 // BOTH its tokens' rows (and the old dx when accumulating) before any arithmetic.
+template <typename T>
+__device__ __forceinline__ f32x4 load4f(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4f(T* p, const f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    bf16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+}
 constexpr int kLnBwdWaves = 8, kLnBwdTok = kS / kLnBwdWaves;
-template <int NQ>
-__global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+template <int NQ, typename TD = float>
+__global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const TD* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ stats, const float* __restrict__ mod,
                                                          long mod_stride, int sc_off, int sh_off, float* __restrict__ dx,
                                                          int accumulate_dx, float* __restrict__ dmod) {
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const floa
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       xv[tt][q] = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
-      dv[tt][q] = *reinterpret_cast<const f32x4*>(dh + t * D + q * 256 + lane * 4);
+      dv[tt][q] = load4f(dh + t * D + q * 256 + lane * 4);
       if (accumulate_dx) ov[tt][q] = *reinterpret_cast<const f32x4*>(dx + t * D + q * 256 + lane * 4);
     }
   }
@@ -753,26 +773,6 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const floa
   }
 }
 
-template <typename T>
-__device__ __forceinline__ f32x4 load4f(const T* p) {
-  if constexpr (sizeof(T) == 4) {
-    return *reinterpret_cast<const f32x4*>(p);
-  } else {
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
-    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-  }
-}
-template <typename T>
-__device__ __forceinline__ void store4f(T* p, const f32x4 v) {
-  if constexpr (sizeof(T) == 4) {
-    *reinterpret_cast<f32x4*>(p) = v;
-  } else {
-    bf16x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-    *reinterpret_cast<bf16x4*>(p) = o;
-  }
-}
 // x_out = x + gate[b] * y
 template <typename TY = float>
 __global__ void gate_res_kernel(const float* __restrict__ x, const TY* __restrict__ y, const float* __restrict__ mod,

@@ -396,6 +396,7 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_grad16 = [] { const char* e = getenv("SCLDM_GRAD16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_mlp_merge = [] { const char* e = getenv("SCLDM_MLP_MERGE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_dhid16 = [] { const char* e = getenv("SCLDM_DHID16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_dgrad_wt = [] { const char* e = getenv("SCLDM_DGRAD_WT"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
@@ -538,8 +539,11 @@ int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int
   return SCLDM_OK;
 }
 int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const float* stats, const float* mod, long mw, int sc_off,
-           int sh_off, float* dx, int accumulate, float* dmod) {
-#define CALL(NQ) hipLaunchKernelGGL(ln_mod_bwd_kernel<NQ>, dim3(n), dim3(64 * kLnBwdWaves), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
+           int sh_off, float* dx, int accumulate, float* dmod, bool dh16 = false) {
+#define CALL(NQ)                                                                                                                              \
+  if (dh16) hipLaunchKernelGGL((ln_mod_bwd_kernel<NQ, __bf16>), dim3(n), dim3(64 * kLnBwdWaves), 0, st, reinterpret_cast<const __bf16*>(dh), x, \
+                               stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod);                                                           \
+  else hipLaunchKernelGGL((ln_mod_bwd_kernel<NQ, float>), dim3(n), dim3(64 * kLnBwdWaves), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
   SCLDM_NQ_SWITCH(D / 256, CALL)
 #undef CALL
   LAUNCH_CHECK();
@@ -563,12 +567,15 @@ int attn_fwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, TO* ao) {
   return SCLDM_OK;
 }
 template <typename TO, typename TI>
-int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const float* dao, TO* dqkv) {
+int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const float* dao, TO* dqkv, bool dao16 = false) {
   if constexpr (sizeof(TO) == 2 && sizeof(TI) == 2) {
     if (g_attn_mfma) {
       const dim3 grid(cdiv(n * n_head, kAttnMfmaWaves)), block(64 * kAttnMfmaWaves);
-      if (D / n_head == 32) hipLaunchKernelGGL(attn_bwd_mfma_kernel<32>, grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
-      else hipLaunchKernelGGL(attn_bwd_mfma_kernel<64>, grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
+      const __bf16* d16 = reinterpret_cast<const __bf16*>(dao);
+      if (dao16 && D / n_head == 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<32, __bf16>), grid, block, 0, st, qkv, d16, n, n_head, D, dqkv);
+      else if (dao16) hipLaunchKernelGGL((attn_bwd_mfma_kernel<64, __bf16>), grid, block, 0, st, qkv, d16, n, n_head, D, dqkv);
+      else if (D / n_head == 32) hipLaunchKernelGGL((attn_bwd_mfma_kernel<32, float>), grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
+      else hipLaunchKernelGGL((attn_bwd_mfma_kernel<64, float>), grid, block, 0, st, qkv, dao, n, n_head, D, dqkv);
       LAUNCH_CHECK();
       return SCLDM_OK;
     }
@@ -886,6 +893,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     const int o = l * 6 * kD;
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
     const W16 wt = (src16 && h->wt16_live) ? wt16_layer(h, l) : W16{};
+    // the gradients that only an elementwise kernel reads next (dh -> LayerNorm backward, dao -> attention backward) leave their data
+    // gradient's epilogue as bf16 arrays, like dhid: half the bytes on both sides
+    const bool g16 = src16 && g_grad16;
+    bool dh_mlp16 = false;
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
     if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
@@ -910,25 +921,28 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(wgrad(da_p, ldab, a.h2, kD, H, kD, g->w1[l], nullptr));
     TRY(wgrad(db_p, ldab, a.h2, kD, H, kD, g->w2[l], nullptr));
     if (src16 && wt.w1 && g_mlp_merge) {
-      TRY(linear_dgrad16(st, reinterpret_cast<const __bf16*>(da_p), ldab, nullptr, (int)T, 2 * Hl, kD, k.dh, kD, false, k, wt.w1));
+      TRY(linear_dgrad16(st, reinterpret_cast<const __bf16*>(da_p), ldab, nullptr, (int)T, 2 * Hl, kD, k.dh, kD, false, k, wt.w1,
+                         g16 ? reinterpret_cast<__bf16*>(k.dh) : nullptr));
+      dh_mlp16 = g16;
     } else {
       TRY(dgrad(da_p, ldab, w->w1[l], wh.w1, wt.w1, H, kD, k.dh, false, false, 2 * Hl));
       TRY(dgrad(db_p, ldab, w->w2[l], wh.w2, wt.w2, H, kD, k.dh, true, false, 2 * Hl));
     }
-    TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod));
+    TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod, dh_mlp16));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
     TRY(join());   // (c_proj's weight gradient read dy)
     gate_bwd(a.y1, o + 2 * kD, dy_attn);
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(dy_attn, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
-    TRY(dgrad(dy_attn, kD, w->proj_w[l], wh.proj_w, wt.proj_w, kD, kD, k.dao, false));
-    if (src16) TRY(attn_bwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), k.dao, reinterpret_cast<__bf16*>(k.dqkv)));
+    const bool dao16 = g16 && g_attn_mfma;   // (the matrix-core attention backward rounds dao to bf16 anyway)
+    TRY(dgrad(dy_attn, kD, w->proj_w[l], wh.proj_w, wt.proj_w, kD, kD, k.dao, false, dao16));
+    if (src16) TRY(attn_bwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), k.dao, reinterpret_cast<__bf16*>(k.dqkv), dao16));
     else TRY(attn_bwd(st, kD, kNH, n, (const float*)a.qkv, k.dao, k.dqkv));
     TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
-    TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false));
-    TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod));
+    TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false, g16));
+    TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16));
     if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
       TRY(wgrad_batch(st, wj, n_wj, T, k.part, k.part_floats));
       n_wj = 0;
