@@ -626,10 +626,13 @@ __device__ __forceinline__ void put4(TO* __restrict__ p, const f32x4& v) {
 
 // h = LN(x) * (1 + scale[b]) + shift[b], LayerNorm without affine (nnets.py:257-258), one wave per token.
 // stats[t] = (mean, rstd).  mod row of sample b at mod + b*mod_stride; scale/shift at column offsets.
-template <int NQ, typename TO = float>
+// Optional fused residual (y != nullptr): x_new = x + gate[b] * y is formed first (the gate_res step of the previous branch:
+// Block.forward, layers.py:219-222), written to x_out, and normalised from registers - the row is read once instead of twice.
+template <int NQ, typename TO = float, typename TY = float>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mod, long mod_stride,
                                                          int sc_off, int sh_off, float eps, long tokens, TO* __restrict__ h,
-                                                         float* __restrict__ stats) {
+                                                         float* __restrict__ stats, const TY* __restrict__ y = nullptr, int g_off = 0,
+                                                         float* __restrict__ x_out = nullptr) {
   constexpr int D = NQ * 256, nq = NQ, kMaxDQ = NQ;
   const int lane = threadIdx.x & 63;
   const long t = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -640,6 +643,19 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   for (int q = 0; q < kMaxDQ; ++q)
     if (q < nq) {
       v[q] = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
+      if (y) {
+        f32x4 yv;
+        if constexpr (sizeof(TY) == 4) {
+          yv = *reinterpret_cast<const f32x4*>(y + t * D + q * 256 + lane * 4);
+        } else {
+          const bf16x4 yb = *reinterpret_cast<const bf16x4*>(y + t * D + q * 256 + lane * 4);
+          yv = f32x4{(float)yb[0], (float)yb[1], (float)yb[2], (float)yb[3]};
+        }
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(mod + (t / kS) * mod_stride + g_off + q * 256 + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[q][i] += gv[i] * yv[i];
+        *reinterpret_cast<f32x4*>(x_out + t * D + q * 256 + lane * 4) = v[q];
+      }
       sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
     }
   const float mean = wave_sum(sum) / (float)D;
@@ -702,8 +718,11 @@ template <int NQ, typename TD = float>
 __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const TD* __restrict__ dh, const float* __restrict__ x,
                                                          const float* __restrict__ stats, const float* __restrict__ mod,
                                                          long mod_stride, int sc_off, int sh_off, float* __restrict__ dx,
-                                                         int accumulate_dx, float* __restrict__ dmod) {
-  __shared__ f32x4 red[2][kLnBwdWaves][64];
+                                                         int accumulate_dx, float* __restrict__ dmod,
+                                                         const __bf16* __restrict__ gy = nullptr, int g_off = 0, __bf16* __restrict__ gdy = nullptr) {
+  // gy != nullptr: the gate backward of the branch that FOLLOWS in the backward order rides along (gate_bwd_kernel's work on the dx
+  // rows this kernel has just produced: gdy = gate[b] * dx as bf16, dmod[g_off ..] = sum_t dx * gy) - dx is not read again
+  __shared__ f32x4 red[3][kLnBwdWaves][64];
   constexpr int D = NQ * 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long b = blockIdx.x;
@@ -715,6 +734,15 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const TD* 
     dsh[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   f32x4 xv[kLnBwdTok][NQ], dv[kLnBwdTok][NQ], ov[kLnBwdTok][NQ];
+  f32x4 gate[NQ], dgate[NQ];
+  bf16x4 yv[kLnBwdTok][NQ];
+  if (gy) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      gate[q] = *reinterpret_cast<const f32x4*>(mod + b * mod_stride + g_off + q * 256 + lane * 4);
+      dgate[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   float mean[kLnBwdTok], rstd[kLnBwdTok];
 #pragma unroll
   for (int tt = 0; tt < kLnBwdTok; ++tt) {
@@ -726,6 +754,7 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const TD* 
       xv[tt][q] = *reinterpret_cast<const f32x4*>(x + t * D + q * 256 + lane * 4);
       dv[tt][q] = load4f(dh + t * D + q * 256 + lane * 4);
       if (accumulate_dx) ov[tt][q] = *reinterpret_cast<const f32x4*>(dx + t * D + q * 256 + lane * 4);
+      if (gy) yv[tt][q] = *reinterpret_cast<const bf16x4*>(gy + t * D + q * 256 + lane * 4);
     }
   }
 #pragma unroll
@@ -752,13 +781,33 @@ __global__ __launch_bounds__(64 * kLnBwdWaves) void ln_mod_bwd_kernel(const TD* 
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = rstd[tt] * (g[q][i] - s1 - xh[q][i] * s2) + (accumulate_dx ? ov[tt][q][i] : 0.f);
       *reinterpret_cast<f32x4*>(dx + t * D + q * 256 + lane * 4) = o;
+      if (gy) {
+        bf16x4 dyv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dyv[i] = (__bf16)(gate[q][i] * o[i]);
+          dgate[q][i] += o[i] * (float)yv[tt][q][i];
+        }
+        *reinterpret_cast<bf16x4*>(gdy + t * D + q * 256 + lane * 4) = dyv;
+      }
     }
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     red[0][wave][lane] = dsc[q];
     red[1][wave][lane] = dsh[q];
+    if (gy) red[2][wave][lane] = dgate[q];
     __syncthreads();
+    if (wave == 2 && gy) {
+      f32x4 s = red[2][0][lane];
+#pragma unroll
+      for (int w = 1; w < kLnBwdWaves; ++w) {
+        const f32x4 o = red[2][w][lane];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[i] += o[i];
+      }
+      *reinterpret_cast<f32x4*>(dmod + b * mod_stride + g_off + q * 256 + lane * 4) = s;
+    }
     if (wave < 2) {
       f32x4 s = red[wave][0][lane];
 #pragma unroll

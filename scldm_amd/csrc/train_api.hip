@@ -396,6 +396,8 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_fuse_gate = [] { const char* e = getenv("SCLDM_FUSE_GATE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_fuse_res = [] { const char* e = getenv("SCLDM_FUSE_RES"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_grad16 = [] { const char* e = getenv("SCLDM_GRAD16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_mlp_merge = [] { const char* e = getenv("SCLDM_MLP_MERGE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_dhid16 = [] { const char* e = getenv("SCLDM_DHID16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
@@ -532,18 +534,30 @@ inline unsigned ew_grid(long count) { return (unsigned)std::max<long>(1, std::mi
 template <typename TO>
 int ln_fwd(hipStream_t st, int D, const float* x, const float* mod, long mw, int sc_off, int sh_off, float eps, long T, TO* h,
            float* stats) {
-#define CALL(NQ) hipLaunchKernelGGL((ln_mod_fwd_kernel<NQ, TO>), dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats)
+#define CALL(NQ) hipLaunchKernelGGL((ln_mod_fwd_kernel<NQ, TO, float>), dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats, (const float*)nullptr, 0, (float*)nullptr)
+  SCLDM_NQ_SWITCH(D / 256, CALL)
+#undef CALL
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+// x_out = x + gate * y, then LayerNorm-modulate of x_out (one pass over the row: ln_mod_fwd_kernel's fused residual)
+template <typename TO, typename TY>
+int ln_fwd_res(hipStream_t st, int D, const float* x, const TY* y, int g_off, float* x_out, const float* mod, long mw, int sc_off, int sh_off,
+               float eps, long T, TO* h, float* stats) {
+#define CALL(NQ) hipLaunchKernelGGL((ln_mod_fwd_kernel<NQ, TO, TY>), dim3(cdiv(T, 4)), dim3(256), 0, st, x, mod, mw, sc_off, sh_off, eps, T, h, stats, y, g_off, x_out)
   SCLDM_NQ_SWITCH(D / 256, CALL)
 #undef CALL
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
 int ln_bwd(hipStream_t st, int D, int n, const float* dh, const float* x, const float* stats, const float* mod, long mw, int sc_off,
-           int sh_off, float* dx, int accumulate, float* dmod, bool dh16 = false) {
+           int sh_off, float* dx, int accumulate, float* dmod, bool dh16 = false, const __bf16* gy = nullptr, int g_off = 0,
+           __bf16* gdy = nullptr) {
+  // gy / g_off / gdy: the gate backward of the next branch in backward order, fused (see ln_mod_bwd_kernel)
 #define CALL(NQ)                                                                                                                              \
   if (dh16) hipLaunchKernelGGL((ln_mod_bwd_kernel<NQ, __bf16>), dim3(n), dim3(64 * kLnBwdWaves), 0, st, reinterpret_cast<const __bf16*>(dh), x, \
-                               stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod);                                                           \
-  else hipLaunchKernelGGL((ln_mod_bwd_kernel<NQ, float>), dim3(n), dim3(64 * kLnBwdWaves), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod)
+                               stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod, gy, g_off, gdy);                                           \
+  else hipLaunchKernelGGL((ln_mod_bwd_kernel<NQ, float>), dim3(n), dim3(64 * kLnBwdWaves), 0, st, dh, x, stats, mod, mw, sc_off, sh_off, dx, accumulate, dmod, gy, g_off, gdy)
   SCLDM_NQ_SWITCH(D / 256, CALL)
 #undef CALL
   LAUNCH_CHECK();
@@ -727,6 +741,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     k.part_floats = half;
   }
   const bool y16 = src16 && g_y16;
+  const bool fuse_res = y16 && g_fuse_res;   // residual step fused into the following LayerNorm-modulate (bf16 branch outputs)
   auto lin = [&](const float* xin, int ldx, const float* W, const __bf16* Wh, int out_f, int in_f, const float* b, float* y,
                  hipStream_t sx = nullptr, bool y16 = false) {
     return src16 ? linear_fwd16(sx ? sx : st, reinterpret_cast<const __bf16*>(xin), ldx, Wh, (int)T, out_f, in_f, b, y, out_f, sx ? k2 : k, y16)
@@ -737,17 +752,23 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     const int o = l * 6 * kD;   // a0..a5 at o + i*D (layers.py:214-216)
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
     float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
-    if (src16) TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h1), a.st1));
-    else TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
+    // (fuse_res: the previous layer's second residual step already produced x_in, h1 and st1 in one pass)
+    if (src16 && !(fuse_res && l > 0)) TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h1), a.st1));
+    else if (!src16) TRY(ln_fwd(st, kD, a.x_in, s.mod, (long)mw, o, o + kD, cfg.layernorm_eps, T, a.h1, a.st1));
     TRY(lin(a.h1, kD, w->attn_w[l], wh.attn_w, 3 * kD, kD, w->attn_b[l], a.qkv, nullptr, src16));   // (bf16 route: qkv itself is a bf16 array)
     if (src16) TRY(attn_fwd(st, kD, kNH, n, reinterpret_cast<const __bf16*>(a.qkv), reinterpret_cast<__bf16*>(a.ao)));
     else TRY(attn_fwd(st, kD, kNH, n, (const float*)a.qkv, a.ao));
     TRY(lin(a.ao, kD, w->proj_w[l], wh.proj_w, kD, kD, w->proj_b[l], a.y1, nullptr, y16));
-    if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, reinterpret_cast<const __bf16*>(a.y1), s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
-    else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
-    LAUNCH_CHECK();
-    if (src16) TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h2), a.st2));
-    else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
+    if (fuse_res) {   // x_mid = x_in + a2 * y1 and h2 = LN(x_mid)(1 + a3) + a4 in one pass over the row
+      TRY(ln_fwd_res(st, kD, a.x_in, reinterpret_cast<const __bf16*>(a.y1), o + 2 * kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T,
+                     reinterpret_cast<__bf16*>(a.h2), a.st2));
+    } else {
+      if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, reinterpret_cast<const __bf16*>(a.y1), s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
+      else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_in, a.y1, s.mod, (long)mw, o + 2 * kD, T, kD, a.x_mid);
+      LAUNCH_CHECK();
+      if (src16) TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, reinterpret_cast<__bf16*>(a.h2), a.st2));
+      else TRY(ln_fwd(st, kD, a.x_mid, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, cfg.layernorm_eps, T, a.h2, a.st2));
+    }
     hipStream_t s2 = nullptr;
     if (overlap) TRY(fused::fork_side(h, st, 2, &s2));
     TRY(lin(a.h2, kD, w->w2[l], wh.w2, H, kD, nullptr, a.b, s2, src16));   // (bf16 route: the pre-activations a, b are bf16 arrays)
@@ -758,13 +779,20 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     else hipLaunchKernelGGL((swiglu_fwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, (const float*)a.a, (const float*)a.b, a.hid, T * H, H, H);
     LAUNCH_CHECK();
     TRY(lin(a.hid, src16 ? Hp : H, w->cproj[l], wh.cproj, kD, H, nullptr, a.y2, nullptr, y16));
-    if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, reinterpret_cast<const __bf16*>(a.y2), s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
-    else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
-    LAUNCH_CHECK();
+    if (fuse_res) {   // x_next = x_mid + a5 * y2 and the NEXT LayerNorm-modulate (the next layer's first, or the final layer's) in one pass
+      const int on = (l + 1) * 6 * kD;
+      if (l + 1 < L) TRY(ln_fwd_res(st, kD, a.x_mid, reinterpret_cast<const __bf16*>(a.y2), o + 5 * kD, x_next, s.mod, (long)mw, on, on + kD, cfg.layernorm_eps, T,
+                                    reinterpret_cast<__bf16*>(s.layer[l + 1].h1), s.layer[l + 1].st1));
+      else TRY(ln_fwd_res(st, kD, a.x_mid, reinterpret_cast<const __bf16*>(a.y2), o + 5 * kD, x_next, s.mod, (long)mw, on + kD, on, cfg.layernorm_eps, T, s.h_f, s.st_f));
+    } else {
+      if (y16) hipLaunchKernelGGL(gate_res_kernel<__bf16>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, reinterpret_cast<const __bf16*>(a.y2), s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
+      else hipLaunchKernelGGL(gate_res_kernel<float>, dim3(ew_grid(T * kD / 4)), dim3(256), 0, st, a.x_mid, a.y2, s.mod, (long)mw, o + 5 * kD, T, kD, x_next);
+      LAUNCH_CHECK();
+    }
   }
   // FinalLayerDit (layers.py:397-401): [shift | scale] = adaLN(c); LN(x) * (1 + scale) + shift; Linear
   const int of = L * 6 * kD;
-  TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
+  if (!(fuse_res && L > 0)) TRY(ln_fwd(st, kD, s.x_last, s.mod, (long)mw, of + kD, of, cfg.layernorm_eps, T, s.h_f, s.st_f));
   TRY(linear_fwd(st, s.h_f, kD, w->fin_w, (int)T, din, kD, w->fin_b, out, din, k));
   return SCLDM_OK;
 }
@@ -888,6 +916,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
       }
     return SCLDM_OK;
   };
+  bool dy_ready = false;
   for (int l = use_fused ? -1 : L - 1; l >= 0; --l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;
@@ -900,8 +929,11 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
     if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
-    gate_bwd(a.y2, o + 5 * kD, k.dy);
-    LAUNCH_CHECK();
+    if (!dy_ready) {   // (else: written by the previous iteration's last LayerNorm backward, see fuse_gate below)
+      gate_bwd(a.y2, o + 5 * kD, k.dy);
+      LAUNCH_CHECK();
+    }
+    dy_ready = false;
     TRY(fork());
     TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
     TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
@@ -928,11 +960,17 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
       TRY(dgrad(da_p, ldab, w->w1[l], wh.w1, wt.w1, H, kD, k.dh, false, false, 2 * Hl));
       TRY(dgrad(db_p, ldab, w->w2[l], wh.w2, wt.w2, H, kD, k.dh, true, false, 2 * Hl));
     }
-    TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod, dh_mlp16));
     // x_mid = x_in + a2 * y1,  y1 = c_proj(ao) + b,  ao = attention(qkv),  qkv = c_attn(h1) + b,  h1 = LN(x_in)(1 + a0) + a1
-    TRY(join());   // (c_proj's weight gradient read dy)
-    gate_bwd(a.y1, o + 2 * kD, dy_attn);
-    LAUNCH_CHECK();
+    const bool fuse_gate = batched && src16 && g_y16 && g_fuse_gate;   // (batched: dy_attn is its own array, nobody waits on it)
+    if (fuse_gate) {   // the attention branch's gate backward rides on the LayerNorm backward that produces its dx
+      TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod, dh_mlp16,
+                 reinterpret_cast<const __bf16*>(a.y1), o + 2 * kD, reinterpret_cast<__bf16*>(dy_attn)));
+    } else {
+      TRY(ln_bwd(st, kD, n, k.dh, a.x_mid, a.st2, s.mod, (long)mw, o + 3 * kD, o + 4 * kD, k.dx, 1, k.dmod, dh_mlp16));
+      TRY(join());   // (c_proj's weight gradient read dy)
+      gate_bwd(a.y1, o + 2 * kD, dy_attn);
+      LAUNCH_CHECK();
+    }
     TRY(fork());
     TRY(wgrad(dy_attn, kD, a.ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]));
     const bool dao16 = g16 && g_attn_mfma;   // (the matrix-core attention backward rounds dao to bf16 anyway)
@@ -942,10 +980,16 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
     TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false, g16));
-    TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16));
     if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
       TRY(wgrad_batch(st, wj, n_wj, T, k.part, k.part_floats));
       n_wj = 0;
+    }
+    if (fuse_gate && l > 0) {   // ... and layer l - 1's MLP gate backward rides on this layer's last LayerNorm backward (dy is free: the batch above read it)
+      TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16,
+                 reinterpret_cast<const __bf16*>(s.layer[l - 1].y2), (l - 1) * 6 * kD + 5 * kD, reinterpret_cast<__bf16*>(k.dy)));
+      dy_ready = true;
+    } else {
+      TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16));
     }
   }
   TRY(join());
