@@ -236,6 +236,22 @@ int launch_bgemm8(const BGemmArgs& g, int blocks, hipStream_t st) {
   return vec_ok ? launch_bgemm8_t<0>(g, blocks, st) : launch_bgemm8_t<1024>(g, blocks, st);
 }
 
+int launch_bgemm8_mc(const BGemmArgs& g, int blocks, hipStream_t st) {   // both operands contiguous along m (weight gradients)
+  static std::atomic<bool> attr_set[kMaxDevices];
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm8_kernel<0, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm8Lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm8_kernel<1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm8Lds));
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
+  }
+  const bool vec_ok = !g.C16 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.ldc * 4) % 4096 != 0;
+  if (vec_ok) hipLaunchKernelGGL((bgemm8_kernel<0, false, false>), dim3(blocks), dim3(512), kBGemm8Lds, st, g);
+  else hipLaunchKernelGGL((bgemm8_kernel<1024, false, false>), dim3(blocks), dim3(512), kBGemm8Lds, st, g);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
 // orientations in use: (KC, KC) forward, (KC, MC) data gradient, (MC, MC) weight gradient.
 int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, int ldb, bool b_kc, float* C, long ldc, int M, int N,
@@ -284,17 +300,27 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
   }
   int rc;
-  const bool use8 = big && a_kc && b_kc && splits == 1 && g_bgemm8;   // LDS-DMA kernel (bgemm8.hpp)
+  const bool use8 = big && a_kc == b_kc && splits == 1 && g_bgemm8 && (a_kc || g_bgemm8_wgrad);   // LDS-DMA kernel (bgemm8.hpp): (KC, KC) and (MC, MC)
   if (big && !use8 && g_bgemm_persist && splits == 1 && blocks > 256) {   // persistent: one workgroup per CU walks the tiles (see bgemm256_kernel)
     g.n_blocks = blocks;
     blocks = 256;
   }
-  if (use8) rc = launch_bgemm8(g, blocks, st);
+  bool rs_split = false;
+  if (use8 && !a_kc && rowsum_out && g.tiles_n > 1 && (size_t)g.tiles_n * M <= part_floats) {   // bias gradient split over the tile columns (see wgrad_batch)
+    g.rowsum = part;
+    g.rowsum_split = 1;
+    rs_split = true;
+  }
+  if (use8) rc = a_kc ? launch_bgemm8(g, blocks, st) : launch_bgemm8_mc(g, blocks, st);
   else if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
                      : launch_bgemm<true, false, false>(g, blocks, st);
   else rc = a_kc ? (b_kc ? launch_bgemm<false, true, true>(g, blocks, st) : launch_bgemm<false, true, false>(g, blocks, st))
                  : launch_bgemm<false, false, false>(g, blocks, st);
   if (rc != SCLDM_OK) return rc;
+  if (rs_split) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, part, g.tiles_n, M, rowsum_out);
+    LAUNCH_CHECK();
+  }
   if (splits > 1) {
     const long total = (long)M * N;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 2048)), dim3(256), 0, st, part,
@@ -396,6 +422,7 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_ada_stacked = [] { const char* e = getenv("SCLDM_ADA_STACKED"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_fuse_gate = [] { const char* e = getenv("SCLDM_FUSE_GATE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_fuse_res = [] { const char* e = getenv("SCLDM_FUSE_RES"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_grad16 = [] { const char* e = getenv("SCLDM_GRAD16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
@@ -1030,10 +1057,25 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(ew_grid((long)n * mw / 4)), dim3(256), 0, st, k.dmod, dmod16, (long)n * mw);
     LAUNCH_CHECK();
     TRY(bgemm(st, dmod16, mw, true, reinterpret_cast<const __bf16*>(h->ada16), kD, false, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
-    for (int l = 0; l <= L; ++l) {
-      TRY(bgemm(st, dmod16 + (size_t)l * 6 * kD, mw, false, reinterpret_cast<const __bf16*>(s.sc), kD, false, l < L ? g->ada_w[l] : g->fin_ada_w, kD,
-                l < L ? 6 * kD : 2 * kD, kD, n, nullptr, false, k.part, k.part_floats, l < L ? g->ada_b[l] : g->fin_ada_b));
-      TRY(fire(SCLDM_GRAD_ADA, l));   // (one stream: issue order is completion order)
+    // one product for every layer's adaLN weight gradient when the caller laid the gradient tensors out as the stacked matrix
+    // (DiT.grad_segments does: all adaLN weights in layer order, then all adaLN biases): 2 336 tiles of 256 x 256 over k = cells
+    // in one launch instead of 25 launches of 96
+    bool stacked = L > 0;
+    for (int l = 0; l < L && stacked; ++l) {
+      const float* nw = l + 1 < L ? g->ada_w[l + 1] : g->fin_ada_w;
+      const float* nb = l + 1 < L ? g->ada_b[l + 1] : g->fin_ada_b;
+      stacked = nw == g->ada_w[l] + (size_t)6 * kD * kD && nb == g->ada_b[l] + (size_t)6 * kD;
+    }
+    if (stacked && g_ada_stacked) {
+      TRY(bgemm(st, dmod16, mw, false, reinterpret_cast<const __bf16*>(s.sc), kD, false, g->ada_w[0], kD, mw, kD, n, nullptr, false, k.part, k.part_floats,
+                g->ada_b[0]));
+      TRY(fire(SCLDM_GRAD_ADA, L));
+    } else {
+      for (int l = 0; l <= L; ++l) {
+        TRY(bgemm(st, dmod16 + (size_t)l * 6 * kD, mw, false, reinterpret_cast<const __bf16*>(s.sc), kD, false, l < L ? g->ada_w[l] : g->fin_ada_w, kD,
+                  l < L ? 6 * kD : 2 * kD, kD, n, nullptr, false, k.part, k.part_floats, l < L ? g->ada_b[l] : g->fin_ada_b));
+        TRY(fire(SCLDM_GRAD_ADA, l));   // (one stream: issue order is completion order)
+      }
     }
   }
   for (int l = (use_fused || ada16) ? L + 1 : 0; l <= L; ++l) {

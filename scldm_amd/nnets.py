@@ -400,16 +400,19 @@ class DiT(nn.Module):
 
     def grad_segments(self):
         """[(kind, layer, [parameters])] in the order scldm_dit_train_backward completes their gradients (include/scldm_hip.h,
-        SCLDM_GRAD_*): the main weights of the layers from LAST to first ("layer", l), then the adaLN projections first layer
-        first ("ada", l; l == n_layer: the final layer's), then everything else ("end")."""
+        SCLDM_GRAD_*): the main weights of the layers from LAST to first ("layer", l), then the adaLN projections ("ada", n_layer: weights
+        in layer order, then biases), then everything else ("end")."""
         segs = []
         for l in range(self.n_layer - 1, -1, -1):
             b = self.blocks[l]
             segs.append(("layer", l, [b.attn.c_attn.weight, b.attn.c_attn.bias, b.attn.c_proj.weight, b.attn.c_proj.bias,
                                       b.mlp.w1.weight, b.mlp.w2.weight, b.mlp.c_proj.weight]))
-        for l in range(self.n_layer):
-            segs.append(("ada", l, [self.blocks[l].adaln_modulation[1].weight, self.blocks[l].adaln_modulation[1].bias]))
-        segs.append(("ada", self.n_layer, [self.final_layer.adaln_modulation[1].weight, self.final_layer.adaln_modulation[1].bias]))
+        # adaLN projections: every weight in layer order (the final layer's last), then every bias - the layout of the stacked matrix,
+        # so that the bf16 route writes all of them with ONE weight-gradient product; they complete together (trigger: ada, n_layer)
+        ada = [self.blocks[l].adaln_modulation[1] for l in range(self.n_layer)] + [self.final_layer.adaln_modulation[1]]
+        for m in ada:
+            segs.append(("ada", self.n_layer, [m.weight]))
+        segs.append(("ada", self.n_layer, [m.bias for m in ada]))
         rest = [self.class_embeddings[n].weight for n in self._class_names]
         rest += [self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias, self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias,
                  self.input_proj.weight, self.input_proj.bias, self.final_layer.linear.weight, self.final_layer.linear.bias]

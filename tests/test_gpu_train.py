@@ -623,9 +623,9 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
         assert res[route].keys() == ref.keys()
         for k, v in res[route].items():
             loose = k.startswith("class_embeddings")        # label tables: atomics
-            # bias gradients of the batched weight-gradient launch: the LDS-DMA kernel sums the token stages per tile column
+            # bias gradients of the weight-gradient launches (batched per layer; stacked adaLN): the LDS-DMA kernel sums the token stages per tile column
             # (v_dot2c pairs, partial vectors added by colsum_final_kernel) - another order than the register-staged kernel's
-            loose = loose or (".attn." in k and k.endswith(".bias"))
+            loose = loose or ((".attn." in k or "adaln_modulation" in k) and k.endswith(".bias"))
             if loose or not exact:
                 assert max_abs_rel(v, ref[k].numpy()) < (1e-5 if exact else 2e-3), (route, ref_route, k)
             else:

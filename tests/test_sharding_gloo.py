@@ -160,7 +160,7 @@ def _small_dit(n_layer=3):
 
 def test_grad_bucket_plan_follows_the_backward_completion_order():
     """The flat gradient buffer is laid out in the order scldm_dit_train_backward completes the gradients (last layer first, then
-    the adaLN projections first layer first, then the ends); buckets are contiguous slices of it that never mix kinds."""
+    the adaLN projections - weights in layer order, then the biases: the stacked matrix of the one-product weight gradient - then the ends); buckets are contiguous slices of it that never mix kinds."""
     m = _small_dit(5)
     params = [p for p in m.parameters() if p is not m.pos_embed]
     per_layer = sum(p.numel() for p in m.grad_segments()[0][2])
@@ -181,7 +181,7 @@ def test_grad_bucket_plan_follows_the_backward_completion_order():
         if bucket_bytes == 1 << 30:
             assert len(plan) == 3
         if bucket_bytes == 1024:
-            assert len(plan) == 5 + 6 + 1                                                                            # one bucket per segment
+            assert len(plan) == 5 + 7 + 1                          # one bucket per segment (adaLN: six weights, then the biases together)
         if bucket_bytes == 4 * per_layer * 2 + 4096:
             assert [b[3] for b in plan if b[2] == "layer"] == [3, 1, 0]                                              # two layers per bucket
 
