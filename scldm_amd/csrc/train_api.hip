@@ -422,6 +422,7 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+const bool g_batch_side = [] { const char* e = getenv("SCLDM_BATCH_SIDE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_ada_stacked = [] { const char* e = getenv("SCLDM_ADA_STACKED"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_fuse_gate = [] { const char* e = getenv("SCLDM_FUSE_GATE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_fuse_res = [] { const char* e = getenv("SCLDM_FUSE_RES"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
@@ -894,6 +895,25 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     batched = wgrad_batch_eligible(probe, 5, T);
   }
   const bool overlap = src16 && g_overlap && !batched;
+  // Batched launch BESIDE the chain (side stream): 196 tiles of a DiT-L layer occupy 196 of the 256 CUs for ~490 us; the next kernels of
+  // the data-gradient chain (c_attn's data gradient, the LayerNorm backward, the next layer's gate backward and c_proj data gradient)
+  // do not touch the batch's operands - with the ONE exception of dy, which therefore alternates between the two halves of its
+  // (fp32-sized) slot - and fill the idle quarter of the chip.  The chain waits for the batch before the first kernel that
+  // overwrites an operand (the next layer's SwiGLU backward: da | db).
+  const bool batch_side = batched && g_batch_side;
+  Scratch kb = k;   // the batch's row-sum partials: the tail of the split-K scratch (the chain's products keep the rest)
+  if (batch_side) {
+    const size_t tail = std::min<size_t>(k.part_floats / 2, (size_t)64 << 10);
+    kb.part = k.part + (k.part_floats - tail);
+    kb.part_floats = tail;
+    k.part_floats -= tail;
+  }
+  bool batch_busy = false;
+  auto join_batch = [&]() -> int {
+    if (!batch_busy) return SCLDM_OK;
+    batch_busy = false;
+    return fused::join_side(h, st, 2);
+  };
   Scratch kw = k;
   if (overlap) {
     const size_t half = (k.part_floats / 2) & ~(size_t)63;
@@ -955,15 +975,22 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     bool dh_mlp16 = false;
     // x_out = x_mid + a5 * y2,  y2 = c_proj(hid),  hid = silu(w1 h2) * (w2 h2),  h2 = LN(x_mid)(1 + a3) + a4
     TRY(join());   // (the previous layer's weight gradients read dy / da / db / dqkv)
-    if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
+    if (l + 1 < L && !batch_side) TRY(fire(SCLDM_GRAD_LAYER, l + 1));   // the main weight gradients of layers l + 1 .. L - 1 are queued before this point
+    float* const dy_alt = reinterpret_cast<float*>(reinterpret_cast<__bf16*>(k.dy) + (size_t)T * kD);   // (second half of dy's fp32-sized slot)
+    float* const dy_cur = (batch_side && ((L - 1 - l) & 1)) ? dy_alt : k.dy;
+    float* const dy_nxt = (batch_side && ((L - 1 - l) & 1)) ? k.dy : (batch_side ? dy_alt : k.dy);
     if (!dy_ready) {   // (else: written by the previous iteration's last LayerNorm backward, see fuse_gate below)
-      gate_bwd(a.y2, o + 5 * kD, k.dy);
+      gate_bwd(a.y2, o + 5 * kD, dy_cur);
       LAUNCH_CHECK();
     }
     dy_ready = false;
     TRY(fork());
-    TRY(wgrad(k.dy, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
-    TRY(dgrad(k.dy, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
+    TRY(wgrad(dy_cur, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
+    TRY(dgrad(dy_cur, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
+    if (batch_side) {   // the previous layer's batch read da | db, dy2, dqkv: from here on they are overwritten
+      TRY(join_batch());
+      if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));
+    }
     // bf16 route: da and db live side by side in one row (da16[t][0 .. Hl) | [Hl .. 2 Hl)): with the transposed copies (w1^T | w2^T laid
     // out the same way) the two data gradients of the MLP are ONE product over k = 2 Hl - one epilogue instead of two and no
     // read-modify-write of dh
@@ -1006,19 +1033,27 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     else TRY(attn_bwd(st, kD, kNH, n, (const float*)a.qkv, k.dao, k.dqkv));
     TRY(fork());
     TRY(wgrad(k.dqkv, 3 * kD, a.h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]));
+    if (batch_side) {   // the layer's five weight gradients, one launch on the side stream; the chain goes on beside it
+      hipStream_t sb = st;
+      TRY(fused::fork_side(h, st, 2, &sb));
+      TRY(wgrad_batch(sb, wj, n_wj, T, kb.part, kb.part_floats));
+      batch_busy = true;
+      n_wj = 0;
+    }
     TRY(dgrad(k.dqkv, 3 * kD, w->attn_w[l], wh.attn_w, wt.attn_w, 3 * kD, kD, k.dh, false, g16));
-    if (batched) {   // the layer's five weight gradients, one launch (same stream: the next layer overwrites their operands after it)
+    if (batched && !batch_side) {   // ... or on the same stream (the next layer overwrites their operands after it)
       TRY(wgrad_batch(st, wj, n_wj, T, k.part, k.part_floats));
       n_wj = 0;
     }
     if (fuse_gate && l > 0) {   // ... and layer l - 1's MLP gate backward rides on this layer's last LayerNorm backward (dy is free: the batch above read it)
       TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16,
-                 reinterpret_cast<const __bf16*>(s.layer[l - 1].y2), (l - 1) * 6 * kD + 5 * kD, reinterpret_cast<__bf16*>(k.dy)));
+                 reinterpret_cast<const __bf16*>(s.layer[l - 1].y2), (l - 1) * 6 * kD + 5 * kD, reinterpret_cast<__bf16*>(dy_nxt)));
       dy_ready = true;
     } else {
       TRY(ln_bwd(st, kD, n, k.dh, a.x_in, a.st1, s.mod, (long)mw, o, o + kD, k.dx, 1, k.dmod, g16));
     }
   }
+  TRY(join_batch());
   TRY(join());
   if (!use_fused) TRY(fire(SCLDM_GRAD_LAYER, 0));
 
