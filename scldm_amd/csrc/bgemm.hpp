@@ -32,6 +32,11 @@ struct BGemmArgs {
   int accumulate;    // C += (only without split-K)
   float* rowsum;     // optional, MC A only: rowsum[z*M + m] = sum_k A(m,k) of this split (first column of tiles)
   int tiles_m, tiles_n, per_xcd;
+  // bgemm8 only - fused SwiGLU epilogues (EPI bits 2048 / 4096 of bgemm8_kernel): the pre-activations a, b as dense bf16 [M][ep_n]
+  // arrays and two / three bf16 outputs with row stride ep_ldo, zero padded up to ep_pad columns
+  const __bf16 *ep_a, *ep_b;
+  __bf16 *ep_o1, *ep_o2, *ep_o3;
+  int ep_n, ep_ldo, ep_pad;
   int rowsum_split;  // bgemm8 only: tile column tn sums the stages t % tiles_n == tn and writes rowsum[tn * M + m] (the host adds the tiles_n partials)
   int n_blocks;      // logical workgroups of this product (a persistent launch walks them with a grid stride; 0: one per launched workgroup)
 };

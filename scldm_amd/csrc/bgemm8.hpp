@@ -452,6 +452,25 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][k][4 * q + e] + ((g.bias && n + e < g.N) ? g.bias[n + e] : 0.f);
+          if constexpr ((PROBE & 2048) != 0) {
+            // c_proj's data gradient with the SwiGLU backward in its epilogue: v = d hid[m][n..n+3] never leaves the registers;
+            // da = d hid * b * s (1 + a (1 - s)), db = d hid * a * s, s = sigmoid(a)   (MLP.forward, layers.py:172-174)
+            const bf16x4_t a4 = *reinterpret_cast<const bf16x4_t*>(g.ep_a + (long)m * g.ep_n + n);
+            const bf16x4_t b4 = *reinterpret_cast<const bf16x4_t*>(g.ep_b + (long)m * g.ep_n + n);
+            const f32x4 av = {(float)a4[0], (float)a4[1], (float)a4[2], (float)a4[3]}, bv = {(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+            bf16x4_t oa, ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sg = 1.0f / (1.0f + __expf(-av[e]));   // (the arithmetic of swiglu_bwd_kernel)
+              oa[e] = (__bf16)(v[e] * bv[e] * sg * (1.0f + av[e] * (1.0f - sg)));
+              ob[e] = (__bf16)(v[e] * av[e] * sg);
+            }
+            *reinterpret_cast<bf16x4_t*>(g.ep_o1 + (long)m * g.ep_ldo + n) = oa;
+            *reinterpret_cast<bf16x4_t*>(g.ep_o2 + (long)m * g.ep_ldo + n) = ob;
+            if (n + 4 >= g.N)
+              for (int p = g.N; p < g.ep_pad; ++p) g.ep_o1[(long)m * g.ep_ldo + p] = g.ep_o2[(long)m * g.ep_ldo + p] = (__bf16)0.f;
+            continue;
+          }
           if (g.C16) {
             bf16x4_t o;
 #pragma unroll

@@ -233,6 +233,7 @@ int launch_bgemm8_t(const BGemmArgs& g, int blocks, hipStream_t st) {
 int launch_bgemm8(const BGemmArgs& g, int blocks, hipStream_t st) {
   const bool vec_ok = g.C16 ? (g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 7) == 0)
                             : (g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.ldc * 4) % 4096 != 0);
+  if (g.ep_a) return launch_bgemm8_t<2048>(g, blocks, st);   // SwiGLU backward in the epilogue (vector form; the host checked the alignment)
   return vec_ok ? launch_bgemm8_t<0>(g, blocks, st) : launch_bgemm8_t<1024>(g, blocks, st);
 }
 
@@ -255,7 +256,8 @@ int launch_bgemm8_mc(const BGemmArgs& g, int blocks, hipStream_t st) {   // both
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
 // orientations in use: (KC, KC) forward, (KC, MC) data gradient, (MC, MC) weight gradient.
 int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, int ldb, bool b_kc, float* C, long ldc, int M, int N,
-          int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr, __bf16* C16 = nullptr) {
+          int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr, __bf16* C16 = nullptr,
+          const BGemmArgs* ep = nullptr) {   // ep: fused-epilogue fields (ep_*) of a product that must run on bgemm8_kernel
   if (M <= 0 || N <= 0 || K <= 0) return SCLDM_OK;
   if (lda % 8 || ldb % 8 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
     return fail(SCLDM_ERR_SHAPE, "bgemm: operands need 16-byte aligned rows");
@@ -264,9 +266,10 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
   BGemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.bias = bias; g.C16 = C16;
   g.M = M; g.N = N; g.K = K;
+  if (ep) { g.ep_a = ep->ep_a; g.ep_b = ep->ep_b; g.ep_o1 = ep->ep_o1; g.ep_o2 = ep->ep_o2; g.ep_o3 = ep->ep_o3; g.ep_n = ep->ep_n; g.ep_ldo = ep->ep_ldo; g.ep_pad = ep->ep_pad; }
   // split K when the output tiles leave most of the workgroup slots empty and the partials are small (weight gradients:
   // K = all tokens); an activation-sized output pays more for the partials round trip than it gains
-  const bool may_split = (long)M * N <= (4L << 20) && !C16;   // (a bf16 result is written by the product's own epilogue: no partials)
+  const bool may_split = (long)M * N <= (4L << 20) && !C16 && !ep;   // (a bf16 result is written by the product's own epilogue: no partials)
   auto pick_splits = [&](long tiles, long slots) {
     int sp = 1;
     if (tiles < slots / 2 && may_split) sp = (int)std::max<long>(1, std::min<long>(std::min<long>(slots / tiles, K / 512), kMaxSplit));
@@ -305,6 +308,7 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     g.n_blocks = blocks;
     blocks = 256;
   }
+  if (ep && !use8) return fail(SCLDM_ERR_SHAPE, "bgemm: a fused epilogue needs the 256-tile LDS-DMA kernel");
   bool rs_split = false;
   if (use8 && !a_kc && rowsum_out && g.tiles_n > 1 && (size_t)g.tiles_n * M <= part_floats) {   // bias gradient split over the tile columns (see wgrad_batch)
     g.rowsum = part;
@@ -422,6 +426,9 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // the branch outputs y1 = proj(ao), y2 = c_proj(hid) of the bf16 route are bf16 arrays (the fused route records them as bf16 too:
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+// (opt-in: measured SLOWER, 46.9 -> 49.3 ms at 1 024 cells - the epilogue of a 256 x 256 tile is the one part of the kernel that nothing
+// overlaps, and the product leaves the group of kernels that run beside the previous layer's batched weight gradient)
+const bool g_fuse_swiglu_bwd = [] { const char* e = getenv("SCLDM_FUSE_SWIGLU_BWD"); return e && atoi(e) != 0; }();
 const bool g_batch_side = [] { const char* e = getenv("SCLDM_BATCH_SIDE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_ada_stacked = [] { const char* e = getenv("SCLDM_ADA_STACKED"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_fuse_gate = [] { const char* e = getenv("SCLDM_FUSE_GATE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
@@ -986,22 +993,40 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     dy_ready = false;
     TRY(fork());
     TRY(wgrad(dy_cur, kD, a.hid, Hl, kD, H, g->cproj[l], nullptr));
-    TRY(dgrad(dy_cur, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
-    if (batch_side) {   // the previous layer's batch read da | db, dy2, dqkv: from here on they are overwritten
-      TRY(join_batch());
-      if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));
-    }
     // bf16 route: da and db live side by side in one row (da16[t][0 .. Hl) | [Hl .. 2 Hl)): with the transposed copies (w1^T | w2^T laid
     // out the same way) the two data gradients of the MLP are ONE product over k = 2 Hl - one epilogue instead of two and no
     // read-modify-write of dh
     float* const da_p = k.da;
     float* const db_p = src16 ? reinterpret_cast<float*>(reinterpret_cast<__bf16*>(k.da) + Hl) : k.db;
     const int ldab = src16 ? 2 * Hl : H;
+    // the SwiGLU backward in the epilogue of c_proj's data gradient (LDS-DMA kernel, transposed copies: large batches): d hid never
+    // leaves the registers, da | db are written by the product itself
+    const bool fuse_swiglu = src16 && wt.cproj && g_fuse_swiglu_bwd && g_bgemm8 && H % 4 == 0;
+    if (fuse_swiglu) {
+      if (batch_side) {   // (the product's epilogue overwrites da | db, which the previous layer's batch reads)
+        TRY(join_batch());
+        if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));
+      }
+      BGemmArgs ep{};
+      ep.ep_a = reinterpret_cast<const __bf16*>(a.a);
+      ep.ep_b = reinterpret_cast<const __bf16*>(a.b);
+      ep.ep_o1 = reinterpret_cast<__bf16*>(da_p);
+      ep.ep_o2 = reinterpret_cast<__bf16*>(db_p);
+      ep.ep_n = H; ep.ep_ldo = ldab; ep.ep_pad = Hl;
+      TRY(bgemm(st, reinterpret_cast<const __bf16*>(dy_cur), kD, true, wt.cproj, (kD + 7) / 8 * 8, true, k.dhid, H, (int)T, H, kD, nullptr, false,
+                k.part, k.part_floats, nullptr, nullptr, &ep));
+    } else {
+    TRY(dgrad(dy_cur, kD, w->cproj[l], wh.cproj, wt.cproj, kD, H, k.dhid, false, g_dhid16));   // (bf16 route: dhid is a bf16 array, like a, b, da, db)
+    if (batch_side) {   // the previous layer's batch read da | db, dy2, dqkv: from here on they are overwritten
+      TRY(join_batch());
+      if (l + 1 < L) TRY(fire(SCLDM_GRAD_LAYER, l + 1));
+    }
     if (src16 && g_dhid16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(k.dhid), reinterpret_cast<const __bf16*>(a.a),
                                   reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(da_p), reinterpret_cast<__bf16*>(db_p), T * H, H, ldab, Hl);
     else if (src16) hipLaunchKernelGGL((swiglu_bwd_kernel<__bf16, __bf16>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, reinterpret_cast<const __bf16*>(a.a),
                                   reinterpret_cast<const __bf16*>(a.b), reinterpret_cast<__bf16*>(da_p), reinterpret_cast<__bf16*>(db_p), T * H, H, ldab, Hl);
     else hipLaunchKernelGGL((swiglu_bwd_kernel<float, float>), dim3(ew_grid(T * H)), dim3(256), 0, st, k.dhid, (const float*)a.a, (const float*)a.b, k.da, k.db, T * H, H, H, H);
+    }
     LAUNCH_CHECK();
     TRY(fork());
     TRY(wgrad(da_p, ldab, a.h2, kD, H, kD, g->w1[l], nullptr));

@@ -608,9 +608,13 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
     import os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gemm_route_child.py")
     res = {}
-    routes = {"lds_dma": dict(SCLDM_BGEMM8="1", SCLDM_DGRAD_WT="1"), "staged": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="1"),
+    # (the opt-in SwiGLU backward fused into c_proj's data gradient keeps d hid in fp32 registers instead of a bf16 array: compared
+    # at 5e-3 as the "fused_swiglu" route)
+    routes = {"lds_dma": dict(SCLDM_BGEMM8="1", SCLDM_DGRAD_WT="1"),
+              "staged": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="1"),
               "lds_dma_two": dict(SCLDM_BGEMM8="1", SCLDM_DGRAD_WT="1", SCLDM_MLP_MERGE="0"),
-              "staged_mc": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="0", SCLDM_MLP_MERGE="0")}
+              "staged_mc": dict(SCLDM_BGEMM8="0", SCLDM_DGRAD_WT="0", SCLDM_MLP_MERGE="0"),
+              "fused_swiglu": dict(SCLDM_FUSE_SWIGLU_BWD="1")}
     for route, env in routes.items():
         out = str(tmp_path / f"route_{route}.pt")
         r = subprocess.run([sys.executable, child, out, str(n_embed), str(n_head), str(n_layer), str(n), "3"],
@@ -618,7 +622,7 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
         assert r.returncode == 0, (route, r.stdout[-2000:], r.stderr[-3000:])
         res[route] = torch.load(out)
 
-    def same(route, ref_route, exact):
+    def same(route, ref_route, exact, tol=2e-3):
         ref = res[ref_route]
         assert res[route].keys() == ref.keys()
         for k, v in res[route].items():
@@ -627,13 +631,14 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
             # (v_dot2c pairs, partial vectors added by colsum_final_kernel) - another order than the register-staged kernel's
             loose = loose or ((".attn." in k or "adaln_modulation" in k) and k.endswith(".bias"))
             if loose or not exact:
-                assert max_abs_rel(v, ref[k].numpy()) < (1e-5 if exact else 2e-3), (route, ref_route, k)
+                assert max_abs_rel(v, ref[k].numpy()) < (1e-5 if exact else tol), (route, ref_route, k)
             else:
                 assert torch.equal(v, ref[k]), (route, ref_route, k, float((v.double() - ref[k].double()).abs().max()))
 
     same("lds_dma", "staged", True)            # LDS-DMA kernels against the register-staged ones, merged MLP data gradient in both
     same("lds_dma_two", "staged_mc", True)     # ... and with two data gradients per MLP: transposed copies against the (KC, MC) products
     same("lds_dma", "staged_mc", False)        # one product over k = 2 hidden against two accumulated ones: another summation order
+    same("fused_swiglu", "staged_mc", False, 5e-3)  # (opt-in epilogue: no bf16 rounding of d hid)
     res = {"1": res["lds_dma"]}
     print(f"[parity] LDS-DMA GEMM vs register-staged GEMM, {n_embed} wide x {n_layer} layers, {16 * n} tokens: pred and "
           f"{len(res['1']) - 1} gradients bit-identical")
