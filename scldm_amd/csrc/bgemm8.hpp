@@ -434,6 +434,50 @@ __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
       for (int k = 0; k < 2; ++k) asm volatile("; keep" ::"v"(acc[i][k]));
     return;
   }
+  if constexpr (TRANS && (PROBE & 8192) != 0) {
+    // bf16 result through LDS (the 256 x 256 bf16 tile is exactly the 128 KB of staging space, free now): every lane writes its
+    // 8-byte pieces into a [256][256] image whose 16-byte chunks are XORed with the row (32 rows of one chunk column -> 32 different
+    // chunks), then the workgroup reads the image row by row - a store instruction covers 2 rows x 512 contiguous bytes instead of
+    // 32 rows x 16 bytes.  N % 4 == 0 (rows of N % 8 == 4 elements: 8-byte aligned rows, the host sends those here only when C16 is).
+    if (g.C16) {
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+      __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read and its last LDS-DMA has landed (vmcnt(0) above)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 128 + i * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int nl = wn * 64 + k * 32 + 8 * q + 4 * (lane >> 5);   // column inside the tile
+            const int n = n0 + nl;
+            bf16x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][k][4 * q + e] + ((g.bias && n + e < g.N) ? g.bias[n + e] : 0.f));
+            const int chunk = (nl >> 3) ^ (r & 31);
+            *reinterpret_cast<bf16x4_t*>(bgemm_smem + r * 512 + chunk * 16 + (nl & 4) * 2) = o;
+          }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = it * 16 + wave * 2 + (lane >> 5), j = lane & 31;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(bgemm_smem + r * 512 + ((j ^ (r & 31)) << 4));
+        if (m0 + r < g.M && n0 + j * 8 < g.N) {
+          __bf16* dst = g.C16 + (long)(m0 + r) * g.N + n0 + j * 8;
+          if (n0 + j * 8 + 8 <= g.N) {
+            *reinterpret_cast<bf16x8*>(dst) = v;
+          } else {   // N % 8 == 4: the row's last piece is half a chunk
+            bf16x4_t lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lo[e] = v[e];
+            *reinterpret_cast<bf16x4_t*>(dst) = lo;
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (TRANS) {
     // acc[i][k][r] = C(m0 + 128 wm + 32 i + lane % 32, n0 + 64 wn + 32 k + acc_row(r, lane / 32)): registers 4 q .. 4 q + 3 are the
     // four consecutive columns 8 q + 4 (lane / 32) .. + 3 of the lane's row - one 16-byte (fp32) or 8-byte (bf16) store per lane and

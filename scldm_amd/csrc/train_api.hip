@@ -195,6 +195,7 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 // whenever both extents reach 256 (tests: ragged tiles at small sizes)
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
+const bool g_epi_lds = [] { const char* e = getenv("SCLDM_EPI_LDS"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_bgemm8 = [] { const char* e = getenv("SCLDM_BGEMM8"); return !e || atoi(e) != 0; }();   // LDS-DMA phase-split kernel for (KC, KC) (A/B switch)
 const bool g_bgemm8_wgrad = [] { const char* e = getenv("SCLDM_BGEMM8_WGRAD"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_bgemm_persist = [] { const char* e = getenv("SCLDM_BGEMM_PERSIST"); return e && atoi(e) != 0; }();   // A/B switch (read at load)
@@ -234,6 +235,9 @@ int launch_bgemm8(const BGemmArgs& g, int blocks, hipStream_t st) {
   const bool vec_ok = g.C16 ? (g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 7) == 0)
                             : (g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.ldc * 4) % 4096 != 0);
   if (g.ep_a) return launch_bgemm8_t<2048>(g, blocks, st);   // SwiGLU backward in the epilogue (vector form; the host checked the alignment)
+  // bf16 results go through LDS (2 rows x 512 contiguous bytes per store instruction; rows of N % 8 == 4 elements are only 8-byte
+  // aligned: global 16-byte stores need dword alignment)
+  if (g.C16 && g_epi_lds && g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 15) == 0) return launch_bgemm8_t<8192>(g, blocks, st);
   return vec_ok ? launch_bgemm8_t<0>(g, blocks, st) : launch_bgemm8_t<1024>(g, blocks, st);
 }
 

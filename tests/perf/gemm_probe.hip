@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
   vs.push_back(variant("bf16 out: bgemm256_kernel", bgemm256_kernel<true, true>, kBGemm2Lds, false)); vs.back().c16 = true;
   vs.push_back(PROBE("8 phases, element-wise fp32 epilogue", 1024, true));
   vs.push_back(PROBE("bf16 out: bgemm8, transposed blocks 8-byte", 0, false)); vs.back().c16 = true;
+  vs.push_back(PROBE("bf16 out: bgemm8, through LDS, 16-byte row stores", 8192, false)); vs.back().c16 = true;
   vs.push_back(PROBE("bf16 out: bgemm8, paired 4-byte stores", 1024, false)); vs.back().c16 = true;
   vs.push_back(PROBE("bf16 out: bgemm8, 2-byte stores", 1024 | 256, false)); vs.back().c16 = true;
   vs.push_back(PROBE("bf16 out: barriers + epilogue only", 7, false)); vs.back().c16 = true;
