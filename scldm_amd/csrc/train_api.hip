@@ -196,6 +196,10 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 const bool g_overlap = [] { const char* e = getenv("SCLDM_TRAIN_OVERLAP"); return !e || atoi(e) != 0; }();   // wgrad side stream (A/B switch)
 const int g_bgemm256 = [] { const char* e = getenv("SCLDM_BGEMM256"); return e ? atoi(e) : 1; }();
 const bool g_epi_lds = [] { const char* e = getenv("SCLDM_EPI_LDS"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
+// 256-tiles from this many tiles on.  224 was the crossover of the register-staged bgemm256_kernel; the LDS-DMA kernel wins from ~96
+// tiles (DiT-L step, profiles/r3_train_ditl_min_tiles.txt: 768 cells 43.0 -> 37.6 ms, 512 cells 30.75 -> 29.1, 384 cells 26.4 -> 25.8,
+// 256 cells 21.3 -> 20.5; at 64 the 256-cell step is back at 21.3)
+const int g_min_tiles256 = [] { const char* e = getenv("SCLDM_MIN_TILES256"); return e ? atoi(e) : 96; }();
 const bool g_bgemm8 = [] { const char* e = getenv("SCLDM_BGEMM8"); return !e || atoi(e) != 0; }();   // LDS-DMA phase-split kernel for (KC, KC) (A/B switch)
 const bool g_bgemm8_wgrad = [] { const char* e = getenv("SCLDM_BGEMM8_WGRAD"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_bgemm_persist = [] { const char* e = getenv("SCLDM_BGEMM_PERSIST"); return e && atoi(e) != 0; }();   // A/B switch (read at load)
@@ -285,7 +289,7 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
   // ~224 workgroups (192 / 176 at 256 cells) or short k ranges per split (832 at 256 cells) the big tile is 0-4 % slower.
   const long tiles256 = (long)cdiv(M, 256) * cdiv(N, 256);
   const int splits256 = pick_splits(tiles256, 256);
-  const bool fills = splits256 == 1 ? tiles256 >= 224 : (tiles256 * splits256 >= 200 && K / splits256 >= 1536);
+  const bool fills = splits256 == 1 ? tiles256 >= g_min_tiles256 : (tiles256 * splits256 >= 200 && K / splits256 >= 1536);
   const bool big = g_bgemm256 && M >= 256 && N >= 256 && (fills || g_bgemm256 == 2);
   const int tile = big ? 256 : 128;
   g.tiles_m = cdiv(M, tile);
@@ -452,7 +456,7 @@ W16 wt16_layer(const scldm_dit* h, int l) {
 // transposed copies only where the data gradients run on 256-tiles (>= 224 tiles for a 1 024-wide output: ~900 cells): below that the
 // (KC, MC) 128-tile products are as fast and the extra 0.2 ms of the transposing cast is a loss (24.6 -> 25.0 ms at 256 cells)
 bool want_wt(const scldm_dit* h, int n) {
-  return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= 224);   // (2: the tests force 256-tiles)
+  return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= g_min_tiles256);   // (2: the tests force 256-tiles)
 }
 int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
