@@ -311,7 +311,8 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
     if (rowsum_out) g.rowsum = part + (size_t)splits * M * N;
   }
   int rc;
-  const bool use8 = big && a_kc == b_kc && splits == 1 && g_bgemm8 && (a_kc || g_bgemm8_wgrad);   // LDS-DMA kernel (bgemm8.hpp): (KC, KC) and (MC, MC)
+  // (bf16 results of the LDS-DMA kernel are stored in pairs at least: rows of an even number of elements)
+  const bool use8 = big && a_kc == b_kc && splits == 1 && g_bgemm8 && (a_kc || g_bgemm8_wgrad) && (!C16 || N % 2 == 0);   // LDS-DMA kernel (bgemm8.hpp): (KC, KC) and (MC, MC)
   if (big && !use8 && g_bgemm_persist && splits == 1 && blocks > 256) {   // persistent: one workgroup per CU walks the tiles (see bgemm256_kernel)
     g.n_blocks = blocks;
     blocks = 256;
