@@ -664,7 +664,8 @@ def main():
                         dtl, _ = time_training(tl, "bf16", device, 4, 2, False, 1)
                         result[key] = {"workload": name, "cells_per_s": tl["B"] / (dtl / 4), "ms_per_step": 1e3 * dtl / 4,
                                        "tflops": 3 * dit_flops(n_embed=1024, n_layer=24) * tl["B"] / (dtl / 4) / 1e12, "dtype": "bf16",
-                                       "path": "generic: bf16 operand arrays + bgemm_kernel / bgemm256_kernel, side streams (DESIGN 4.4b)"}
+                                       "path": "generic: bf16 operand arrays, LDS-DMA 256-tile GEMMs (bgemm8_kernel) / bgemm_kernel, matrix-core attention, "
+                                               "batched weight gradients beside the chain (DESIGN 4.4b, 4.4c)"}
                         torch.cuda.empty_cache()
                 except Exception as e:   # an extra: never takes the headline line down
                     result["training_step_ditl"] = {"error": repr(e)}
