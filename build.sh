@@ -39,3 +39,10 @@ done
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/vae_train_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o"
 echo "built $OUT"
+# the stand-alone GEMM harness (tests/perf/gemm_probe.hip: ablation timings + the bitwise kernel-against-kernel check that
+# tests/test_gpu_gemm_probe.py runs); rebuilt when one of its headers is newer
+P=tests/perf/gemm_probe
+if [ ! -x "$P" ] || [ "$P.hip" -nt "$P" ] || [ scldm_amd/csrc/bgemm8.hpp -nt "$P" ] || [ scldm_amd/csrc/bgemm.hpp -nt "$P" ] || [ scldm_amd/csrc/common.hpp -nt "$P" ]; then
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include "$P.hip" -o "$P" 2> build/gemm_probe.log || { cat build/gemm_probe.log >&2; exit 1; }
+  echo "built $P"
+fi
