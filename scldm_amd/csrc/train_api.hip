@@ -454,10 +454,12 @@ W16 wt16_layer(const scldm_dit* h, int l) {
 // allocations and the cast-job table of the bf16 weight mirror (synchronises `st` when the table is re-uploaded): everything
 // that is not a kernel launch.  scldm_dit_train_prepare runs it ahead of the first step; refresh_w16 falls back to it when
 // the parameters' device pointers are not the ones it was prepared for.
-// transposed copies only where the data gradients run on 256-tiles (>= 224 tiles for a 1 024-wide output: ~900 cells): below that the
-// (KC, MC) 128-tile products are as fast and the extra 0.2 ms of the transposing cast is a loss (24.6 -> 25.0 ms at 256 cells)
+// transposed copies of the weights for the data gradients (k-contiguous B operands; the two MLP data gradients as one product)
 bool want_wt(const scldm_dit* h, int n) {
-  return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= g_min_tiles256);   // (2: the tests force 256-tiles)
+  // (from 32 tiles = 128 cells of a 1 024-wide model on: the merged MLP data gradient pays for the 0.2 ms transposing cast even on the
+  // 128-tile kernel - DiT-L step at 256 cells 20.3 -> 19.3 ms, at 128 cells 16.23 -> 16.19)
+  static const int wt_min = [] { const char* e = getenv("SCLDM_WT_MIN_TILES"); return e ? atoi(e) : 32; }();
+  return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= wt_min);   // (2: the tests force 256-tiles)
 }
 int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
