@@ -61,6 +61,8 @@ struct scldm_dit {
   size_t w16_layer_elems;
   void* wt16;               // the same matrices transposed ([in][out], rows padded to a multiple of 8): k-contiguous operands of the data gradients
   size_t wt16_layer_elems;
+  int n_cast_first;         // cast jobs that run ahead of the forward (adaLN + the first layers); the rest runs beside it
+  bool cast_side_busy;      // the side-stream cast of this step has not been joined yet
   bool wt16_live;           // the current step's forward refreshed the transposed copies (large batches only)
   void* ada16;              // [mod_w][D] bf16: every adaLN Linear's weight stacked (one GEMM for all layers' modulation vectors)
   float* ada_ball;          // [mod_w] fp32: their biases, stacked

@@ -461,6 +461,10 @@ bool want_wt(const scldm_dit* h, int n) {
   static const int wt_min = [] { const char* e = getenv("SCLDM_WT_MIN_TILES"); return e ? atoi(e) : 32; }();
   return g_dgrad_wt && (g_bgemm256 == 2 || cdiv((long)n * kS, 256L) * cdiv((long)h->cfg.n_embed, 256L) >= wt_min);   // (2: the tests force 256-tiles)
 }
+constexpr int kCastAhead = 2;
+// (opt-in: measured +-0 - 45.7 / 45.8 against 45.8 / 45.8 ms at 1 024 cells, 19.4 / 19.45 against 19.4 / 19.6 at 256: the cast's 2.7 GB
+// slow the kernels it runs beside by what it saves)
+const bool g_cast_side = [] { const char* e = getenv("SCLDM_CAST_SIDE"); return e && atoi(e) != 0; }();
 int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st) {
   const size_t D = h->cfg.n_embed, H = h->cfg.hidden_dim, Hp = hidden16(h);
   const int L = h->cfg.n_layer;
@@ -481,6 +485,15 @@ int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st)
   key.push_back(wt ? h->wt16 : nullptr);
   if (key != h->w16_key || !h->d_cast_jobs) {
     std::vector<CastJob> jobs;
+    // every adaLN Linear stacked in the order of the modulation vector's columns: layer l rows [6 D l, 6 D (l+1)), then the final layer's 2 D
+    __bf16* a16 = reinterpret_cast<__bf16*>(h->ada16);
+    for (int l = 0; l <= L; ++l) {
+      const int rows = (int)(l < L ? 6 * D : 2 * D);
+      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0, nullptr, 0, 0});
+      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1, nullptr, 0, 0});
+    }
+    // ... then the layers in order: the first two are cast ahead of the forward, the rest beside it (refresh_w16)
+    int n_first = (int)jobs.size();
     for (int l = 0; l < L; ++l) {
       const W16 d = w16_layer(h, l);
       const W16 dt = wt ? wt16_layer(h, l) : W16{};
@@ -490,19 +503,14 @@ int prepare_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st)
       jobs.push_back(CastJob{w->w1[l], tp(d.w1), (int)H, (int)D, (int)D, 0, tp(dt.w1), (int)(2 * Hp), (int)Hp});
       jobs.push_back(CastJob{w->w2[l], tp(d.w2), (int)H, (int)D, (int)D, 0, tp(dt.w2), (int)(2 * Hp), (int)Hp});
       jobs.push_back(CastJob{w->cproj[l], tp(d.cproj), (int)D, (int)H, (int)Hp, 0, tp(dt.cproj), (int)D, (int)D});
-    }
-    // every adaLN Linear stacked in the order of the modulation vector's columns: layer l rows [6 D l, 6 D (l+1)), then the final layer's 2 D
-    __bf16* a16 = reinterpret_cast<__bf16*>(h->ada16);
-    for (int l = 0; l <= L; ++l) {
-      const int rows = (int)(l < L ? 6 * D : 2 * D);
-      jobs.push_back(CastJob{l < L ? w->ada_w[l] : w->fin_ada_w, a16 + (size_t)l * 6 * D * D, rows, (int)D, (int)D, 0, nullptr, 0, 0});
-      jobs.push_back(CastJob{l < L ? w->ada_b[l] : w->fin_ada_b, reinterpret_cast<__bf16*>(h->ada_ball + (size_t)l * 6 * D), 1, rows, rows, 1, nullptr, 0, 0});
+      if (l < kCastAhead) n_first = (int)jobs.size();
     }
     if (!h->d_cast_jobs) HIP_TRY(hipMalloc(&h->d_cast_jobs, jobs.size() * sizeof(CastJob)));
     // (synchronous copy of a pageable vector: only when the parameters' device pointers changed)
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(h->d_cast_jobs, jobs.data(), jobs.size() * sizeof(CastJob), hipMemcpyHostToDevice));
     h->n_cast_jobs = (int)jobs.size();
+    h->n_cast_first = n_first;
     h->w16_key = key;
   }
   return SCLDM_OK;
@@ -511,9 +519,26 @@ int refresh_w16(scldm_dit* h, const scldm_dit_weights* w, int n, hipStream_t st)
   if (h->cfg.n_layer == 0) return SCLDM_OK;
   int rc = prepare_w16(h, w, n, st);   // no-op (a pointer-list compare) once prepared for these parameters
   if (rc != SCLDM_OK) return rc;
-  hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, h->n_cast_jobs), dim3(256), 0, st, (const CastJob*)h->d_cast_jobs, h->n_cast_jobs);
+  // the adaLN matrices and the first kCastAhead layers on `st`; the other layers on a side stream beside the forward of those
+  // layers (2.7 GB of HBM traffic for DiT-L that nothing waits for until layer kCastAhead: the forward joins there)
+  const CastJob* jobs = (const CastJob*)h->d_cast_jobs;
+  const int first = g_cast_side ? h->n_cast_first : h->n_cast_jobs, rest = h->n_cast_jobs - first;
+  hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, first), dim3(256), 0, st, jobs, first);
   LAUNCH_CHECK();
+  if (rest > 0) {
+    hipStream_t ss = st;
+    rc = fused::fork_side(h, st, 0, &ss);
+    if (rc != SCLDM_OK) return rc;
+    hipLaunchKernelGGL(cast_jobs_kernel, dim3(64, rest), dim3(256), 0, ss, jobs + first, rest);
+    LAUNCH_CHECK();
+    h->cast_side_busy = true;
+  }
   return SCLDM_OK;
+}
+int join_cast(scldm_dit* h, hipStream_t st) {   // the forward, before the first layer whose copies the side stream writes
+  if (!h->cast_side_busy) return SCLDM_OK;
+  h->cast_side_busy = false;
+  return fused::join_side(h, st, 0);
 }
 
 // (ldw: elements per row of the bf16 weight copy = `in` rounded up to a multiple of 8)
@@ -796,6 +821,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   for (int l = 0; l < L; ++l) {
     LayerSaved& a = s.layer[l];
     const int o = l * 6 * kD;   // a0..a5 at o + i*D (layers.py:214-216)
+    if (src16 && l == kCastAhead) TRY(join_cast(h, st));
     const W16 wh = src16 ? w16_layer(h, l) : W16{};
     float* x_next = l + 1 < L ? s.layer[l + 1].x_in : s.x_last;
     // (fuse_res: the previous layer's second residual step already produced x_in, h1 and st1 in one pass)
