@@ -28,6 +28,7 @@
 //   EXIT every wave drains vmcnt(0) before the epilogue: an LDS-DMA write must not land after the workgroup released its LDS.
 // Edges: rows beyond M / N and k chunks beyond K are requested with a vector offset outside the descriptor: the DMA writes zeros.
 #pragma once
+#include <type_traits>
 #include "bgemm.hpp"
 
 namespace scldm {
