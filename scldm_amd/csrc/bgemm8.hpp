@@ -1,5 +1,7 @@
-// 256 x 256 bf16-source GEMM for two operands contiguous along k (forward products X W^T, and data gradients against the
-// transposed bf16 weight copy), built around LDS-DMA and a phase-split schedule instead of bgemm256_kernel's register staging.
+// 256 x 256 bf16-source GEMM built around LDS-DMA and a phase-split schedule instead of bgemm256_kernel's register staging:
+// both operands contiguous along k (forward products X W^T, data gradients against the transposed bf16 weight copies) or both
+// contiguous along m (weight gradients: m-contiguous unit images, transposing fragment reads - see the staging / read notes in the
+// body).  DESIGN.md 4.4c; measurements and ablations: tests/perf/gemm_probe.hip, profiles/r3_gemm_probe_*.txt.
 //
 // What bgemm256_kernel pays per 64-k stage (8 waves, 32 MFMAs each = 2 048 MFMA cycles per SIMD): 192 KB of fragment reads
 // (768 LDS cycles) AND 64 ds_write_b128 wave-instructions whose VGPR -> LDS transfer costs 13 cycles each (832 cycles, not
@@ -27,6 +29,10 @@
 //        barrier;
 //   EXIT every wave drains vmcnt(0) before the epilogue: an LDS-DMA write must not land after the workgroup released its LDS.
 // Edges: rows beyond M / N and k chunks beyond K are requested with a vector offset outside the descriptor: the DMA writes zeros.
+// Epilogues (EPI = the template's first argument): 0 - accumulators hold C^T blocks (MFMA operands swapped, exact), a lane stores 16
+// (fp32) / 8 (bf16) contiguous bytes; 8192 - bf16 results through an XOR-swizzled image in the freed staging space, 2 rows x 512
+// contiguous bytes per store instruction; 1024 - untransposed blocks, element-wise (fp32 rows a multiple of 4 KB apart);
+// 2048 - opt-in SwiGLU backward on top of 0 (measured slower).  Results are bit-identical to bgemm256_kernel in every form.
 #pragma once
 #include <type_traits>
 #include "bgemm.hpp"
@@ -52,8 +58,8 @@ __device__ __forceinline__ void g8_lds_dma16(bg_u32x4 rsrc, unsigned voff, unsig
 // PROBE (tests/perf/gemm_probe.hip only; the product instantiates 0): timing ablations that break the result - 1: no staging
 // inside the loop, 2: no fragment reads, 4: no MFMAs, 8: no stagger between the wave groups, 16: no s_setprio, 32: no barriers.
 // 64 (result stays exact): the staging unit of a phase is issued between its MFMAs instead of ahead of its fragment reads;
-// 128 (exact): two phases of 16 MFMAs per stage; 256 (exact): bf16 results stored element by element; 1024 (exact): untransposed
-// accumulator blocks with the element-wise epilogue.
+// 128 (exact): two phases of 16 MFMAs per stage; 256 (exact): bf16 results stored element by element; 512: no stores;
+// 1024 / 2048 / 8192 (exact): the epilogue forms listed above.
 template <int PROBE = 0, bool A_KC = true, bool B_KC = true>
 __device__ __forceinline__ void bgemm8_body(const BGemmArgs& g, const int bid) {
   extern __shared__ __attribute__((aligned(16))) char bgemm_smem[];
