@@ -10,6 +10,7 @@
 #include "train.hpp"
 #include "bgemm.hpp"
 #include "bgemm8.hpp"
+#include "bgemm4.hpp"
 #include "attn_mfma.hpp"
 #include "train_fused.hpp"
 
@@ -261,6 +262,35 @@ int launch_bgemm8_mc(const BGemmArgs& g, int blocks, hipStream_t st) {   // both
   return SCLDM_OK;
 }
 
+// 128 x 128 LDS-DMA kernel (bgemm4.hpp) for (KC, KC) products that do not fill the chip with 256-tiles
+// SCLDM_BGEMM4: 0 = never (default), 1 = every (KC, KC) product of the small-tile class, 2 = the forward's only (read at load).
+// Opt-in: stand-alone the kernel is bit-identical to bgemm_kernel and 5-35 % faster per product (profiles/r3_gemm_probe_small.txt), inside
+// the training step it measured +-0 (forward only) to -3 % (everywhere): DiT-L at 256 cells 19.4 / 19.8 against 19.25 ms, 512 x 12 at
+// 512 cells 8.1 / 8.5 against 8.16 (profiles/r3_train_bgemm4_modes.txt) - its one-stage prefetch suffers next to the kernels it shares
+// the chip with, where bgemm_kernel keeps two register stages in flight.
+const int g_bgemm4 = [] { const char* e = getenv("SCLDM_BGEMM4"); return e ? atoi(e) : 0; }();
+thread_local bool t_in_backward = false;   // set by scldm_dit_train_backward around its launches
+template <int EPI>
+int launch_bgemm4_t(const BGemmArgs& g, int blocks, hipStream_t st) {
+  static std::atomic<bool> attr_set[kMaxDevices];
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
+    HIP_TRY(hipFuncSetAttribute((const void*)bgemm4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kBGemm4Lds));
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(bgemm4_kernel<EPI>, dim3(blocks), dim3(256), kBGemm4Lds, st, g);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+int launch_bgemm4(const BGemmArgs& g, int blocks, hipStream_t st) {
+  // results through LDS need whole 16-byte pieces per row: fp32 - N, ldc multiples of 4 and a 16-byte aligned base; bf16 - N % 4 == 0
+  // (rows of N % 8 == 4 elements are 8-byte aligned: global 16-byte stores need dword alignment only)
+  const bool lds_ok = g.C16 ? (g.N % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 15) == 0)
+                            : (g.N % 4 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+  return lds_ok ? launch_bgemm4_t<0>(g, blocks, st) : launch_bgemm4_t<1>(g, blocks, st);
+}
+
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); *_kc: the operand is contiguous along k (else along m / n).  Operand
 // orientations in use: (KC, KC) forward, (KC, MC) data gradient, (MC, MC) weight gradient.
 int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, int ldb, bool b_kc, float* C, long ldc, int M, int N,
@@ -327,6 +357,7 @@ int bgemm(hipStream_t st, const __bf16* A, int lda, bool a_kc, const __bf16* B, 
   if (use8) rc = a_kc ? launch_bgemm8(g, blocks, st) : launch_bgemm8_mc(g, blocks, st);
   else if (big) rc = a_kc ? (b_kc ? launch_bgemm<true, true, true>(g, blocks, st) : launch_bgemm<true, true, false>(g, blocks, st))
                      : launch_bgemm<true, false, false>(g, blocks, st);
+  else if (a_kc && b_kc && !ep && (g_bgemm4 == 1 || (g_bgemm4 == 2 && !t_in_backward))) rc = launch_bgemm4(g, blocks, st);
   else rc = a_kc ? (b_kc ? launch_bgemm<false, true, true>(g, blocks, st) : launch_bgemm<false, true, false>(g, blocks, st))
                  : launch_bgemm<false, false, false>(g, blocks, st);
   if (rc != SCLDM_OK) return rc;
@@ -882,6 +913,7 @@ extern "C" int scldm_dit_train_set_grad_events(scldm_dit* h, void* const* events
 extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* g, const float* x,
                                         const int64_t* const* labels, const float* dout, int n, float* dx_out, int precision,
                                         void* saved_, void* ws, void* stream_) {
+  struct InBackward { InBackward() { t_in_backward = true; } ~InBackward() { t_in_backward = false; } } in_backward_scope;
   precision = train_precision(precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");

@@ -12,7 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <array>
-#include "../../scldm_amd/csrc/bgemm8.hpp"
+#include "../../scldm_amd/csrc/bgemm4.hpp"
 using namespace scldm;
 using namespace scldm::train;
 
@@ -28,24 +28,36 @@ struct Variant {
   bool exact;   // the result must equal the register-staged kernel's bit for bit
   bool c16 = false;   // bf16 output (C16) instead of fp32
   bool split = false; // mc: row sums split over the tile columns
+  bool t128 = false;  // 128 x 128 tiles, 256 threads (bgemm_kernel / bgemm4_kernel)
   std::vector<float> us;
 };
 template <typename K>
-static Variant variant(const char* name, K kern, int smem, bool exact) {
+static Variant variant(const char* name, K kern, int smem, bool exact, int threads = 512) {
   set_lds(kern, smem);
-  return Variant{name, [kern, smem](int blocks, const BGemmArgs& g) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, 0, g); }, exact, false, {}};
+  Variant v{name, [kern, smem, threads](int blocks, const BGemmArgs& g) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), smem, 0, g); }, exact, false, {}};
+  v.t128 = threads == 256;
+  return v;
 }
 #define PROBE(name, bits, exact) variant(name, bgemm8_kernel<bits>, kBGemm8Lds, exact)
 
 int main(int argc, char** argv) {
   const bool mc = argc > 1 && !strcmp(argv[1], "mc");   // weight-gradient orientation: both operands contiguous along m (A[k][m], B[k][n])
-  if (mc) { --argc; ++argv; }
+  const bool small = argc > 1 && !strcmp(argv[1], "small");   // the 128 x 128-tile kernels (bgemm_kernel against bgemm4_kernel)
+  if (mc || small) { --argc; ++argv; }
   std::vector<std::array<int, 3>> shapes;
   for (int i = 1; i + 2 < argc; i += 3) shapes.push_back({atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2])});
   const bool explicit_shapes = !shapes.empty();
   if (shapes.empty()) shapes = {{16384, 3072, 1024}, {16384, 1024, 1024}, {16384, 1024, 2736}, {16384, 2736, 1024}, {16384, 1024, 8192}};
   std::vector<Variant> vs;
-  if (mc) {
+  if (small) {
+    if (!explicit_shapes) shapes = {{4096, 1024, 1024}, {4096, 1024, 5472}, {4096, 1024, 3072}, {2048, 1024, 2736}, {8192, 512, 512}, {1000, 520, 328}};
+    vs.push_back(variant("bgemm_kernel<KC,KC> (register staging, 128 tiles)", bgemm_kernel<true, true>, kBGemmLds, true, 256));
+    vs.push_back(variant("bgemm4_kernel<0> (LDS-DMA, results through LDS)", bgemm4_kernel<0>, kBGemm4Lds, true, 256));
+    vs.push_back(variant("bgemm4_kernel<1> (LDS-DMA, element-wise stores)", bgemm4_kernel<1>, kBGemm4Lds, true, 256));
+    vs.push_back(variant("bf16 out: bgemm_kernel", bgemm_kernel<true, true>, kBGemmLds, false, 256)); vs.back().c16 = true;
+    vs.push_back(variant("bf16 out: bgemm4_kernel<0>", bgemm4_kernel<0>, kBGemm4Lds, false, 256)); vs.back().c16 = true;
+    vs.push_back(variant("bf16 out: bgemm4_kernel<1>", bgemm4_kernel<1>, kBGemm4Lds, false, 256)); vs.back().c16 = true;
+  } else if (mc) {
     if (!explicit_shapes) shapes = {{3072, 1024, 16384}, {2732, 1024, 16384}, {1024, 2732, 16384}, {1000, 520, 4000}};
     vs.push_back(variant("bgemm256_kernel<MC,MC> (register staging)", bgemm256_kernel<false, false>, kBGemm2Lds, true));
     vs.push_back(variant("bgemm8_kernel<MC,MC>, element-wise epilogue", bgemm8_kernel<1024, false, false>, kBGemm8Lds, true));
@@ -100,12 +112,13 @@ int main(int argc, char** argv) {
     if (mc) g.rowsum = RS0;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.kchunk = (K + 63) / 64 * 64; g.splits = 1;
-    g.tiles_m = (M + 255) / 256; g.tiles_n = (N + 255) / 256;
+    const int TS = small ? 128 : 256;
+    g.tiles_m = (M + TS - 1) / TS; g.tiles_n = (N + TS - 1) / TS;
     const int tiles = g.tiles_m * g.tiles_n;
     g.per_xcd = (tiles + 7) / 8;
     const int blocks = 8 * g.per_xcd;
     const double flop = 2.0 * M * N * K;
-    printf("M=%d N=%d K=%d (%d tiles of 256 x 256, %.2f rounds of 256 CUs)\n", M, N, K, tiles, tiles / 256.0);
+    printf("M=%d N=%d K=%d (%d tiles of %d x %d, %.2f rounds of %d workgroup slots)\n", M, N, K, tiles, TS, TS, tiles / (small ? 512.0 : 256.0), small ? 512 : 256);
     // exactness first (one launch each), then interleaved timing rounds (median of 7 rounds x 10 launches per variant)
     std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
     g.C = C0;

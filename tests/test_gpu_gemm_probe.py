@@ -43,3 +43,10 @@ def test_m_contiguous_products_are_bit_identical_and_row_sums_agree():
     sums = re.findall(r"row sums: max \|diff\| ([\d.e+-]+) against max \|value\| ([\d.e+-]+)", out)
     assert len(sums) >= 8 and all(float(d) <= 1e-5 * max(1.0, float(v)) for d, v in sums), sums
     print(f"[parity] bgemm8_kernel<MC, MC> vs bgemm256_kernel: {n} comparisons identical, {len(sums)} row-sum vectors within 1e-5")
+
+
+def test_small_tile_lds_dma_kernel_is_bit_identical_to_the_register_staged_one():
+    """bgemm4_kernel (128 x 128 tiles, two workgroups per CU, results through LDS or element-wise) against bgemm_kernel<KC, KC>."""
+    out = _probe("small", 1000, 520, 328, 4096, 1024, 1024, 300, 264, 64, 2100, 2732, 1096, 777, 1024, 2736)
+    n = _check(out, 5 * 4)
+    print(f"[parity] bgemm4_kernel vs bgemm_kernel: {n} kernel x shape comparisons, every element identical")
