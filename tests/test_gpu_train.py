@@ -618,6 +618,8 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
               # the batched weight gradient on the main stream instead of beside the chain: same kernels, same operands - any
               # difference would be a race between the two streams (dy's two halves, the join ahead of the SwiGLU backward)
               "batch_on_main": dict(SCLDM_BATCH_SIDE="0")}
+    if n < 128:    # (not batched / no merged products at these sizes: the three kernel routes only)
+        routes = {k: v for k, v in routes.items() if k in ("lds_dma", "staged", "staged_mc")}
     for route, env in routes.items():
         out = str(tmp_path / f"route_{route}.pt")
         r = subprocess.run([sys.executable, child, out, str(n_embed), str(n_head), str(n_layer), str(n), "3"],
@@ -639,10 +641,11 @@ def test_lds_dma_gemm_is_bit_identical_to_the_register_staged_gemm(n_embed, n_he
                 assert torch.equal(v, ref[k]), (route, ref_route, k, float((v.double() - ref[k].double()).abs().max()))
 
     same("lds_dma", "staged", True)            # LDS-DMA kernels against the register-staged ones, merged MLP data gradient in both
-    same("lds_dma_two", "staged_mc", True)     # ... and with two data gradients per MLP: transposed copies against the (KC, MC) products
     same("lds_dma", "staged_mc", False)        # one product over k = 2 hidden against two accumulated ones: another summation order
-    same("fused_swiglu", "staged_mc", False, 5e-3)  # (opt-in epilogue: no bf16 rounding of d hid)
-    same("batch_on_main", "lds_dma", True)     # side stream or not: bit for bit
+    if "lds_dma_two" in res:
+        same("lds_dma_two", "staged_mc", True)     # two data gradients per MLP: transposed copies against the (KC, MC) products
+        same("fused_swiglu", "staged_mc", False, 5e-3)  # (opt-in epilogue: no bf16 rounding of d hid)
+        same("batch_on_main", "lds_dma", True)     # side stream or not: bit for bit
     res = {"1": res["lds_dma"]}
     print(f"[parity] LDS-DMA GEMM vs register-staged GEMM, {n_embed} wide x {n_layer} layers, {16 * n} tokens: pred and "
           f"{len(res['1']) - 1} gradients bit-identical")
