@@ -207,6 +207,21 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
     return dt, blocks, out, (z2, cond2, scales, B)
 
 
+def time_steps_each(m, wl, device, steps, warmup, seed=1234):
+    """Seconds of each of `steps` single-GPU steps (synchronised individually) after `warmup` untimed ones; returns (times, inputs)."""
+    B = wl["B"]
+    z2, cond2, scales = make_inputs(wl, B, device, seed=seed)
+    run_steps(m, wl, z2, cond2, scales, warmup, False, 1)
+    sync(device)
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        run_steps(m, wl, z2, cond2, scales, 1, False, 1)
+        sync(device)
+        ts.append(time.perf_counter() - t0)
+    return ts, (z2, cond2, scales, B)
+
+
 def cross_rank_check(m, wl, out, B, device, world, rank, n_check=8):
     """Self-validation of the sharded run (no curve can be measured on a 1-GPU lease: this makes the first N-GPU run its own test):
     rank 0 regenerates `n_check` cells of ANOTHER rank's shard from that rank's seed, integrates them locally with its own copy of
@@ -370,6 +385,7 @@ def decode_inclusive(m, wl, device, n_genes=17002):
 
 
 ARITH = {
+    "bf16": "bf16 operands (8 mantissa bits: narrower than the reference's TF32), v_mfma_f32_32x32x16_bf16, fp32 accumulate / LN / softmax / residual",
     "bf16x3": "operands split into hi + lo bf16, 3 x v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate / LN / softmax / residual",
     "fp16": "fp16 operands (10 mantissa bits = TF32, the reference's set_float32_matmul_precision('high') class), v_mfma_f32_32x32x16_f16, "
             "fp32 accumulate / LN / softmax / residual",
@@ -405,7 +421,7 @@ def encode_record(device, cells=1024):
     return rec
 
 
-def precision_path(wl, device, prec, ref_cells=64):
+def precision_path(wl, device, prec, steps, warmup, ref_cells=64):
     """The same workload at another operand precision: throughput, fused-kernel roofline against ITS peak, and the error of every
     fast precision against the exact-fp32 path (itself pinned to the reference's golden vectors at ~6e-7 by tests/) on `ref_cells`
     cells x 8 Euler evaluations: scale-relative max error and the elementwise relative error floored at 1 % of max|ref|.
@@ -413,9 +429,11 @@ def precision_path(wl, device, prec, ref_cells=64):
       reference_class_path = 'fp16'   (TF32's mantissa: the arithmetic the reference itself computes in; ~1e-3 vs exact fp32, as
                                        the reference's own TF32 mode is - tests/test_gpu_dit.py asserts <= 1.5 x a TF32-operand oracle)"""
     m3 = make_model(wl, prec, device)
-    dt, blocks, _, (z2, cond2, scales, B) = time_workload(m3, wl, device, 1, 1, False, 1, 0, time_blocks=True)
+    # timed exactly like the headline: the same number of steps after the same number of warm-up steps
+    dt, blocks, _, (z2, cond2, scales, B) = time_workload(m3, wl, device, steps, warmup, False, 1, 0, time_blocks=True)
+    dt /= steps
     n_fwd = (2 + n_passes(wl)) * B
-    rec = {"precision": prec, "cells_per_s": B / dt, "ms_per_step": 1e3 * dt, "arithmetic": ARITH[prec],
+    rec = {"precision": prec, "cells_per_s": B / dt, "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup, "arithmetic": ARITH[prec],
            "dit_fwd_mfma_frac": executed_flops_per_eval(wl, B, cond2) * wl["evals"] / dt / PEAK[prec]}
     if blocks and blocks[0] > 0:
         rec["roofline"] = fused_kernel_roofline(m3, blocks, n_fwd, prec, wl, wl["evals"])
@@ -481,6 +499,77 @@ def cpu_baseline(m, wl, target_s=6.0):
             "sample": f"{cells} cells x all {n_evals} CFG evaluations ({wl['method']}), fp32 torch CPU ops on {threads} threads "
                       f"(calibration, s per cell-evaluation by thread count: {', '.join(f'{k}: {v:.4f}' for k, v in sorted(tried.items()))}), "
                       f"median of 3 solves ({', '.join(f'{t:.2f}' for t in times)} s) after one warm-up solve; measured, not extrapolated"}
+
+
+def default_sampler_record(m, wl, device, cells=4096):
+    """The reference's DEFAULT sampler (LatentDiffusion.sample -> Sampler.sample_ode() with no arguments: adaptive dopri5, atol = rtol =
+    1e-5; src/scldm/models.py:793, transport/transport.py:324-331): host-driven Dormand-Prince steps over the fused forward_with_cfg.
+    cells/s = requested cells / wall time of one solve (median of 3 after one warm-up solve); the number of CFG evaluations the
+    controller took is reported beside it."""
+    B = min(cells, wl["B"])
+    w2 = dict(wl); w2["B"] = B
+    z2, cond2, scales = make_inputs(w2, B, device, seed=77)
+    from scldm_amd.transport import Sampler, create_transport
+    fn = Sampler(create_transport()).sample_ode()              # exactly the reference's call
+    model_fn = lambda x, t, **kw: m.forward_with_cfg(x, t, **kw, cfg_scale=scales)
+    fn(z2, model_fn, condition=cond2)
+    sync(device)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fn(z2, model_fn, condition=cond2)
+        sync(device)
+        ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    st = getattr(fn, "last_stats", {}) or {}
+    ev = st.get("evaluations")
+    rec = {"sampler": "dopri5 (atol = rtol = 1e-5, 50 save points): Sampler.sample_ode() defaults", "cells_per_gpu": B, "cells_per_s": B / dt,
+           "ms_per_solve": 1e3 * dt, "cfg_evaluations": ev, "accepted_steps": len(st.get("accepted_steps", [])),
+           "rejected_steps": len(st.get("rejected_steps", [])), "precision": m.precision}
+    if ev:
+        n_fwd = (2 + n_passes(wl)) * B
+        rec["dit_fwd_mfma_frac"] = n_fwd * FLOPS_TRUNK_PER_SAMPLE_FWD * ev / dt / PEAK[m.precision]
+    return rec
+
+
+def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
+    """BASELINE configs[0] on the GPU: one VAE optimisation step = TransformerVAE.forward -> -log_nb_positive(...).sum(1).mean() ->
+    HIP backward -> fused AdamW (src/scldm/models.py:243-249, vae.py:29-56) at the dentate_gyrus shape.  FLOPs per cell: forward =
+    encode (S x 6 528 + 1.5e6) + decode (G x 23 104 + 3.3e6), backward counted as 2 x forward."""
+    from scldm_amd.distributions import log_nb_positive
+    rec = {}
+    for B in batches:
+        vae = make_vae(n_genes, device).train()
+        g = torch.Generator().manual_seed(5)
+        counts = torch.poisson(torch.full((B, n_genes), 0.5), generator=g).to(device)
+        genes = torch.arange(n_genes, device=device).repeat(B, 1)
+        gs = torch.stack([torch.sort(torch.randperm(n_genes, generator=g)[:S]).values for _ in range(B)]).to(device)
+        cs = counts.gather(1, gs)
+        lib = counts.sum(1, keepdim=True)
+        opt = torch.optim.AdamW(vae.parameters(), lr=1e-3, fused=True)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            params, _ = vae(counts, genes, lib, cs, gs)
+            loss = (-log_nb_positive(counts, params["mu"], params["theta"])).sum(1).mean()
+            loss.backward()
+            opt.step()
+            return loss
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        n = 10 if B <= 64 else 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        flops = 3 * B * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6 + n_genes * MCAB_DECODE_FLOPS_PER_GENE + 3.3e6)
+        rec[f"b{B}"] = {"cells": B, "n_genes": n_genes, "tokens_per_cell": S, "ms_per_step": 1e3 * dt, "cells_per_s": B / dt,
+                        "tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / PEAK["fp32"], "final_loss": float(loss.detach())}
+        del vae, opt
+        torch.cuda.empty_cache()
+    return rec
 
 
 _T0 = time.perf_counter()
@@ -626,23 +715,44 @@ def main():
     if rank == 0 and not dist_on and not fake:
         if not args.no_extra:
             if args.precision != "bf16x3":
-                result["parity_path"] = precision_path(wl, device, "bf16x3")
+                result["parity_path"] = precision_path(wl, device, "bf16x3", args.steps, args.warmup)
                 note("parity path done")
             if args.precision != "fp16":
-                result["reference_class_path"] = precision_path(wl, device, "fp16")
+                result["reference_class_path"] = precision_path(wl, device, "fp16", args.steps, args.warmup)
                 note("reference-class (fp16) path done")
+            if args.precision != "bf16":
+                result["throughput_path"] = precision_path(wl, device, "bf16", args.steps, args.warmup)
+                note("bf16 throughput path done")
             extra = []
             for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100", "parse1m_b8192_euler100_strong"):
                 if name == args.workload:
                     continue
                 w2 = dict(WORKLOADS[name])
                 m2 = make_model(w2, args.precision, device)
-                d2, _, _, (_, c2, _, B2) = time_workload(m2, w2, device, 1, 1, False, 1, 0, time_blocks=False)
-                extra.append({"workload": name, "cells_per_s": B2 / d2, "ms_per_step": 1e3 * d2,
+                # median of >= 5 individually synchronised steps after >= 2 warm-up steps (single-step timings carry +-10 %)
+                n_t, n_w = max(5, min(args.steps, 7)), max(2, args.warmup)
+                ts, (_, c2, _, B2) = time_steps_each(m2, w2, device, n_t, n_w)
+                d2 = statistics.median(ts)
+                extra.append({"workload": name, "cells_per_s": B2 / d2, "ms_per_step": 1e3 * d2, "steps": n_t, "warmup": n_w,
+                              "spread": (max(ts) - min(ts)) / d2, "ms_each": [round(1e3 * t, 3) for t in ts],
                               "dit_fwd_mfma_frac": executed_flops_per_eval(w2, B2, c2) * w2["evals"] / d2 / PEAK[args.precision]})
                 del m2
             result["other_workloads"] = extra
             note("other workloads done")
+            if wl["scale"] == 1.0 and n_passes(wl) == 1:
+                # the product's opt-in shortcut for guidance exactly 1.0 (SCLDM_OPT_CFG1_DIRECT): guided rows = conditional output, 2B
+                # instead of 3B sample-forwards per evaluation.  Reported beside the headline, never as it.
+                m.guidance1_direct = True
+                ts, _ = time_steps_each(m, wl, device, 3, 1)
+                m.guidance1_direct = False
+                dg = statistics.median(ts)
+                result["guidance1_direct"] = {"cells_per_s": wl["B"] / dg, "ms_per_step": 1e3 * dg, "sample_forwards_per_evaluation_per_gpu": 2 * wl["B"],
+                                              "note": "opt-in (DiT.guidance1_direct): at guidance scale exactly 1.0 u2 + 1.0 * (c2 - u2) == c2 up to one "
+                                                      "fp32 rounding, so the second half's unconditional forward is skipped; within 1e-6 of the default path "
+                                                      "(tests/test_gpu_dit.py); the headline above runs all 3B sample-forwards"}
+                note("guidance-1 direct done")
+            result["default_sampler"] = default_sampler_record(m, wl, device)
+            note("default (dopri5) sampler done")
             result["with_vae_decode"] = decode_inclusive(m, wl, device)
             note("decode done")
             result["with_vae_encode"] = encode_record(device)
@@ -656,6 +766,11 @@ def main():
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
                                                 "per layer (DESIGN 4.4a)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.4)"}
             note("training step done")
+            try:
+                result["vae_training_step"] = vae_training_record(device)
+            except Exception as e:   # an extra: never takes the headline line down
+                result["vae_training_step"] = {"error": repr(e)}
+            note("VAE training step done")
             if tprec == "bf16":   # BASELINE configs[4] names a DiT-L denoiser: the same step on that shape (generic path, bf16 arrays + bgemm)
                 try:
                     torch.cuda.empty_cache()
@@ -667,6 +782,17 @@ def main():
                                        "path": "generic: bf16 operand arrays, LDS-DMA 256-tile GEMMs (bgemm8_kernel) / bgemm_kernel, matrix-core attention, "
                                                "batched weight gradients beside the chain (DESIGN 4.4b, 4.4c)"}
                         torch.cuda.empty_cache()
+                    # the same DiT-L shape sampling (generic GEMM route under forward_with_cfg; 20 Euler CFG evaluations, 256 cells)
+                    wL = dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=256, evals=20, method="euler", scale=1.0,
+                              shape=dict(n_embed=1024, n_layer=24, n_head=16))
+                    mL = make_model(wL, "bf16", device)
+                    tsL, _ = time_steps_each(mL, wL, device, 3, 1)
+                    dL = statistics.median(tsL)
+                    result["ditl_sampling"] = {"cells": 256, "cfg_evaluations": 20, "cells_per_s": 256 / dL, "ms_per_solve": 1e3 * dL,
+                                               "cells_per_s_at_100_evaluations": 256 / (dL * 5),
+                                               "tflops": 3 * 256 * dit_flops(n_embed=1024, n_layer=24) * 20 / dL / 1e12, "dtype": "bf16"}
+                    del mL
+                    torch.cuda.empty_cache()
                 except Exception as e:   # an extra: never takes the headline line down
                     result["training_step_ditl"] = {"error": repr(e)}
                 note("DiT-L training step done")

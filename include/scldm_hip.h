@@ -168,6 +168,15 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
                      int n_pass, const uint32_t* pass_mask, const float* pass_scale, int n_steps, int method,
                      int precision, void* ws, void* stream);
 
+/* Options of a handle (read by the calls that follow).
+ * SCLDM_OPT_CFG1_DIRECT (default 0): with ONE conditional pass of guidance scale exactly 1.0 and a scalar t (scldm_sample_ode,
+ *   scldm_dit_forward_cfg with t_stride 0), DiT.forward_with_cfg's guided half u2 + 1.0 * (c2 - u2) (nnets.py:368,376) is c2 up to
+ *   one fp32 rounding of that expression: the unconditional forward over the second half is not run (2B sample-forwards per
+ *   evaluation instead of 3B) and the conditional output is returned as the guided rows.  Off: the reference's arithmetic, term by
+ *   term.  The reference's own configs use guidance 1.0 for dentate_gyrus / parse1m (datamodule/default.yaml:46-47). */
+#define SCLDM_OPT_CFG1_DIRECT 1
+int scldm_dit_set_option(scldm_dit* h, int option, int value);
+
 /* DiT layers one fused-kernel launch runs (4 by default, SCLDM_LPL=1..4: the residual stays in registers between them; 0 for a
  * handle outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
 int scldm_dit_layers_per_launch(const scldm_dit* h);

@@ -16,6 +16,7 @@ PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
 METHOD_EULER, METHOD_HEUN = 0, 1
 PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16}
 METHODS = {"euler": METHOD_EULER, "heun": METHOD_HEUN}
+OPT_CFG1_DIRECT = 1   # scldm_dit_set_option (include/scldm_hip.h)
 
 c_float_p = C.POINTER(C.c_float)
 c_void_pp = C.POINTER(C.c_void_p)
@@ -80,6 +81,7 @@ def lib() -> C.CDLL:
     L.scldm_dit_label_errors.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
     L.scldm_dit_mod_width.argtypes = [C.c_void_p]
     L.scldm_dit_layers_per_launch.argtypes = [C.c_void_p]
+    L.scldm_dit_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.scldm_dit_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.scldm_dit_workspace_bytes.restype = C.c_size_t
     L.scldm_dit_cond_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, c_void_pp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -87,7 +87,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_NTT")) h->force_x3_ntt = atoi(e);
-  h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..4 for A/B runs)
+  h->lpl = std::min(4, kMaxLayersPerLaunch);   // layers per fused launch (SCLDM_LPL=1..kMaxLayersPerLaunch for A/B runs)
   if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   h->groups = 1;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
@@ -182,6 +182,11 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
 
 extern "C" int scldm_dit_mod_width(const scldm_dit* h) { return h ? h->mod_w : 0; }
 extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h->fused) ? h->lpl : 0; }
+extern "C" int scldm_dit_set_option(scldm_dit* h, int option, int value) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (option == SCLDM_OPT_CFG1_DIRECT) { h->cfg1_direct = value != 0; return SCLDM_OK; }
+  return fail(SCLDM_ERR_SHAPE, "unknown option %d", option);
+}
 
 // fingerprint the parameter tensors, compare with the fingerprint of the packed copies, re-pack if they differ (all on
 // device, in stream order; `force` makes the first pack after scldm_dit_load_weights unconditional)
@@ -613,6 +618,7 @@ extern "C" int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, c
 // One CFG evaluation: dz (2B, e) = forward_with_cfg(z, t); t_dev/t_stride describe the device-side t.
 struct CfgPlan {
   int B, P, U, uncond_rows, n_fwd, n_rows;
+  bool direct;   // SCLDM_OPT_CFG1_DIRECT applies: rows [B, 2B) run the conditional forward only (guided = conditional at scale 1)
   const int64_t* const* ulabels;
   const int32_t* cell_row;
   uint32_t mask[SCLDM_MAX_CLASSES];
@@ -622,8 +628,12 @@ struct CfgPlan {
 // plan (optional, device): plan[0] == 0 selects the dense plan (one row per sample-forward: uncond_rows = n_direct, U = B, no
 // cell_row) over the uniform one given by the arguments
 __global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_t* __restrict__ cell_row, int n_direct,
-                                          int uncond_rows, int B, int U, int P, const int* __restrict__ plan = nullptr) {
+                                          int uncond_rows, int B, int U, int P, const int* __restrict__ plan = nullptr, int direct = 0) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (direct) {   // 2B sample-forwards: the first half unconditional (one shared row), the second half with its label rows
+    if (s < 2 * B) ri[s] = s < B ? 0 : uncond_rows + (cell_row ? cell_row[s - B] : s - B);
+    return;
+  }
   if (s >= n_direct + P * B) return;
   if (plan && plan[0] == 0) {
     uncond_rows = n_direct;
@@ -680,6 +690,8 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
     }
   }
   if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr))) return rc;
+  if (pl.direct)   // guided rows = the conditional forward itself: the trunk writes dz, no blend
+    return trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st);
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;
   CfgArgs ca;
   ca.v = w.v;
@@ -712,6 +724,7 @@ static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, i
   pl.n_rows = (t_stride == 2) ? 2 * B + n_pass * B /* the larger, dense plan sizes the workspace */ : pl.uncond_rows + pl.P * pl.U;
   pl.ulabels = ulabels;
   pl.cell_row = cell_row;
+  pl.direct = h->cfg1_direct && t_stride == 0 && n_pass == 1 && pass_scale[0] == 1.0f;
   for (int p = 0; p < n_pass; ++p) {
     pl.mask[p] = pass_mask[p];
     pl.scale[p] = pass_scale[p];
@@ -735,7 +748,7 @@ extern "C" int scldm_dit_forward_cfg(scldm_dit* h, const float* x, const float* 
     LAUNCH_CHECK();
   }
   fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, t_stride == 2 ? 1 : pl.uncond_rows, B, pl.U, pl.P,
-                                                                   t_stride == 2 ? h->d_plan : nullptr);
+                                                                   t_stride == 2 ? h->d_plan : nullptr, pl.direct);
   LAUNCH_CHECK();
   return cfg_eval(h, pl, x, t, t_stride, w, out, precision, st);
 }
@@ -758,7 +771,7 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
   if ((rc = make_plan(h, pl, ulabels, n_urows, cell_row, B, n_pass, pass_mask, pass_scale, 0))) return rc;
   hipStream_t st = (hipStream_t)stream_;
   Ws w = carve(h, ws_, pl.n_fwd, pl.n_rows, 2 * B);
-  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, 1, B, pl.U, pl.P);
+  fill_cfg_row_index_kernel<<<cdiv(pl.n_fwd, 256), 256, 0, st>>>(w.ridx, cell_row, 2 * B, 1, B, pl.U, pl.P, nullptr, pl.direct);
   LAUNCH_CHECK();
   const size_t n = (size_t)2 * B * 16 * h->cfg.n_embed_input;
   const int steps = n_steps + 1;

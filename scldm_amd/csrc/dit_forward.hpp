@@ -75,7 +75,17 @@ constexpr int kD = 256;        // n_embed
 constexpr int kHC = 128;       // hidden chunk per workgroup (4 waves x 32)
 constexpr int kModBlock = 6 * kD;
 constexpr int kDbgStamps = 32;
-constexpr int kMaxLayersPerLaunch = 4;   // layer slots instantiated in the fused kernel (code size grows with it: ~30 KB of ISA per slot)
+// layer slots instantiated in the fused kernel (code size grows with it: ~30 KB of ISA per slot); -DSCLDM_MAX_LPL=8 builds the
+// whole-network launch (A/B: small batches, where launch boundaries and residual hand-offs weigh most)
+#ifndef SCLDM_MAX_LPL
+#define SCLDM_MAX_LPL 4
+#endif
+constexpr int kMaxLayersPerLaunch = SCLDM_MAX_LPL;
+// 1: every workgroup touches its share of the NEXT layer's weight stream (one 4-byte load per 128-byte line) at the start of a
+// layer, so that the stream's first-touch misses (each XCD's 4 MB L2 holds ~2 layers) are taken a layer ahead of the ring.
+#ifndef SCLDM_L2WARM
+#define SCLDM_L2WARM 0
+#endif
 
 // Phase stamps (s_memtime) for the debug build (first layer only); compiles to nothing otherwise.
 #ifdef SCLDM_PHASE_TIMING
@@ -733,6 +743,18 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
                                  : *reinterpret_cast<const f32x4*>(a.b_proj + li * kD + (idx - 3 * kD / 4) * 4);
   }
   float* BIAS = reinterpret_cast<float*>(HB);
+#if SCLDM_L2WARM
+  // L2 warm-up of the next layer's stream (the first layer's for the last one: the next evaluation starts there).  The 64
+  // workgroups an XCD runs at a time (consecutive blockIdx / 8) split the 1.6 MB into 128-byte lines; one dword per line.
+  unsigned warm = 0;
+  {
+    const long lbytes = a.w_layer_elems * (long)sizeof(E);
+    const char* nxt = reinterpret_cast<const char*>(a.w_stream) + (layer + 1 < a.n_layer ? (long)(li + 1) * lbytes : -(long)a.layer * lbytes);
+    const int lines = (int)(lbytes >> 7), per = (lines + 63) >> 6;
+    const int ln = ((blockIdx.x >> 3) & 63) * per + tid;
+    if (tid < per && ln < lines) warm = *reinterpret_cast<const unsigned*>(nxt + ((long)ln << 7));
+  }
+#endif
 
   f32x16 acc[FT][NTT];
   const float* bq = BIAS;
@@ -741,6 +763,9 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
   // ---- LN1 + modulate(a0 = scale, a1 = shift) -> XA (the staged adaLN vectors are published on the way) ----
   SCLDM_STAMP(21);
   ln_modulate_store<OP, NTT, FT, 22>(xr, MOD, 0, 1, a.eps, RED, XA, L::XA_LD, wave, lane, a.dbg, [&] {
+#if SCLDM_L2WARM
+    asm volatile("" :: "v"(warm));   // the warm-up load retires with the staged vectors (issued together): no later wait inherits it
+#endif
 #pragma unroll
     for (int j = 0; j < kModLd; ++j)
       if (tid + NT * j < NS * kModBlock / 4) {
@@ -1131,7 +1156,13 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
   if (a.n_here > 1) layer_body(std::integral_constant<int, 1>{});
   if (a.n_here > 2) layer_body(std::integral_constant<int, 2>{});
   if (a.n_here > 3) layer_body(std::integral_constant<int, 3>{});
-  static_assert(kMaxLayersPerLaunch == 4, "one layer_body call per slot");
+#if SCLDM_MAX_LPL > 4
+  if (a.n_here > 4) layer_body(std::integral_constant<int, 4>{});
+  if (a.n_here > 5) layer_body(std::integral_constant<int, 5>{});
+  if (a.n_here > 6) layer_body(std::integral_constant<int, 6>{});
+  if (a.n_here > 7) layer_body(std::integral_constant<int, 7>{});
+#endif
+  static_assert(kMaxLayersPerLaunch == 4 || kMaxLayersPerLaunch == 8, "one layer_body call per slot");
   SCLDM_STAMP_END(14);
 }
 

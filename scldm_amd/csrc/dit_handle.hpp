@@ -27,6 +27,7 @@ struct scldm_dit {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   int lpl;         // DiT layers per fused-kernel launch (1..4)
+  int cfg1_direct = 0;  // SCLDM_OPT_CFG1_DIRECT (scldm_dit_set_option)
   int groups;      // tile groups per layer launch (SCLDM_GROUPS, read once at create)
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
   int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)

@@ -914,6 +914,9 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
                                         const int64_t* const* labels, const float* dout, int n, float* dx_out, int precision,
                                         void* saved_, void* ws, void* stream_) {
   struct InBackward { InBackward() { t_in_backward = true; } ~InBackward() { t_in_backward = false; } } in_backward_scope;
+  // the gradient-ready events belong to THIS call only: whatever way it returns, none of the raw hipEvent_t handles survives on the
+  // handle (the caller may destroy them right after; a later backward without set_grad_events must not record into them)
+  struct DropEvents { scldm_dit* h; ~DropEvents() { if (h) h->grad_events.clear(); } } drop_events_scope{h};
   precision = train_precision(precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");

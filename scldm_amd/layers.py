@@ -20,6 +20,13 @@ def swiglu_hidden(n_embed: int, multiple_of: int) -> int:
     return multiple_of * ((h + multiple_of - 1) // multiple_of)
 
 
+def _no_dropout(dropout: float, who: str) -> None:
+    """The fused kernels have no dropout stage: every reference config sets dropout 0.0 (ldm_base.yaml:21, vae_base.yaml:14).  A
+    non-zero rate would silently train a different model than the reference (resid_dropout, layers.py:140-157,246-262)."""
+    if float(dropout) != 0.0:
+        raise NotImplementedError(f"{who}: dropout={dropout} is not supported by the fused HIP kernels (the reference configs use 0.0)")
+
+
 class _Fused(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover - guard only
         raise RuntimeError(f"{type(self).__name__} is a parameter container: its math is fused into the owning "
@@ -32,6 +39,7 @@ class SelfAttention(_Fused):
     def __init__(self, n_embed: int, n_head: int, dropout: float, bias: bool):
         super().__init__()
         assert n_embed % n_head == 0
+        _no_dropout(dropout, "SelfAttention")
         self.n_head, self.n_embed, self.dropout = n_head, n_embed, dropout
         self.c_attn = nn.Linear(n_embed, 3 * n_embed, bias=bias)
         self.c_proj = nn.Linear(n_embed, n_embed, bias=bias)
@@ -42,6 +50,7 @@ class CrossAttention(_Fused):
 
     def __init__(self, n_embed: int, n_head: int, dropout: float, bias: bool):
         super().__init__()
+        _no_dropout(dropout, "CrossAttention")
         self.n_head, self.n_embed = n_head, n_embed
         self.c_attn = nn.Linear(n_embed, 2 * n_embed, bias=bias)
         self.c_attn_q = nn.Linear(n_embed, n_embed, bias=bias)

@@ -217,6 +217,11 @@ class DiT(nn.Module):
         self.final_layer = FinalLayerDit(n_embed, n_embed_input, bias, layernorm_eps)
         self.precision = os.environ.get("SCLDM_PRECISION", "fp32")
         self.detect_uniform_t = True   # forward_with_cfg: test a dense t for uniformity on device (no host sync); see there
+        # Non-reference knob, off by default: with ONE conditional pass at guidance scale exactly 1.0 the guided half
+        # u2 + 1.0 * (c2 - u2) (nnets.py:368,376) equals the conditional output c2 up to one fp32 rounding, so the fused sampler /
+        # scalar-t forward_with_cfg skip the unconditional forward of the second half (2B instead of 3B sample-forwards per
+        # evaluation: 1.5 x the cells/s at the reference's default guidance of dentate_gyrus / parse1m).
+        self.guidance1_direct = False
         self._handle = None
         self._weights_key = None
         self._ws = None
@@ -296,6 +301,7 @@ class DiT(nn.Module):
             # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation)
             with torch.cuda.device(self.pos_embed.device):
                 _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
+        L.scldm_dit_set_option(self._handle, _lib.OPT_CFG1_DIRECT, int(bool(getattr(self, "guidance1_direct", False))))
         if self.precision == "fp16" and self.__dict__.get("_fp16_checked") != self._weights_key:
             # once per (re)load: the fp16 stream's range report (one stream synchronisation).  `.data` updates that are picked up
             # by the fingerprint re-pack are not re-checked: call fp16_weight_report() after such an update if in doubt.
@@ -342,7 +348,8 @@ class DiT(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
-        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_grad_segs", "_pos_idx", "_param_list", "_prepared_key", "_grad_sync"):
+        for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_grad_segs", "_pos_idx", "_param_list", "_prepared_key", "_grad_sync",
+                  "_train_step_sync", "_fp16_checked"):
             state.pop(k, None)
         return state
 
@@ -664,8 +671,8 @@ class DiT(nn.Module):
     # ------------------------------------------------------------------ forward_with_cfg (nnets.py:336-378)
     def forward_with_cfg(self, x: torch.Tensor, t: torch.Tensor, condition: dict[str, torch.Tensor] | None = None,
                          cfg_scale: dict[str, float] | None = None) -> torch.Tensor:
-        if self.training:
-            raise NotImplementedError("forward_with_cfg is an inference path; call .eval() first")
+        if self.training:   # the reference's forward_with_cfg works in either mode (it passes force_drop_ids=False, nnets.py:353,367,375)
+            return self._composed_forward_with_cfg(x, t, condition, cfg_scale)
         if not self.fused_shape:
             xg, tg = _require_cuda_f32("x", x), _require_cuda_f32("t", t)
             if xg.shape[0] % 2 or xg.shape[1:] != (self.seq_len, self.n_embed_input) or tg.shape != (xg.shape[0],):
@@ -701,6 +708,30 @@ class DiT(nn.Module):
         del keep
         return out
 
+    def _composed_forward_with_cfg(self, x, t, condition, cfg_scale):
+        """forward_with_cfg of a module in TRAINING mode: composed from `forward(..., force_drop_ids=False)` calls exactly as the
+        reference composes it (nnets.py:336-378), so that its training-mode semantics carry over - the joint strategy draws its
+        label-dropout mask whenever `self.training` (nnets.py:440-445, also inside a CFG evaluation), and the result is
+        differentiable when gradients are enabled.  Eval mode takes the fused single-call path instead."""
+        n = x.shape[0]
+        B = n // 2
+        if n != 2 * B or tuple(t.shape) != (n,):
+            raise ValueError(f"expected x (2B,{self.seq_len},{self.n_embed_input}) and t (2B,), got {tuple(x.shape)}, {tuple(t.shape)}")
+        self._need_null_row("forward_with_cfg (the unconditional pass)")
+        uncond = {c: torch.full((n,), v, device=x.device, dtype=torch.long) for c, v in self.class_vocab_sizes.items()}
+        u = self.forward(x, t, uncond, force_drop_ids=False)                      # :346-353
+        u1, u2 = u[:B], u[B:]
+        g = u2.clone()
+        if condition is not None and cfg_scale is not None:
+            x2, t2 = x[B:], t[B:]
+            if self.condition_strategy == "joint":                               # :362-368
+                full = {k: v[B:] for k, v in condition.items()}
+                g = g + (sum(cfg_scale.values()) / len(cfg_scale)) * (self.forward(x2, t2, full, force_drop_ids=False) - u2)
+            else:                                                                # :370-376
+                for c, sc in cfg_scale.items():
+                    g = g + float(sc) * (self.forward(x2, t2, {c: condition[c][B:]}, force_drop_ids=False) - u2)
+        return torch.cat([u1, g], dim=0)
+
     def forward_with_cfg_joint(self, x: torch.Tensor, t: torch.Tensor, condition: dict[str, torch.Tensor] | None = None,
                                cfg_scale: dict[str, float] | None = None) -> torch.Tensor:
         """Mirror of nnets.py:299-334 (no caller in the reference; kept for API completeness): unconditional pass on every
@@ -723,15 +754,17 @@ class DiT(nn.Module):
         reference meaning (grid POINTS: num_steps-1 Euler evaluations).  Returns the final state (what the
         reference indexes with [-1], models.py:812).
         """
-        if self.training:
-            raise NotImplementedError("sampling is an inference path; call .eval() first")
         if num_steps < 2:
             raise ValueError("num_steps must be >= 2 (grid points)")
         if sampling_method.lower() == "dopri5":   # adaptive solve: host-driven steps over the fused forward_with_cfg
             from .transport import Sampler, create_transport
             fn = Sampler(create_transport()).sample_ode(sampling_method="dopri5", num_steps=2, atol=atol, rtol=rtol)
             return fn(_require_cuda_f32("z", z), self.forward_with_cfg, condition=condition, cfg_scale=cfg_scale)[-1]
-        if not self.fused_shape:   # fixed-grid Euler / Heun over the generic forward_with_cfg (same grid as the fused loop)
+        if self.training or not self.fused_shape:
+            # fixed-grid Euler / Heun over forward_with_cfg, one evaluation per call (same grid as the fused loop): shapes outside
+            # the fused family, and modules left in training mode (the reference samples in whatever mode the caller left the
+            # model in; forward_with_cfg then carries the training-mode label handling)
+            fwd = self._generic_forward_with_cfg if not self.fused_shape else self.forward_with_cfg
             z = _require_cuda_f32("z", z).clone()
             method = sampling_method.lower()
             if method not in _lib.METHODS:
@@ -739,12 +772,12 @@ class DiT(nn.Module):
             hstep = 1.0 / (num_steps - 1)
             for i in range(num_steps - 1):
                 t0 = torch.full((z.shape[0],), i * hstep, device=z.device)
-                k1 = self._generic_forward_with_cfg(z, t0, condition, cfg_scale)
+                k1 = fwd(z, t0, condition, cfg_scale)
                 if method == "euler":
                     z = z + hstep * k1
                 else:
                     t1 = torch.full((z.shape[0],), (i + 1) * hstep, device=z.device)
-                    k2 = self._generic_forward_with_cfg(z + hstep * k1, t1, condition, cfg_scale)
+                    k2 = fwd(z + hstep * k1, t1, condition, cfg_scale)
                     z = z + (0.5 * hstep) * (k1 + k2)
             return z
         self._need_null_row("CFG sampling (the unconditional pass)")

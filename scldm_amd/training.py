@@ -111,6 +111,7 @@ class OverlappedGradSync:
         self.collectives = 0
         self.copies = 0
         self._works, self._flat, self._plan, self._events, self._side = [], None, None, None, None
+        self._params, self._offs = None, None
         self.handled = False
 
     def active(self) -> bool:
@@ -120,6 +121,7 @@ class OverlappedGradSync:
         dit.__dict__["_grad_sync"] = self
         self.handled = False
         self.collectives = 0
+        self.copies = 0
 
     @staticmethod
     def detach(dit) -> None:
@@ -127,7 +129,19 @@ class OverlappedGradSync:
 
     # ---- called by scldm_amd.nnets._DiTTrainFn.backward -----------------------------------------------------------------------
     def before_backward(self, dit, L, h) -> None:
+        if self._works or self._flat is not None:
+            raise RuntimeError("OverlappedGradSync: a second backward started before finish() consumed the first one's all-reduces "
+                               "(one backward per step; call finish() - train_step does - before the next)")
         self._plan = dit.grad_bucket_plan(self.bucket_bytes)
+        # the in-place exchange relies on autograd ADOPTING the views of the flat buffer as .grad (no clone, no accumulation into an
+        # older .grad while the side stream is still reducing the buffer): gradients must be None when the backward starts
+        self._offs = dit.__dict__["_grad_offsets"]
+        self._params = [p for p in dit.parameters() if id(p) in self._offs]
+        stale = sum(p.grad is not None for p in self._params)
+        if stale:
+            raise RuntimeError(f"OverlappedGradSync: {stale} parameter(s) still hold a .grad from an earlier backward; gradient "
+                               "accumulation is not supported on the overlapped path - call optimizer.zero_grad(set_to_none=True) "
+                               "first, or use allreduce_gradients() after the last backward")
         dev = dit.pos_embed.device
         if dev.type != "cuda":
             self._events = None
@@ -145,6 +159,8 @@ class OverlappedGradSync:
         _lib.check(L.scldm_dit_train_set_grad_events(h, C.cast(ev, _lib.c_void_pp), kd, ly, n), "scldm_dit_train_set_grad_events")
 
     def after_backward(self, flat: torch.Tensor) -> None:
+        if self._works or self._flat is not None:
+            raise RuntimeError("OverlappedGradSync.after_backward called twice before finish()")
         self._flat = flat
         self._works = []
         op = dist.ReduceOp.SUM
@@ -164,12 +180,31 @@ class OverlappedGradSync:
         self.handled = True
 
     def finish(self) -> None:
-        """The current stream waits for every bucket; gradients become the mean over ranks."""
+        """The current stream waits for every bucket; gradients become the mean over ranks.  Every .grad must be the view of the
+        flat buffer the backward returned for it: a parameter whose .grad is something else (autograd cloned the view instead of
+        adopting it) gets the reduced slice copied in (`copies` counts them; the clone may have been taken while the side stream
+        was reducing the buffer, so its contents are not trusted)."""
         for w in self._works:
             w.wait()
-        if self._flat is not None and self.average:
-            self._flat.div_(dist.get_world_size(self.group))
-        self._works, self._flat, self._events = [], None, None
+        flat = self._flat
+        if flat is not None and self.average:
+            flat.div_(dist.get_world_size(self.group))
+        if flat is not None and self._params is not None:
+            base, es = flat.data_ptr(), flat.element_size()
+            for p in self._params:
+                g = p.grad
+                if g is None:
+                    continue
+                o = self._offs[id(p)]
+                if g.data_ptr() != base + es * o or not g.is_contiguous():
+                    with torch.no_grad():
+                        g.copy_(flat[o:o + p.numel()].view(p.shape))
+                    self.copies += 1
+            if self.copies:
+                import warnings
+                warnings.warn(f"OverlappedGradSync: autograd did not adopt {self.copies} gradient view(s) of the flat buffer; the reduced "
+                              "values were copied into .grad (slower; results are correct)", RuntimeWarning, stacklevel=2)
+        self._works, self._flat, self._events, self._params, self._offs = [], None, None, None, None
 
 
 def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str, torch.Tensor], group=None,

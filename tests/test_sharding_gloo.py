@@ -247,3 +247,109 @@ def test_overlapped_grad_sync_reduces_every_bucket_in_place(bucket_bytes):
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in results), results
     assert all(calls == expect for _, _, calls, expect in results), results
+
+
+# ---- the in-place exchange through REAL autograd (AccumulateGrad must adopt the views of the flat buffer) ---------------
+class _FlatGradFn(torch.autograd.Function):
+    """CPU stand-in for scldm_amd.nnets._DiTTrainFn: the backward fills ONE flat buffer (rank-dependent values), calls the
+    OverlappedGradSync hooks around the fill exactly where the HIP backward calls them, and returns views of the buffer."""
+
+    @staticmethod
+    def forward(ctx, module, scale, *params):
+        ctx.module, ctx.scale, ctx.params = module, scale, params
+        return sum((p.detach() * 0).sum() for p in params) + torch.zeros(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, params = ctx.module, ctx.params
+        m._weights_struct(tuple(m.parameters()))
+        offs, total = m.__dict__["_grad_offsets"], m.__dict__["_grad_numel"]
+        sync = m.__dict__.get("_grad_sync")
+        if sync is not None:
+            sync.before_backward(m, None, None)
+        flat = torch.zeros(total)
+        for i, p in enumerate(params):
+            if id(p) in offs:
+                flat[offs[id(p)]:offs[id(p)] + p.numel()] = ctx.scale * (i + 1)
+        if sync is not None:
+            sync.after_backward(flat)
+        return (None, None, *[flat[offs[id(p)]:offs[id(p)] + p.numel()].view(p.shape) if id(p) in offs else None for p in params])
+
+
+def _autograd_overlap_worker(rank, world, port, out_q):
+    from scldm_amd import training
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = _small_dit(2)
+    params = tuple(p for p in m.parameters() if p.requires_grad)
+    sync = training.OverlappedGradSync(None, 1 << 20)
+    res = {}
+    # (1) one backward per step through real autograd: every .grad is the adopted view, holds the MEAN over ranks, no copies
+    sync.attach(m)
+    loss = _FlatGradFn.apply(m, float(rank + 1), *params)
+    loss.backward()
+    training.OverlappedGradSync.detach(m)
+    sync.finish()
+    mean = sum(r + 1 for r in range(world)) / world
+    res["mean"] = all(torch.allclose(p.grad, torch.full_like(p, mean * (i + 1))) for i, p in enumerate(params))
+    res["copies"] = sync.copies
+    res["collectives"] = sync.collectives
+    st = {p.grad.untyped_storage().data_ptr() for p in params}
+    res["one_storage"] = len(st) == 1
+    # (2) gradient accumulation (a .grad left over from the previous step) is refused loudly instead of racing with the side stream
+    sync.attach(m)
+    try:
+        _FlatGradFn.apply(m, 1.0, *params).backward()
+        res["accumulation_refused"] = False
+    except RuntimeError as e:
+        res["accumulation_refused"] = "zero_grad" in str(e)
+    training.OverlappedGradSync.detach(m)
+    # (3) a second backward before finish() is refused
+    for p in params:
+        p.grad = None
+    sync2 = training.OverlappedGradSync(None, 1 << 20)
+    sync2.attach(m)
+    _FlatGradFn.apply(m, 1.0, *params).backward()
+    for p in params:
+        p.grad = None
+    try:
+        _FlatGradFn.apply(m, 1.0, *params).backward()
+        res["double_backward_refused"] = False
+    except RuntimeError as e:
+        res["double_backward_refused"] = "finish" in str(e)
+    training.OverlappedGradSync.detach(m)
+    sync2.finish()
+    # (4) a .grad that is NOT the adopted view (a clone) receives the reduced values by copy, and the copy is counted
+    for p in params:
+        p.grad = None
+    sync3 = training.OverlappedGradSync(None, 1 << 20)
+    sync3.attach(m)
+    _FlatGradFn.apply(m, float(rank + 1), *params).backward()
+    training.OverlappedGradSync.detach(m)
+    params[0].grad = torch.full_like(params[0], -123.0)        # what a clone taken mid-reduction could look like: garbage
+    import warnings
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        sync3.finish()
+    res["clone_repaired"] = bool(torch.allclose(params[0].grad, torch.full_like(params[0], mean * 1))) and sync3.copies == 1 and len(wlist) == 1
+    out_q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_overlapped_grad_sync_through_real_autograd():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_autograd_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert res["mean"] and res["copies"] == 0 and res["one_storage"] and res["collectives"] >= 1, (rank, res)
+        assert res["accumulation_refused"] and res["double_backward_refused"] and res["clone_repaired"], (rank, res)
