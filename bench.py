@@ -395,28 +395,32 @@ ARITH = {
 MCAB_ENCODE_FLOPS_PER_GENE = 6_528    # 41.6 MFLOP per cell at S = 6 147 incl. the 16-token trunk (1.5 MFLOP)
 
 
-def encode_record(device, cells=1024):
+def encode_record(device, batches=(1024, 4096)):
     """MCAB pooling + encoder trunk (TransformerVAE.encode) on synthetic counts, both VAE precisions, with a roofline against the
     fp32-MFMA / bf16-MFMA peak: the dentate_gyrus size (G = 17 002 vocabulary, S = 6 147 tokens per cell) and the hlca size
-    (27 997 / 10 186).  Algorithmic FLOPs per cell: S x 6 528 + 1.5e6."""
+    (27 997 / 10 186).  Algorithmic FLOPs per cell: S x 6 528 + 1.5e6.  Keys without a batch suffix are 1 024 cells (the
+    per-GPU shard of configs[3]); `_b4096` is the north-star batch (the 16-token trunk is a fixed ~0.12 ms per call up to ~4 096 cells)."""
     rec = {}
     for name, n_genes, S in (("dentate", 17002, 6147), ("hlca", 27997, 10186)):
         vae = make_vae(n_genes, device)
-        g = torch.Generator().manual_seed(11)
-        genes = torch.stack([torch.randperm(n_genes, generator=g)[:S] for _ in range(8)]).repeat(cells // 8, 1).to(device)
-        counts = torch.poisson(torch.full((cells, S), 1.5), generator=g).to(device)
-        flops = cells * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6)
-        for prec in ("fp32", "bf16"):
-            vae.precision = prec
-            vae.encode(counts, genes); torch.cuda.synchronize()
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter(); vae.encode(counts, genes); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-            dt = statistics.median(ts)
-            ach = flops / dt / 1e12
-            rec[f"{name}_{prec}"] = {"cells": cells, "tokens_per_cell": S, "cells_per_s": cells / dt, "ms": 1e3 * dt,
-                                     "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK[prec] / 1e12, "unit": "TFLOP/s",
-                                                  "frac": ach / (PEAK[prec] / 1e12), "hbm_in_GBps": cells * S * 12 / dt / 1e9}}
+        for cells in batches:
+            g = torch.Generator().manual_seed(11)
+            genes = torch.stack([torch.randperm(n_genes, generator=g)[:S] for _ in range(8)]).repeat(cells // 8, 1).to(device)
+            counts = torch.poisson(torch.full((cells, S), 1.5), generator=g).to(device)
+            flops = cells * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6)
+            for prec in ("fp32", "bf16"):
+                vae.precision = prec
+                vae.encode(counts, genes); torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter(); vae.encode(counts, genes); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                dt = statistics.median(ts)
+                ach = flops / dt / 1e12
+                key = f"{name}_{prec}" + ("" if cells == 1024 else f"_b{cells}")
+                rec[key] = {"cells": cells, "tokens_per_cell": S, "cells_per_s": cells / dt, "ms": 1e3 * dt,
+                            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK[prec] / 1e12, "unit": "TFLOP/s",
+                                         "frac": ach / (PEAK[prec] / 1e12), "hbm_in_GBps": cells * S * 12 / dt / 1e9}}
+            del genes, counts
         del vae
     return rec
 

@@ -324,6 +324,11 @@ typedef struct {
 int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out);
 void scldm_vae_destroy(scldm_vae* h);
 int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, void* stream);
+/* Same parameter tensors as the last scldm_vae_load_weights (the pointers are remembered), possibly updated in place: a 64-bit
+ * fingerprint of every source tensor is compared ON DEVICE with that of the packed copies and the re-pack (one launch over a job
+ * table + the two derived tables) runs only if it moved - five small launches, no host synchronisation.  What the Python face calls
+ * before every encode / decode whose parameter storages and version counters are unchanged (`.data` updates are invisible to both). */
+int scldm_vae_refresh_weights(scldm_vae* h, void* stream);
 size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G);
 
 /* TransformerVAE.encode (vae.py:58-69): counts (B,S) fp32, genes (B,S) int64 -> z (B,16,n_lat). */

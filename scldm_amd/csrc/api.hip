@@ -87,9 +87,11 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_NTT")) h->force_x3_ntt = atoi(e);
-  h->lpl = std::min(4, kMaxLayersPerLaunch);   // layers per fused launch (SCLDM_LPL=1..kMaxLayersPerLaunch for A/B runs)
+  h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..kMaxLayersPerLaunch for A/B runs)
   if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   h->groups = 1;
+  if (const char* e = getenv("SCLDM_ADALN_VALU")) h->adaln_valu = atoi(e) != 0;
+  if (const char* e = getenv("SCLDM_ADALN_EXACT")) h->adaln_exact = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
   h->dbg_layer = -1;
   if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
@@ -137,6 +139,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->emb, (size_t)(emb_rows > 0 ? emb_rows : 1) * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->ada_t, (size_t)256 * h->mod_w * 4);
   if (e == hipSuccess) e = alloc((void**)&h->ada_b, (size_t)h->mod_w * 4);
+  if (e == hipSuccess) e = alloc((void**)&h->ada_x3, (size_t)256 * h->mod_w * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_wt, (size_t)din * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_w, (size_t)din * 256 * 4);
   if (e == hipSuccess) e = alloc((void**)&h->in_b, 256 * 4);
@@ -167,7 +170,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
       if (h->stream[p][f]) (void)hipFree(h->stream[p][f]);
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
-  void* ptrs[] = {h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
+  void* ptrs[] = {h->ada_x3, h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
                   h->b_proj, h->label_err, h->d_plan, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->wt16, h->d_cast_jobs, h->ada16, h->ada_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -288,11 +291,13 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
     add(kPackTranspose, 1536 * 256, {src(w->ada_w[i], 1536 * 256)}, h->ada_t, {1536, 256, mw, i * 1536});
     add(kPackCopy, 1536, {src(w->ada_b[i], 1536)}, h->ada_b + i * 1536, {});
     train = false;
+    add(kPackAdaX3, 1536 * 256, {w->ada_w[i]}, h->ada_x3, {i * 1536});
   }
   train = true;
   add(kPackTranspose, 512 * 256, {src(w->fin_ada_w, 512 * 256)}, h->ada_t, {512, 256, mw, L * 1536});
   add(kPackCopy, 512, {src(w->fin_ada_b, 512)}, h->ada_b + L * 1536, {});
   train = false;
+  add(kPackAdaX3, 512 * 256, {w->fin_ada_w}, h->ada_x3, {L * 1536});
   add(kPackTranspose, 256 * 256, {src(w->t_w0, 256 * 256)}, h->w0t, {256, 256, 256, 0});
   add(kPackTranspose, 256 * 256, {src(w->t_w2, 256 * 256)}, h->w2t, {256, 256, 256, 0});
   add(kPackCopy, 256, {src(w->t_b0, 256)}, h->b0, {});
@@ -443,9 +448,29 @@ static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
-static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st, const int* rows_dev = nullptr) {
-  dim3 grid(cdiv(h->mod_w, 64), cdiv(rows, kAdaRU));
-  adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w, rows_dev);
+// prec: the precision policy of the forward that consumes the vectors.  fp32 (and callers without a policy): exact fp32 on the
+// matrix pipe; the fast policies: split-bf16 operands (their own arithmetic class or finer).  Within a policy every output element
+// is one fixed-order sum whatever the number of rows (a cell's vectors never depend on its batch).
+static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st, const int* rows_dev = nullptr,
+                        int prec = SCLDM_PREC_FP32) {
+  if (prec != SCLDM_PREC_FP32 && !h->adaln_valu && !h->adaln_exact) {
+    const bf16x8x2* wf = reinterpret_cast<const bf16x8x2*>(h->ada_x3);
+    const int n_tiles = h->mod_w / 32;
+    if (rows <= 128) {   // few rows: one column tile per wave (every wave's latency chain as short as possible)
+      adaln_x3_kernel<1><<<dim3(cdiv(n_tiles, 4), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
+    } else {             // many rows: the split of a wave's 32 rows is amortised over four column tiles
+      adaln_x3_kernel<4><<<dim3(cdiv(n_tiles, 16), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
+    }
+    LAUNCH_CHECK();
+    return SCLDM_OK;
+  }
+  if (h->adaln_valu) {   // SCLDM_ADALN_VALU=1 (read once at create): the round-1 VALU kernel, for A/B runs
+    dim3 grid(cdiv(h->mod_w, 64), cdiv(rows, kAdaRU));
+    adaln_all_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w, rows_dev);
+  } else {
+    dim3 grid(cdiv(h->mod_w, 128), cdiv(rows, 32));
+    adaln_mfma_kernel<<<grid, 256, 0, st>>>(silu_c, h->ada_t, h->ada_b, mod, rows, h->mod_w, rows_dev);
+  }
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -609,7 +634,7 @@ extern "C" int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, c
   hipStream_t st = (hipStream_t)stream_;
   Ws w = carve(h, ws_, n, n, 0);
   if ((rc = launch_cond(h, t, 1, labels, 0xffffffffu, n, w.silu, st))) return rc;
-  if ((rc = launch_adaln(h, w.silu, w.mod, n, st))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, n, st, nullptr, precision))) return rc;
   iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(w.ridx, n);
   LAUNCH_CHECK();
   return trunk(h, x, n, 1, n, w.mod, w.ridx, w.h, out, precision, st);
@@ -689,7 +714,7 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
         return rc;
     }
   }
-  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec))) return rc;
   if (pl.direct)   // guided rows = the conditional forward itself: the trunk writes dz, no blend
     return trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st);
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;

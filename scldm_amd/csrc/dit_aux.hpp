@@ -140,7 +140,7 @@ __device__ __forceinline__ void pack_store(void* out, long long idx, float val, 
 // All packing of one scldm_dit_load_weights call is ONE launch over a table of jobs (was ~80 launches), so that it can
 // also be re-run conditionally, on device, by scldm_dit_refresh_weights: every block first reads the `dirty` word.
 // ------------------------------------------------------------------------------------------------
-enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFinal = 3, kPackLayerBwd = 4 };
+enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFinal = 3, kPackLayerBwd = 4, kPackAdaX3 = 5 };
 struct PackJob {
   int kind;
   int first_block;      // first 256-thread block of this job
@@ -171,6 +171,16 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       const int N = j.p[0], K = j.p[1], ldo = j.p[2], col0 = j.p[3];
       const int n = (int)(idx % N), k = (int)(idx / N);
       reinterpret_cast<float*>(j.d)[(size_t)k * ldo + col0 + n] = j.s[0][(size_t)n * K + k];
+      break;
+    }
+    case kPackAdaX3: {  // adaLN weight (N, 256) -> split-bf16 B fragments of adaln_x3_kernel: [n tile][k step][lane][hi x 8 | lo x 8]
+      const int n = (int)(idx >> 8) + j.p[0], k = (int)(idx & 255);
+      const float v = j.s[0][idx];
+      __bf16 hi, lo;
+      OpBF16x3::split(v, hi, lo);
+      const size_t base = ((((size_t)(n >> 5) * 16 + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) << 4) + (k & 7);
+      reinterpret_cast<__bf16*>(j.d)[base] = hi;
+      reinterpret_cast<__bf16*>(j.d)[base + 8] = lo;
       break;
     }
     case kPackLayerBwd:
@@ -419,6 +429,99 @@ __global__ __launch_bounds__(256) void adaln_all_kernel(const float* __restrict_
   if (n < mod_w) {
     for (int r = kq; r < kAdaRU; r += 4)
       if (u0 + r < rows) mod[(size_t)(u0 + r) * mod_w + n] = bias[n] + part[0][r][col] + part[1][r][col] + part[2][r][col] + part[3][r][col];
+  }
+}
+
+// The same product on the matrix pipe, exact fp32 (v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain): one wave = a 32-row x 32-column
+// tile over K = 256, lane (row r = lane & 31, half h = lane >> 5) holds the 128 k-values h * 128 .. + 127 of ITS conditioning row in
+// registers (32 float4) and streams the matching weight rows (one coalesced 128-byte segment per half-wave and k).  Every output
+// element is one fixed-order sum over k whatever the number of rows and wherever its row sits in a tile: a cell's adaLN vectors do
+// not depend on the batch it is sampled in (what the sharded sampler's bit-equality self-check relies on).
+// Why: joint / multi-class conditioning has hundreds of unique label tuples per batch (parse1m: ~750 rows at 1 024 cells); the VALU
+// kernel above re-reads the 13 MB weight matrix once per 8 rows - 100 us per CFG evaluation, 13.6 % of the GPU time of that workload
+// (profiles/r4a_parse1m_b1024_kernel_stats.txt).
+__global__ __launch_bounds__(256, 2) void adaln_mfma_kernel(const float* __restrict__ silu_c, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ mod,
+                                                            int rows, int mod_w, const int* __restrict__ rows_dev = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int u0 = blockIdx.y * 32;
+  if (rows_dev) rows = *rows_dev;
+  if (u0 >= rows) return;
+  const int n0 = (blockIdx.x * 4 + wave) * 32;
+  if (n0 >= mod_w) return;   // (wave-uniform)
+  const int ur = min(u0 + c32, rows - 1);
+  const int n = min(n0 + c32, mod_w - 1);
+  f32x4 a4[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) a4[j] = *reinterpret_cast<const f32x4*>(silu_c + (size_t)ur * 256 + hh * 128 + 4 * j);
+  const float* wcol = wt + (size_t)(hh * 128) * mod_w + n;
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // weight values in chunks of 16 k, the next chunk requested before this chunk's 16 MFMAs (64 cycles each)
+  float bcur[16], bnxt[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bcur[i] = wcol[(size_t)i * mod_w];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    if (ch + 1 < 8) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bnxt[i] = wcol[(size_t)((ch + 1) * 16 + i) * mod_w];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[ch * 4 + (i >> 2)][i & 3], bcur[i], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bcur[i] = bnxt[i];
+  }
+  if (n0 + c32 < mod_w) {
+    const float bn = bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int u = u0 + acc_row(r, hh);
+      if (u < rows) mod[(size_t)u * mod_w + n] = acc[r] + bn;
+    }
+  }
+}
+
+// The same product with split-bf16 operands (the arithmetic class of the bf16x3 policy: hi * hi + hi * lo + lo * hi, fp32 accumulate,
+// ~2^-17 relative) for the fast precision policies: 48 bf16 MFMAs of 32 cycles per 32 x 32 tile instead of 128 fp32 MFMAs of 64.
+// The weights are pre-split at load time into B fragments (kPackAdaX3), a wave splits its 32 conditioning rows once and walks NTW
+// column tiles with them.  Every output element is the same fixed sequence of MFMAs over k whatever NTW and the number of rows, so
+// the host may pick NTW by row count (more waves for few rows) without changing a bit of the result.
+template <int NTW>
+__global__ __launch_bounds__(256, 2) void adaln_x3_kernel(const float* __restrict__ silu_c, const bf16x8x2* __restrict__ wfrag,
+                                                          const float* __restrict__ bias, float* __restrict__ mod,
+                                                          int rows, int mod_w, const int* __restrict__ rows_dev = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  const int u0 = blockIdx.y * 32;
+  if (rows_dev) rows = *rows_dev;
+  if (u0 >= rows) return;
+  const int n_tiles = mod_w >> 5;
+  const int nt0 = (blockIdx.x * 4 + wave) * NTW;
+  if (nt0 >= n_tiles) return;   // (wave-uniform)
+  const float* arow = silu_c + (size_t)min(u0 + c32, rows - 1) * 256 + hh * 8;
+  bf16x8x2 af[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(arow + s * 16), hi4 = *reinterpret_cast<const f32x4*>(arow + s * 16 + 4);
+    const float t8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    af[s] = OpBF16x3::pack8(t8);
+  }
+#pragma unroll 1
+  for (int t = 0; t < NTW; ++t) {
+    const int nt = nt0 + t;
+    if (nt >= n_tiles) break;
+    const bf16x8x2* wf = wfrag + (size_t)nt * 16 * 64 + lane;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = OpBF16x3::mma(af[s], wf[s * 64], acc);
+    const int n = nt * 32 + c32;
+    const float bn = bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int u = u0 + acc_row(r, hh);
+      if (u < rows) mod[(size_t)u * mod_w + n] = acc[r] + bn;
+    }
   }
 }
 

@@ -75,12 +75,15 @@ constexpr int kD = 256;        // n_embed
 constexpr int kHC = 128;       // hidden chunk per workgroup (4 waves x 32)
 constexpr int kModBlock = 6 * kD;
 constexpr int kDbgStamps = 32;
-// layer slots instantiated in the fused kernel (code size grows with it: ~30 KB of ISA per slot); -DSCLDM_MAX_LPL=8 builds the
-// whole-network launch (A/B: small batches, where launch boundaries and residual hand-offs weigh most)
+// layer slots instantiated in the fused kernel (code size grows with it: ~30 KB of ISA per slot).  Round 4: EIGHT for the inference
+// kernels - the whole reference network in one launch, no residual hand-off through HBM at all (same-box interleaved A/B,
+// profiles/r4a_ab_lpl8_l2warm.txt: +0.8 % at 4 096 cells, +2.0 % at 1 024, +1.9 % at 512 over four); the recording (training)
+// instantiation keeps four (-DSCLDM_MAX_LPL=4 restores four everywhere).
 #ifndef SCLDM_MAX_LPL
-#define SCLDM_MAX_LPL 4
+#define SCLDM_MAX_LPL 8
 #endif
 constexpr int kMaxLayersPerLaunch = SCLDM_MAX_LPL;
+constexpr int kMaxLayersPerLaunchRec = 4;
 // 1: every workgroup touches its share of the NEXT layer's weight stream (one 4-byte load per 128-byte line) at the start of a
 // layer, so that the stream's first-touch misses (each XCD's 4 MB L2 holds ~2 layers) are taken a layer ahead of the ring.
 #ifndef SCLDM_L2WARM
@@ -1157,10 +1160,12 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
   if (a.n_here > 2) layer_body(std::integral_constant<int, 2>{});
   if (a.n_here > 3) layer_body(std::integral_constant<int, 3>{});
 #if SCLDM_MAX_LPL > 4
-  if (a.n_here > 4) layer_body(std::integral_constant<int, 4>{});
-  if (a.n_here > 5) layer_body(std::integral_constant<int, 5>{});
-  if (a.n_here > 6) layer_body(std::integral_constant<int, 6>{});
-  if (a.n_here > 7) layer_body(std::integral_constant<int, 7>{});
+  if constexpr (!REC) {
+    if (a.n_here > 4) layer_body(std::integral_constant<int, 4>{});
+    if (a.n_here > 5) layer_body(std::integral_constant<int, 5>{});
+    if (a.n_here > 6) layer_body(std::integral_constant<int, 6>{});
+    if (a.n_here > 7) layer_body(std::integral_constant<int, 7>{});
+  }
 #endif
   static_assert(kMaxLayersPerLaunch == 4 || kMaxLayersPerLaunch == 8, "one layer_body call per slot");
   SCLDM_STAMP_END(14);

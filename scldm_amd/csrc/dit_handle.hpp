@@ -19,6 +19,7 @@ struct scldm_dit {
   float* emb;                      // concatenated class tables
   int emb_row0[SCLDM_MAX_CLASSES];
   float *ada_t, *ada_b;            // (256, mod_w), (mod_w)
+  void* ada_x3;                    // the same matrix as split-bf16 B fragments [mod_w / 32][16][64][hi 8 | lo 8] (adaln_x3_kernel)
   float *in_wt, *in_b, *pos;       // (Din,256), (256), (16,256)
   float* in_w;                     // (256,Din) as stored
   float* fin_b;                    // (Din)
@@ -27,6 +28,8 @@ struct scldm_dit {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   int lpl;         // DiT layers per fused-kernel launch (1..4)
+  bool adaln_exact = false;  // SCLDM_ADALN_EXACT: adaln_mfma_kernel (exact fp32) for every precision policy (A/B)
+  bool adaln_valu = false;   // SCLDM_ADALN_VALU: adaln_all_kernel instead of adaln_mfma_kernel (A/B)
   int cfg1_direct = 0;  // SCLDM_OPT_CFG1_DIRECT (scldm_dit_set_option)
   int groups;      // tile groups per layer launch (SCLDM_GROUPS, read once at create)
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)

@@ -78,6 +78,86 @@ __global__ void pack_frag32_pad_kernel(const float* __restrict__ W, int ld, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The whole re-pack as ONE launch over a job table (round 4; scldm_vae_load_weights used to issue ~100 small launches and ~50
+// device-to-device copies, and the Python face synchronised the host at every encode / decode to compare weight norms).  A job is
+// one of the index maps above or a plain copy; every job owns kVaeJobBlocks workgroups.  `dirty` (device) gates the launch: the
+// fingerprint of the source tensors is compared on device (vae_fingerprint_kernel / vae_fp_compare_kernel, the DiT's scheme), so a
+// refresh costs five small launches and NO host round trip, and `.data` updates of the parameters are still picked up.
+// ------------------------------------------------------------------------------------------------
+enum : int { VJ_COPY = 0, VJ_FRAG32 = 1, VJ_FRAG32_HALVES = 2, VJ_W12 = 3, VJ_WC = 4, VJ_PAD = 5 };
+struct VaePackJob {
+  int kind, p0, p1, p2;       // COPY: n; FRAG32 / HALVES: ld; W12 / WC: H; PAD: ld, rows, K
+  const float* src0;
+  const float* src1;
+  float* dst;
+};
+constexpr int kVaeJobBlocks = 24;   // x 256 threads >= the largest job (w12: kHTiles * 1024 elements; copies up to 6 144 floats)
+__global__ __launch_bounds__(256) void vae_pack_jobs_kernel(const VaePackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty) {
+  if (dirty && dirty[0] == 0) return;
+  const VaePackJob j = jobs[blockIdx.x / kVaeJobBlocks];
+  const int idx = (blockIdx.x % kVaeJobBlocks) * 256 + threadIdx.x;
+  const int l = idx & 63;
+  switch (j.kind) {
+    case VJ_COPY:
+      if (idx < j.p0) j.dst[idx] = j.src0[idx];
+      break;
+    case VJ_FRAG32: {
+      if (idx >= 16 * 64) return;
+      const int s = idx >> 6;
+      j.dst[((s >> 2) * 64 + l) * 4 + (s & 3)] = j.src0[(l & 31) * j.p0 + acc_row(s, l >> 5)];
+    } break;
+    case VJ_FRAG32_HALVES: {
+      if (idx >= 16 * 64) return;
+      const int s = idx >> 6;
+      j.dst[((s >> 2) * 64 + l) * 4 + (s & 3)] = j.src0[(l & 31) * j.p0 + 16 * (l >> 5) + s];
+    } break;
+    case VJ_W12: {
+      if (idx >= kHTiles * 16 * 64) return;
+      const int s = (idx >> 6) & 15, u = idx >> 10;
+      const int r = l & 31, hid = 16 * u + (r & 15);
+      const float* src = (r < 16) ? j.src0 : j.src1;
+      j.dst[(size_t)u * 1024 + ((s >> 2) * 64 + l) * 4 + (s & 3)] = (hid < j.p0) ? src[hid * kE + acc_row(s, l >> 5)] : 0.f;
+    } break;
+    case VJ_WC: {
+      if (idx >= kHTiles * 8 * 64) return;
+      const int r = (idx >> 6) & 7, u = idx >> 9;
+      const int hid = 16 * u + acc_row(r, l >> 5);
+      j.dst[(size_t)u * 512 + ((r >> 2) * 64 + l) * 4 + (r & 3)] = (hid < j.p0) ? j.src0[(l & 31) * j.p0 + hid] : 0.f;
+    } break;
+    case VJ_PAD: {
+      if (idx >= 16 * 64) return;
+      const int s = idx >> 6, row = l & 31, k = acc_row(s, l >> 5);
+      j.dst[((s >> 2) * 64 + l) * 4 + (s & 3)] = (row < j.p1 && k < j.p2) ? j.src0[row * j.p0 + k] : 0.f;
+    } break;
+  }
+}
+// 64-bit position-dependent wrapping sum of every source tensor (tensor blockIdx.x split over 8 workgroups); see dit_aux.hpp
+struct VaeFpSrc { const uint32_t* p; long long n; };
+__global__ __launch_bounds__(256) void vae_fingerprint_kernel(const VaeFpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
+  const VaeFpSrc s = src[blockIdx.x];
+  if (s.n <= 0) return;
+  const long long chunk = ((s.n + 7) / 8 + 255) / 256 * 256;
+  const long long lo = (long long)blockIdx.y * chunk, hi = lo + chunk < s.n ? lo + chunk : s.n;
+  if (lo >= s.n) return;
+  unsigned long long hsum = 0;
+  for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) {
+    const unsigned long long v = s.p[pos];
+    hsum += (v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1 + blockIdx.x * 7919ll)) * 0xBF58476D1CE4E5B9ull ^ (v << 29);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
+}
+// state[0] = accumulator of this pass, state[1] = fingerprint of the packed copies; dirty[0] = re-pack?, dirty[1] = force
+__global__ void vae_fp_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty) {
+  dirty[0] = (state[0] != state[1]) || dirty[1];
+  dirty[1] = 0;
+  state[1] = state[0];
+  state[0] = 0;
+}
+__global__ void vae_set_word_kernel(int* p, int v) { *p = v; }
+
+// ------------------------------------------------------------------------------------------------
 // The 16-token trunk: n_layer non-adaLN Blocks (affine LN, 8 heads x 4, SwiGLU, no biases; layers.py:222-226) on the
 // (16, 32) state of a cell.  TWO cells travel as one 32-token MFMA tile through the whole network, carried by the two waves
 // of a workgroup (trunk_blocks below says how they share a layer; round 1 ran one cell per 64-thread workgroup on the VALU with
@@ -430,7 +510,9 @@ __global__ __launch_bounds__(64 * kTrunkWaves, 2) void dec_cell_kernel(const Dec
 
 // Per-gene query table (run once per weight load): Qtab[g] = c_attn_q(LN_1q(emb[g])) / sqrt(8)
 __global__ void dec_qtab_kernel(const float* __restrict__ emb, const float* __restrict__ lnw, const float* __restrict__ lnb,
-                                const float* __restrict__ wq, float* __restrict__ qtab, int rows, float eps) {
+                                const float* __restrict__ wq, float* __restrict__ qtab, int rows, float eps,
+                                const int* __restrict__ gate = nullptr) {
+  if (gate && *gate == 0) return;   // scldm_vae_refresh_weights: the packed copies are up to date
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= rows) return;
   float v[kE], s = 0.f;
@@ -1073,8 +1155,9 @@ __global__ __launch_bounds__(64 * kTrunkWaves, 2) void enc_cell_kernel(const Enc
 //   lane(col = hl*16 + q, hh): c_attn_q(LN_1q(inducing[q]))[k] log2(e) / sqrt(8) if head(k) == 2t + hl else 0, k = acc_row(8t + jj, hh)
 __global__ __launch_bounds__(64) void enc_qfrag_kernel(const float* __restrict__ ind, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, const float* __restrict__ wq,
-                                                       float* __restrict__ out, float eps) {
+                                                       float* __restrict__ out, float eps, const int* __restrict__ gate = nullptr) {
   __shared__ float qp[kNI][kE];
+  if (gate && *gate == 0) return;   // (uniform: before any barrier)
   const int lane = threadIdx.x;
   if (lane < kNI) {
     float v[kE], s = 0.f;

@@ -566,9 +566,10 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
   a.rec_y2 = rec.y2;
   a.rec_stride = (long)pad4(n) * 16 * kD;
   const int tiles = pad4(n) / 4;   // the kernel clamps the samples past n to the last real one and never stores their output
-  for (int i = 0; i < c.n_layer; i += h->lpl) {
+  const int lpl_rec = std::min(h->lpl, kMaxLayersPerLaunchRec);   // the recording instantiation has four layer slots
+  for (int i = 0; i < c.n_layer; i += lpl_rec) {
     a.layer = i;
-    a.n_here = std::min(h->lpl, c.n_layer - i);
+    a.n_here = std::min(lpl_rec, c.n_layer - i);
     a.w_stream = (const char*)h->stream[SCLDM_PREC_BF16][1] + (size_t)i * layer_elems * 2;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;

@@ -54,6 +54,10 @@ extern "C" int scldm_vae_create(const scldm_vae_config* cfg, scldm_vae** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&h->qtab, (size_t)(cfg->n_genes + 1) * 32 * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&h->small, (size_t)S_TOTAL * 4);
   if (e == hipSuccess) e = hipMemset(h->small, 0, (size_t)S_TOTAL * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_fp_state, 16);
+  if (e == hipSuccess) e = hipMemset(h->d_fp_state, 0, 16);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_dirty, 8);
+  if (e == hipSuccess) e = hipMemset(h->d_dirty, 0, 8);
   if (e != hipSuccess) {
     int rc = fail(SCLDM_ERR_HIP, "hipMalloc failed in scldm_vae_create: %s", hipGetErrorString(e));
     scldm_vae_destroy(h);
@@ -68,28 +72,64 @@ extern "C" void scldm_vae_destroy(scldm_vae* h) {
   float* ptrs[] = {h->enc_trunk, h->dec_trunk, h->frag_cell, h->frag_dec, h->frag_dec_halves, h->frag_enc_k, h->frag_enc_v, h->frag_enc_q, h->qtab, h->small};
   for (float* p : ptrs)
     if (p) (void)hipFree(p);
+  void* more[] = {h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty};
+  for (void* p : more)
+    if (p) (void)hipFree(p);
   delete h;
 }
 
-static int copy_d2d(float* dst, const float* src, size_t n, hipStream_t st) {
-  HIP_TRY(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, st));
-  return SCLDM_OK;
-}
-
-static int pack_trunk(float* dst, const scldm_vae_block* blocks, int n_layer, int H, hipStream_t st) {
+// ---- weight (re-)packing: one job table, one launch (mcab.hpp: vae_pack_jobs_kernel) -------------------------------------------
+namespace {
+struct JobList {
+  std::vector<VaePackJob> jobs;
+  std::vector<VaeFpSrc> fps;
+  void src(const float* p, long long n) {
+    if (p && n > 0) fps.push_back(VaeFpSrc{reinterpret_cast<const uint32_t*>(p), n});
+  }
+  void copy(float* dst, const float* s, int n) { jobs.push_back(VaePackJob{VJ_COPY, n, 0, 0, s, nullptr, dst}); }
+  void frag32(const float* W, int ld, float* dst) { jobs.push_back(VaePackJob{VJ_FRAG32, ld, 0, 0, W, nullptr, dst}); }
+  void halves(const float* W, int ld, float* dst) { jobs.push_back(VaePackJob{VJ_FRAG32_HALVES, ld, 0, 0, W, nullptr, dst}); }
+  void w12(const float* w1, const float* w2, int H, float* dst) { jobs.push_back(VaePackJob{VJ_W12, H, 0, 0, w1, w2, dst}); }
+  void wc(const float* Wc, int H, float* dst) { jobs.push_back(VaePackJob{VJ_WC, H, 0, 0, Wc, nullptr, dst}); }
+  void pad(const float* W, int ld, int rows, int K, float* dst) { jobs.push_back(VaePackJob{VJ_PAD, ld, rows, K, W, nullptr, dst}); }
+};
+void trunk_jobs(JobList& jl, float* dst, const scldm_vae_block* blocks, int n_layer, int H) {
   for (int i = 0; i < n_layer; ++i) {
     float* w = dst + (size_t)i * kTrunkLayerFloats;
     const scldm_vae_block& b = blocks[i];
-    int rc;
-    if ((rc = copy_d2d(w + T_LN1W, b.ln1_w, 32, st)) || (rc = copy_d2d(w + T_LN1B, b.ln1_b, 32, st)) ||
-        (rc = copy_d2d(w + T_LN2W, b.ln2_w, 32, st)) || (rc = copy_d2d(w + T_LN2B, b.ln2_b, 32, st)))
-      return rc;
-    for (int t = 0; t < 3; ++t) pack_frag32_kernel<<<4, 256, 0, st>>>(b.attn_w + t * 32 * 32, 32, w + T_QKV + t * 1024);   // q | k | v rows
-    pack_frag32_kernel<<<4, 256, 0, st>>>(b.proj_w, 32, w + T_PROJ);
-    pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(b.w1, b.w2, H, w + T_W12);
-    pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(b.cproj, H, w + T_WC);
-    LAUNCH_CHECK();
+    jl.copy(w + T_LN1W, b.ln1_w, 32); jl.copy(w + T_LN1B, b.ln1_b, 32); jl.copy(w + T_LN2W, b.ln2_w, 32); jl.copy(w + T_LN2B, b.ln2_b, 32);
+    for (int t = 0; t < 3; ++t) jl.frag32(b.attn_w + t * 32 * 32, 32, w + T_QKV + t * 1024);   // q | k | v rows
+    jl.frag32(b.proj_w, 32, w + T_PROJ);
+    jl.w12(b.w1, b.w2, H, w + T_W12);
+    jl.wc(b.cproj, H, w + T_WC);
+    jl.src(b.ln1_w, 32); jl.src(b.ln1_b, 32); jl.src(b.ln2_w, 32); jl.src(b.ln2_b, 32); jl.src(b.attn_w, 96 * 32); jl.src(b.proj_w, 1024);
+    jl.src(b.w1, (long long)H * 32); jl.src(b.w2, (long long)H * 32); jl.src(b.cproj, (long long)32 * H);
   }
+}
+template <typename T>
+int upload(void** dev, int* cap, const std::vector<T>& v) {
+  if ((int)v.size() > *cap) {
+    if (*dev) (void)hipFree(*dev);
+    *dev = nullptr;
+    HIP_TRY(hipMalloc(dev, v.size() * sizeof(T)));
+    *cap = (int)v.size();
+  }
+  HIP_TRY(hipMemcpy(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return SCLDM_OK;
+}
+}  // namespace
+
+// fingerprint of every source tensor -> device-side compare -> the gated re-pack: five small launches, no host round trip
+int scldm_vae_refresh(scldm_vae* h, bool force, hipStream_t st) {
+  const scldm_vae_config& c = h->cfg;
+  if (force) vae_set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);
+  vae_fingerprint_kernel<<<dim3(h->n_fp, 8), 256, 0, st>>>((const VaeFpSrc*)h->d_fp_src, h->d_fp_state);
+  vae_fp_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
+  vae_pack_jobs_kernel<<<h->n_jobs * kVaeJobBlocks, 256, 0, st>>>((const VaePackJob*)h->d_jobs, h->n_jobs, h->d_dirty);
+  enc_qfrag_kernel<<<1, 64, 0, st>>>(h->q_ind, h->q_eln_w, h->q_eln_b, h->q_ewq, h->frag_enc_q, c.layernorm_eps, h->d_dirty);
+  dec_qtab_kernel<<<cdiv(c.n_genes + 1, 128), 128, 0, st>>>(h->emb, h->q_dln_w, h->q_dln_b, h->q_dwq, h->qtab, c.n_genes + 1, c.layernorm_eps,
+                                                            h->d_dirty);
+  LAUNCH_CHECK();
   return SCLDM_OK;
 }
 
@@ -98,50 +138,62 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   hipStream_t st = (hipStream_t)stream_;
   const scldm_vae_config& c = h->cfg;
   const int H = c.hidden_dim, nl = c.n_embed_latent;
-  int rc;
-  if ((rc = pack_trunk(h->enc_trunk, w->enc_blocks, c.n_layer, H, st))) return rc;
-  if ((rc = pack_trunk(h->dec_trunk, w->dec_blocks, c.n_layer, H, st))) return rc;
+  if (c.positional_encoding && !w->enc_pos_embed) return fail(SCLDM_ERR_SHAPE, "positional_encoding set but enc_pos_embed is NULL");
+  JobList jl;
+  trunk_jobs(jl, h->enc_trunk, w->enc_blocks, c.n_layer, H);
+  trunk_jobs(jl, h->dec_trunk, w->dec_blocks, c.n_layer, H);
   float* s = h->small;
   const scldm_vae_cross &ec = w->enc_cross, &dc = w->dec_cross;
-  if ((rc = copy_d2d(s + S_ENC_LN1W, ec.ln1_w, 32, st)) || (rc = copy_d2d(s + S_ENC_LN1B, ec.ln1_b, 32, st)) ||
-      (rc = copy_d2d(s + S_ENC_LN2W, ec.ln2_w, 32, st)) || (rc = copy_d2d(s + S_ENC_LN2B, ec.ln2_b, 32, st)) ||
-      (rc = copy_d2d(s + S_ENC_PROJ, ec.attn_proj, 1024, st)) || (rc = copy_d2d(s + S_ENC_W1, ec.w1, (size_t)H * 32, st)) ||
-      (rc = copy_d2d(s + S_ENC_W2, ec.w2, (size_t)H * 32, st)) || (rc = copy_d2d(s + S_ENC_CP, ec.cproj, (size_t)32 * H, st)) ||
-      (rc = copy_d2d(s + S_ENC_IND, w->inducing_points, 512, st)) ||
-      (rc = copy_d2d(s + S_ENC_LAT, w->enc_latent_w, (size_t)nl * 32, st)) ||
-      (rc = copy_d2d(s + S_DEC_LAT, w->dec_latent_w, (size_t)32 * nl, st)) ||
-      (rc = copy_d2d(s + S_DEC_LN1W, dc.ln1_w, 32, st)) || (rc = copy_d2d(s + S_DEC_LN1B, dc.ln1_b, 32, st)) ||
-      (rc = copy_d2d(s + S_DEC_KV, dc.attn_kv, 64 * 32, st)) || (rc = copy_d2d(s + S_DEC_LN2W, dc.ln2_w, 32, st)) ||
-      (rc = copy_d2d(s + S_DEC_LN2B, dc.ln2_b, 32, st)) || (rc = copy_d2d(s + S_HEAD_W, w->head_w, 32, st)) ||
-      (rc = copy_d2d(s + S_HEAD_B, w->head_b, 1, st)))
-    return rc;
-  if (c.positional_encoding) {
-    if (!w->enc_pos_embed) return fail(SCLDM_ERR_SHAPE, "positional_encoding set but enc_pos_embed is NULL");
-    if ((rc = copy_d2d(s + S_ENC_POS, w->enc_pos_embed, 512, st))) return rc;
-  }
+  jl.copy(s + S_ENC_LN1W, ec.ln1_w, 32); jl.copy(s + S_ENC_LN1B, ec.ln1_b, 32); jl.copy(s + S_ENC_LN2W, ec.ln2_w, 32); jl.copy(s + S_ENC_LN2B, ec.ln2_b, 32);
+  jl.copy(s + S_ENC_PROJ, ec.attn_proj, 1024); jl.copy(s + S_ENC_W1, ec.w1, H * 32); jl.copy(s + S_ENC_W2, ec.w2, H * 32); jl.copy(s + S_ENC_CP, ec.cproj, 32 * H);
+  jl.copy(s + S_ENC_IND, w->inducing_points, 512); jl.copy(s + S_ENC_LAT, w->enc_latent_w, nl * 32); jl.copy(s + S_DEC_LAT, w->dec_latent_w, 32 * nl);
+  jl.copy(s + S_DEC_LN1W, dc.ln1_w, 32); jl.copy(s + S_DEC_LN1B, dc.ln1_b, 32); jl.copy(s + S_DEC_KV, dc.attn_kv, 64 * 32);
+  jl.copy(s + S_DEC_LN2W, dc.ln2_w, 32); jl.copy(s + S_DEC_LN2B, dc.ln2_b, 32); jl.copy(s + S_HEAD_W, w->head_w, 32); jl.copy(s + S_HEAD_B, w->head_b, 1);
+  if (c.positional_encoding) jl.copy(s + S_ENC_POS, w->enc_pos_embed, 512);
   // MFMA fragments
   float* fc = h->frag_cell;
-  pack_frag32_pad_kernel<<<4, 256, 0, st>>>(w->dec_latent_w, nl, 32, nl, fc + F_DEC_LAT);
-  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_kv, 32, fc + F_DEC_KV);
-  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_kv + 32 * 32, 32, fc + F_DEC_KV + 1024);
-  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_proj, 32, fc + F_ENC_PROJ);
-  pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(ec.w1, ec.w2, H, fc + F_ENC_W12);
-  pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(ec.cproj, H, fc + F_ENC_WC);
-  pack_frag32_pad_kernel<<<4, 256, 0, st>>>(w->enc_latent_w, 32, nl, 32, fc + F_ENC_LAT);
-  pack_frag32_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec);                                  // 16 fragments
-  pack_frag32_halves_kernel<<<4, 256, 0, st>>>(dc.attn_proj, 32, h->frag_dec_halves);                    // the same, k in lane-half order (fp32 path)
-  pack_frag_w12_kernel<<<cdiv(kHTiles * 1024, 256), 256, 0, st>>>(dc.w1, dc.w2, H, h->frag_dec + 16 * 64);  // 96
-  pack_frag_wc_kernel<<<cdiv(kHTiles * 512, 256), 256, 0, st>>>(dc.cproj, H, h->frag_dec + (16 + 96) * 64); // 48
-  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_kv, 32, h->frag_enc_k);                                   // K rows 0-31
-  pack_frag32_kernel<<<4, 256, 0, st>>>(ec.attn_kv + 32 * 32, 32, h->frag_enc_v);                         // V rows 32-63
-  enc_qfrag_kernel<<<1, 64, 0, st>>>(w->inducing_points, ec.ln1q_w, ec.ln1q_b, ec.attn_q, h->frag_enc_q, c.layernorm_eps);
-  dec_qtab_kernel<<<cdiv(c.n_genes + 1, 128), 128, 0, st>>>(w->gene_embedding, dc.ln1q_w, dc.ln1q_b, dc.attn_q, h->qtab,
-                                                            c.n_genes + 1, c.layernorm_eps);
-  LAUNCH_CHECK();
+  jl.pad(w->dec_latent_w, nl, 32, nl, fc + F_DEC_LAT);
+  jl.frag32(dc.attn_kv, 32, fc + F_DEC_KV);
+  jl.frag32(dc.attn_kv + 32 * 32, 32, fc + F_DEC_KV + 1024);
+  jl.frag32(ec.attn_proj, 32, fc + F_ENC_PROJ);
+  jl.w12(ec.w1, ec.w2, H, fc + F_ENC_W12);
+  jl.wc(ec.cproj, H, fc + F_ENC_WC);
+  jl.pad(w->enc_latent_w, 32, nl, 32, fc + F_ENC_LAT);
+  jl.frag32(dc.attn_proj, 32, h->frag_dec);                                  // 16 fragments
+  jl.halves(dc.attn_proj, 32, h->frag_dec_halves);                           // the same, k in lane-half order (fp32 path)
+  jl.w12(dc.w1, dc.w2, H, h->frag_dec + 16 * 64);                            // 96
+  jl.wc(dc.cproj, H, h->frag_dec + (16 + 96) * 64);                          // 48
+  jl.frag32(ec.attn_kv, 32, h->frag_enc_k);                                  // K rows 0-31
+  jl.frag32(ec.attn_kv + 32 * 32, 32, h->frag_enc_v);                        // V rows 32-63
+  // every tensor a packed copy or a derived table depends on (theta and the gene embedding are read live by the kernels; the
+  // embedding also feeds the decoder's query table)
+  for (const scldm_vae_cross* cr : {&ec, &dc}) {
+    jl.src(cr->ln1_w, 32); jl.src(cr->ln1_b, 32); jl.src(cr->ln1q_w, 32); jl.src(cr->ln1q_b, 32); jl.src(cr->attn_kv, 64 * 32); jl.src(cr->attn_q, 1024);
+    jl.src(cr->attn_proj, 1024); jl.src(cr->ln2_w, 32); jl.src(cr->ln2_b, 32); jl.src(cr->w1, (long long)H * 32); jl.src(cr->w2, (long long)H * 32);
+    jl.src(cr->cproj, (long long)32 * H);
+  }
+  jl.src(w->inducing_points, 512); jl.src(w->enc_latent_w, (long long)nl * 32); jl.src(w->dec_latent_w, (long long)32 * nl);
+  jl.src(w->head_w, 32); jl.src(w->head_b, 1); jl.src(w->gene_embedding, (long long)(c.n_genes + 1) * 32);
+  if (c.positional_encoding) jl.src(w->enc_pos_embed, 512);
+  for (const VaePackJob& j : jl.jobs)
+    if (!j.src0 || !j.dst || (j.kind == VJ_W12 && !j.src1)) return fail(SCLDM_ERR_SHAPE, "scldm_vae_load_weights: a weight pointer is NULL");
+  int rc;
+  if ((rc = upload(&h->d_jobs, &h->jobs_cap, jl.jobs)) || (rc = upload(&h->d_fp_src, &h->fp_cap, jl.fps))) return rc;
+  h->n_jobs = (int)jl.jobs.size();
+  h->n_fp = (int)jl.fps.size();
+  h->q_ind = w->inducing_points; h->q_eln_w = ec.ln1q_w; h->q_eln_b = ec.ln1q_b; h->q_ewq = ec.attn_q;
+  h->q_dln_w = dc.ln1q_w; h->q_dln_b = dc.ln1q_b; h->q_dwq = dc.attn_q;
   h->emb = w->gene_embedding;
   h->theta = w->theta;
+  if ((rc = scldm_vae_refresh(h, true, st))) return rc;
   h->loaded = true;
   return SCLDM_OK;
+}
+
+extern "C" int scldm_vae_refresh_weights(scldm_vae* h, void* stream_) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
+  if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_vae_load_weights has not been called");
+  return scldm_vae_refresh(h, false, (hipStream_t)stream_);
 }
 
 static int vae_ready(const scldm_vae* h) {

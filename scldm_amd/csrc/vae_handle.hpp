@@ -20,9 +20,19 @@ struct scldm_vae {
   // borrowed (caller-owned, must stay alive): the big tables
   const float* emb;
   const float* theta;
+  // re-pack job table + fingerprint state (scldm_vae_load_weights builds them, scldm_vae_refresh_weights runs them)
+  void* d_jobs;                 // device VaePackJob[n_jobs]
+  int n_jobs, jobs_cap;
+  void* d_fp_src;               // device VaeFpSrc[n_fp]
+  int n_fp, fp_cap;
+  unsigned long long* d_fp_state;   // [0] accumulator, [1] fingerprint of the packed copies
+  int* d_dirty;                 // [0] re-pack?, [1] force
+  // sources of the two derived tables (enc_qfrag_kernel, dec_qtab_kernel)
+  const float *q_ind, *q_eln_w, *q_eln_b, *q_ewq, *q_dln_w, *q_dln_b, *q_dwq;
 };
 
 // vae_api.hip internals used by the training entry points: TransformerVAE.encode that also leaves the pooling's attention output
 // (B, 16, 32) and the log2-domain log-sum-exp of its scaled scores (B, 4, 16) in caller-provided buffers (either may be NULL)
+int scldm_vae_refresh(scldm_vae* h, bool force, hipStream_t st);
 int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision, float* pooled,
                         float* lse2, hipStream_t st);

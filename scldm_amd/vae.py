@@ -116,13 +116,19 @@ class TransformerVAE(nn.Module):
                 _lib.check(L.scldm_vae_create(C.byref(cfg), C.byref(h)), "scldm_vae_create")
             self._handle = h
         params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        # in-place updates through `.data` (EMA-style) change neither the storage nor torch's version counter: the per-tensor
-        # norms are compared on device as well (one small host synchronisation per encode / decode call, both ms-scale)
-        fp = torch.stack(torch._foreach_norm(params)) if self.check_weight_fingerprint else None
-        if key != self._weights_key or (fp is not None and (self._weights_fp is None or not torch.equal(fp, self._weights_fp))):
-            self._load_weights(L)
-            self._weights_key, self._weights_fp = key, fp
+        key = tuple(p.data_ptr() for p in params)
+        ver = tuple(p._version for p in params)
+        if key != self._weights_key:
+            self._load_weights(L)             # new storages: the job / fingerprint tables are rebuilt, everything is re-packed
+            self._weights_key, self._weights_fp = key, ver
+        elif ver != self._weights_fp or self.check_weight_fingerprint:
+            # same storages: an optimiser step (version counters moved) or possibly an in-place update through `.data` (EMA-style,
+            # invisible to the counters).  Either way the C side compares a device-side fingerprint of every source tensor with that
+            # of the packed copies and re-packs in stream order if it moved: five small launches, no host synchronisation (round 3
+            # compared per-tensor norms on the host - one sync per encode / decode call - and re-issued ~150 launches per re-pack).
+            with torch.cuda.device(emb.device):
+                _lib.check(L.scldm_vae_refresh_weights(self._handle, _stream_ptr()), "scldm_vae_refresh_weights")
+            self._weights_fp = ver
         return L, self._handle
 
     def invalidate_weights(self) -> None:

@@ -168,11 +168,15 @@ def test_long_trajectories_at_every_precision(tag, vocab, strategy, method, step
     cond = {k: torch.randint(0, v, (B,), generator=gen).repeat(2) for k, v in vocab.items()}
     scales = {k: scale for k in vocab}
     sd64 = {k: v.double() for k, v in sd.items()}
-    ref64 = sample_ode_fixed(z2.double(), lambda xx, tt: dit_forward_with_cfg(sd64, cfg, xx, tt, cond, scales), steps, method)
-    f32 = lambda xx, tt: dit_forward_with_cfg(sd, cfg, xx, tt, cond, scales)
-    e_cpu32 = max_abs_rel(sample_ode_fixed(z2, f32, steps, method), ref64.float())
-    with matmul_operand_bits(10):
-        e_tf32 = max_abs_rel(sample_ode_fixed(z2, f32, steps, method), ref64.float())
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(16, n_thr))     # (an all-cores OpenMP team on these 384-row GEMMs is pathological on the 256-thread GPU hosts)
+    try:
+        ref64 = sample_ode_fixed(z2.double(), lambda xx, tt: dit_forward_with_cfg(sd64, cfg, xx, tt, cond, scales), steps, method)
+        f32 = lambda xx, tt: dit_forward_with_cfg(sd, cfg, xx, tt, cond, scales)
+        with matmul_operand_bits(10):
+            e_tf32 = max_abs_rel(sample_ode_fixed(z2, f32, steps, method), ref64.float())
+    finally:
+        torch.set_num_threads(n_thr)
     condg = {k: v.cuda() for k, v in cond.items()}
     errs = {}
     for prec in ("fp32", "bf16x3", "fp16", "bf16"):
@@ -182,7 +186,7 @@ def test_long_trajectories_at_every_precision(tag, vocab, strategy, method, step
         errs[prec] = max_abs_rel(out.cpu(), ref64.float())
     n_eval = (steps - 1) * (2 if method == "heun" else 1)
     print(f"[parity] long trajectory {tag} ({n_eval} CFG evaluations, guidance {scale}) vs float64 oracle: "
-          + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()) + f"; CPU fp32 oracle {e_cpu32:.3e}, TF32-operand oracle {e_tf32:.3e}")
+          + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()) + f"; TF32-operand oracle {e_tf32:.3e}")
     assert errs["fp32"] < TOL_FP32 and errs["bf16x3"] < TOL_FP32
     assert errs["fp16"] <= TF32_FACTOR * e_tf32
     assert errs["bf16"] < TOL_BF16
