@@ -181,6 +181,12 @@ int scldm_dit_set_option(scldm_dit* h, int option, int value);
  * handle outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
 int scldm_dit_layers_per_launch(const scldm_dit* h);
 
+/* Measurement aid (bench.py): TFLOP/s a register-only v_mfma_f32_32x32x16_bf16 loop sustains on the current device for about
+ * `iters` x 5 x 16 MFMAs per wave (fill 0: zero operands, 1: uniform [-1, 1), 2: N(0, 1)); same instruction stream for every fill -
+ * the part clocks to its power budget, so the figure for realistic operands is the ceiling an MFMA-bound kernel can reach on this
+ * device, below the nominal 2.5 PFLOP/s.  Synchronises the device. */
+int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops);
+
 /* Timing hook for bench.py: when enabled, every fused-block launch is bracketed by HIP events on its
  * own stream; scldm_dit_block_timing drains them (synchronises) and returns launches and total ms. */
 void scldm_dit_block_timing_enable(scldm_dit* h, int enable);

@@ -92,7 +92,28 @@ def round_operand(x: torch.Tensor) -> torch.Tensor:
     return i.view(torch.float32)
 
 
+class _RoundedMatmul(torch.autograd.Function):
+    """a @ b with both operands rounded - in the forward AND in the two backward products (d a = r(g) r(b)^T, d b = r(a)^T r(g)):
+    what a TF32 matmul library does to every GEMM of a training step, so that autograd over the oracle under
+    `matmul_operand_bits(10)` is the reference's training arithmetic (train_ldm.py:18), gradients included."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return round_operand(a) @ round_operand(b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        rg = round_operand(g.contiguous())
+        ga = (rg @ round_operand(b).transpose(-1, -2)).sum_to_size(a.shape)
+        gb = (round_operand(a).transpose(-1, -2) @ rg).sum_to_size(b.shape)
+        return ga, gb
+
+
 def matmul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    if _OPERAND_BITS is not None and torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return _RoundedMatmul.apply(a, b)
     return round_operand(a) @ round_operand(b)
 
 

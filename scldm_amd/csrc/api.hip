@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 
+#include <cmath>
 #include "api_common.hpp"
 #include "dit_aux.hpp"
 #include "dit_forward.hpp"
@@ -275,7 +276,7 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
         if (!h->stream[p][f]) continue;
         const int nc = h->n_chunks[f], hf = h->half[f];
         const long long npk = (long long)4 * units_per_layer(nc, hf) * 1024;
-        train = p == SCLDM_PREC_BF16 && f == 1;
+        train = (p == SCLDM_PREC_BF16 || p == SCLDM_PREC_FP16) && f == 1;   // (the training launch masks the precision it runs in)
         add(kPackLayer, npk, {w->attn_w[i], w->proj_w[i], w->w1[i], w->w2[i], w->cproj[i]}, h->stream[p][f], {H, nc, hf, f + 1, p}, npk * i);
         train = false;
       }
@@ -310,7 +311,7 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
   train = false;
   src(w->fin_w, (long long)din * 256);
   for (int p = 0; p < kNPrec; ++p) {
-    train = p == SCLDM_PREC_BF16;
+    train = p == SCLDM_PREC_BF16 || p == SCLDM_PREC_FP16;
     add(kPackFinal, 16 * 512, {w->fin_w}, h->wfinal[p], {din, p});
   }
   train = true;
@@ -846,6 +847,86 @@ extern "C" int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* tot
   if (total_ms) *total_ms = tot;
   h->ev_used = 0;
   return SCLDM_OK;
+}
+
+// ---- measurement aid: what the matrix pipe sustains on THIS device under its power budget -------------------------------------------
+// A register-only v_mfma_f32_32x32x16_bf16 loop (two waves per SIMD, four independent accumulators, no memory traffic) on operand
+// fragments of a given fill.  The instruction stream is the same for every fill; the rate differs because the part clocks to its
+// power budget (MI355X_MICROARCH.md "DVFS give-back"): zero operands run near the nominal 2.5 PFLOP/s, N(0,1) operands at about half
+// of it (profiles/r4c_mfma_power_ceiling.txt).  bench.py reports the figure beside roofline.frac, whose denominator stays nominal.
+__global__ __launch_bounds__(256, 2) void mfma_ceiling_kernel(const bf16x8* __restrict__ frags, float* __restrict__ out, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = frags[(i * 2 + 0) * 64 + lane];
+    b[i] = frags[(i * 2 + 1) * 64 + lane];
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[(i + 2 * u + 1) & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;   // keeps the loop alive; never true in practice
+}
+extern "C" int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops) {
+  if (!tflops || fill < 0 || fill > 2 || iters < 1) return fail(SCLDM_ERR_SHAPE, "scldm_mfma_sustained_tflops: bad argument");
+  const int blocks = 512, launches = 5;   // 2 workgroups of 4 waves per CU
+  std::vector<__bf16> hfr(8 * 64 * 8);
+  unsigned long long st = 0x9E3779B97F4A7C15ull;   // splitmix64: the same fragments on every box
+  auto u01 = [&]() {
+    st += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return ((double)(z >> 11) + 0.5) / 9007199254740992.0;
+  };
+  for (auto& v : hfr) {
+    float x = 0.f;
+    if (fill == 1) x = (float)(2.0 * u01() - 1.0);
+    if (fill == 2) x = (float)(sqrt(-2.0 * log(u01())) * cos(6.283185307179586 * u01()));
+    v = (__bf16)x;
+  }
+  bf16x8* d_fr = nullptr;
+  float* d_out = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_fr, hfr.size() * sizeof(__bf16)));
+  hipError_t e = hipMalloc((void**)&d_out, (size_t)blocks * 256 * sizeof(float));
+  if (e != hipSuccess) { (void)hipFree(d_fr); return fail(SCLDM_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = SCLDM_OK;
+  auto run = [&]() -> int {
+    HIP_TRY(hipMemcpy(d_fr, hfr.data(), hfr.size() * sizeof(__bf16), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    mfma_ceiling_kernel<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters / 8 + 1);   // warm-up
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipEventRecord(e0, 0));
+    for (int k = 0; k < launches; ++k) mfma_ceiling_kernel<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = (double)launches * blocks * 4.0 * iters * 16.0 * 2.0 * 32 * 32 * 16 / ((double)ms * 1e9);
+    return SCLDM_OK;
+  };
+  rc = run();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_fr);
+  (void)hipFree(d_out);
+  return rc;
 }
 
 // Debug hook: device buffer receiving per-(block, wave) s_memtime phase stamps of the LAST fused-block launch

@@ -151,7 +151,7 @@ struct PackJob {
   long long d_off;      // element offset added to the destination index (layer: start of the layer's stream)
 };
 // prec_mask: bit p set = pack the streams of precision p (kPackLayer / kPackFinal jobs of other precisions are skipped - the
-// training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set.
+// training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set (bit 9: as fp16 instead of bf16).
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty,
                                                         unsigned prec_mask, int* __restrict__ fp16_stats = nullptr) {
   if (dirty && *dirty == 0) return;
@@ -183,10 +183,13 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
       reinterpret_cast<__bf16*>(j.d)[base + 8] = lo;
       break;
     }
-    case kPackLayerBwd:
+    case kPackLayerBwd: {   // bit 9: the step's operand type is fp16 (same 16-bit stream, re-packed every training step)
       if (!(prec_mask & 0x100u)) return;
-      reinterpret_cast<__bf16*>(j.d)[j.d_off + idx] = (__bf16)pack_bwd_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0]);
+      const float v = pack_bwd_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0]);
+      if (prec_mask & 0x200u) reinterpret_cast<_Float16*>(j.d)[j.d_off + idx] = (_Float16)v;
+      else reinterpret_cast<__bf16*>(j.d)[j.d_off + idx] = (__bf16)v;
       break;
+    }
     case kPackLayer:
       if (!((prec_mask >> j.p[4]) & 1u)) return;
       pack_store(j.d, j.d_off + idx,

@@ -14,17 +14,23 @@
 // Shape: 8 waves, wave w owns the 32 features [32w, 32w+32) = attention head w; GEMMs are computed transposed exactly as in
 // the forward kernel (weights streamed L2 -> VGPR ring as pre-packed fragments, activations as [token][feature] bf16 LDS
 // images), so every matrix product below is a gemm_pass over a different packed stream (dit_aux.hpp: pack_bwd_val).
-#pragma once
+//
+// Included once per 16-bit operand policy (round 4): the including translation unit defines SCLDM_BWD_NS (namespace of this
+// instantiation) and SCLDM_BWD_OP (OpBF16, or OpFP16 = the reference's TF32 mantissa; its gradients are loss-scaled by the caller,
+// train_api.hip) before each inclusion.  Nothing below depends on the element type beyond OP.
 #include "bwd_layout.hpp"
 #include "dit_forward.hpp"
+#if !defined(SCLDM_BWD_NS) || !defined(SCLDM_BWD_OP)
+#error "define SCLDM_BWD_NS and SCLDM_BWD_OP before including dit_backward.hpp"
+#endif
 
 namespace scldm {
-namespace bwd {
+namespace SCLDM_BWD_NS {
 
-using OP = OpBF16;
-using E = __bf16;
-using Frag = bf16x8;
-using Quad = bf16x4;
+using OP = SCLDM_BWD_OP;
+using E = OP::E;
+using Frag = OP::Frag;
+using Quad = OP::Quad;
 constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
 constexpr int PF = 8;   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
 constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;   // bf16 elements per image row (+16 B pad)
@@ -46,16 +52,16 @@ constexpr int LDS_BYTES = BIAS_OFF + 3 * kD * 4;
 
 struct BwdArgs {
   const float* x_in;      // record: residual entering this layer (tile layout of the 4-wave forward kernel)
-  const __bf16* y1;       // record: c_proj(attention) + bias
-  const __bf16* y2;       // record: MLP output
+  const E* y1;            // record: c_proj(attention) + bias
+  const E* y2;            // record: MLP output
   float* dx;              // in: gradient w.r.t. the layer output; out: w.r.t. the layer input (tile layout)
   const float* mod;       // (n, mod_stride) adaLN vectors; this layer's six at mod_off
   float* dmod;            // same indexing: gradient w.r.t. the adaLN vectors
   int mod_stride, mod_off;
-  const __bf16* w_stream; // this layer's backward stream (pack_bwd_val)
+  const E* w_stream;      // this layer's backward stream (pack_bwd_val)
   const float* b_qkv;     // (768) c_attn bias of this layer
   // operand pairs of the weight-gradient GEMMs, plain [token][ld] bf16
-  __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
+  E *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
   int n;                  // real samples; the last tile may be padded (its padding samples repeat the last real one, gradient zero)
   float eps, attn_scale, attn_scale_log2e;
   unsigned long long* dbg;   // optional phase stamps [block][wave][16] (SCLDM_BWD_DBG=1; nullptr otherwise)
@@ -113,7 +119,7 @@ __device__ __forceinline__ void tr_write_own(E* T, const float (&v)[8], int sp, 
 // 16h + (j&3) + 8 (j>>2) + 4 hh): the order pack8() gives the register-built partner operand
 __device__ __forceinline__ Frag tr_read(const E* T, int c32, int hh, int h) {
   const E* p = T + c32 * TR_LD + 16 * h + 4 * hh;
-  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p), b = *reinterpret_cast<const bf16x4*>(p + 8);
+  const Quad a = *reinterpret_cast<const Quad*>(p), b = *reinterpret_cast<const Quad*>(p + 8);
   Frag f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
@@ -161,12 +167,12 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
         for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = t4[i];
       }
   };
-  auto load_bf16 = [&](const __bf16* base, float (&dst)[NTT][16]) {
+  auto load_bf16 = [&](const E* base, float (&dst)[NTT][16]) {   // (a 16-bit record array of the operand type)
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const bf16x4 t4 = *reinterpret_cast<const bf16x4*>(base + tile_off(tt, q));
+        const Quad t4 = *reinterpret_cast<const Quad*>(base + tile_off(tt, q));
 #pragma unroll
         for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = (float)t4[i];
       }

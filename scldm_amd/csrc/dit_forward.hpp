@@ -139,8 +139,8 @@ struct FwdArgs {
   // rec_x[n_layer] = the final layer's input) and the two gated branch outputs y1 = c_proj(attention) + b, y2 = MLP (bf16),
   // all in the hand-off buffer's private tile layout.  rec_stride = elements per layer (= padded tokens * 256).
   float* rec_x;
-  __bf16* rec_y1;
-  __bf16* rec_y2;
+  void* rec_y1;             // (16-bit elements of the kernel's operand type: bf16, or fp16 for the OpFP16 instantiation)
+  void* rec_y2;
   long rec_stride;
   unsigned long long* dbg;  // phase stamps [block][wave][kDbgStamps]; only -DSCLDM_PHASE_TIMING builds write
 };
@@ -602,18 +602,17 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
           *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
         }
   };
-  auto rec_store_y = [&](const f32x16 (&src)[FT][NTT], __bf16* base, int layer_idx) {
-    __bf16* yw = base + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
+  auto rec_store_y = [&](const f32x16 (&src)[FT][NTT], void* base, int layer_idx) {
+    E* yw = reinterpret_cast<E*>(base) + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          bf16x4 t4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) t4[i] = (__bf16)src[ft][tt][q * 4 + i];
-          *reinterpret_cast<bf16x4*>(yw + ((tt * FT + ft) * 4 + q) * 256) = t4;
+          if constexpr (sizeof(E) == 2)   // (the recording instantiations are the 16-bit policies)
+            *reinterpret_cast<Quad*>(yw + ((tt * FT + ft) * 4 + q) * 256) =
+                OP::pack4(src[ft][tt][q * 4 + 0], src[ft][tt][q * 4 + 1], src[ft][tt][q * 4 + 2], src[ft][tt][q * 4 + 3]);
         }
   };
   // Up to four consecutive layers per launch: the body below is instantiated once per layer slot (compile-time `li`), the

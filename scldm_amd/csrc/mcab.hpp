@@ -904,15 +904,19 @@ struct EncPoolArgs {
 #ifndef SCLDM_ENC_MINW
 #define SCLDM_ENC_MINW 3
 #endif
-template <bool BF>
-__global__ __launch_bounds__(256, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(const EncPoolArgs a) {
+// NW = waves per cell (round 4).  A cell is one workgroup; with four waves of 168 registers a CU holds three cells, so 1 024 cells are
+// 1.33 rounds of the chip's 768 slots - the second round a third full.  Six waves per cell (two cells per CU, 512 slots) make it two
+// full rounds of cells that each finish in 4/6 of the time; the gene tiles are dealt round-robin over the waves and merged in wave
+// order at the end, so NW changes the summation order of the online softmax merge (not its value beyond fp32 rounding).
+template <bool BF, int NW = 4>
+__global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(const EncPoolArgs a) {
   __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
   __shared__ float VEC[2 * kE];
-  __shared__ float MRG[4][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]
+  __shared__ float MRG[NW][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hh = lane >> 5;
   const int cell = blockIdx.x;
-  for (int i = tid; i < 4 * 64; i += 256) {
+  for (int i = tid; i < 4 * 64; i += 64 * NW) {
     KF[i] = reinterpret_cast<const f32x4*>(a.kfrag)[i];
     VF[i] = reinterpret_cast<const f32x4*>(a.vfrag)[i];
     QF[i] = reinterpret_cast<const f32x4*>(a.qfrag)[i];
@@ -944,22 +948,22 @@ __global__ __launch_bounds__(256, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(
   float c_cur = 0.f, c_nxt = 0.f;
   f32x4 e_cur[4];
   if constexpr (PF) {
-    g_nxt = a.genes[idx_of(wave + 4)];
+    g_nxt = a.genes[idx_of(wave + NW)];
     c_cur = a.counts[idx_of(wave)];
-    c_nxt = a.counts[idx_of(wave + 4)];
+    c_nxt = a.counts[idx_of(wave + NW)];
     const long long g0 = a.genes[idx_of(wave)];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) e_cur[qd] = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g0 * kE + qd * 8 + hh * 4);
   }
-  for (int tile = wave; tile < n_tiles; tile += 4) {
+  for (int tile = wave; tile < n_tiles; tile += NW) {
     const bool valid = tile * 32 + c32 < a.S;
     float x[16], s = 0.f;
     if constexpr (PF) {
       f32x4 e_nxt[4];
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) e_nxt[qd] = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g_nxt * kE + qd * 8 + hh * 4);
-      const long long g_n2 = a.genes[idx_of(tile + 8)];
-      const float c_n2 = a.counts[idx_of(tile + 8)];
+      const long long g_n2 = a.genes[idx_of(tile + 2 * NW)];
+      const float c_n2 = a.counts[idx_of(tile + 2 * NW)];
       const float lc = valid ? log1pf(c_cur) : 0.f;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
@@ -1064,11 +1068,11 @@ __global__ __launch_bounds__(256, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float M = MRG[0][t][lane][0];
-      for (int w = 1; w < 4; ++w) M = fmaxf(M, MRG[w][t][lane][0]);
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, MRG[w][t][lane][0]);
       float L = 0.f, o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = 0.f;
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         const float sc = __builtin_amdgcn_exp2f(MRG[w][t][lane][0] - M);
         L += MRG[w][t][lane][1] * sc;
 #pragma unroll

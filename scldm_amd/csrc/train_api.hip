@@ -702,14 +702,20 @@ int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const flo
   return SCLDM_OK;
 }
 
-// The split-bf16 and fp16 policies exist in the fused inference kernel only; on the training / generic entry points a request for it is
-// served by the exact-fp32 GEMM route (same parity class: fp32 products are a superset of bf16x3's accuracy).
-inline int train_precision(int precision) { return (precision == SCLDM_PREC_BF16X3 || precision == SCLDM_PREC_FP16) ? SCLDM_PREC_FP32 : precision; }
+// The split-bf16 policy exists in the fused inference kernel only; on the training / generic entry points a request for it is served by
+// the exact-fp32 GEMM route (same parity class: fp32 products are a superset of bf16x3's accuracy).  fp16 - the reference's own
+// arithmetic class, TF32's mantissa (train_ldm.py:18) - TRAINS on the fused route of the base shape since round 4 (fp16 operands in the
+// recording forward, the fused backward layer and the weight-gradient GEMMs; the small GEMMs around them exact fp32; the backward
+// loss-scaled on device); shapes outside the fused family keep the exact-fp32 route for it.
+inline int train_precision(const scldm_dit* h, int n, int precision) {
+  if (precision == SCLDM_PREC_FP16 && h && fused::eligible(h, n, SCLDM_PREC_FP16)) return SCLDM_PREC_FP16;
+  return (precision == SCLDM_PREC_BF16X3 || precision == SCLDM_PREC_FP16) ? SCLDM_PREC_FP32 : precision;
+}
 
 int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
-  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
-  g_bf16 = precision == SCLDM_PREC_BF16;
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  g_bf16 = precision == SCLDM_PREC_BF16;   // (fp16: the GEMMs outside the fused layers are exact fp32)
   if (n < 1) return fail(SCLDM_ERR_SHAPE, "n must be >= 1");
   const scldm_dit_config& c = h->cfg;
   const int hd = c.n_head > 0 ? c.n_embed / c.n_head : 0;
@@ -735,12 +741,12 @@ extern "C" size_t scldm_dit_train_saved_bytes(const scldm_dit* h, int n) {
 }
 extern "C" size_t scldm_dit_train_saved_bytes_for(const scldm_dit* h, int n, int precision) {
   if (!h || n < 1) return 0;
-  precision = train_precision(precision);
+  precision = train_precision(h, n, precision);
   return carve_saved(h, n, nullptr, fused::eligible(h, n, precision)).bytes;
 }
 extern "C" size_t scldm_dit_train_workspace_bytes_for(const scldm_dit* h, int n, int precision) {
   if (!h || n < 1) return 0;
-  precision = train_precision(precision);
+  precision = train_precision(h, n, precision);
   const bool f = fused::eligible(h, n, precision);
   return carve_scratch(h, n, nullptr, f).bytes + (f ? fused::carve_scratch(h, n, nullptr).bytes : 0);
 }
@@ -752,8 +758,8 @@ extern "C" size_t scldm_dit_train_workspace_bytes(const scldm_dit* h, int n) {
 
 extern "C" int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w, int n, int precision, void* stream_) {
   if (!h || !w) return fail(SCLDM_ERR_SHAPE, "null argument");
-  precision = train_precision(precision);
-  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  precision = train_precision(h, n, precision);
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
   hipStream_t st = (hipStream_t)stream_;
   if (fused::eligible(h, n, precision)) return fused::prepare_tables(h, w, st);
   if (src16_eligible(h, n, precision)) return prepare_w16(h, w, n, st);
@@ -763,7 +769,7 @@ extern "C" int scldm_dit_train_prepare(scldm_dit* h, const scldm_dit_weights* w,
 extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w, const float* x, const float* t,
                                        const int64_t* const* labels, int n, float* out, int precision, void* saved_, void* ws,
                                        void* stream_) {
-  precision = train_precision(precision);
+  precision = train_precision(h, n, precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!x || !t || !out) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
@@ -775,7 +781,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
   Saved s = carve_saved(h, n, saved_, use_fused);
   Scratch k = carve_scratch(h, n, ws, use_fused);
 
-  if (use_fused) TRY(fused::prepare(h, w, st));   // weight re-pack on a side stream, next to the conditioning below
+  if (use_fused) TRY(fused::prepare(h, w, st, precision));   // weight re-pack on a side stream, next to the conditioning below
   // bf16-source route (bgemm.hpp): h1, ao, h2, hid and SiLU(c) live as bf16 arrays in their (fp32-sized) slots of the saved block,
   // the weights as per-step bf16 copies; same sequence of kernels otherwise
   const bool src16 = src16_eligible(h, n, precision);
@@ -826,7 +832,7 @@ extern "C" int scldm_dit_train_forward(scldm_dit* h, const scldm_dit_weights* w,
     // gated branch outputs; 32 KB per cell per layer) instead of ~290 KB of saved activations
     const fused::Record rec = fused::carve_record(h, n, s.layer[0].x_in);
     const fused::Scratch fs = fused::carve_scratch(h, n, reinterpret_cast<char*>(ws) + k.bytes);
-    return fused::forward(h, x, s.mod, n, out, rec, fs, st);
+    return fused::forward(h, x, s.mod, n, out, rec, fs, st, precision);
   }
   // x_0 = input_proj(x) + pos_embed (nnets.py:290)
   float* x0 = L > 0 ? s.layer[0].x_in : s.x_last;
@@ -917,7 +923,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // the gradient-ready events belong to THIS call only: whatever way it returns, none of the raw hipEvent_t handles survives on the
   // handle (the caller may destroy them right after; a later backward without set_grad_events must not record into them)
   struct DropEvents { scldm_dit* h; ~DropEvents() { if (h) h->grad_events.clear(); } } drop_events_scope{h};
-  precision = train_precision(precision);
+  precision = train_precision(h, n, precision);
   TRY(check_common(h, w, n, precision, saved_, ws));
   if (!g || !x || !dout) return fail(SCLDM_ERR_SHAPE, "null argument");
   hipStream_t st = (hipStream_t)stream_;
@@ -935,6 +941,14 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // ---- final layer ----
   const int of = L * 6 * kD;
   const bool edge = use_fused && fused::edge_kernels_available(h);   // both ends of the backward as single kernels on the tile layout
+  // fp16 policy: gradients of a mean loss are ~1e-6 - below fp16's normal range.  The whole backward is linear in dout, so it runs on
+  // S * dout (S a power of two chosen ON DEVICE so that max |S dout| lands in [8, 16): no host read) and every gradient it produced is
+  // multiplied by 1 / S at the end (exact: powers of two) - before any gradient-ready event is recorded.
+  const bool f16 = use_fused && precision == SCLDM_PREC_FP16;
+  if (f16) {
+    TRY(fused::scale_dout(dout, (long)T * din, fs, st));
+    dout = fs.dout_s;
+  }
   if (edge) {
     TRY(fused::final_backward(h, rec.x + (size_t)L * T_pad * kD, s.mod, dout, w->fin_w, n, fs.dx, k.dmod, g->fin_w, g->fin_b, fs.edge_part, st));
   } else {
@@ -948,7 +962,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     if (use_fused) TRY(fused::to_tile(k.dx, fs.dx, n, st));
   }
   if (use_fused) {
-    TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st));
+    TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision));
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
   // bf16-source route: dy, dqkv, da, db (consumed only by GEMMs) are bf16 arrays in their slots of the scratch block
@@ -1035,6 +1049,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // gradient-ready events (scldm_dit_train_set_grad_events): `st` is ordered after every kernel that writes the gradients an event
   // stands for when it is recorded.  Events the route cannot time individually fire at the end of the call.
   auto fire = [&](int kind, int layer) -> int {
+    if (f16 && kind != SCLDM_GRAD_END) return SCLDM_OK;   // (loss-scaled backward: nothing is final before the un-scaling pass at the end)
     for (auto& e : h->grad_events)
       if (!e.fired && (kind == SCLDM_GRAD_END || (e.kind == kind && (kind == SCLDM_GRAD_LAYER ? e.layer >= layer : e.layer <= layer)))) {
         HIP_TRY(hipEventRecord(e.ev, st));
@@ -1246,6 +1261,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
   if (s_in != st) TRY(fused::join_side(h, st, 0));
   if (s_ada != st) TRY(fused::join_side(h, st, 1));
+  if (f16) TRY(fused::unscale_grads(h, g, dx_out, (long)T * din, fs, st));
   TRY(fire(SCLDM_GRAD_END, 0));
   h->grad_events.clear();
   return SCLDM_OK;

@@ -10,7 +10,17 @@
 #include <vector>
 
 #include "api_common.hpp"
+// the fused backward layer, once per 16-bit operand policy (see the header of dit_backward.hpp)
+#define SCLDM_BWD_NS bwd
+#define SCLDM_BWD_OP OpBF16
 #include "dit_backward.hpp"
+#undef SCLDM_BWD_NS
+#undef SCLDM_BWD_OP
+#define SCLDM_BWD_NS bwdh
+#define SCLDM_BWD_OP OpFP16
+#include "dit_backward.hpp"
+#undef SCLDM_BWD_NS
+#undef SCLDM_BWD_OP
 #include "dit_forward.hpp"
 
 namespace scldm {
@@ -91,14 +101,23 @@ struct OperandLoader {
     for (int p = 0; p < 4; ++p)
       d[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ((unsigned)(t0 + 16 * p + 4 * wave) * (unsigned)ld + (unsigned)m0) * 2u, 0);
   }
-  // rs[e] += the stage's values of feature 8 (lane % 16) + e (this thread's four tokens)
+  // rs[e] += the stage's values of feature 8 (lane % 16) + e (this thread's four tokens); F16: the operands are fp16, else bf16
+  template <bool F16>
   __device__ __forceinline__ void add_rowsum(float (&rs)[8]) const {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        rs[2 * i] += __uint_as_float(d[p][i] << 16);
-        rs[2 * i + 1] += __uint_as_float(d[p][i] & 0xffff0000u);
+        if constexpr (F16) {
+          typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+          union { unsigned u; f16x2 h; } c;
+          c.u = d[p][i];
+          rs[2 * i] += (float)c.h[0];
+          rs[2 * i + 1] += (float)c.h[1];
+        } else {
+          rs[2 * i] += __uint_as_float(d[p][i] << 16);
+          rs[2 * i + 1] += __uint_as_float(d[p][i] & 0xffff0000u);
+        }
       }
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S) const {
@@ -121,6 +140,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* __restrict__ S, int f0, 
 }
 
 constexpr int kWgradLds = 2 * 2 * kWK * kWLD * 2;   // two buffers x two operands = 80 KB: two workgroups per CU
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) char wgrad_smem[];
   auto As = [&](int b) { return reinterpret_cast<__bf16*>(wgrad_smem) + b * (kWK * kWLD); };
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   lb[0].load(rb, j.ldb, n0, t_beg);
   la[1].load(ra, j.lda, m0, t_beg + min(1, n_it - 1) * kWK);
   lb[1].load(rb, j.ldb, n0, t_beg + min(1, n_it - 1) * kWK);
-  if (want_rs) la[0].add_rowsum(rs);
+  if (want_rs) la[0].template add_rowsum<F16>(rs);
   la[0].store(As(0));
   lb[0].store(Bs(0));
   lds_barrier();
@@ -185,10 +205,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[k], acc[i][k], 0, 0, 0);
+        for (int k = 0; k < 2; ++k) {
+          if constexpr (F16) {
+            union { bf16x8 b; f16x8 h; } ua, ub;   // (the 16-bit pieces travel untyped through the loads and the transposing reads)
+            ua.b = af[i];
+            ub.b = bf[k];
+            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.h, ub.h, acc[i][k], 0, 0, 0);
+          } else {
+            acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[k], acc[i][k], 0, 0, 0);
+          }
+        }
     }
     if (it + 1 < n_it) {
-      if (want_rs) la[SLOT ^ 1].add_rowsum(rs);
+      if (want_rs) la[SLOT ^ 1].template add_rowsum<F16>(rs);
       la[SLOT ^ 1].store(As(buf ^ 1));
       lb[SLOT ^ 1].store(Bs(buf ^ 1));
     }
@@ -418,6 +447,41 @@ __global__ void scatter_ada_kernel(const float* __restrict__ dw_all, const float
 
 
 
+// ---- loss scaling of the fp16 backward -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void loss_scale_kernel(const float* __restrict__ dout, long n, float* __restrict__ scale) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(dout[i]));   // (NaN / inf: fmaxf drops NaN, inf is caught below)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    float S = 1.0f;
+    if (m > 0.f && m < 3.0e38f) S = exp2f(fminf(fmaxf(floorf(log2f(8.0f / m)), -24.f), 60.f));
+    scale[0] = S;
+    scale[1] = 1.0f / S;
+  }
+}
+__global__ void scale_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale, float* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * scale[0];
+}
+constexpr int kMaxUnscale = 16 * 10 + SCLDM_MAX_CLASSES + 16;
+struct UnscaleArgs {
+  float* p[kMaxUnscale];
+  int n[kMaxUnscale];
+  int count;
+  const float* scale;
+};
+__global__ __launch_bounds__(256) void unscale_kernel(const UnscaleArgs a) {
+  float* __restrict__ p = a.p[blockIdx.x];
+  const int n = a.n[blockIdx.x];
+  const float inv = a.scale[1];
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] *= inv;
+}
+
 }  // namespace
 
 static inline int pad4(int n) { return (n + 3) / 4 * 4; }   // whole 64-token tiles; samples past n are tile padding
@@ -458,13 +522,19 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.part = c.take<float>(part_floats(h));
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.edge_part = c.take<float>(edge_part_floats(h));
+  s.dout_s = c.take<float>(T * 32);
+  s.scale = c.take<float>(64);
   s.bytes = c.off;
   return s;
 }
 
 bool eligible(const scldm_dit* h, int n, int precision) {
   // h->train_fused: SCLDM_TRAIN_FUSED=0 at handle creation keeps the base shape on the generic GEMM-based path (A/B runs, tests)
-  return h && h->train_fused && h->bwd_stream && h->fused && precision == SCLDM_PREC_BF16 && n >= 1 && n <= 65536 /* operand arrays stay under the 2 GB a buffer descriptor addresses */ && h->stream[SCLDM_PREC_BF16][1] != nullptr &&
+  // precision: bf16, or fp16 (the reference's TF32 mantissa; its backward is loss-scaled by the caller and un-scaled through a by-value
+  // pointer table, hence the layer bound)
+  if (precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16) return false;
+  if (precision == SCLDM_PREC_FP16 && (h == nullptr || h->cfg.n_layer > kMaxFp16TrainLayers)) return false;
+  return h && h->train_fused && h->bwd_stream && h->fused && n >= 1 && n <= 65536 /* operand arrays stay under the 2 GB a buffer descriptor addresses */ && h->stream[precision][1] != nullptr &&
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
@@ -481,14 +551,15 @@ int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
   return SCLDM_OK;
 }
-int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precision) {
   int rc = prepare_tables(h, w, st);
   if (rc) return rc;
   // The re-pack (90 us, memory bound) runs on a side stream next to the conditioning MLP, which reads the live parameters:
   // forked here, joined by prepare_join() before the first consumer of a packed copy.
   HIP_TRY(hipEventRecord(h->fork_ev, st));            // everything queued so far (the previous step's optimizer update) comes first
   HIP_TRY(hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
-  rc = scldm_run_pack(h, true, (1u << SCLDM_PREC_BF16) | 0x100u, h->side[0]);
+  // bit 9: the backward stream is packed as fp16 (same buffer: it is re-packed every step, in the step's operand type)
+  rc = scldm_run_pack(h, true, (1u << precision) | 0x100u | (precision == SCLDM_PREC_FP16 ? 0x200u : 0u), h->side[0]);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->join_ev[0], h->side[0]));
   return SCLDM_OK;
@@ -515,15 +586,17 @@ int prepare_join(scldm_dit* h, hipStream_t st) {
   return SCLDM_OK;
 }
 
-int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st) {
-  using L = FwdLayout<OpBF16, 2, 2>;
-  auto kern = dit_forward_kernel<OpBF16, 2, 2, true>;
-  static bool attr_set[64] = {};
+int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st, int precision) {
+  using L = FwdLayout<OpBF16, 2, 2>;   // (the fp16 policy has the same layout)
+  static_assert(FwdLayout<OpFP16, 2, 2>::LDS_BYTES == L::LDS_BYTES && FwdLayout<OpFP16, 2, 2>::NT == L::NT, "fp16 = the bf16 kernel's shape");
+  const bool f16 = precision == SCLDM_PREC_FP16;
+  void (*kern)(const FwdArgs) = f16 ? dit_forward_kernel<OpFP16, 2, 2, true> : dit_forward_kernel<OpBF16, 2, 2, true>;
+  static bool attr_set[2][64] = {};
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+  if (dev < 0 || dev >= 64 || !attr_set[f16][dev]) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    if (dev >= 0 && dev < 64) attr_set[f16][dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
   if (h->iota_n < n) {   // identity row index, kept on the handle (grown on demand)
@@ -544,7 +617,7 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
   a.x = s.handoff;
   a.mod = mod;
   a.row_index = h->iota;
-  a.w_final = h->wfinal[SCLDM_PREC_BF16];
+  a.w_final = h->wfinal[precision];
   a.in_wt = h->in_wt;
   a.in_w = h->in_w;
   a.in_b = h->in_b;
@@ -570,7 +643,7 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
   for (int i = 0; i < c.n_layer; i += lpl_rec) {
     a.layer = i;
     a.n_here = std::min(lpl_rec, c.n_layer - i);
-    a.w_stream = (const char*)h->stream[SCLDM_PREC_BF16][1] + (size_t)i * layer_elems * 2;
+    a.w_stream = (const char*)h->stream[precision][1] + (size_t)i * layer_elems * 2;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;
     kern<<<tiles, L::NT, L::LDS_BYTES, st>>>(a);
@@ -664,55 +737,73 @@ int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_al
   return SCLDM_OK;
 }
 
-int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
-                    hipStream_t st) {
-  static bool attr_set[64] = {};
+namespace {
+struct BwdBF16 {
+  using Args = bwd::BwdArgs;
+  using E = __bf16;
+  static constexpr bool kF16 = false;
+  static constexpr int NW = bwd::NW, NT = bwd::NT, LDS_BYTES = bwd::LDS_BYTES;
+  static void launch(int tiles, hipStream_t st, const Args& a) { bwd::dit_backward_kernel<<<tiles, NT, LDS_BYTES, st>>>(a); }
+  static const void* kernel() { return (const void*)bwd::dit_backward_kernel; }
+};
+struct BwdFP16 {
+  using Args = bwdh::BwdArgs;
+  using E = _Float16;
+  static constexpr bool kF16 = true;
+  static constexpr int NW = bwdh::NW, NT = bwdh::NT, LDS_BYTES = bwdh::LDS_BYTES;
+  static void launch(int tiles, hipStream_t st, const Args& a) { bwdh::dit_backward_kernel<<<tiles, NT, LDS_BYTES, st>>>(a); }
+  static const void* kernel() { return (const void*)bwdh::dit_backward_kernel; }
+};
+}  // namespace
+
+template <typename BW>
+static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
+                             hipStream_t st) {
+  using E16 = typename BW::E;
+  static bool attr_set[64] = {};   // (per instantiation)
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)bwd::dit_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bwd::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(BW::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, BW::LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)wgrad_bf16_kernel<BW::kF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
-  static bool wattr_set[64] = {};
-  if (dev < 0 || dev >= 64 || !wattr_set[dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds));
-    if (dev >= 0 && dev < 64) wattr_set[dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
   const int tiles = pad4(n) / 4, T = pad4(n) * 16, H = c.hidden_dim;   // the padding tokens carry zero gradients into the operand pairs
   const size_t TD = (size_t)T * kD;
-  const size_t bwd_layer_elems = (size_t)bwd::NW * kBwdUnitsLayer * 512;
+  const size_t bwd_layer_elems = (size_t)BW::NW * kBwdUnitsLayer * 512;
   for (int l = c.n_layer - 1; l >= 0; --l) {
-    bwd::BwdArgs a{};
+    typename BW::Args a{};
     a.x_in = rec.x + (size_t)l * TD;
-    a.y1 = rec.y1 + (size_t)l * TD;
-    a.y2 = rec.y2 + (size_t)l * TD;
+    a.y1 = reinterpret_cast<const E16*>(rec.y1) + (size_t)l * TD;
+    a.y2 = reinterpret_cast<const E16*>(rec.y2) + (size_t)l * TD;
     a.dx = s.dx;
     a.mod = mod;
     a.dmod = dmod;
     a.mod_stride = h->mod_w;
     a.mod_off = l * kModBlock;
-    a.w_stream = reinterpret_cast<const __bf16*>(h->bwd_stream) + (size_t)l * bwd_layer_elems;
+    a.w_stream = reinterpret_cast<const E16*>(h->bwd_stream) + (size_t)l * bwd_layer_elems;
     a.b_qkv = h->b_qkv + (size_t)l * 768;
-    a.e_h1 = s.e_h1; a.e_dqkv = s.e_dqkv; a.e_ao = s.e_ao; a.e_dy1 = s.e_dy1; a.e_h2 = s.e_h2;
-    a.e_da = s.e_da; a.e_db = s.e_db; a.e_hid = s.e_hid; a.e_dy2 = s.e_dy2;
+    auto e16 = [](__bf16* p) { return reinterpret_cast<E16*>(p); };   // (16-bit slots; the element type is the step's operand type)
+    a.e_h1 = e16(s.e_h1); a.e_dqkv = e16(s.e_dqkv); a.e_ao = e16(s.e_ao); a.e_dy1 = e16(s.e_dy1); a.e_h2 = e16(s.e_h2);
+    a.e_da = e16(s.e_da); a.e_db = e16(s.e_db); a.e_hid = e16(s.e_hid); a.e_dy2 = e16(s.e_dy2);
     a.n = n;
     a.eps = c.layernorm_eps;
     a.attn_scale = 1.0f / sqrtf(32.0f);
     a.attn_scale_log2e = 1.4426950408889634f / sqrtf(32.0f);
     static unsigned long long* dbg_buf = nullptr;   // SCLDM_BWD_DBG=1: phase stamps of layer 0's launch, printed per step (debug aid)
     const bool want_dbg = l == 0 && h->bwd_dbg;
-    if (want_dbg && !dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, (size_t)16384 * bwd::NW * 16 * 8));
+    if (want_dbg && !dbg_buf) HIP_TRY(hipMalloc(&dbg_buf, (size_t)16384 * BW::NW * 16 * 8));
     a.dbg = (want_dbg && tiles <= 16384) ? dbg_buf : nullptr;
-    bwd::dit_backward_kernel<<<tiles, bwd::NT, bwd::LDS_BYTES, st>>>(a);
+    BW::launch(tiles, st, a);
     LAUNCH_CHECK();
     if (a.dbg) {
       HIP_TRY(hipStreamSynchronize(st));
-      std::vector<unsigned long long> hst((size_t)tiles * bwd::NW * 16);
+      std::vector<unsigned long long> hst((size_t)tiles * BW::NW * 16);
       HIP_TRY(hipMemcpy(hst.data(), dbg_buf, hst.size() * 8, hipMemcpyDeviceToHost));
       double acc[16] = {0};
       for (int b = 0; b < tiles; ++b)
-        for (int i = 1; i < 14; ++i) acc[i] += (double)(hst[((size_t)b * bwd::NW) * 16 + i] - hst[((size_t)b * bwd::NW) * 16 + i - 1]);
+        for (int i = 1; i < 14; ++i) acc[i] += (double)(hst[((size_t)b * BW::NW) * 16 + i] - hst[((size_t)b * BW::NW) * 16 + i - 1]);
       fprintf(stderr, "[bwd phases, wave 0, mean cycles]");
       for (int i = 1; i < 14; ++i) fprintf(stderr, " %d:%.0f", i, acc[i] / tiles);
       fprintf(stderr, "\n");
@@ -759,7 +850,7 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     wa.part = s.part;
     const int splits = cdiv(T, wa.kchunk);
     wa.splits = splits;
-    wgrad_bf16_kernel<<<tile0 * splits, 256, kWgradLds, st>>>(wa);
+    wgrad_bf16_kernel<BW::kF16><<<tile0 * splits, 256, kWgradLds, st>>>(wa);
     LAUNCH_CHECK();
     ra.n_jobs = nr;
     ra.splits = splits;
@@ -768,6 +859,40 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
     wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, st>>>(ra);
     LAUNCH_CHECK();
   }
+  return SCLDM_OK;
+}
+
+int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
+                    hipStream_t st, int precision) {
+  return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16>(h, g, mod, dmod, n, rec, s, st) : backward_layers_t<BwdBF16>(h, g, mod, dmod, n, rec, s, st);
+}
+
+int scale_dout(const float* dout, long n_elem, const Scratch& s, hipStream_t st) {
+  loss_scale_kernel<<<1, 1024, 0, st>>>(dout, n_elem, s.scale);
+  scale_copy_kernel<<<cdiv(n_elem, 256), 256, 0, st>>>(dout, s.scale, s.dout_s, n_elem);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
+int unscale_grads(scldm_dit* h, const scldm_dit_grads* g, float* dx_out, long dx_elems, const Scratch& s, hipStream_t st) {
+  const scldm_dit_config& c = h->cfg;
+  const int L = c.n_layer, H = c.hidden_dim, din = c.n_embed_input;
+  UnscaleArgs a{};
+  auto add = [&](float* p, long n) {
+    if (p && n > 0 && a.count < kMaxUnscale) { a.p[a.count] = p; a.n[a.count] = (int)n; ++a.count; }
+  };
+  for (int l = 0; l < L; ++l) {
+    add(g->attn_w[l], 3 * kD * kD); add(g->attn_b[l], 3 * kD); add(g->proj_w[l], kD * kD); add(g->proj_b[l], kD);
+    add(g->w1[l], (long)H * kD); add(g->w2[l], (long)H * kD); add(g->cproj[l], (long)H * kD);
+    add(g->ada_w[l], 6 * kD * kD); add(g->ada_b[l], 6 * kD);
+  }
+  for (int ci = 0; ci < c.n_classes; ++ci) add(g->class_emb[ci], (long)h->tab_rows[ci] * kD);
+  add(g->fin_ada_w, 2 * kD * kD); add(g->fin_ada_b, 2 * kD); add(g->t_w0, kD * 256); add(g->t_b0, kD); add(g->t_w2, kD * kD); add(g->t_b2, kD);
+  add(g->in_w, (long)kD * din); add(g->in_b, kD); add(g->fin_w, (long)din * kD); add(g->fin_b, din); add(g->pos_embed, 16 * kD);
+  add(dx_out, dx_elems);
+  a.scale = s.scale;
+  unscale_kernel<<<dim3(a.count, 32), 256, 0, st>>>(a);
+  LAUNCH_CHECK();
   return SCLDM_OK;
 }
 

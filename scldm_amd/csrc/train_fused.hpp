@@ -29,25 +29,28 @@ struct Scratch {
   float* part;      // split-K partials of one layer's five weight gradients + two bias gradients
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
+  float* dout_s;    // fp16 policy: the loss-scaled copy of d loss / d output (n x 16 x n_embed_input)
+  float* scale;     // fp16 policy: [0] loss scale S (a power of two), [1] 1 / S - decided on device from max |dout|
   size_t bytes;
 };
 Scratch carve_scratch(const scldm_dit* h, int n, void* base);
 
-bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision and batch served by the fused path
+constexpr int kMaxFp16TrainLayers = 16;   // the fp16 backward un-scales every gradient tensor through a by-value pointer table
+bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision (bf16 | fp16) and batch served by the fused path
 
 // refresh the packed forward (bf16) and backward weight streams from the live parameters
 int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // pack-job tables, side streams, events (no kernel work)
-int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // forks the re-pack onto a side stream
+int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precision);   // forks the re-pack (of that precision's streams) onto a side stream
 int prepare_join(scldm_dit* h, hipStream_t st);                           // `st` waits for it (before the first packed copy is read)
 // trunk forward (input projection .. final layer) with the record; mod = (n, mod_w) adaLN vectors
-int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st);
+int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st, int precision);
 // plain [T][256] fp32 <-> tile layout
 int to_tile(const float* plain, float* tile, int n, hipStream_t st);
 int to_plain(const float* tile, float* plain, int n, hipStream_t st);
 // all L layers, last to first: s.dx (tile layout) holds d loss / d x_L on entry and d loss / d x_0 on return; dmod gets the
 // gradients of the layers' adaLN vectors; g receives attn_w/attn_b/proj_w/proj_b/w1/w2/cproj of every layer
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
-                    hipStream_t st);
+                    hipStream_t st, int precision);
 
 // The two ends of the backward as single kernels on the tile layout (n_embed_input 8 / 16 / 32):
 //   final_backward: LayerNorm + Linear of the final layer: dx (tile layout), d(shift, scale) into dmod, d fin_w, d fin_b
@@ -60,6 +63,11 @@ int inproj_backward(scldm_dit* h, const float* dx, const float* x, int n, float*
 // independent tails of the backward run next to each other: side stream k starts after what `st` holds / `st` waits for it
 int fork_side(scldm_dit* h, hipStream_t st, int k, hipStream_t* out);
 int join_side(scldm_dit* h, hipStream_t st, int k);
+
+// fp16 policy: loss scaling of the backward.  scale_dout: S = 2^floor(log2(8 / max |dout|)) (device side, no host read), dout_s = S dout;
+// unscale: every tensor of `g` (and dx_out, when given) times 1 / S in one launch over a by-value pointer table.
+int scale_dout(const float* dout, long n_elem, const Scratch& s, hipStream_t st);
+int unscale_grads(scldm_dit* h, const scldm_dit_grads* g, float* dx_out, long dx_elems, const Scratch& s, hipStream_t st);
 
 // (mod_w, 256) stacked weight gradient + (mod_w) stacked bias gradient -> g->ada_w[l] / ada_b[l] / fin_ada_w / fin_ada_b
 int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_all, const float* db_all, hipStream_t st);

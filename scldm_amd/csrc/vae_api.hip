@@ -225,8 +225,12 @@ int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes,
   p.ln1_w = h->small + S_ENC_LN1W; p.ln1_b = h->small + S_ENC_LN1B;
   p.kfrag = h->frag_enc_k; p.vfrag = h->frag_enc_v; p.qfrag = h->frag_enc_q;
   p.pooled = pooled; p.lse2 = lse2; p.S = S; p.eps = c.layernorm_eps;
-  if (precision == SCLDM_PREC_BF16) enc_pool_kernel<true><<<B, 256, 0, st>>>(p);
-  else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
+  static const int enc_nw = getenv("SCLDM_ENC_WAVES") ? atoi(getenv("SCLDM_ENC_WAVES")) : 4;   // waves per cell of the bf16-operand pooling kernel (A/B: 4 | 6 | 8)
+  if (precision == SCLDM_PREC_BF16) {
+    if (enc_nw == 6) enc_pool_kernel<true, 6><<<B, 384, 0, st>>>(p);
+    else if (enc_nw == 8) enc_pool_kernel<true, 8><<<B, 512, 0, st>>>(p);
+    else enc_pool_kernel<true><<<B, 256, 0, st>>>(p);
+  } else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
   LAUNCH_CHECK();
   EncCellArgs e;
   e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.proj_frag = h->frag_cell + F_ENC_PROJ;

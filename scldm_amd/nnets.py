@@ -168,8 +168,10 @@ class DiT(nn.Module):
     product sum; both inside the 1e-4 parity gate vs exact fp32), "fp16" (fp16 operands = TF32's 10 mantissa bits, the
     arithmetic the reference itself runs under `set_float32_matmul_precision("high")`, inference.py:26 - ~1e-3 vs exact fp32,
     like the reference; weights are range-checked against +-65 504 when packed) or "bf16" (8 bits: throughput path); default
-    from $SCLDM_PRECISION, else "fp32".  "bf16x3" and "fp16" are policies of the fused inference kernels: in training mode and
-    on shapes outside the fused family (e.g. a DiT-L) they are served by the exact-fp32 GEMM route.
+    from $SCLDM_PRECISION, else "fp32".  Training: "bf16" and - since round 4 - "fp16" (the reference's own training arithmetic class,
+    train_ldm.py:18) run the fused route of the base shape at the matrix-core rate (fp16: backward loss-scaled on device, the small
+    GEMMs around the fused layers exact fp32); "bf16x3", and "fp16" on shapes outside the fused family (e.g. a DiT-L), are served by the
+    exact-fp32 GEMM route.
 
     The fused inference kernels read PACKED copies of the parameters.  They are refreshed automatically when a parameter's
     storage or torch version counter changes, and an on-device fingerprint of the parameters is re-checked at every call so

