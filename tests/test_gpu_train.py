@@ -243,11 +243,14 @@ def test_fp16_training_loop_with_label_dropout_and_tiny_gradients():
     m, sd, cfg = build(vocab, "joint", 8, 85)
     m.cfg_dropout_prob = 0.8
     m.precision = "fp16"
-    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, fused=True)
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, eps=1e-20)   # (eps far below the down-scaled gradients: Adam's update is scale-free then)
     tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
     gen = torch.Generator(device="cuda").manual_seed(3)
     n = 128
     x1 = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    x0 = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    t = torch.rand(n, device="cuda", generator=gen)
+    tr.sample = lambda x1_: (t, x0, x1_)        # one fixed batch: the loss is a deterministic function of the parameters
     cond = {"cell_line": torch.randint(0, 4, (n,), device="cuda", generator=gen), "gene": torch.randint(0, 2024, (n,), device="cuda", generator=gen)}
     losses = []
     for _ in range(8):
