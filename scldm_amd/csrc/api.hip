@@ -93,6 +93,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   h->groups = 1;
   if (const char* e = getenv("SCLDM_ADALN_VALU")) h->adaln_valu = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_ADALN_EXACT")) h->adaln_exact = atoi(e) != 0;
+  if (const char* e = getenv("SCLDM_ADALN_ROWTILE")) h->adaln_rowtile = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
   h->dbg_layer = -1;
   if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
@@ -389,6 +390,7 @@ struct Ws {
   float* v;       // (n_fwd, 16*din)
   float* mod;     // (n_rows, mod_w)
   float* silu;    // (n_rows, 256)
+  void* asplit;   // (pad32(n_rows), 256) split-bf16 A fragments of the conditioning rows (adaln_x3_block_kernel)
   float* temb;    // (256) timestep embedding shared by all rows of a scalar-t step
   int32_t* ridx;  // (n_fwd)
   float* dz;      // (n_state, e)
@@ -406,6 +408,7 @@ static Ws carve(const scldm_dit* h, void* base, int n_fwd, int n_rows, int n_sta
   w.v = (float*)take((size_t)n_fwd * e * 4);
   w.mod = (float*)take((size_t)n_rows * h->mod_w * 4);
   w.silu = (float*)take((size_t)(n_rows + 1) * 256 * 4);  // +1 spare row (device scalar t)
+  w.asplit = take((size_t)((n_rows + 31) / 32 * 32) * 256 * 4);
   w.temb = (float*)take((size_t)kMaxTembEvals * 256 * 4);  // per-evaluation timestep embeddings of a whole solve
   w.ridx = (int32_t*)take((size_t)n_fwd * 4);
   w.dz = (float*)take((size_t)n_state * e * 4);
@@ -453,14 +456,17 @@ static int launch_cond(scldm_dit* h, const float* t, int t_stride, const int64_t
 // matrix pipe; the fast policies: split-bf16 operands (their own arithmetic class or finer).  Within a policy every output element
 // is one fixed-order sum whatever the number of rows (a cell's vectors never depend on its batch).
 static int launch_adaln(scldm_dit* h, const float* silu_c, float* mod, int rows, hipStream_t st, const int* rows_dev = nullptr,
-                        int prec = SCLDM_PREC_FP32) {
+                        int prec = SCLDM_PREC_FP32, void* asplit = nullptr) {
   if (prec != SCLDM_PREC_FP32 && !h->adaln_valu && !h->adaln_exact) {
     const bf16x8x2* wf = reinterpret_cast<const bf16x8x2*>(h->ada_x3);
     const int n_tiles = h->mod_w / 32;
-    if (rows <= 128) {   // few rows: one column tile per wave (every wave's latency chain as short as possible)
-      adaln_x3_kernel<1><<<dim3(cdiv(n_tiles, 4), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
-    } else {             // many rows: the split of a wave's 32 rows is amortised over four column tiles
-      adaln_x3_kernel<4><<<dim3(cdiv(n_tiles, 16), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
+    if (rows <= 128 || !asplit || h->adaln_rowtile) {   // few rows: one column tile per wave (every wave's latency chain as short as possible)
+      if (rows <= 128) adaln_x3_kernel<1><<<dim3(cdiv(n_tiles, 4), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
+      else adaln_x3_kernel<4><<<dim3(cdiv(n_tiles, 16), cdiv(rows, 32)), 256, 0, st>>>(silu_c, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
+    } else {             // many rows: rows split once, 128 x 128 blocks (the weights are read once per 128 rows); same bits
+      bf16x8x2* af = reinterpret_cast<bf16x8x2*>(asplit);
+      adaln_split_rows_kernel<<<cdiv(rows, 32) * 4, 256, 0, st>>>(silu_c, af, rows, rows_dev);
+      adaln_x3_block_kernel<<<dim3(cdiv(n_tiles, 4), cdiv(rows, 128)), 256, 0, st>>>(af, wf, h->ada_b, mod, rows, h->mod_w, rows_dev);
     }
     LAUNCH_CHECK();
     return SCLDM_OK;
@@ -635,7 +641,7 @@ extern "C" int scldm_dit_forward(scldm_dit* h, const float* x, const float* t, c
   hipStream_t st = (hipStream_t)stream_;
   Ws w = carve(h, ws_, n, n, 0);
   if ((rc = launch_cond(h, t, 1, labels, 0xffffffffu, n, w.silu, st))) return rc;
-  if ((rc = launch_adaln(h, w.silu, w.mod, n, st, nullptr, precision))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, n, st, nullptr, precision, w.asplit))) return rc;
   iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(w.ridx, n);
   LAUNCH_CHECK();
   return trunk(h, x, n, 1, n, w.mod, w.ridx, w.h, out, precision, st);
@@ -715,7 +721,7 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
         return rc;
     }
   }
-  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec))) return rc;
+  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec, w.asplit))) return rc;
   if (pl.direct)   // guided rows = the conditional forward itself: the trunk writes dz, no blend
     return trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st);
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;

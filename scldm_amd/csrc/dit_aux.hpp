@@ -528,6 +528,64 @@ __global__ __launch_bounds__(256, 2) void adaln_x3_kernel(const float* __restric
   }
 }
 
+// Many rows (joint conditioning: hundreds of unique label tuples per batch): the one-row-tile kernel above re-reads the 13 MB fragment
+// stream once per 32 rows - 315 MB and 70 us per call at 750 rows (profiles/r4e_parse1m_b1024_kernel_stats.txt), bandwidth-bound far above
+// its 10 us of MFMAs.  Two kernels instead: (1) the conditioning rows are split ONCE into A fragments [row tile][k step][lane][hi 8 | lo 8];
+// (2) a workgroup owns a 128-row x 128-column block, wave (wr, wc) its 64 x 64 quadrant - per k step two A and two B fragments
+// (32 bytes per lane each) feed four tiles x three MFMAs, the weights are read once per 128 rows.  Bit-identical to adaln_x3_kernel: an
+// output element is the same sequence of MFMAs over k, and the split is the same function of the same fp32 value.
+__global__ __launch_bounds__(256) void adaln_split_rows_kernel(const float* __restrict__ silu_c, bf16x8x2* __restrict__ afrag, int rows,
+                                                               const int* __restrict__ rows_dev = nullptr) {
+  if (rows_dev) rows = *rows_dev;
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // (row tile, k step, lane)
+  const int lane = idx & 63, s = (idx >> 6) & 15, rt = idx >> 10;
+  if (rt * 32 >= rows) return;
+  const float* src = silu_c + (size_t)min(rt * 32 + (lane & 31), rows - 1) * 256 + s * 16 + (lane >> 5) * 8;
+  const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+  const float t8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  afrag[idx] = OpBF16x3::pack8(t8);
+}
+__global__ __launch_bounds__(256, 2) void adaln_x3_block_kernel(const bf16x8x2* __restrict__ afrag, const bf16x8x2* __restrict__ wfrag,
+                                                                const float* __restrict__ bias, float* __restrict__ mod, int rows, int mod_w,
+                                                                const int* __restrict__ rows_dev = nullptr) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = lane & 31, hh = lane >> 5;
+  if (rows_dev) rows = *rows_dev;
+  const int rt0 = blockIdx.y * 4 + (wave >> 1) * 2;       // first of this wave's two row tiles
+  if (blockIdx.y * 128 >= rows) return;
+  const int n_tiles = mod_w >> 5, n_rt = (rows + 31) >> 5;
+  const int nt0 = blockIdx.x * 4 + (wave & 1) * 2;        // first of its two column tiles
+  if (nt0 >= n_tiles || rt0 >= n_rt) return;              // (wave-uniform; no barrier in this kernel)
+  const bool r1 = rt0 + 1 < n_rt, n1 = nt0 + 1 < n_tiles;
+  const bf16x8x2* a0 = afrag + (size_t)rt0 * 16 * 64 + lane;
+  const bf16x8x2* a1 = afrag + (size_t)(r1 ? rt0 + 1 : rt0) * 16 * 64 + lane;
+  const bf16x8x2* b0 = wfrag + (size_t)nt0 * 16 * 64 + lane;
+  const bf16x8x2* b1 = wfrag + (size_t)(n1 ? nt0 + 1 : nt0) * 16 * 64 + lane;
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[2][2] = {{z, z}, {z, z}};
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const bf16x8x2 fa0 = a0[s * 64], fa1 = a1[s * 64], fb0 = b0[s * 64], fb1 = b1[s * 64];
+    acc[0][0] = OpBF16x3::mma(fa0, fb0, acc[0][0]);
+    acc[0][1] = OpBF16x3::mma(fa0, fb1, acc[0][1]);
+    acc[1][0] = OpBF16x3::mma(fa1, fb0, acc[1][0]);
+    acc[1][1] = OpBF16x3::mma(fa1, fb1, acc[1][1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if ((i == 1 && !r1) || (j == 1 && !n1)) continue;
+      const int n = (nt0 + j) * 32 + c32;
+      const float bn = bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int u = (rt0 + i) * 32 + acc_row(r, hh);
+        if (u < rows) mod[(size_t)u * mod_w + n] = acc[i][j][r] + bn;
+      }
+    }
+}
+
 // plan[0] = 1 if every t[i] == t[0] (the scalar an ODE solver broadcasts, integrators.py:103-104) else 0; plan[1] = the number of
 // conditioning rows of the plan that follows (rows_uniform or rows_dense).  One workgroup; NaNs compare unequal (dense plan).
 __global__ __launch_bounds__(256) void uniform_t_kernel(const float* __restrict__ t, int n, int rows_uniform, int rows_dense,

@@ -28,6 +28,7 @@ struct scldm_dit {
   std::vector<hipEvent_t> ev;
   size_t ev_used;
   int lpl;         // DiT layers per fused-kernel launch (1..4)
+  bool adaln_rowtile = false;  // SCLDM_ADALN_ROWTILE: adaln_x3_kernel<4> instead of the 128 x 128-block kernel above 128 rows (A/B)
   bool adaln_exact = false;  // SCLDM_ADALN_EXACT: adaln_mfma_kernel (exact fp32) for every precision policy (A/B)
   bool adaln_valu = false;   // SCLDM_ADALN_VALU: adaln_all_kernel instead of adaln_mfma_kernel (A/B)
   int cfg1_direct = 0;  // SCLDM_OPT_CFG1_DIRECT (scldm_dit_set_option)

@@ -279,6 +279,45 @@ def test_guidance1_direct_option_matches_the_reference_arithmetic(name):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "fp32"])
+def test_adaln_kernels_give_a_cell_the_same_bits_in_any_batch(precision):
+    """The adaLN projection runs on the matrix pipe with a kernel chosen by the number of unique conditioning rows (one row tile per wave
+    up to 128 rows, rows split once + 128 x 128 blocks above; exact fp32 for the fp32 policy).  Every output element is one fixed
+    sequence of MFMAs over k in all of them, so a cell's result must not depend on the batch it is evaluated in: 400 cells with ~390
+    unique joint label tuples evaluated whole (block kernel) == the same cells in chunks of 40 (row-tile kernel), bit for bit."""
+    from scldm_amd.nnets import DiT
+    vocab = {"cell_type": 18, "cytokine": 91}
+    kw = dict(n_embed=256, n_embed_input=16, n_layer=2, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",
+              multiple_of=4, layernorm_eps=1e-8, class_vocab_sizes=vocab, cfg_dropout_prob=0.8, condition_strategy="joint")
+    m = DiT(**kw)
+    sd = make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 99)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.precision = precision
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    B = 400
+    z0 = torch.randn(B, 16, 16, device="cuda", generator=gen)
+    cond = {k: torch.randint(0, v, (B,), device="cuda", generator=gen) for k, v in vocab.items()}
+    scales = {k: 1.3 for k in vocab}
+    def run(lo, hi):
+        z2 = torch.cat([z0[lo:hi], z0[lo:hi]])
+        c2 = {k: torch.cat([v[lo:hi], v[lo:hi]]) for k, v in cond.items()}
+        return m.sample_ode_cfg(z2, c2, scales, 3, "euler")
+    whole = run(0, B)
+    assert len(torch.unique(torch.stack([cond["cell_type"], cond["cytokine"]], 1), dim=0)) > 128
+    for lo in range(0, B, 40):
+        part = run(lo, lo + 40)
+        assert torch.equal(part[:40], whole[lo:lo + 40]) and torch.equal(part[40:], whole[B + lo:B + lo + 40]), lo
+    if precision != "fp32":
+        cfg = DiTConfig(n_layer=2, class_vocab_sizes=vocab, condition_strategy="joint")
+        idx = torch.arange(0, B, 57)
+        z2 = torch.cat([z0[idx], z0[idx]]).cpu()
+        c2 = {k: torch.cat([v[idx], v[idx]]).cpu() for k, v in cond.items()}
+        ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd, cfg, x, t, c2, scales), 3, "euler")
+        got = torch.cat([whole[idx], whole[idx + B]]).cpu()
+        assert max_abs_rel(got, ref) < (TOL_FP32 if precision == "bf16x3" else TOL_BF16)
+
+
 def test_fp16_weight_range_check():
     """Weights beyond the fp16 range are refused when the fp16 stream is packed (VERDICT r2 next #4: pack-time range check)."""
     g, m, cfg, sd = build("dit_base", "fp16")
