@@ -734,7 +734,7 @@ def main():
             rl["traffic_ratio"] = (traffic / rl["algorithmic_hbm_bytes_per_launch"]) if traffic else None
             result["roofline"] = rl
     note(f"main workload done: {value:.0f} cells/s")
-    if rank == 0 and not fake and "roofline" in result:
+    if rank == 0 and not fake and "roofline" in result and not args.no_extra:   # (--no-extra: profiling runs keep their kernel list clean)
         try:
             ceil = mfma_ceiling_record()
             result["mfma_sustained_ceiling"] = ceil

@@ -678,8 +678,9 @@ __global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_
 }
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 
+// euler_z / euler_h: the caller's Euler update z += h * dz is applied by the blend kernel itself (one launch less per evaluation)
 static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
-                    float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr) {
+                    float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr, float* euler_z = nullptr, float euler_h = 0.f) {
   int rc;
   const int* gate = t_stride == 2 ? h->d_plan : nullptr;   // dense t, uniformity decided on device: both plans are enqueued, one runs
   const int rows_u = 1 + pl.P * pl.U, rows_d = 2 * pl.B + pl.P * pl.B;
@@ -722,8 +723,15 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
     }
   }
   if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec, w.asplit))) return rc;
-  if (pl.direct)   // guided rows = the conditional forward itself: the trunk writes dz, no blend
-    return trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st);
+  if (pl.direct) {  // guided rows = the conditional forward itself: the trunk writes dz, no blend
+    if ((rc = trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st))) return rc;
+    if (euler_z) {
+      const size_t n = (size_t)2 * pl.B * 16 * h->cfg.n_embed_input;
+      axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(euler_z, dz, euler_z, euler_h, n);
+      LAUNCH_CHECK();
+    }
+    return SCLDM_OK;
+  }
   if ((rc = trunk(h, z, 2 * pl.B, pl.B, pl.n_fwd, w.mod, w.ridx, w.h, w.v, prec, st))) return rc;
   CfgArgs ca;
   ca.v = w.v;
@@ -732,6 +740,8 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
   ca.e = 16 * h->cfg.n_embed_input;
   ca.P = pl.P;
   for (int p = 0; p < SCLDM_MAX_CLASSES; ++p) ca.scale[p] = p < pl.P ? pl.scale[p] : 0.f;
+  ca.z = euler_z;
+  ca.hstep = euler_h;
   const size_t n = (size_t)2 * pl.B * ca.e;
   cfg_blend_kernel<<<cdiv(n, 256), 256, 0, st>>>(ca);
   LAUNCH_CHECK();
@@ -819,8 +829,7 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
     const float hs = t1 - t0;
     if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t0);
     if (method == SCLDM_METHOD_EULER) {
-      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)i * 256 : nullptr))) return rc;
-      axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, z, hs, n);
+      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)i * 256 : nullptr, z, hs))) return rc;
     } else {
       if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)(2 * i) * 256 : nullptr))) return rc;
       axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.ztmp, hs, n);

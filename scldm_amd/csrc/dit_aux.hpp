@@ -615,6 +615,8 @@ struct CfgArgs {
   float* dz;       // (2B, e) may alias nothing else
   int B, e, P;     // e = elements per sample (16*din)
   float scale[kMaxClasses];
+  float* z;        // optional (Euler step fused into the blend, round 4): z[idx] += hstep * dz[idx] instead of storing dz
+  float hstep;
 };
 __global__ void cfg_blend_kernel(const CfgArgs a) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -625,7 +627,8 @@ __global__ void cfg_blend_kernel(const CfgArgs a) {
     const float u = r;
     for (int p = 0; p < a.P; ++p) r += a.scale[p] * (a.v[2 * half + (size_t)p * half + (idx - half)] - u);
   }
-  a.dz[idx] = r;
+  if (a.z) a.z[idx] = a.z[idx] + a.hstep * r;   // (the expression of axpy_kernel: same bits as blend + axpy)
+  else a.dz[idx] = r;
 }
 
 // out = z + h * k

@@ -5,9 +5,9 @@ tag=${1:-r3}
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 mkdir -p gpurun_out
 o=gpurun_out/$tag
-timeout 1200 python bench.py --steps 3 > ${o}_bench_default.json 2> ${o}_bench_default.err; tail -c 600 ${o}_bench_default.json; echo
-timeout 300 python bench.py --precision fp16 --steps 2 --no-extra --no-cpu-baseline > ${o}_bench_fp16.json 2>/dev/null
-timeout 300 python bench.py --precision bf16x3 --steps 2 --no-extra --no-cpu-baseline > ${o}_bench_bf16x3.json 2>/dev/null
+timeout 1500 python bench.py --steps 20 --warmup 5 > ${o}_bench_default.json 2> ${o}_bench_default.err; tail -c 600 ${o}_bench_default.json; echo
+timeout 300 python bench.py --precision fp16 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > ${o}_bench_fp16.json 2>/dev/null
+timeout 300 python bench.py --precision bf16x3 --steps 10 --warmup 2 --no-extra --no-cpu-baseline > ${o}_bench_bf16x3.json 2>/dev/null
 timeout 300 python bench.py --precision fp32 --steps 1 --no-extra --no-cpu-baseline > ${o}_bench_fp32.json 2>/dev/null
 BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 1 --no-extra --no-cpu-baseline > ${o}_bench_rccl_world1.json 2>/dev/null
 timeout 300 python bench.py --workload replogle_train_ditl_b1024 --steps 4 --warmup 2 > ${o}_bench_replogle_train_ditl_b1024.json 2>/dev/null
@@ -19,6 +19,9 @@ ROCPROF_ROWS=16 bash tools/rocprof_stats.sh ${tag}_stats_ditl1024 tests/perf/tra
 timeout 300 python tests/perf/train_scale.py > ${o}_train_scale.txt 2>&1
 timeout 300 python tests/perf/train_scale.py nogc > ${o}_train_scale_nogc.txt 2>&1
 timeout 300 python tests/perf/vae_train_bench.py 32 128 512 > ${o}_vae_train_bench.txt 2>&1
+ROCPROF_ROWS=12 bash tools/rocprof_stats.sh ${tag}_stats_parse1m bench.py --workload parse1m_b1024_euler100 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > ${o}_parse1m_b1024_kernel_stats.txt 2>&1
+ROCPROF_ROWS=12 bash tools/rocprof_stats.sh ${tag}_stats_train_fp16 bench.py --workload replogle_train_b1024 --precision fp16 --steps 20 --warmup 5 > ${o}_train_fp16_b1024_kernel_stats.txt 2>&1
+timeout 120 python tests/perf/power_probe.py 4096 30 > ${o}_power_probe.txt 2>&1
 K=dit_forward
 for prec in bf16 fp16; do
 bash tools/rocprof_pmc.sh ${tag}_pmc1_$prec "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" $K tests/perf/dit_profile.py $prec 6 > ${o}_pmc_sq_$prec.txt 2>&1
