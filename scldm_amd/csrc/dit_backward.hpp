@@ -32,7 +32,10 @@ using E = OP::E;
 using Frag = OP::Frag;
 using Quad = OP::Quad;
 constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
-constexpr int PF = 8;   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
+#ifndef SCLDM_BWD_PF
+#define SCLDM_BWD_PF 8
+#endif
+constexpr int PF = SCLDM_BWD_PF;   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
 constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;   // bf16 elements per image row (+16 B pad)
 constexpr int R0_OFF = 0;                                   // h2 image, later h1 image
 constexpr int R1_OFF = R0_OFF + TM * XA_LD * 2;             // dy2 image, later dy1 image
