@@ -94,6 +94,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_ADALN_VALU")) h->adaln_valu = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_ADALN_EXACT")) h->adaln_exact = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_ADALN_ROWTILE")) h->adaln_rowtile = atoi(e) != 0;
+  if (const char* e = getenv("SCLDM_COND_AHEAD")) h->cond_ahead = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
   h->dbg_layer = -1;
   if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
@@ -182,6 +183,9 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->join_ev[g]) (void)hipEventDestroy(h->join_ev[g]);
   }
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  if (h->cond_stream) (void)hipStreamDestroy(h->cond_stream);
+  for (hipEvent_t ev : {h->ev_cond[0], h->ev_cond[1], h->ev_free[0], h->ev_free[1], h->ev_ready})
+    if (ev) (void)hipEventDestroy(ev);
   delete h;
 }
 
@@ -391,6 +395,8 @@ struct Ws {
   float* mod;     // (n_rows, mod_w)
   float* silu;    // (n_rows, 256)
   void* asplit;   // (pad32(n_rows), 256) split-bf16 A fragments of the conditioning rows (adaln_x3_block_kernel)
+  float *mod2, *silu2;   // second conditioning buffer set (n_state > 0: the fused sampler prepares evaluation e + 1 beside evaluation e)
+  void* asplit2;
   float* temb;    // (256) timestep embedding shared by all rows of a scalar-t step
   int32_t* ridx;  // (n_fwd)
   float* dz;      // (n_state, e)
@@ -409,6 +415,13 @@ static Ws carve(const scldm_dit* h, void* base, int n_fwd, int n_rows, int n_sta
   w.mod = (float*)take((size_t)n_rows * h->mod_w * 4);
   w.silu = (float*)take((size_t)(n_rows + 1) * 256 * 4);  // +1 spare row (device scalar t)
   w.asplit = take((size_t)((n_rows + 31) / 32 * 32) * 256 * 4);
+  w.mod2 = w.silu2 = nullptr;
+  w.asplit2 = nullptr;
+  if (n_state > 0) {
+    w.mod2 = (float*)take((size_t)n_rows * h->mod_w * 4);
+    w.silu2 = (float*)take((size_t)(n_rows + 1) * 256 * 4);
+    w.asplit2 = take((size_t)((n_rows + 31) / 32 * 32) * 256 * 4);
+  }
   w.temb = (float*)take((size_t)kMaxTembEvals * 256 * 4);  // per-evaluation timestep embeddings of a whole solve
   w.ridx = (int32_t*)take((size_t)n_fwd * 4);
   w.dz = (float*)take((size_t)n_state * e * 4);
@@ -678,9 +691,10 @@ __global__ void fill_cfg_row_index_kernel(int32_t* __restrict__ ri, const int32_
 }
 __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 
-// euler_z / euler_h: the caller's Euler update z += h * dz is applied by the blend kernel itself (one launch less per evaluation)
-static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
-                    float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr, float* euler_z = nullptr, float euler_h = 0.f) {
+// The conditioning of one CFG evaluation (timestep rows, class embeddings, adaLN projection -> w.mod): depends on t and the labels
+// only, never on the state.
+static int cfg_cond(scldm_dit* h, const CfgPlan& pl, const float* t_dev, int t_stride, const Ws& w, int prec, hipStream_t st,
+                    const float* temb_pre = nullptr) {
   int rc;
   const int* gate = t_stride == 2 ? h->d_plan : nullptr;   // dense t, uniformity decided on device: both plans are enqueued, one runs
   const int rows_u = 1 + pl.P * pl.U, rows_d = 2 * pl.B + pl.P * pl.B;
@@ -722,7 +736,14 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
         return rc;
     }
   }
-  if ((rc = launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec, w.asplit))) return rc;
+  return launch_adaln(h, w.silu, w.mod, t_stride == 2 ? rows_d : pl.n_rows, st, t_stride == 2 ? h->d_plan + 1 : nullptr, prec, w.asplit);
+}
+
+// The state-dependent part: the trunk over every sample-forward of the evaluation, then the CFG blend.
+// euler_z / euler_h: the caller's Euler update z += h * dz is applied by the blend kernel itself (one launch less per evaluation)
+static int cfg_trunk(scldm_dit* h, const CfgPlan& pl, const float* z, const Ws& w, float* dz, int prec, hipStream_t st,
+                     float* euler_z = nullptr, float euler_h = 0.f) {
+  int rc;
   if (pl.direct) {  // guided rows = the conditional forward itself: the trunk writes dz, no blend
     if ((rc = trunk(h, z, 2 * pl.B, pl.B, 2 * pl.B, w.mod, w.ridx, w.h, dz, prec, st))) return rc;
     if (euler_z) {
@@ -746,6 +767,14 @@ static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float
   cfg_blend_kernel<<<cdiv(n, 256), 256, 0, st>>>(ca);
   LAUNCH_CHECK();
   return SCLDM_OK;
+}
+
+// One CFG evaluation: dz (2B, e) = forward_with_cfg(z, t); t_dev/t_stride describe the device-side t.
+static int cfg_eval(scldm_dit* h, const CfgPlan& pl, const float* z, const float* t_dev, int t_stride, const Ws& w,
+                    float* dz, int prec, hipStream_t st, const float* temb_pre = nullptr, float* euler_z = nullptr, float euler_h = 0.f) {
+  int rc = cfg_cond(h, pl, t_dev, t_stride, w, prec, st, temb_pre);
+  if (rc) return rc;
+  return cfg_trunk(h, pl, z, w, dz, prec, st, euler_z, euler_h);
 }
 
 static int make_plan(scldm_dit* h, CfgPlan& pl, const int64_t* const* ulabels, int n_urows, const int32_t* cell_row, int B,
@@ -824,17 +853,56 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
     t_embed_all_kernel<<<n_evals, 256, 0, st>>>(steps, method == SCLDM_METHOD_HEUN, h->w0t, h->b0, h->w2t, h->b2, w.temb);
     LAUNCH_CHECK();
   }
+  // Conditioning ahead (round 4): the adaLN vectors of evaluation e + 1 depend on t and the labels only, so they are prepared on a
+  // second stream into the OTHER of two buffer sets while the trunk of evaluation e runs (its waves fill the CUs the trunk's last,
+  // partial round leaves idle: 36 us of adaLN projection per evaluation at 1 024 joint-conditioned cells).  Needs every evaluation's
+  // timestep embedding up front (`pre`).  ev_cond[b]: set b is ready; ev_free[b]: the trunk that read set b is done.  All work of the
+  // second stream is joined into `st` before the last trunk, i.e. before this call's last kernel.
+  const bool ahead = pre && h->cond_ahead && w.mod2 != nullptr && n_evals > 1;
+  Ws wb[2] = {w, w};
+  wb[1].mod = w.mod2;
+  wb[1].silu = w.silu2;
+  wb[1].asplit = w.asplit2;
+  if (ahead) {
+    if (!h->cond_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->cond_stream, hipStreamNonBlocking));
+      for (hipEvent_t* ev : {&h->ev_cond[0], &h->ev_cond[1], &h->ev_free[0], &h->ev_free[1], &h->ev_ready})
+        HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(h->ev_ready, st));                       // timestep embeddings, row index, packed weights: all queued on st
+    HIP_TRY(hipStreamWaitEvent(h->cond_stream, h->ev_ready, 0));
+    if ((rc = cfg_cond(h, pl, tscal, 0, wb[0], precision, st, w.temb))) return rc;   // evaluation 0: in line
+  }
+  int e_idx = 0;   // running evaluation index
+  // one evaluation: (ahead) queue the conditioning of the next one on the second stream, wait for this one's, run the trunk
+  auto eval = [&](const float* zin, float tval, float* dz, float* euler_z, float euler_h) -> int {
+    const int e = e_idx++;
+    if (!ahead) {
+      if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, tval);
+      return cfg_eval(h, pl, zin, tscal, 0, w, dz, precision, st, pre ? w.temb + (size_t)e * 256 : nullptr, euler_z, euler_h);
+    }
+    const int b = e & 1;
+    if (e + 1 < n_evals) {
+      if (e >= 1) HIP_TRY(hipStreamWaitEvent(h->cond_stream, h->ev_free[b ^ 1], 0));   // the trunk of evaluation e - 1 read set b ^ 1
+      int rc2 = cfg_cond(h, pl, tscal, 0, wb[b ^ 1], precision, h->cond_stream, w.temb + (size_t)(e + 1) * 256);
+      if (rc2) return rc2;
+      HIP_TRY(hipEventRecord(h->ev_cond[b ^ 1], h->cond_stream));
+    }
+    if (e >= 1) HIP_TRY(hipStreamWaitEvent(st, h->ev_cond[b], 0));
+    int rc2 = cfg_trunk(h, pl, zin, wb[b], dz, precision, st, euler_z, euler_h);
+    if (rc2) return rc2;
+    HIP_TRY(hipEventRecord(h->ev_free[b], st));
+    return SCLDM_OK;
+  };
   for (int i = 0; i < n_steps; ++i) {
     const float t0 = linspace01(i, steps), t1 = linspace01(i + 1, steps);
     const float hs = t1 - t0;
-    if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t0);
     if (method == SCLDM_METHOD_EULER) {
-      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)i * 256 : nullptr, z, hs))) return rc;
+      if ((rc = eval(z, t0, w.dz, z, hs))) return rc;
     } else {
-      if ((rc = cfg_eval(h, pl, z, tscal, 0, w, w.dz, precision, st, pre ? w.temb + (size_t)(2 * i) * 256 : nullptr))) return rc;
+      if ((rc = eval(z, t0, w.dz, nullptr, 0.f))) return rc;
       axpy_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.ztmp, hs, n);
-      if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, t1);
-      if ((rc = cfg_eval(h, pl, w.ztmp, tscal, 0, w, w.k2, precision, st, pre ? w.temb + (size_t)(2 * i + 1) * 256 : nullptr))) return rc;
+      if ((rc = eval(w.ztmp, t1, w.k2, nullptr, 0.f))) return rc;
       heun_kernel<<<cdiv(n, 256), 256, 0, st>>>(z, w.dz, w.k2, 0.5f * hs, n);
     }
     LAUNCH_CHECK();

@@ -47,6 +47,11 @@ struct scldm_dit {
   int* d_dirty;    // [0] re-pack flag written by the compare kernel, [1] force flag
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
   hipEvent_t fork_ev, join_ev[3];
+  // fused sampler: the conditioning of evaluation e + 1 (timestep rows + adaLN projection: independent of the state z) runs on its own
+  // stream beside the trunk of evaluation e, into the other of two buffer sets (scldm_sample_ode)
+  hipStream_t cond_stream = nullptr;
+  hipEvent_t ev_cond[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_ready = nullptr;
+  bool cond_ahead = true;   // SCLDM_COND_AHEAD=0: conditioning in line with the trunk (A/B)
   int force_ft, force_x3_ft, force_x3_ntt;
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
   // fused training path (train_fused.hip)
