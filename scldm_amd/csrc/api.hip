@@ -853,7 +853,7 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
     t_embed_all_kernel<<<n_evals, 256, 0, st>>>(steps, method == SCLDM_METHOD_HEUN, h->w0t, h->b0, h->w2t, h->b2, w.temb);
     LAUNCH_CHECK();
   }
-  // Conditioning ahead (round 4): the adaLN vectors of evaluation e + 1 depend on t and the labels only, so they are prepared on a
+  // Conditioning ahead (round 4, opt-in SCLDM_COND_AHEAD=1): the adaLN vectors of evaluation e + 1 depend on t and the labels only, so they are prepared on a
   // second stream into the OTHER of two buffer sets while the trunk of evaluation e runs (its waves fill the CUs the trunk's last,
   // partial round leaves idle: 36 us of adaLN projection per evaluation at 1 024 joint-conditioned cells).  Needs every evaluation's
   // timestep embedding up front (`pre`).  ev_cond[b]: set b is ready; ev_free[b]: the trunk that read set b is done.  All work of the
@@ -865,7 +865,13 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
   wb[1].asplit = w.asplit2;
   if (ahead) {
     if (!h->cond_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&h->cond_stream, hipStreamNonBlocking));
+      // LOWEST priority: the projection's workgroups are dispatched only when no workgroup of the trunk is pending, i.e. into the slots the
+      // trunk's last, partial round leaves idle - at normal priority they take slots from the trunk's FIRST round and cost more than they
+      // hide (same-box A/B: parse1m 1 024 cells -1.5 %, profiles/r4h_ab_cond_ahead.txt).  At lowest priority the trunk still runs 18 us
+      // longer beside it while 36 us are hidden: +0.5 % at 1 024 joint-conditioned cells, -0.8 % at 512 cells, -0.2 % at 4 096 - not the default.
+      int prio_least = 0, prio_greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+      HIP_TRY(hipStreamCreateWithPriority(&h->cond_stream, hipStreamNonBlocking, prio_least));
       for (hipEvent_t* ev : {&h->ev_cond[0], &h->ev_cond[1], &h->ev_free[0], &h->ev_free[1], &h->ev_ready})
         HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
