@@ -56,8 +56,9 @@ __device__ __forceinline__ float pack_layer_val(const float* __restrict__ Wqkv, 
     const int v = u - 64, c = v / kUnitsPerChunk, vv = v % kUnitsPerChunk;
     if (vv < 16) {
       // FT=2: units 0-7 = tile 0, units 8-15 = tile 1, each unit = k-steps (2j, 2j+1) of that tile (gemm_pass_tile)
-      const int tile = (FT == 2) ? (vv >> 3) : ft;
-      const int ks = (FT == 2) ? (2 * (vv & 7) + ft) : vv;
+      // (SCLDM_W12_PAIR: unit vv = k-step vv of BOTH tiles, an ordinary two-tile gemm_pass)
+      const int tile = (FT == 2 && !SCLDM_W12_PAIR) ? (vv >> 3) : ft;
+      const int ks = (FT == 2 && !SCLDM_W12_PAIR) ? (2 * (vv & 7) + ft) : vv;
       const int hid = c * kHC + (w * FT + tile) * 16 + (r & 15);
       const float* src = (r < 16) ? W1 : W2;
       val = (hid < H) ? src[(size_t)hid * 256 + ks * 16 + k8] * ((r < 16) ? s1 : s2) : 0.f;

@@ -89,6 +89,18 @@ constexpr int kMaxLayersPerLaunchRec = 4;
 #ifndef SCLDM_L2WARM
 #define SCLDM_L2WARM 0
 #endif
+// Timing proxies (deliberately WRONG results; libx_* experiment builds only): bit 0 no weight-ring refills, bit 1 no activation-fragment
+// LDS reads, bit 2 no SwiGLU transcendental work.  What each costs in time AND clock under the power budget.
+#ifndef SCLDM_PROXY
+#define SCLDM_PROXY 0
+#endif
+// 1: the SwiGLU up-projection of a full chunk is ONE two-tile pass (each activation fragment read from LDS feeds two MFMAs instead of
+// one: -31 % LDS fragment reads per layer; the packer then orders a chunk's W12 units k-step by k-step).  Round 4 proxy: the fragment
+// reads cost 2 % in cycles but 7 % under the power budget (profiles/r4j_timing_proxies_random_vs_zero.txt).  With round 4's kernel the
+// two-tile pass spills 178 VGPRs (64 accumulators more are live next to the residual and the x-row registers), so it stays off.
+#ifndef SCLDM_W12_PAIR
+#define SCLDM_W12_PAIR 0
+#endif
 
 // Phase stamps (s_memtime) for the debug build (first layer only); compiles to nothing otherwise.
 #ifdef SCLDM_PHASE_TIMING
@@ -256,8 +268,13 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
   auto step = [&](int ks, int s, bool first) {
     Frag bnext[NTT];
     // B fragments of k-step ks+1 (after the last k-step this reads the row pad / next row: valid LDS, never used)
+#if SCLDM_PROXY & 2    // timing proxy 2 (WRONG RESULTS): the activation fragments are read once per pass - what the LDS fragment reads cost
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) bnext[tt] = bcur[tt];
+#else
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 1) * 16);
+#endif
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
@@ -266,8 +283,10 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
         else acc[ft][tt] = OP::mma(ws.ring[s][ft], bcur[tt], first ? (init ? init[ft] : zero) : acc[ft][tt]);
       }
     }
+#if !(SCLDM_PROXY & 1)   // timing proxy 1 (WRONG RESULTS): the weight ring is never refilled - what the L2 -> VGPR weight stream costs
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.fetch(ft);  // refill the slot just consumed: PF k-steps ahead
+#endif
     ws.advance(FT);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
@@ -320,7 +339,10 @@ __device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, P
     for (int half = 0; half < 2; ++half) {
       const int ks = 2 * u + half;
       Frag bnext[NTT];
-#if SCLDM_BPF >= 2
+#if SCLDM_PROXY & 2
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) bnext[tt] = bcur[tt];
+#elif SCLDM_BPF >= 2
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) bnext[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb + (ks + 2) * 16);
 #else
@@ -337,8 +359,10 @@ __device__ __forceinline__ void gemm_pass_tile(f32x16 (&acc)[NTT], WStream<OP, P
       for (int tt = 0; tt < NTT; ++tt) bcur[tt] = bnext[tt];
 #endif
       if (half == 1) {
+#if !(SCLDM_PROXY & 1)
         ws.ring[s][0] = ws.fetch(0);
         ws.ring[s][1] = ws.fetch(1);
+#endif
         ws.advance(2);
       }
       if (OP::kPin) {
@@ -1021,7 +1045,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
     Quad hq[TILES][NTT][2];
     // one 32-row tile per pass: a two-tile up-projection pass (activation fragments read once) was measured at 30 spilled
     // VGPRs and +1 % kernel time
-    constexpr bool kPair = false;
+    constexpr bool kPair = SCLDM_W12_PAIR != 0;
     auto swiglu_pack = [&](const f32x16 (&t_acc)[NTT], Quad (&out)[NTT][2]) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
@@ -1029,7 +1053,11 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
         for (int q = 0; q < 2; ++q) {
           float h[4];
 #pragma unroll
+#if SCLDM_PROXY & 4    // timing proxy 4 (WRONG RESULTS): SwiGLU replaced by a single multiply - what its exposed VALU costs
+          for (int i = 0; i < 4; ++i) h[i] = t_acc[tt][q * 4 + i] * t_acc[tt][8 + q * 4 + i];
+#else
           for (int i = 0; i < 4; ++i) h[i] = OP::swiglu(t_acc[tt][q * 4 + i], t_acc[tt][8 + q * 4 + i]);
+#endif
           out[tt][q] = OP::pack4(h[0], h[1], h[2], h[3]);
         }
     };

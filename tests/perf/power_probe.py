@@ -9,8 +9,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 evals = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 wl = dict(WORKLOADS["dentate_b4096_euler100"]); wl["B"] = B; wl["evals"] = evals
 dev = torch.device("cuda")
-for prec in ("bf16", "fp16"):
-    for fill in ("random", "zero", "random_x1e-3", "random"):
+precs = os.environ.get("PROBE_PRECS", "bf16,fp16").split(",")
+fills = os.environ.get("PROBE_FILLS", "random,zero,random_x1e-3,random").split(",")
+for prec in precs:
+    for fill in fills:
         m = make_model(wl, prec, dev)
         with torch.no_grad():
             for p in m.parameters():
