@@ -5,7 +5,7 @@
 #include <vector>
 
 #include "vae_handle.hpp"
-#include "vae_train.hpp"
+#include "vae_train_wide.hpp"
 
 using namespace scldm;
 using namespace scldm::vtrain;
@@ -41,9 +41,15 @@ Saved carve_saved(int B, void* base) {
   return s;
 }
 
+// SCLDM_VAE_CELL_WIDE=0: the first version of the cell-side kernels (one token per lane, four cells per wave) for A/B runs
+bool cell_wide() {
+  static const bool on = [] { const char* e = getenv("SCLDM_VAE_CELL_WIDE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 struct Ws {
   float *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
-  int tilesD, chunksD, tilesE, chunksE, quads;
+  int tilesD, chunksD, tilesE, chunksE, quads, cparts;
   size_t bytes;
 };
 Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
@@ -68,8 +74,9 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   w.bsum = k.take((size_t)B);
   w.p_gene = k.take((size_t)B * w.chunksD * DP_SIZE);
   w.p_dkv = k.take((size_t)B * w.chunksD * kT * 64);
-  w.p_dcell = k.take((size_t)w.quads * dc_size(L));
-  w.p_ecell = k.take((size_t)w.quads * ec_size(L));
+  w.cparts = cell_wide() ? B : w.quads;     // cell-side partials: one per cell (vae_train_wide.hpp) or one per four cells
+  w.p_dcell = k.take((size_t)w.cparts * dc_size(L));
+  w.p_ecell = k.take((size_t)w.cparts * ec_size(L));
   w.p_pool = k.take((size_t)B * w.chunksE * EP_SIZE);
   w.bytes = k.off;
   return w;
@@ -194,14 +201,26 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ea.w_lat = w->enc_latent_w; ea.xsave = k.xs_enc; ea.ysave = k.ysave;
   ea.dz_a = k.dz_dec; ea.dz_b = dz; ea.dao = k.dao; ea.dgq = k.dgq; ea.part = k.p_ecell;
   ea.B = B; ea.n_lat = nl; ea.n_layer = L; ea.eps = eps;
-  enc_cell_fwd_kernel<<<k.quads, 64, 0, st>>>(ea);
+  const bool wd = cell_wide();
+  if (wd) {
+    static const int attr = [] {
+      int rc = 0;
+      for (const void* f : {(const void*)wide::enc_cell_fwd_kernel, (const void*)wide::enc_cell_bwd_kernel, (const void*)wide::dec_cell_fwd_kernel,
+                            (const void*)wide::dec_cell_bwd_kernel})
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES) != hipSuccess) rc = 1;
+      return rc;
+    }();
+    if (attr) return fail(SCLDM_ERR_HIP, "hipFuncSetAttribute(cell-side LDS) failed");
+    wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(ea);
+  } else enc_cell_fwd_kernel<<<k.quads, 64, 0, st>>>(ea);
   LAUNCH_CHECK();
   DecCellTrainArgs da{};
   da.z = z; da.w_in = w->dec_latent_w; da.blocks = blocks_of(w->dec_blocks, L, wct(2 + L), H);
   da.cln1_w = w->dec_cross.ln1_w; da.cln1_b = w->dec_cross.ln1_b; da.wkv = w->dec_cross.attn_kv;
   da.xsave = k.xs_dec; da.kv = k.kv; da.dkv_part = k.p_dkv; da.chunks = k.chunksD; da.dz = k.dz_dec; da.part = k.p_dcell;
   da.B = B; da.n_lat = nl; da.n_layer = L; da.eps = eps;
-  if (nl <= 16) dec_cell_fwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
+  if (wd) wide::dec_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(da);
+  else if (nl <= 16) dec_cell_fwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
   else dec_cell_fwd_kernel<32><<<k.quads, 64, 0, st>>>(da);
   LAUNCH_CHECK();
   // ---- NB head, then the per-gene decoder chain
@@ -215,10 +234,12 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ga.g_emb = g_emb; ga.part = k.p_gene; ga.dkv_part = k.p_dkv; ga.G = G; ga.tiles = k.tilesD; ga.eps = eps;
   dec_gene_bwd_kernel<<<dim3(k.chunksD, B), 64, 0, st>>>(ga);
   LAUNCH_CHECK();
-  if (nl <= 16) dec_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
+  if (wd) wide::dec_cell_bwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(da);
+  else if (nl <= 16) dec_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
   else dec_cell_bwd_kernel<32><<<k.quads, 64, 0, st>>>(da);
   LAUNCH_CHECK();
-  if (nl <= 16) enc_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(ea);
+  if (wd) wide::enc_cell_bwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(ea);
+  else if (nl <= 16) enc_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(ea);
   else enc_cell_bwd_kernel<32><<<k.quads, 64, 0, st>>>(ea);
   LAUNCH_CHECK();
   EncPoolBwdArgs pa{};
@@ -255,7 +276,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     j.vec(G_(g->dec_cross.ln1_w), dc_off_cln1w(L), 32);
     j.vec(G_(g->dec_cross.ln1_b), dc_off_cln1b(L), 32);
     j.mat(G_(g->dec_latent_w), dc_off_win(L), 32, nl, 32, nl);
-    if ((rc = j.run(k.p_dcell, k.quads, dc_size(L), st))) return rc;
+    if ((rc = j.run(k.p_dcell, k.cparts, dc_size(L), st))) return rc;
   }
   {
     Jobs j;   // encoder cell side
@@ -269,7 +290,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     j.vec(G_(gc.ln2_b), ec_off_ln2b(L), 32);
     j.mat(G_(g->enc_latent_w), ec_off_wlat(L), nl, 32, 32, 32);
     j.vec(G_(g->inducing_points), ec_off_ind(L), 512);
-    if ((rc = j.run(k.p_ecell, k.quads, ec_size(L), st))) return rc;
+    if ((rc = j.run(k.p_ecell, k.cparts, ec_size(L), st))) return rc;
   }
   {
     Jobs j;   // encoder pooling

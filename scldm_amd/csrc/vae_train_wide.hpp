@@ -1,0 +1,712 @@
+// The 16-token side of a cell in the VAE training backward (row V1), second version: ONE WORKGROUP OF 256 THREADS PER CELL.
+//   trunk Blocks                               src/scldm/layers.py:222-226 (x += c_proj(attn(LN_1 x)); x += MLP(LN_2 x); 8 heads x 4)
+//   encoder ends (c_proj of the pooling, LN_2, MLP, pos, latent Linear + LN)   layers.py:326-330, nnets.py:139-144
+//   decoder ends (LN, latent Linear, K|V = c_attn(LN_1 h))                     nnets.py:196-208, layers.py:312-318
+// The first version (vae_train.hpp: one token per lane, four cells per wave, weights as SGPR operands) walks eight layers in one
+// wave: at batch 32 that is 8 waves on 1 024 SIMDs, 3.3-3.7 ms per kernel whatever the batch, with 3.4-4.4 k spilled registers.
+// Here a token is spread over 16 lanes (a DPP row: LayerNorm statistics are row rotations), a cell's 16 tokens over the four waves
+// of a workgroup, and every operand lives in LDS:
+//   * a layer's five weight matrices (50 KB, rows padded to 36 floats) are copied into LDS once per layer by all 256 threads,
+//     the next layer's copy in flight (registers) while the current layer's weight gradients are contracted;
+//   * y = W x: lane (token, j) owns outputs j, j + 16, ... and reads whole weight rows as 16-byte pieces (conflict-free: 36 j mod 64
+//     are distinct multiples of 4) against its token's activation row (broadcast);
+//   * dx = W^T dy: lane (token, j) owns input features 4 (j & 7) .. + 3 for the output rows whose bit 3 equals j >> 3 (the two
+//     halves are 8 rows = 32 banks apart), one row_ror:8 adds the halves;
+//   * dW = sum over the cell's 16 tokens of dy (x) x: 8 lanes per output row, 4 input features each; one partial per CELL, added in
+//     index order by reduce_jobs_kernel (deterministic);
+//   * attention (8 heads x 4, 16 keys): lane = (token, head, half of the keys); softmax / dq / dk / dv partner sums are quad_perm
+//     exchanges; the probabilities stay in registers from the recompute to the backward.
+// A token's lanes sit in one wave, so most steps need only wave-level ordering; workgroup barriers stand where tokens meet (K / V,
+// the key-side backward, the weight gradients, the weight copy): four per layer.
+#pragma once
+#include "vae_train.hpp"
+
+namespace scldm {
+namespace vtrain {
+namespace wide {
+
+constexpr int kThreads = 256;
+constexpr int kP = 36;     // floats per 32-wide LDS row
+constexpr int kQ = 100;    // floats per 96-wide LDS row (100 mod 64 = 36: the same bank walk as kP)
+constexpr int kPS = 17;    // pitch of the probability / d-score rows of the key-side exchange
+
+// ---- LDS map (float offsets) ------------------------------------------------------------------------------------------------------
+constexpr int W_QKV = 0, W_P = W_QKV + 96 * kP, W_1 = W_P + 32 * kP, W_2 = W_1 + 96 * kP, W_CT = W_2 + 96 * kP;
+constexpr int W_E1 = W_CT + 96 * kP;        // 64 rows: an "end" matrix (c_attn K|V of the decoder's cross attention)
+constexpr int W_E2 = W_E1 + 64 * kP;        // 32 rows: latent Linear (either side), padded to 32 x 32
+constexpr int A_X = W_E2 + 32 * kP;         // layer input
+constexpr int A_HN = A_X + 16 * kP;
+constexpr int A_AO = A_HN + 16 * kP;
+constexpr int A_H2 = A_AO + 16 * kP;
+constexpr int A_DM0 = A_H2 + 16 * kP;       // gradient w.r.t. the layer's output (ping)
+constexpr int A_DM1 = A_DM0 + 16 * kP;      // ... (pong)
+constexpr int A_DX1 = A_DM1 + 16 * kP;      // gradient w.r.t. x1 = x + c_proj(attn)
+constexpr int A_DAO = A_DX1 + 16 * kP;
+constexpr int A_DH2 = A_DAO + 16 * kP;
+constexpr int A_T2 = A_DH2 + 16 * kP;       // dh2 * xhat2 (LN_2 weight gradient terms)
+constexpr int A_DHN = A_T2 + 16 * kP;
+constexpr int A_T1 = A_DHN + 16 * kP;
+constexpr int A_QKV = A_T1 + 16 * kP;
+constexpr int A_DA = A_QKV + 16 * kQ;
+constexpr int A_DB = A_DA + 16 * kQ;
+constexpr int A_HID = A_DB + 16 * kQ;
+constexpr int A_DQKV = A_HID + 16 * kQ;
+constexpr int A_PP = A_DQKV + 16 * kQ;      // [head][query][key] probabilities
+constexpr int A_DS = A_PP + 8 * 16 * kPS;   // ... d scores (scaled)
+constexpr int LDS_FLOATS = A_DS + 8 * 16 * kPS;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;
+static_assert(LDS_BYTES <= 160 * 1024, "cell-side LDS image");
+
+// ---- synchronisation ----------------------------------------------------------------------------------------------------------------
+// tsync: orders LDS traffic among the 16 lanes of a token (one wave: LDS instructions of a wave complete in order, the fences stop
+// the compiler from moving them).  SCLDM_VAE_TSYNC_WG=1 builds with full barriers instead (A/B and debugging).
+#ifndef SCLDM_VAE_TSYNC_WG
+#define SCLDM_VAE_TSYNC_WG 0
+#endif
+__device__ __forceinline__ void tsync() {
+#if SCLDM_VAE_TSYNC_WG
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
+// ---- lane exchanges -----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ror8(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)); }
+__device__ __forceinline__ float row16_sum(float v) {
+  v += ror8(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float pair_get(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)); }   // lane ^ 1
+__device__ __forceinline__ float pair_sum(float v) { return v + pair_get(v); }
+__device__ __forceinline__ f32x4 pair_sum4(f32x4 v) { return f32x4{pair_sum(v[0]), pair_sum(v[1]), pair_sum(v[2]), pair_sum(v[3])}; }
+__device__ __forceinline__ f32x4 half_sum4(f32x4 v) { return f32x4{v[0] + ror8(v[0]), v[1] + ror8(v[1]), v[2] + ror8(v[2]), v[3] + ror8(v[3])}; }
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return fmaf(a[3], b[3], fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]))); }
+__device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 c) { return f32x4{fmaf(s, a[0], c[0]), fmaf(s, a[1], c[1]), fmaf(s, a[2], c[2]), fmaf(s, a[3], c[3])}; }
+__device__ __forceinline__ const f32x4* v4(const float* p) { return reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4* v4(float* p) { return reinterpret_cast<f32x4*>(p); }
+#define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
+
+// ---- weight copies into LDS ---------------------------------------------------------------------------------------------------------
+// rows of 32 floats (row-major, contiguous) -> [rows_total][kP]; rows >= rows_valid are zero.  Split into a load half (registers) and
+// a store half so that the loads of the next layer fly during the weight-gradient contraction.
+template <int ROWS>
+struct RowCopy {
+  static constexpr int N = (ROWS * 8 + kThreads - 1) / kThreads;
+  f32x4 r[N];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int rows_valid, int tid) {
+    const bool al = (reinterpret_cast<size_t>(src) & 15) == 0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int idx = tid + n * kThreads, row = idx >> 3;
+      f32x4 v = kZero4;
+      if (idx < ROWS * 8 && row < rows_valid) {
+        if (al) v = v4(src)[idx];
+        else { const float* s = src + (size_t)idx * 4; v = f32x4{s[0], s[1], s[2], s[3]}; }
+      }
+      r[n] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ dst, int tid) const {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const int idx = tid + n * kThreads;
+      if (idx < ROWS * 8) *v4(dst + (idx >> 3) * kP + 4 * (idx & 7)) = r[n];
+    }
+  }
+};
+struct LayerCopy {
+  RowCopy<96> qkv, w1, w2, wct;
+  RowCopy<32> wp;
+  __device__ __forceinline__ void load(const BlockW& w, int tid) {
+    qkv.load(w.wqkv, 96, tid); wp.load(w.wp, 32, tid); w1.load(w.mlp.w1, w.mlp.H, tid); w2.load(w.mlp.w2, w.mlp.H, tid); wct.load(w.mlp.wct, w.mlp.H, tid);
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+    qkv.store(S + W_QKV, tid); wp.store(S + W_P, tid); w1.store(S + W_1, tid); w2.store(S + W_2, tid); wct.store(S + W_CT, tid);
+  }
+};
+// a small matrix with its own source pitch -> [rows_total][kP], zero padded (the latent Linears: (32, n_lat) / (n_lat, 32))
+__device__ __forceinline__ void copy_small(float* __restrict__ dst, const float* __restrict__ src, int rows_valid, int cols_valid, int ld, int rows_total, int tid) {
+  for (int idx = tid; idx < rows_total * 32; idx += kThreads) {
+    const int r = idx >> 5, c = idx & 31;
+    dst[r * kP + c] = (r < rows_valid && c < cols_valid) ? src[(size_t)r * ld + c] : 0.f;
+  }
+}
+
+// ---- the three contractions -----------------------------------------------------------------------------------------------------------
+// y[o] = W[o][:] . x for o = j, j + 16, ...: f(m, o, value)
+template <int OUT, class F>
+__device__ __forceinline__ void lin32(const float* __restrict__ W, const float* __restrict__ xrow, int j, F f) {
+  f32x4 x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = v4(xrow)[q];
+#pragma unroll
+  for (int m = 0; m < OUT / 16; ++m) {
+    const int o = j + 16 * m;
+    const f32x4* wr = v4(W + o * kP);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      const f32x4 wa = wr[q], wb = wr[q + 1];
+      s0 = fmaf(wa[0], x[q][0], s0); s0 = fmaf(wa[1], x[q][1], s0); s0 = fmaf(wa[2], x[q][2], s0); s0 = fmaf(wa[3], x[q][3], s0);
+      s1 = fmaf(wb[0], x[q + 1][0], s1); s1 = fmaf(wb[1], x[q + 1][1], s1); s1 = fmaf(wb[2], x[q + 1][2], s1); s1 = fmaf(wb[3], x[q + 1][3], s1);
+    }
+    f(m, o, s0 + s1);
+  }
+}
+// acc[c] += sum over the rows o with ((o >> 3) & 1) == (j >> 3) of W[o][4 (j & 7) + c] dy[o]   (finish with half_sum4)
+template <int OUT>
+__device__ __forceinline__ void lin32_t_acc(const float* __restrict__ W, const float* __restrict__ dyrow, int j, f32x4& acc) {
+  const int ib = j & 7, hf = j >> 3;
+#pragma unroll
+  for (int g = 0; g < OUT / 16; ++g)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int o0 = 16 * g + 8 * hf + 4 * c;
+      const f32x4 d = *v4(dyrow + o0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fma4(d[e], *v4(W + (o0 + e) * kP + 4 * ib), acc);
+    }
+}
+// dW[o][i] = sum_t DY[t][o] X[t][i] for o = tid >> 3 (+ 32 m), i = 4 (tid & 7) .. + 3; stored at dst[o * ld_o + i * ld_i]
+template <int OUT>
+__device__ __forceinline__ void wgrad(const float* __restrict__ DY, int py, const float* __restrict__ X, float* __restrict__ dst, int ld_o, int ld_i, int tid) {
+  const int i4 = tid & 7, oo = tid >> 3;
+  f32x4 acc[OUT / 32];
+#pragma unroll
+  for (int m = 0; m < OUT / 32; ++m) acc[m] = kZero4;
+#pragma unroll 4
+  for (int t = 0; t < kT; ++t) {
+    const f32x4 xv = *v4(X + t * kP + 4 * i4);
+#pragma unroll
+    for (int m = 0; m < OUT / 32; ++m) acc[m] = fma4(DY[t * py + oo + 32 * m], xv, acc[m]);
+  }
+#pragma unroll
+  for (int m = 0; m < OUT / 32; ++m) {
+    const int o = oo + 32 * m;
+    if (ld_i == 1) *v4(dst + (size_t)o * ld_o + 4 * i4) = acc[m];
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[(size_t)o * ld_o + (size_t)(4 * i4 + e) * ld_i] = acc[m][e];
+    }
+  }
+}
+// column sums over the 16 tokens: threads 0..31 of a 64-thread group -> A, 32..63 -> B
+__device__ __forceinline__ float colsum16(const float* __restrict__ A, int f) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < kT; ++t) s += A[t * kP + f];
+  return s;
+}
+
+// ---- LayerNorm on a lane's two features (j, j + 16) ---------------------------------------------------------------------------------
+struct Ln { float h0, h1, r; };
+__device__ __forceinline__ Ln ln_own(float v0, float v1, float eps) {
+  const float mean = row16_sum(v0 + v1) * (1.0f / 32);
+  const float d0 = v0 - mean, d1 = v1 - mean;
+  const float var = row16_sum(fmaf(d0, d0, d1 * d1)) * (1.0f / 32);
+  Ln s;
+  s.r = 1.0f / sqrtf(var + eps);
+  s.h0 = d0 * s.r;
+  s.h1 = d1 * s.r;
+  return s;
+}
+// gradient through xhat = (x - mean) rstd given d xhat of the two features
+__device__ __forceinline__ void ln_back(const Ln& s, float g0, float g1, float& o0, float& o1) {
+  const float a = row16_sum(g0 + g1) * (1.0f / 32);
+  const float b = row16_sum(fmaf(g0, s.h0, g1 * s.h1)) * (1.0f / 32);
+  o0 = s.r * (g0 - a - s.h0 * b);
+  o1 = s.r * (g1 - a - s.h1 * b);
+}
+
+// ---- per-lane state of a Block between its recompute and its backward -----------------------------------------------------------------
+struct BlockState {
+  float x0, x1;        // layer input (features j, j + 16)
+  Ln n1, n2;
+  float m0, m1;        // x1 = x + c_proj(attn)
+  float p[8];          // probabilities of (token, head j >> 1) over keys 8 (j & 1) ..
+};
+
+// LN_1 -> qkv -> attention -> c_proj -> LN_2: leaves HN, QKV, AO, H2 in LDS
+__device__ __forceinline__ void block_front(const BlockW& w, float* __restrict__ S, int tok, int j, float eps, BlockState& b) {
+  b.n1 = ln_own(b.x0, b.x1, eps);
+  S[A_HN + tok * kP + j] = fmaf(b.n1.h0, w.ln1_w[j], w.ln1_b[j]);
+  S[A_HN + tok * kP + j + 16] = fmaf(b.n1.h1, w.ln1_w[j + 16], w.ln1_b[j + 16]);
+  tsync();
+  lin32<96>(S + W_QKV, S + A_HN + tok * kP, j, [&](int, int o, float v) { S[A_QKV + tok * kQ + o] = v; });
+  __syncthreads();
+  {
+    const int h = j >> 1, kh = j & 1;
+    const f32x4 q = *v4(S + A_QKV + tok * kQ + 4 * h);
+    float s[8], mx = -3.0e38f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      s[kk] = dot4(q, *v4(S + A_QKV + (8 * kh + kk) * kQ + 32 + 4 * h)) * kTScale;
+      mx = fmaxf(mx, s[kk]);
+    }
+    mx = fmaxf(mx, pair_get(mx));
+    float l = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) l += __expf(s[kk] - mx);
+    l = pair_sum(l);
+    const float lse = mx + __logf(l);
+    f32x4 ao = kZero4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      b.p[kk] = __expf(s[kk] - lse);
+      ao = fma4(b.p[kk], *v4(S + A_QKV + (8 * kh + kk) * kQ + 64 + 4 * h), ao);
+    }
+    ao = pair_sum4(ao);
+    if (kh == 0) *v4(S + A_AO + tok * kP + 4 * h) = ao;
+  }
+  tsync();
+  lin32<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = b.x0 + v; else b.m1 = b.x1 + v; });
+  b.n2 = ln_own(b.m0, b.m1, eps);
+  S[A_H2 + tok * kP + j] = fmaf(b.n2.h0, w.ln2_w[j], w.ln2_b[j]);
+  S[A_H2 + tok * kP + j + 16] = fmaf(b.n2.h1, w.ln2_w[j + 16], w.ln2_b[j + 16]);
+  tsync();
+}
+
+// SwiGLU forward from H2: returns MLP(h2) for the lane's two features (through A_DH2 as the exchange row)
+__device__ __forceinline__ void mlp_forward(float* __restrict__ S, int tok, int j, float& y0, float& y1) {
+  float a[6], g[6];
+  lin32<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
+  lin32<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
+#pragma unroll
+  for (int m = 0; m < 6; ++m) S[A_HID + tok * kQ + j + 16 * m] = a[m] * sigm(a[m]) * g[m];
+  tsync();
+  f32x4 acc = kZero4;
+  lin32_t_acc<96>(S + W_CT, S + A_HID + tok * kQ, j, acc);
+  acc = half_sum4(acc);
+  if (j < 8) *v4(S + A_DH2 + tok * kP + 4 * j) = acc;
+  tsync();
+  y0 = S[A_DH2 + tok * kP + j];
+  y1 = S[A_DH2 + tok * kP + j + 16];
+  tsync();
+}
+
+// SwiGLU + LN_2 backward.  In: H2, dm rows at DM (LDS), the lane's dm values d0 / d1, LN_2 state.  Out: DA, DB, HID, DH2, T2 (LDS) and
+// the gradient w.r.t. the LN_2 input INCLUDING the residual path (d0 / d1 updated in place).
+__device__ __forceinline__ void mlp_back(float* __restrict__ S, int DM, const float* __restrict__ ln2_w, const Ln& n2, int tok, int j, float& d0, float& d1) {
+  float a[6], g[6];
+  lin32<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
+  lin32<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
+  lin32<96>(S + W_CT, S + DM + tok * kP, j, [&](int m, int o, float dh) {
+    const float s = sigm(a[m]), sa = a[m] * s;
+    S[A_HID + tok * kQ + o] = sa * g[m];
+    S[A_DA + tok * kQ + o] = dh * g[m] * (s * (1.0f + a[m] * (1.0f - s)));
+    S[A_DB + tok * kQ + o] = dh * sa;
+  });
+  tsync();
+  f32x4 acc = kZero4;
+  lin32_t_acc<96>(S + W_1, S + A_DA + tok * kQ, j, acc);
+  lin32_t_acc<96>(S + W_2, S + A_DB + tok * kQ, j, acc);
+  acc = half_sum4(acc);
+  if (j < 8) *v4(S + A_DH2 + tok * kP + 4 * j) = acc;
+  tsync();
+  const float h0 = S[A_DH2 + tok * kP + j], h1 = S[A_DH2 + tok * kP + j + 16];
+  S[A_T2 + tok * kP + j] = h0 * n2.h0;
+  S[A_T2 + tok * kP + j + 16] = h1 * n2.h1;
+  float o0, o1;
+  ln_back(n2, h0 * ln2_w[j], h1 * ln2_w[j + 16], o0, o1);
+  d0 += o0;
+  d1 += o1;
+}
+
+// attention + LN_1 backward.  In: the lane's d x1 (d0 / d1; also written to DX1).  Out: DAO, DQKV, DHN, T1 in LDS; d0 / d1 = d x.
+__device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S, int tok, int j, const BlockState& b, float& d0, float& d1) {
+  S[A_DX1 + tok * kP + j] = d0;
+  S[A_DX1 + tok * kP + j + 16] = d1;
+  tsync();
+  {
+    f32x4 acc = kZero4;
+    lin32_t_acc<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
+    acc = half_sum4(acc);
+    if (j < 8) *v4(S + A_DAO + tok * kP + 4 * j) = acc;
+  }
+  tsync();
+  const int h = j >> 1, kh = j & 1;
+  {
+    const f32x4 dao = *v4(S + A_DAO + tok * kP + 4 * h);
+    float dp[8], dg = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      dp[kk] = dot4(dao, *v4(S + A_QKV + (8 * kh + kk) * kQ + 64 + 4 * h));
+      dg = fmaf(b.p[kk], dp[kk], dg);
+    }
+    dg = pair_sum(dg);
+    f32x4 dq = kZero4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float ds = b.p[kk] * (dp[kk] - dg) * kTScale;
+      dq = fma4(ds, *v4(S + A_QKV + (8 * kh + kk) * kQ + 32 + 4 * h), dq);
+      S[A_DS + (h * 16 + tok) * kPS + 8 * kh + kk] = ds;
+      S[A_PP + (h * 16 + tok) * kPS + 8 * kh + kk] = b.p[kk];
+    }
+    dq = pair_sum4(dq);
+    if (kh == 0) *v4(S + A_DQKV + tok * kQ + 4 * h) = dq;
+  }
+  __syncthreads();
+  {   // key side: this lane's token is the KEY; queries 8 kh .. 8 kh + 7
+    f32x4 dk = kZero4, dv = kZero4;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int t = 8 * kh + tt;
+      dk = fma4(S[A_DS + (h * 16 + t) * kPS + tok], *v4(S + A_QKV + t * kQ + 4 * h), dk);
+      dv = fma4(S[A_PP + (h * 16 + t) * kPS + tok], *v4(S + A_DAO + t * kP + 4 * h), dv);
+    }
+    dk = pair_sum4(dk);
+    dv = pair_sum4(dv);
+    if (kh == 0) {
+      *v4(S + A_DQKV + tok * kQ + 32 + 4 * h) = dk;
+      *v4(S + A_DQKV + tok * kQ + 64 + 4 * h) = dv;
+    }
+  }
+  tsync();
+  {
+    f32x4 acc = kZero4;
+    lin32_t_acc<96>(S + W_QKV, S + A_DQKV + tok * kQ, j, acc);
+    acc = half_sum4(acc);
+    if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
+  }
+  tsync();
+  const float h0 = S[A_DHN + tok * kP + j], h1 = S[A_DHN + tok * kP + j + 16];
+  S[A_T1 + tok * kP + j] = h0 * b.n1.h0;
+  S[A_T1 + tok * kP + j + 16] = h1 * b.n1.h1;
+  float o0, o1;
+  ln_back(b.n1, h0 * w.ln1_w[j], h1 * w.ln1_w[j + 16], o0, o1);
+  d0 += o0;
+  d1 += o1;
+}
+
+// the MLP's three weight gradients + LN_2's vectors of one partial (threads 0..63 write the vectors)
+__device__ __forceinline__ void mlp_wgrads(float* __restrict__ S, int DM, float* __restrict__ P1, float* __restrict__ P2, float* __restrict__ PC,
+                                           float* __restrict__ PLW, float* __restrict__ PLB, int tid) {
+  wgrad<96>(S + A_DA, kQ, S + A_H2, P1, 32, 1, tid);
+  wgrad<96>(S + A_DB, kQ, S + A_H2, P2, 32, 1, tid);
+  wgrad<96>(S + A_HID, kQ, S + DM, PC, 1, kHP, tid);      // dWc[i][u] = sum_t dm[t][i] hid[t][u]
+  if (tid < 32) PLW[tid] = colsum16(S + A_T2, tid);
+  else if (tid < 64) PLB[tid - 32] = colsum16(S + A_DH2, tid - 32);
+}
+
+// backward of one Block.  In: x of the layer in b.x0 / b.x1, dm rows at DM (LDS) and d0 / d1; the layer's weights in LDS.
+// Out: d0 / d1 = gradient w.r.t. the layer's input, also written as rows to DN; the layer's partial to P.  `next`: the weights to put
+// into LDS for whatever runs after this layer (loaded during the weight-gradient contraction), or nullptr.
+__device__ __forceinline__ void block_back(const BlockW& w, const BlockW* next, float* __restrict__ S, int DM, int DN, float* __restrict__ P,
+                                           int tid, float eps, BlockState& b, float& d0, float& d1) {
+  const int tok = tid >> 4, j = tid & 15;
+  block_front(w, S, tok, j, eps, b);
+  mlp_back(S, DM, w.ln2_w, b.n2, tok, j, d0, d1);
+  attn_back(w, S, tok, j, b, d0, d1);
+  S[DN + tok * kP + j] = d0;
+  S[DN + tok * kP + j + 16] = d1;
+  __syncthreads();                       // every token's rows are complete; nobody reads the weights any more
+  LayerCopy lc;
+  if (next) lc.load(*next, tid);
+  wgrad<96>(S + A_DQKV, kQ, S + A_HN, P + TP_WQKV, 32, 1, tid);
+  wgrad<32>(S + A_DX1, kP, S + A_AO, P + TP_WP, 32, 1, tid);
+  mlp_wgrads(S, DM, P + TP_W1, P + TP_W2, P + TP_WC, P + TP_LN2W, P + TP_LN2B, tid);
+  if (tid >= 64 && tid < 96) P[TP_LN1W + tid - 64] = colsum16(S + A_T1, tid - 64);
+  else if (tid >= 96 && tid < 128) P[TP_LN1B + tid - 96] = colsum16(S + A_DHN, tid - 96);
+  if (next) lc.store(S, tid);
+  __syncthreads();
+}
+
+// forward of one Block (x in b.x0 / b.x1 -> out in the same)
+__device__ __forceinline__ void block_forward(const BlockW& w, float* __restrict__ S, int tok, int j, float eps, BlockState& b) {
+  block_front(w, S, tok, j, eps, b);
+  float y0, y1;
+  mlp_forward(S, tok, j, y0, y1);
+  b.x0 = b.m0 + y0;
+  b.x1 = b.m1 + y1;
+}
+
+// =================================================================================================================================
+// Decoder cell side
+// =================================================================================================================================
+// z -> LN (no affine, over n_lat) for the lane's features j, j + 16 (zero beyond n_lat)
+__device__ __forceinline__ void latent_ln(float z0, float z1, int n_lat, int j, float eps, float& zn0, float& zn1, float& rz) {
+  const bool in0 = j < n_lat, in1 = j + 16 < n_lat;
+  const float inv = 1.0f / n_lat;
+  const float mean = row16_sum((in0 ? z0 : 0.f) + (in1 ? z1 : 0.f)) * inv;
+  const float e0 = in0 ? z0 - mean : 0.f, e1 = in1 ? z1 - mean : 0.f;
+  rz = 1.0f / sqrtf(row16_sum(fmaf(e0, e0, e1 * e1)) * inv + eps);
+  zn0 = e0 * rz;
+  zn1 = e1 * rz;
+}
+
+__global__ __launch_bounds__(kThreads) void dec_cell_fwd_kernel(const DecCellTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, cell = blockIdx.x, L = a.n_layer;
+  LayerCopy lc;
+  if (L > 0) lc.load(a.blocks.b[0], tid);
+  copy_small(S + W_E2, a.w_in, 32, a.n_lat, a.n_lat, 32, tid);
+  RowCopy<64> ckv;
+  ckv.load(a.wkv, 64, tid);
+  ckv.store(S + W_E1, tid);
+  if (L > 0) lc.store(S, tid);
+  const float* zr = a.z + ((size_t)cell * kT + tok) * a.n_lat;
+  float zn0, zn1, rz;
+  latent_ln(j < a.n_lat ? zr[j] : 0.f, j + 16 < a.n_lat ? zr[j + 16] : 0.f, a.n_lat, j, a.eps, zn0, zn1, rz);
+  S[A_X + tok * kP + j] = zn0;
+  S[A_X + tok * kP + j + 16] = zn1;
+  __syncthreads();
+  BlockState b;
+  lin32<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.x0 = v; else b.x1 = v; });
+  float* XS = a.xsave + ((size_t)cell * (L + 1) * kT + tok) * 32;
+  for (int l = 0; l < L; ++l) {
+    XS[(size_t)l * kT * 32 + j] = b.x0;
+    XS[(size_t)l * kT * 32 + j + 16] = b.x1;
+    if (l + 1 < L) lc.load(a.blocks.b[l + 1], tid);
+    block_forward(a.blocks.b[l], S, tok, j, a.eps, b);
+    __syncthreads();
+    if (l + 1 < L) { lc.store(S, tid); __syncthreads(); }
+  }
+  XS[(size_t)L * kT * 32 + j] = b.x0;
+  XS[(size_t)L * kT * 32 + j + 16] = b.x1;
+  const Ln n = ln_own(b.x0, b.x1, a.eps);
+  S[A_HN + tok * kP + j] = fmaf(n.h0, a.cln1_w[j], a.cln1_b[j]);
+  S[A_HN + tok * kP + j + 16] = fmaf(n.h1, a.cln1_w[j + 16], a.cln1_b[j + 16]);
+  tsync();
+  float* kv = a.kv + ((size_t)cell * kT + tok) * 64;
+  lin32<64>(S + W_E1, S + A_HN + tok * kP, j, [&](int, int o, float v) { kv[o] = v; });
+}
+
+__global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, cell = blockIdx.x, L = a.n_layer;
+  float* P = a.part + (size_t)cell * dc_size(L);
+  const float* XS = a.xsave + ((size_t)cell * (L + 1) * kT + tok) * 32;
+  LayerCopy lc;
+  if (L > 0) lc.load(a.blocks.b[L - 1], tid);
+  copy_small(S + W_E2, a.w_in, 32, a.n_lat, a.n_lat, 32, tid);
+  {
+    RowCopy<64> ckv;
+    ckv.load(a.wkv, 64, tid);
+    ckv.store(S + W_E1, tid);
+  }
+  // d kv of this token (outputs j, j + 16, j + 32, j + 48): the per-chunk partials in index order
+  {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.chunks; ++c) {
+      const float* src = a.dkv_part + ((size_t)(cell * a.chunks + c) * kT + tok) * 64;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) s[m] += src[j + 16 * m];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) S[A_DQKV + tok * kQ + j + 16 * m] = s[m];
+  }
+  BlockState b;
+  b.x0 = XS[(size_t)L * kT * 32 + j];
+  b.x1 = XS[(size_t)L * kT * 32 + j + 16];
+  const Ln n = ln_own(b.x0, b.x1, a.eps);
+  S[A_HN + tok * kP + j] = fmaf(n.h0, a.cln1_w[j], a.cln1_b[j]);
+  S[A_HN + tok * kP + j + 16] = fmaf(n.h1, a.cln1_w[j + 16], a.cln1_b[j + 16]);
+  __syncthreads();
+  {
+    f32x4 acc = kZero4;
+    lin32_t_acc<64>(S + W_E1, S + A_DQKV + tok * kQ, j, acc);
+    acc = half_sum4(acc);
+    if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
+  }
+  tsync();
+  float d0, d1;
+  {
+    const float h0 = S[A_DHN + tok * kP + j], h1 = S[A_DHN + tok * kP + j + 16];
+    S[A_T1 + tok * kP + j] = h0 * n.h0;
+    S[A_T1 + tok * kP + j + 16] = h1 * n.h1;
+    ln_back(n, h0 * a.cln1_w[j], h1 * a.cln1_w[j + 16], d0, d1);
+  }
+  int DM = A_DM0, DN = A_DM1;
+  S[DM + tok * kP + j] = d0;
+  S[DM + tok * kP + j + 16] = d1;
+  __syncthreads();
+  wgrad<64>(S + A_DQKV, kQ, S + A_HN, P + dc_off_wkv(L), 32, 1, tid);
+  if (tid < 32) P[dc_off_cln1w(L) + tid] = colsum16(S + A_T1, tid);
+  else if (tid < 64) P[dc_off_cln1b(L) + tid - 32] = colsum16(S + A_DHN, tid - 32);
+  if (L > 0) lc.store(S, tid);
+  __syncthreads();
+  for (int l = L - 1; l >= 0; --l) {
+    b.x0 = XS[(size_t)l * kT * 32 + j];
+    b.x1 = XS[(size_t)l * kT * 32 + j + 16];
+    block_back(a.blocks.b[l], l > 0 ? &a.blocks.b[l - 1] : nullptr, S, DM, DN, P + (size_t)l * TP_SIZE, tid, a.eps, b, d0, d1);
+    const int t = DM; DM = DN; DN = t;
+  }
+  // x0 = W_in LN(z): d W_in (stored [32][32], columns >= n_lat zero), d z
+  const float* zr = a.z + ((size_t)cell * kT + tok) * a.n_lat;
+  float zn0, zn1, rz;
+  latent_ln(j < a.n_lat ? zr[j] : 0.f, j + 16 < a.n_lat ? zr[j + 16] : 0.f, a.n_lat, j, a.eps, zn0, zn1, rz);
+  S[A_X + tok * kP + j] = zn0;
+  S[A_X + tok * kP + j + 16] = zn1;
+  {
+    f32x4 acc = kZero4;
+    lin32_t_acc<32>(S + W_E2, S + DM + tok * kP, j, acc);
+    acc = half_sum4(acc);
+    if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
+  }
+  __syncthreads();
+  wgrad<32>(S + DM, kP, S + A_X, P + dc_off_win(L), 32, 1, tid);
+  {
+    const bool in0 = j < a.n_lat, in1 = j + 16 < a.n_lat;
+    const float g0 = in0 ? S[A_DHN + tok * kP + j] : 0.f, g1 = in1 ? S[A_DHN + tok * kP + j + 16] : 0.f;
+    const float inv = 1.0f / a.n_lat;
+    const float sa = row16_sum(g0 + g1) * inv, sb = row16_sum(fmaf(g0, zn0, g1 * zn1)) * inv;
+    float* dz = a.dz + ((size_t)cell * kT + tok) * a.n_lat;
+    if (in0) dz[j] = rz * (g0 - sa - zn0 * sb);
+    if (in1) dz[j + 16] = rz * (g1 - sa - zn1 * sb);
+  }
+}
+
+// =================================================================================================================================
+// Encoder cell side:  y = inducing + Wp ao; y2 = y + MLP(LN_2 y) + pos; n_layer Blocks -> hL; zl = W_lat hL; z = LN(zl)
+// The pooling's c_proj / MLP sit in the W_P / W_1 / W_2 / W_CT slots like a layer without attention.
+// =================================================================================================================================
+struct CrossCopy {
+  RowCopy<96> w1, w2, wct;
+  RowCopy<32> wp;
+  __device__ __forceinline__ void load(const EncCellTrainArgs& a, int tid) {
+    wp.load(a.wp, 32, tid); w1.load(a.cmlp.w1, a.cmlp.H, tid); w2.load(a.cmlp.w2, a.cmlp.H, tid); wct.load(a.cmlp.wct, a.cmlp.H, tid);
+  }
+  __device__ __forceinline__ void store(float* __restrict__ S, int tid) const {
+    wp.store(S + W_P, tid); w1.store(S + W_1, tid); w2.store(S + W_2, tid); wct.store(S + W_CT, tid);
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void enc_cell_fwd_kernel(const EncCellTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, cell = blockIdx.x, L = a.n_layer;
+  {
+    CrossCopy cc;
+    cc.load(a, tid);
+    cc.store(S, tid);
+  }
+  const float* ao = a.pooled + ((size_t)cell * kT + tok) * 32;
+  S[A_AO + tok * kP + j] = ao[j];
+  S[A_AO + tok * kP + j + 16] = ao[j + 16];
+  __syncthreads();
+  LayerCopy lc;
+  if (L > 0) lc.load(a.blocks.b[0], tid);
+  BlockState b;
+  lin32<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = a.ind[tok * 32 + j] + v; else b.m1 = a.ind[tok * 32 + j + 16] + v; });
+  float* ys = a.ysave + ((size_t)cell * kT + tok) * 32;
+  ys[j] = b.m0;
+  ys[j + 16] = b.m1;
+  b.n2 = ln_own(b.m0, b.m1, a.eps);
+  S[A_H2 + tok * kP + j] = fmaf(b.n2.h0, a.cln2_w[j], a.cln2_b[j]);
+  S[A_H2 + tok * kP + j + 16] = fmaf(b.n2.h1, a.cln2_w[j + 16], a.cln2_b[j + 16]);
+  tsync();
+  float y0, y1;
+  mlp_forward(S, tok, j, y0, y1);
+  b.x0 = b.m0 + y0 + (a.pos ? a.pos[tok * 32 + j] : 0.f);
+  b.x1 = b.m1 + y1 + (a.pos ? a.pos[tok * 32 + j + 16] : 0.f);
+  __syncthreads();
+  if (L > 0) { lc.store(S, tid); __syncthreads(); }
+  float* XS = a.xsave + ((size_t)cell * (L + 1) * kT + tok) * 32;
+  for (int l = 0; l < L; ++l) {
+    XS[(size_t)l * kT * 32 + j] = b.x0;
+    XS[(size_t)l * kT * 32 + j + 16] = b.x1;
+    if (l + 1 < L) lc.load(a.blocks.b[l + 1], tid);
+    block_forward(a.blocks.b[l], S, tok, j, a.eps, b);
+    __syncthreads();
+    if (l + 1 < L) { lc.store(S, tid); __syncthreads(); }
+  }
+  XS[(size_t)L * kT * 32 + j] = b.x0;
+  XS[(size_t)L * kT * 32 + j + 16] = b.x1;
+}
+
+__global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, cell = blockIdx.x, L = a.n_layer;
+  float* P = a.part + (size_t)cell * ec_size(L);
+  const float* XS = a.xsave + ((size_t)cell * (L + 1) * kT + tok) * 32;
+  LayerCopy lc;
+  if (L > 0) lc.load(a.blocks.b[L - 1], tid);
+  copy_small(S + W_E2, a.w_lat, a.n_lat, 32, 32, 32, tid);
+  BlockState b;
+  b.x0 = XS[(size_t)L * kT * 32 + j];
+  b.x1 = XS[(size_t)L * kT * 32 + j + 16];
+  S[A_X + tok * kP + j] = b.x0;
+  S[A_X + tok * kP + j + 16] = b.x1;
+  __syncthreads();
+  // zl = W_lat hL; z = LN(zl) over n_lat entries; dz = dz_a + dz_b
+  float d0, d1;
+  {
+    float zl0 = 0.f, zl1 = 0.f, zn0, zn1, rz;
+    lin32<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) zl0 = v; else zl1 = v; });
+    latent_ln(zl0, zl1, a.n_lat, j, a.eps, zn0, zn1, rz);
+    const bool in0 = j < a.n_lat, in1 = j + 16 < a.n_lat;
+    const size_t zi = ((size_t)cell * kT + tok) * a.n_lat;
+    const float g0 = in0 ? (a.dz_a ? a.dz_a[zi + j] : 0.f) + (a.dz_b ? a.dz_b[zi + j] : 0.f) : 0.f;
+    const float g1 = in1 ? (a.dz_a ? a.dz_a[zi + j + 16] : 0.f) + (a.dz_b ? a.dz_b[zi + j + 16] : 0.f) : 0.f;
+    const float inv = 1.0f / a.n_lat;
+    const float sa = row16_sum(g0 + g1) * inv, sb = row16_sum(fmaf(g0, zn0, g1 * zn1)) * inv;
+    S[A_DX1 + tok * kP + j] = in0 ? rz * (g0 - sa - zn0 * sb) : 0.f;          // d zl rows
+    S[A_DX1 + tok * kP + j + 16] = in1 ? rz * (g1 - sa - zn1 * sb) : 0.f;
+    tsync();
+    f32x4 acc = kZero4;
+    lin32_t_acc<32>(S + W_E2, S + A_DX1 + tok * kP, j, acc);
+    acc = half_sum4(acc);
+    if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
+    tsync();
+    d0 = S[A_DHN + tok * kP + j];
+    d1 = S[A_DHN + tok * kP + j + 16];
+  }
+  int DM = A_DM0, DN = A_DM1;
+  S[DM + tok * kP + j] = d0;
+  S[DM + tok * kP + j + 16] = d1;
+  __syncthreads();
+  wgrad<32>(S + A_DX1, kP, S + A_X, P + ec_off_wlat(L), 32, 1, tid);
+  if (L > 0) lc.store(S, tid);
+  __syncthreads();
+  for (int l = L - 1; l >= 0; --l) {
+    b.x0 = XS[(size_t)l * kT * 32 + j];
+    b.x1 = XS[(size_t)l * kT * 32 + j + 16];
+    block_back(a.blocks.b[l], l > 0 ? &a.blocks.b[l - 1] : nullptr, S, DM, DN, P + (size_t)l * TP_SIZE, tid, a.eps, b, d0, d1);
+    const int t = DM; DM = DN; DN = t;
+  }
+  {   // the pooling's c_proj / MLP take the layer slots (same row counts; the qkv slot stays unused)
+    CrossCopy cc;
+    cc.load(a, tid);
+    cc.store(S, tid);
+  }
+  // x0 = y + MLP(LN_2 y) + pos  (pos_embed is frozen: nnets.py:103-106)
+  const float* ys = a.ysave + ((size_t)cell * kT + tok) * 32;
+  const float* ao = a.pooled + ((size_t)cell * kT + tok) * 32;
+  b.m0 = ys[j];
+  b.m1 = ys[j + 16];
+  S[A_AO + tok * kP + j] = ao[j];
+  S[A_AO + tok * kP + j + 16] = ao[j + 16];
+  b.n2 = ln_own(b.m0, b.m1, a.eps);
+  S[A_H2 + tok * kP + j] = fmaf(b.n2.h0, a.cln2_w[j], a.cln2_b[j]);
+  S[A_H2 + tok * kP + j + 16] = fmaf(b.n2.h1, a.cln2_w[j + 16], a.cln2_b[j + 16]);
+  __syncthreads();
+  mlp_back(S, DM, a.cln2_w, b.n2, tok, j, d0, d1);         // d0 / d1 = d y
+  S[A_DX1 + tok * kP + j] = d0;
+  S[A_DX1 + tok * kP + j + 16] = d1;
+  P[ec_off_ind(L) + tok * 32 + j] = d0;                     // d inducing of this cell
+  P[ec_off_ind(L) + tok * 32 + j + 16] = d1;
+  tsync();
+  {
+    f32x4 acc = kZero4;
+    lin32_t_acc<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
+    acc = half_sum4(acc);                                    // d ao[4 (j & 7) .. + 3]
+    if (j < 8) {
+      *v4(a.dao + ((size_t)cell * kT + tok) * 32 + 4 * j) = acc;
+      // sum_d dao[h, d] ao[h, d] per pooling head (4 heads x 8): lanes 2 h, 2 h + 1
+      const float s = pair_sum(dot4(acc, *v4(S + A_AO + tok * kP + 4 * j)));
+      if ((j & 1) == 0) a.dgq[((size_t)cell * 4 + (j >> 1)) * kT + tok] = s;
+    }
+  }
+  __syncthreads();
+  wgrad<32>(S + A_DX1, kP, S + A_AO, P + ec_off_wp(L), 32, 1, tid);
+  mlp_wgrads(S, DM, P + ec_off_w1(L), P + ec_off_w2(L), P + ec_off_wc(L), P + ec_off_ln2w(L), P + ec_off_ln2b(L), tid);
+}
+
+}  // namespace wide
+}  // namespace vtrain
+}  // namespace scldm
