@@ -24,9 +24,9 @@ struct Carver {
 
 // tiles of 64 tokens per workgroup / workgroups per cell of the two gene-axis kernels: about 2048 workgroups in flight, so that
 // one partial per workgroup stays small next to the work it summarises
-void split_tiles(int n_tok, int B, int* tiles, int* chunks) {
+void split_tiles(int n_tok, int B, int* tiles, int* chunks, int wgs = 2048) {
   const int per_cell = cdiv(n_tok, 64);
-  const int want = std::max(1, std::min(per_cell, 2048 / std::max(B, 1)));
+  const int want = std::max(1, std::min(per_cell, wgs / std::max(B, 1)));
   *tiles = cdiv(per_cell, want);
   *chunks = cdiv(per_cell, *tiles);
 }
@@ -47,6 +47,12 @@ bool cell_wide() {
   return on;
 }
 
+// SCLDM_VAE_GENE_WIDE=0: the first version of the gene-axis backward kernels (one token per lane)
+bool gene_wide() {
+  static const bool on = [] { const char* e = getenv("SCLDM_VAE_GENE_WIDE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 struct Ws {
   float *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
   int tilesD, chunksD, tilesE, chunksE, quads, cparts;
@@ -58,7 +64,7 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   Carver k{reinterpret_cast<char*>(base)};
   Ws w;
   split_tiles(G, B, &w.tilesD, &w.chunksD);
-  split_tiles(S, B, &w.tilesE, &w.chunksE);
+  split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? 1024 : 2048);   // (the second version's workgroups are four waves)
   w.quads = cdiv(B, 4);
   w.wct = k.take((size_t)(2 + 2 * L) * kHP * 32);
   w.Q = k.take(512);
@@ -202,15 +208,18 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ea.dz_a = k.dz_dec; ea.dz_b = dz; ea.dao = k.dao; ea.dgq = k.dgq; ea.part = k.p_ecell;
   ea.B = B; ea.n_lat = nl; ea.n_layer = L; ea.eps = eps;
   const bool wd = cell_wide();
-  if (wd) {
+  {
     static const int attr = [] {
       int rc = 0;
       for (const void* f : {(const void*)wide::enc_cell_fwd_kernel, (const void*)wide::enc_cell_bwd_kernel, (const void*)wide::dec_cell_fwd_kernel,
                             (const void*)wide::dec_cell_bwd_kernel})
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES) != hipSuccess) rc = 1;
+      if (hipFuncSetAttribute((const void*)wide::enc_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::PB_BYTES) != hipSuccess) rc = 1;
       return rc;
     }();
-    if (attr) return fail(SCLDM_ERR_HIP, "hipFuncSetAttribute(cell-side LDS) failed");
+    if (attr) return fail(SCLDM_ERR_HIP, "hipFuncSetAttribute (LDS size of the VAE training kernels) failed");
+  }
+  if (wd) {
     wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(ea);
   } else enc_cell_fwd_kernel<<<k.quads, 64, 0, st>>>(ea);
   LAUNCH_CHECK();
@@ -246,7 +255,8 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   pa.counts = counts_subset; pa.genes = genes_subset; pa.emb = w->gene_embedding;
   pa.ln1_w = w->enc_cross.ln1_w; pa.ln1_b = w->enc_cross.ln1_b; pa.wkv = w->enc_cross.attn_kv; pa.Q = k.Q; pa.lse2 = sv.lse2;
   pa.dao = k.dao; pa.dgq = k.dgq; pa.g_emb = g_emb; pa.part = k.p_pool; pa.S = S; pa.tiles = k.tilesE; pa.eps = eps;
-  enc_pool_bwd_kernel<<<dim3(k.chunksE, B), 64, 0, st>>>(pa);
+  if (gene_wide()) wide::enc_pool_bwd_kernel<<<dim3(k.chunksE, B), wide::kThreads, wide::PB_BYTES, st>>>(pa);
+  else enc_pool_bwd_kernel<<<dim3(k.chunksE, B), 64, 0, st>>>(pa);
   LAUNCH_CHECK();
 
   // ---- partial sums -> parameter gradients

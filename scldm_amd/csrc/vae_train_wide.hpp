@@ -707,6 +707,147 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
   mlp_wgrads(S, DM, P + ec_off_w1(L), P + ec_off_w2(L), P + ec_off_wc(L), P + ec_off_ln2w(L), P + ec_off_ln2b(L), tid);
 }
 
+// =================================================================================================================================
+// Encoder MCAB pooling backward, key side (layers.py:111-118, 248-264, 325-326), second version: 16 lanes per gene token, four
+// tokens per wave, the four waves of a workgroup independent (no workgroup barrier inside the token loop).
+//   x = E[gene] log1p(count); xn = LN_1(x); k | v = c_attn xn; p[i][h] = exp2(log2e / sqrt 8 * Q[i][h] . k[h] - lse2[i][h])
+// Sums over tokens (d c_attn 64 x 32, dQ 64 x 8, LN_1's vectors) are contracted per wave over its four tokens into 41 registers
+// per lane that live across the whole token range; the four waves are added through LDS in wave order at the end (deterministic).
+// grid = (chunks, B); partial per workgroup: EP_* of vae_train.hpp (only the block-diagonal entries of EP_DQ are written - the only
+// ones fold_dq_kernel reads).  Gene-embedding gradient by atomics, as before.
+// =================================================================================================================================
+constexpr int kP64 = 68;                                   // floats per 64-wide row
+constexpr int PB_W = 0, PB_Q = PB_W + 64 * kP, PB_DAO = PB_Q + 16 * kP, PB_LSE = PB_DAO + 16 * kP, PB_DG = PB_LSE + 64, PB_WAVE = PB_DG + 64;
+constexpr int PW_XN = 0, PW_TX = PW_XN + 4 * kP, PW_T1 = PW_TX + 4 * kP, PW_KV = PW_T1 + 4 * kP, PW_DKV = PW_KV + 4 * kP64, PW_DSV = PW_DKV + 4 * kP64,
+              PW_SIZE = PW_DSV + 4 * kP64;
+constexpr int PB_ACC = 2048 + 512 + 64;                    // one wave's accumulators in the final exchange
+constexpr int PB_FLOATS = (PB_WAVE + 4 * PW_SIZE) > 4 * PB_ACC ? (PB_WAVE + 4 * PW_SIZE) : 4 * PB_ACC;
+constexpr int PB_BYTES = PB_FLOATS * 4;
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ f32x4 quad_sum4(f32x4 v) { return f32x4{quad_sum(v[0]), quad_sum(v[1]), quad_sum(v[2]), quad_sum(v[3])}; }
+
+__global__ __launch_bounds__(kThreads) void enc_pool_bwd_kernel(const EncPoolBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, tk = lane >> 4, j = lane & 15;
+  const int chunk = blockIdx.x, cell = blockIdx.y, nch = gridDim.x;
+  constexpr float kS2 = 1.4426950408889634f * 0.35355339059327373f;   // log2(e) / sqrt(8)
+  constexpr float kScale = 0.35355339059327373f;
+  {
+    RowCopy<64> cw;
+    cw.load(a.wkv, 64, tid);
+    cw.store(S + PB_W, tid);
+    for (int idx = tid; idx < 512; idx += kThreads) {
+      S[PB_Q + (idx >> 5) * kP + (idx & 31)] = a.Q[idx];
+      S[PB_DAO + (idx >> 5) * kP + (idx & 31)] = a.dao[(size_t)cell * 512 + idx];
+    }
+    if (tid < 64) { S[PB_LSE + tid] = a.lse2[(size_t)cell * 64 + tid]; S[PB_DG + tid] = a.dgq[(size_t)cell * 64 + tid]; }
+  }
+  __syncthreads();
+  float* __restrict__ Wv = S + PB_WAVE + wave * PW_SIZE;
+  const float lw0 = a.ln1_w[j], lw1 = a.ln1_w[j + 16], lb0 = a.ln1_b[j], lb1 = a.ln1_b[j + 16];
+  const int begin = chunk * a.tiles * 64, end = min(a.S, begin + a.tiles * 64);
+  const int h = j >> 2, iq = j & 3;
+  f32x4 gw[8];          // d c_attn[o = (lane >> 3) + 8 m][4 (lane & 7) ..]
+  f32x4 gqa = kZero4, gqb = kZero4;   // dQ[(head, query) = lane][d = 0 .. 7 of that head]
+  float gln = 0.f;      // lanes < 32: LN_1 weight gradient of feature lane; lanes >= 32: bias gradient of feature lane - 32
+#pragma unroll
+  for (int m = 0; m < 8; ++m) gw[m] = kZero4;
+  for (int s0 = begin + wave * 4; s0 < end; s0 += 16) {
+    const int s = s0 + tk;
+    const bool valid = s < end;
+    const size_t si = (size_t)cell * a.S + (valid ? s : end - 1);
+    const long long gene = a.genes[si];
+    const float lc = log1pf(a.counts[si]);
+    const float* e = a.emb + (size_t)gene * 32;
+    const Ln n = ln_own(e[j] * lc, e[j + 16] * lc, a.eps);
+    Wv[PW_XN + tk * kP + j] = fmaf(n.h0, lw0, lb0);
+    Wv[PW_XN + tk * kP + j + 16] = fmaf(n.h1, lw1, lb1);
+    tsync();
+    lin32<64>(S + PB_W, Wv + PW_XN + tk * kP, j, [&](int, int o, float v) { Wv[PW_KV + tk * kP64 + o] = v; });
+    tsync();
+    {
+      const f32x4 ka = *v4(Wv + PW_KV + tk * kP64 + 8 * h), kb = *v4(Wv + PW_KV + tk * kP64 + 8 * h + 4);
+      const f32x4 va = *v4(Wv + PW_KV + tk * kP64 + 32 + 8 * h), vb = *v4(Wv + PW_KV + tk * kP64 + 32 + 8 * h + 4);
+      f32x4 dka = kZero4, dkb = kZero4, dva = kZero4, dvb = kZero4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = 4 * iq + q;
+        const f32x4 qa = *v4(S + PB_Q + i * kP + 8 * h), qb = *v4(S + PB_Q + i * kP + 8 * h + 4);
+        const f32x4 da = *v4(S + PB_DAO + i * kP + 8 * h), db = *v4(S + PB_DAO + i * kP + 8 * h + 4);
+        const float sc = dot4(qa, ka) + dot4(qb, kb), dp = dot4(da, va) + dot4(db, vb);
+        const float pp = valid ? __builtin_amdgcn_exp2f(sc * kS2 - S[PB_LSE + h * 16 + i]) : 0.f;
+        const float ds = pp * (dp - S[PB_DG + h * 16 + i]) * kScale;
+        Wv[PW_DSV + tk * kP64 + h * 16 + i] = ds;
+        dka = fma4(ds, qa, dka); dkb = fma4(ds, qb, dkb);
+        dva = fma4(pp, da, dva); dvb = fma4(pp, db, dvb);
+      }
+      dka = quad_sum4(dka); dkb = quad_sum4(dkb); dva = quad_sum4(dva); dvb = quad_sum4(dvb);
+      const f32x4 mine = iq == 0 ? dka : iq == 1 ? dkb : iq == 2 ? dva : dvb;
+      *v4(Wv + PW_DKV + tk * kP64 + (iq >> 1) * 32 + 8 * h + 4 * (iq & 1)) = mine;
+    }
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<64>(S + PB_W, Wv + PW_DKV + tk * kP64, j, acc);
+      acc = half_sum4(acc);
+      if (j < 8) *v4(Wv + PW_TX + tk * kP + 4 * j) = acc;
+    }
+    {   // token-axis contractions over this wave's four tokens
+      const int i4 = lane & 7, oo = lane >> 3, hq = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 xv = *v4(Wv + PW_XN + t * kP + 4 * i4);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) gw[m] = fma4(Wv[PW_DKV + t * kP64 + oo + 8 * m], xv, gw[m]);
+        const float ds = Wv[PW_DSV + t * kP64 + lane];
+        gqa = fma4(ds, *v4(Wv + PW_KV + t * kP64 + 8 * hq), gqa);
+        gqb = fma4(ds, *v4(Wv + PW_KV + t * kP64 + 8 * hq + 4), gqb);
+      }
+    }
+    tsync();
+    const float g0 = Wv[PW_TX + tk * kP + j], g1 = Wv[PW_TX + tk * kP + j + 16];
+    Wv[PW_T1 + tk * kP + j] = g0 * n.h0;
+    Wv[PW_T1 + tk * kP + j + 16] = g1 * n.h1;
+    float o0, o1;
+    ln_back(n, g0 * lw0, g1 * lw1, o0, o1);
+    if (valid && lc != 0.f) {
+      float* ge = a.g_emb + (size_t)gene * 32;
+      atomicAdd(ge + j, o0 * lc);
+      atomicAdd(ge + j + 16, o1 * lc);
+    }
+    tsync();
+    {
+      const float* src = (lane < 32 ? Wv + PW_T1 : Wv + PW_TX) + (lane & 31);
+      gln += (src[0] + src[kP]) + (src[2 * kP] + src[3 * kP]);
+    }
+    tsync();
+  }
+  // the four waves' sums -> one partial
+  __syncthreads();
+  {
+    float* R = S + wave * PB_ACC;
+    const int i4 = lane & 7, oo = lane >> 3;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) *v4(R + (oo + 8 * m) * 32 + 4 * i4) = gw[m];
+    *v4(R + 2048 + lane * 8) = gqa;
+    *v4(R + 2048 + lane * 8 + 4) = gqb;
+    R[2560 + lane] = gln;
+  }
+  __syncthreads();
+  float* P = a.part + (size_t)(cell * nch + chunk) * EP_SIZE;
+  for (int idx = tid; idx < PB_ACC; idx += kThreads) {
+    const float v = ((S[idx] + S[PB_ACC + idx]) + S[2 * PB_ACC + idx]) + S[3 * PB_ACC + idx];
+    if (idx < 2048) P[EP_WKV + idx] = v;
+    else if (idx < 2560) { const int e = idx - 2048, hi = e >> 3, dd = e & 7; P[EP_DQ + hi * 32 + 8 * (hi >> 4) + dd] = v; }
+    else P[EP_LN1W + idx - 2560] = v;
+  }
+}
+
 }  // namespace wide
 }  // namespace vtrain
 }  // namespace scldm
