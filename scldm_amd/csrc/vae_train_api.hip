@@ -63,7 +63,7 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   const int L = c.n_layer;
   Carver k{reinterpret_cast<char*>(base)};
   Ws w;
-  split_tiles(G, B, &w.tilesD, &w.chunksD);
+  split_tiles(G, B, &w.tilesD, &w.chunksD, gene_wide() ? 1024 : 2048);
   split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? 1024 : 2048);   // (the second version's workgroups are four waves)
   w.quads = cdiv(B, 4);
   w.wct = k.take((size_t)(2 + 2 * L) * kHP * 32);
@@ -215,6 +215,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
                             (const void*)wide::dec_cell_bwd_kernel})
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES) != hipSuccess) rc = 1;
       if (hipFuncSetAttribute((const void*)wide::enc_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::PB_BYTES) != hipSuccess) rc = 1;
+      if (hipFuncSetAttribute((const void*)wide::dec_gene_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::G_BYTES) != hipSuccess) rc = 1;
       return rc;
     }();
     if (attr) return fail(SCLDM_ERR_HIP, "hipFuncSetAttribute (LDS size of the VAE training kernels) failed");
@@ -241,7 +242,8 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ga.ln2_w = w->dec_cross.ln2_w; ga.ln2_b = w->dec_cross.ln2_b; ga.head_w = w->head_w;
   ga.mlp = mlp_of(w->dec_cross.w1, w->dec_cross.w2, wct(1), H);
   ga.g_emb = g_emb; ga.part = k.p_gene; ga.dkv_part = k.p_dkv; ga.G = G; ga.tiles = k.tilesD; ga.eps = eps;
-  dec_gene_bwd_kernel<<<dim3(k.chunksD, B), 64, 0, st>>>(ga);
+  if (gene_wide()) wide::dec_gene_bwd_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::G_BYTES, st>>>(ga);
+  else dec_gene_bwd_kernel<<<dim3(k.chunksD, B), 64, 0, st>>>(ga);
   LAUNCH_CHECK();
   if (wd) wide::dec_cell_bwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(da);
   else if (nl <= 16) dec_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(da);

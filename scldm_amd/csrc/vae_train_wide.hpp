@@ -848,6 +848,264 @@ __global__ __launch_bounds__(kThreads) void enc_pool_bwd_kernel(const EncPoolBwd
   }
 }
 
+// =================================================================================================================================
+// Decoder MCAB, per-gene chain backward (layers.py:305-330 with q = gene embeddings, nnets.py:206-208; NB logit head), second
+// version: 16 lanes per decoded gene, 16 genes per workgroup step, two workgroups per CU.
+//   q0 = E[gene]; qn = LN_1q(q0); qq = Wq qn; ao = softmax(qq K^T / sqrt 8) V (4 heads x 8, 16 latent keys of the cell);
+//   y = q0 + Wp ao; h2 = LN_2(y); yo = y + Wc (silu(W1 h2) * W2 h2); logit = w_head . yo + b
+// What makes it cheap: the gradient entering the MLP is RANK ONE per gene, d yo = dlogit * w_head.  So
+//   d hid = dlogit * c0 with c0 = Wc^T w_head (one 96-vector per launch, not a Linear per gene),
+//   d Wc  = w_head (x) c with c = sum_genes dlogit * hid  (a 96-vector of running sums, not a 32 x 96 contraction),
+//   d w_head = sum dlogit * y + Wc c  (the MLP's forward output is never formed),
+// and Wc leaves the per-gene path altogether.  Token-axis sums that are plain column sums (LN vectors, head, c) are running sums in
+// the lanes' own registers, folded over the 16 gene slots once at the end; the outer products (d Wq, d Wp, d W1, d W2, dK | dV of
+// the cell) are contracted over the step's 16 genes from LDS rows into 36 accumulator registers per thread that live across the
+// whole gene range.  grid = (chunks, B); partial per workgroup: DP_* of vae_train.hpp, dkv_part as before; dE[gene] by atomics.
+// =================================================================================================================================
+constexpr int G_WQ = 0, G_WP = G_WQ + 32 * kP, G_W1 = G_WP + 32 * kP, G_W2 = G_W1 + 96 * kP, G_KV = G_W2 + 96 * kP;
+constexpr int G_QN = G_KV + 16 * kP64, G_QQ = G_QN + 16 * kP, G_AO = G_QQ + 16 * kP, G_H2 = G_AO + 16 * kP, G_DY = G_H2 + 16 * kP,
+              G_DAO = G_DY + 16 * kP, G_DQQ = G_DAO + 16 * kP, G_TX = G_DQQ + 16 * kP, G_DA = G_TX + 16 * kP, G_DB = G_DA + 16 * kQ,
+              G_PP = G_DB + 16 * kQ, G_DS = G_PP + 16 * kP64, G_FLOATS = G_DS + 16 * kP64;
+constexpr int G_BYTES = G_FLOATS * 4;
+static_assert(G_BYTES <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+  return v;
+}
+// acc[m] += sum_t DY[t][oo + 32 m] X[t][4 i4 ..]
+template <int OUT>
+__device__ __forceinline__ void wgrad_acc(const float* __restrict__ DY, int py, const float* __restrict__ X, f32x4* __restrict__ acc, int tid) {
+  const int i4 = tid & 7, oo = tid >> 3;
+#pragma unroll 4
+  for (int t = 0; t < kT; ++t) {
+    const f32x4 xv = *v4(X + t * kP + 4 * i4);
+#pragma unroll
+    for (int m = 0; m < OUT / 32; ++m) acc[m] = fma4(DY[t * py + oo + 32 * m], xv, acc[m]);
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, chunk = blockIdx.x, cell = blockIdx.y, nch = gridDim.x;
+  constexpr float kScale = 0.35355339059327373f;   // 1 / sqrt(8)
+  const int H = a.mlp.H;
+  {
+    RowCopy<32> cq, cp;
+    RowCopy<96> c1, c2;
+    cq.load(a.wq, 32, tid); cp.load(a.wp, 32, tid); c1.load(a.mlp.w1, H, tid); c2.load(a.mlp.w2, H, tid);
+    cq.store(S + G_WQ, tid); cp.store(S + G_WP, tid); c1.store(S + G_W1, tid); c2.store(S + G_W2, tid);
+    for (int idx = tid; idx < kT * 64; idx += kThreads) S[G_KV + (idx >> 6) * kP64 + (idx & 63)] = a.kv[(size_t)cell * (kT * 64) + idx];
+  }
+  // c0[u] = sum_i Wc[i][u] w_head[i] for this lane's hidden units u = j + 16 m (zero beyond H)
+  float c0[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) {
+    const int u = j + 16 * m;
+    float s = 0.f;
+    if (u < H)
+      for (int i = 0; i < 32; ++i) s = fmaf(a.mlp.wct[u * 32 + i], a.head_w[i], s);
+    c0[m] = s;
+  }
+  const float l1w0 = a.ln1q_w[j], l1w1 = a.ln1q_w[j + 16], l1b0 = a.ln1q_b[j], l1b1 = a.ln1q_b[j + 16];
+  const float l2w0 = a.ln2_w[j], l2w1 = a.ln2_w[j + 16], l2b0 = a.ln2_b[j], l2b1 = a.ln2_b[j + 16];
+  const float hw0 = a.head_w[j], hw1 = a.head_w[j + 16];
+  __syncthreads();
+  f32x4 gq[1] = {kZero4}, gp[1] = {kZero4}, g1[3] = {kZero4, kZero4, kZero4}, g2[3] = {kZero4, kZero4, kZero4}, gkv = kZero4;
+  float vs[16];       // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each), c (six hidden units)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) vs[i] = 0.f;
+  const int h = j >> 2, jq = j & 3;
+  const int begin = chunk * a.tiles * 64, end = min(a.G, begin + a.tiles * 64);
+  for (int g0 = begin; g0 < end; g0 += 16) {
+    const int g = g0 + tok;
+    const bool valid = g < end;
+    const size_t gi = (size_t)cell * a.G + (valid ? g : end - 1);
+    const long long gene = a.genes[gi];
+    const float dlog = valid ? a.dl[gi] : 0.f;
+    const float* e = a.emb + (size_t)gene * 32;
+    const float q00 = e[j], q01 = e[j + 16];
+    const Ln n1 = ln_own(q00, q01, a.eps);
+    S[G_QN + tok * kP + j] = fmaf(n1.h0, l1w0, l1b0);
+    S[G_QN + tok * kP + j + 16] = fmaf(n1.h1, l1w1, l1b1);
+    tsync();
+    lin32<32>(S + G_WQ, S + G_QN + tok * kP, j, [&](int, int o, float v) { S[G_QQ + tok * kP + o] = v; });
+    tsync();
+    float p[4];
+    {
+      const f32x4 qa = *v4(S + G_QQ + tok * kP + 8 * h), qb = *v4(S + G_QQ + tok * kP + 8 * h + 4);
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        p[kk] = (dot4(qa, *v4(K)) + dot4(qb, *v4(K + 4))) * kScale;
+        mx = fmaxf(mx, p[kk]);
+      }
+      mx = quad_max(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
+      const float inv = 1.0f / quad_sum(l);
+      f32x4 aa = kZero4, ab = kZero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        p[kk] *= inv;
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        aa = fma4(p[kk], *v4(V), aa);
+        ab = fma4(p[kk], *v4(V + 4), ab);
+      }
+      aa = quad_sum4(aa);
+      ab = quad_sum4(ab);
+      if (jq < 2) *v4(S + G_AO + tok * kP + 8 * h + 4 * jq) = jq == 0 ? aa : ab;
+      *v4(S + G_PP + tok * kP64 + h * 16 + 4 * jq) = f32x4{p[0], p[1], p[2], p[3]};
+    }
+    tsync();
+    float y0 = q00, y1 = q01;
+    lin32<32>(S + G_WP, S + G_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) y0 += v; else y1 += v; });
+    const Ln n2 = ln_own(y0, y1, a.eps);
+    S[G_H2 + tok * kP + j] = fmaf(n2.h0, l2w0, l2b0);
+    S[G_H2 + tok * kP + j + 16] = fmaf(n2.h1, l2w1, l2b1);
+    tsync();
+    {
+      float aa[6], bb[6];
+      lin32<96>(S + G_W1, S + G_H2 + tok * kP, j, [&](int m, int, float v) { aa[m] = v; });
+      lin32<96>(S + G_W2, S + G_H2 + tok * kP, j, [&](int m, int, float v) { bb[m] = v; });
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        const float s = sigm(aa[m]), sa = aa[m] * s, dh = dlog * c0[m];
+        vs[10 + m] = fmaf(dlog, sa * bb[m], vs[10 + m]);
+        S[G_DA + tok * kQ + j + 16 * m] = dh * bb[m] * (s * (1.0f + aa[m] * (1.0f - s)));
+        S[G_DB + tok * kQ + j + 16 * m] = dh * sa;
+      }
+    }
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<96>(S + G_W1, S + G_DA + tok * kQ, j, acc);
+      lin32_t_acc<96>(S + G_W2, S + G_DB + tok * kQ, j, acc);
+      acc = half_sum4(acc);
+      if (j < 8) *v4(S + G_TX + tok * kP + 4 * j) = acc;
+    }
+    tsync();
+    float d0, d1;
+    {
+      const float t0 = S[G_TX + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16];
+      vs[4] = fmaf(t0, n2.h0, vs[4]); vs[5] = fmaf(t1, n2.h1, vs[5]); vs[6] += t0; vs[7] += t1;
+      vs[8] = fmaf(dlog, y0, vs[8]); vs[9] = fmaf(dlog, y1, vs[9]);
+      ln_back(n2, t0 * l2w0, t1 * l2w1, d0, d1);
+      d0 = fmaf(dlog, hw0, d0);
+      d1 = fmaf(dlog, hw1, d1);
+    }
+    S[G_DY + tok * kP + j] = d0;
+    S[G_DY + tok * kP + j + 16] = d1;
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<32>(S + G_WP, S + G_DY + tok * kP, j, acc);
+      acc = half_sum4(acc);
+      if (j < 8) *v4(S + G_DAO + tok * kP + 4 * j) = acc;
+    }
+    tsync();
+    {
+      const f32x4 da = *v4(S + G_DAO + tok * kP + 8 * h), db = *v4(S + G_DAO + tok * kP + 8 * h + 4);
+      float dp[4], dg = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        dp[kk] = dot4(da, *v4(V)) + dot4(db, *v4(V + 4));
+        dg = fmaf(p[kk], dp[kk], dg);
+      }
+      dg = quad_sum(dg);
+      f32x4 qa = kZero4, qb = kZero4, dsv;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float ds = p[kk] * (dp[kk] - dg) * kScale;
+        dsv[kk] = ds;
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        qa = fma4(ds, *v4(K), qa);
+        qb = fma4(ds, *v4(K + 4), qb);
+      }
+      qa = quad_sum4(qa);
+      qb = quad_sum4(qb);
+      if (jq < 2) *v4(S + G_DQQ + tok * kP + 8 * h + 4 * jq) = jq == 0 ? qa : qb;
+      *v4(S + G_DS + tok * kP64 + h * 16 + 4 * jq) = dsv;
+    }
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<32>(S + G_WQ, S + G_DQQ + tok * kP, j, acc);
+      acc = half_sum4(acc);
+      tsync();      // (G_TX of this gene was read above; the fence keeps the store below it)
+      if (j < 8) *v4(S + G_TX + tok * kP + 4 * j) = acc;
+    }
+    tsync();
+    {
+      const float t0 = S[G_TX + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16];
+      vs[0] = fmaf(t0, n1.h0, vs[0]); vs[1] = fmaf(t1, n1.h1, vs[1]); vs[2] += t0; vs[3] += t1;
+      float o0, o1;
+      ln_back(n1, t0 * l1w0, t1 * l1w1, o0, o1);
+      if (valid && dlog != 0.f) {
+        float* ge = a.g_emb + (size_t)gene * 32;
+        atomicAdd(ge + j, d0 + o0);
+        atomicAdd(ge + j + 16, d1 + o1);
+      }
+    }
+    __syncthreads();
+    wgrad_acc<32>(S + G_DQQ, kP, S + G_QN, gq, tid);
+    wgrad_acc<32>(S + G_DY, kP, S + G_AO, gp, tid);
+    wgrad_acc<96>(S + G_DA, kQ, S + G_H2, g1, tid);
+    wgrad_acc<96>(S + G_DB, kQ, S + G_H2, g2, tid);
+    {   // dK | dV of the cell: thread = (key, four of the 64 columns)
+      const int key = tid >> 4, f4 = tid & 15, hh = (f4 & 7) >> 1;
+      const float* sc = S + (f4 < 8 ? G_DS : G_PP) + hh * 16 + key;
+      const float* vec = S + (f4 < 8 ? G_QQ : G_DAO) + 4 * (f4 & 7);
+#pragma unroll 4
+      for (int t = 0; t < kT; ++t) gkv = fma4(sc[t * kP64], *v4(vec + t * kP), gkv);
+    }
+    __syncthreads();
+  }
+  // ---- one partial per workgroup
+  float* P = a.part + (size_t)(cell * nch + chunk) * DP_SIZE;
+  {
+    const int i4 = tid & 7, oo = tid >> 3;
+    *v4(P + DP_WQ + oo * 32 + 4 * i4) = gq[0];
+    *v4(P + DP_WP + oo * 32 + 4 * i4) = gp[0];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      *v4(P + DP_W1 + (oo + 32 * m) * 32 + 4 * i4) = g1[m];
+      *v4(P + DP_W2 + (oo + 32 * m) * 32 + 4 * i4) = g2[m];
+    }
+    *v4(a.dkv_part + (size_t)(cell * nch + chunk) * (kT * 64) + (tid >> 4) * 64 + 4 * (tid & 15)) = gkv;
+  }
+  // the 16 gene slots' running sums: R[slot][16 values][16 lanes]
+  float* R = S;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) R[(tok * 16 + i) * 16 + j] = vs[i];
+  __syncthreads();
+  {
+    const int i = tid >> 4;       // value index, lane j
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < kT; ++t) s += R[(t * 16 + i) * 16 + j];
+    __syncthreads();
+    // feature / hidden-unit index of value i in lane j
+    if (i < 10) {
+      const int f = j + 16 * (i & 1);
+      const int off = i < 2 ? DP_LN1QW : i < 4 ? DP_LN1QB : i < 6 ? DP_LN2W : i < 8 ? DP_LN2B : -1;
+      if (off >= 0) P[off + f] = s;
+      else R[512 + f] = s;                       // head: sum dlogit * y (completed below)
+    } else R[j + 16 * (i - 10)] = s;             // c[u]
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float s = R[512 + tid];
+    for (int u = 0; u < H; ++u) s = fmaf(a.mlp.wct[u * 32 + tid], R[u], s);
+    P[DP_HEADW + tid] = s;
+  }
+  for (int idx = tid; idx < 32 * kHP; idx += kThreads) P[DP_WC + idx] = a.head_w[idx / kHP] * R[idx % kHP];
+}
+
 }  // namespace wide
 }  // namespace vtrain
 }  // namespace scldm
