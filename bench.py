@@ -570,11 +570,14 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
         lib = counts.sum(1, keepdim=True)
         opt = torch.optim.AdamW(vae.parameters(), lr=1e-3, fused=True)
 
-        def step():
+        def step(ev=None):
             opt.zero_grad(set_to_none=True)
+            if ev: ev[0].record()
             params, _ = vae(counts, genes, lib, cs, gs)
             loss = (-log_nb_positive(counts, params["mu"], params["theta"])).sum(1).mean()
+            if ev: ev[1].record()
             loss.backward()
+            if ev: ev[2].record()
             opt.step()
             return loss
         for _ in range(3):
@@ -586,8 +589,18 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
             loss = step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
+        # device time of the forward (+ loss) and of the backward, medians of separately recorded steps
+        fwd, bwd = [], []
+        for _ in range(5):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            step(ev)
+            torch.cuda.synchronize()
+            fwd.append(ev[0].elapsed_time(ev[1]))
+            bwd.append(ev[1].elapsed_time(ev[2]))
+        fwd_ms, bwd_ms = statistics.median(fwd), statistics.median(bwd)
         flops = 3 * B * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6 + n_genes * MCAB_DECODE_FLOPS_PER_GENE + 3.3e6)
         rec[f"b{B}"] = {"cells": B, "n_genes": n_genes, "tokens_per_cell": S, "ms_per_step": 1e3 * dt, "cells_per_s": B / dt,
+                        "forward_and_loss_ms": fwd_ms, "backward_ms": bwd_ms, "backward_over_forward": bwd_ms / fwd_ms,
                         "tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / PEAK["fp32"], "final_loss": float(loss.detach())}
         del vae, opt
         torch.cuda.empty_cache()

@@ -175,6 +175,10 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
  *   evaluation instead of 3B) and the conditional output is returned as the guided rows.  Off: the reference's arithmetic, term by
  *   term.  The reference's own configs use guidance 1.0 for dentate_gyrus / parse1m (datamodule/default.yaml:46-47). */
 #define SCLDM_OPT_CFG1_DIRECT 1
+/* SCLDM_OPT_TAIL_SPLIT (default 0; bf16 / fp16 policies): the tiles of a trunk launch's partial last round that would run beside an
+ * empty workgroup slot are launched as 32-token tiles (two per 64-token tile) next to the 64-token launch.  Results are bit-identical
+ * either way (tested); measured 2-12 % SLOWER (a 32-token tile streams twice the weight bytes per token), so it stays an A/B knob. */
+#define SCLDM_OPT_TAIL_SPLIT 2
 int scldm_dit_set_option(scldm_dit* h, int option, int value);
 
 /* DiT layers one fused-kernel launch runs (4 by default, SCLDM_LPL=1..4: the residual stays in registers between them; 0 for a

@@ -16,7 +16,8 @@ PREC_FP32, PREC_BF16, PREC_BF16X3, PREC_FP16 = 0, 1, 2, 3
 METHOD_EULER, METHOD_HEUN = 0, 1
 PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "fp16": PREC_FP16}
 METHODS = {"euler": METHOD_EULER, "heun": METHOD_HEUN}
-OPT_CFG1_DIRECT = 1   # scldm_dit_set_option (include/scldm_hip.h)
+OPT_CFG1_DIRECT = 1
+OPT_TAIL_SPLIT = 2   # scldm_dit_set_option (include/scldm_hip.h)
 
 c_float_p = C.POINTER(C.c_float)
 c_void_pp = C.POINTER(C.c_void_p)

@@ -96,6 +96,13 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_ADALN_ROWTILE")) h->adaln_rowtile = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_COND_AHEAD")) h->cond_ahead = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
+  if (const char* e = getenv("SCLDM_TAIL_SPLIT")) h->tail_split = atoi(e) != 0;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      h->n_cu = prop.multiProcessorCount;
+  }
   h->dbg_layer = -1;
   if (const char* e = getenv("SCLDM_DBG_LAYER")) h->dbg_layer = atoi(e);
   h->train_fused = true;
@@ -194,6 +201,7 @@ extern "C" int scldm_dit_layers_per_launch(const scldm_dit* h) { return (h && h-
 extern "C" int scldm_dit_set_option(scldm_dit* h, int option, int value) {
   if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
   if (option == SCLDM_OPT_CFG1_DIRECT) { h->cfg1_direct = value != 0; return SCLDM_OK; }
+  if (option == SCLDM_OPT_TAIL_SPLIT) { h->tail_split = value != 0; return SCLDM_OK; }
   return fail(SCLDM_ERR_SHAPE, "unknown option %d", option);
 }
 
@@ -516,9 +524,9 @@ static int launch_fwd(int prec, int ntt, int ft, const FwdArgs& a, hipStream_t s
   if (prec == SCLDM_PREC_FP32) return launch_fwd_t<OpF32, 2, 2>(a, st);
   if (prec == SCLDM_PREC_BF16X3)
     return ft == 1 ? launch_fwd_t<OpBF16x3, 2, 1>(a, st) : ntt == 1 ? launch_fwd_t<OpBF16x3, 1, 2>(a, st) : launch_fwd_t<OpBF16x3, 2, 2>(a, st);
-  if (prec == SCLDM_PREC_FP16) return ft == 1 ? launch_fwd_t<OpFP16, 2, 1>(a, st) : launch_fwd_t<OpFP16, 2, 2>(a, st);
+  if (prec == SCLDM_PREC_FP16) return ft == 1 ? launch_fwd_t<OpFP16, 2, 1>(a, st) : ntt == 1 ? launch_fwd_t<OpFP16, 1, 2>(a, st) : launch_fwd_t<OpFP16, 2, 2>(a, st);
   if (ft == 1) return launch_fwd_t<OpBF16, 2, 1>(a, st);
-  return launch_fwd_t<OpBF16, 2, 2>(a, st);
+  return ntt == 1 ? launch_fwd_t<OpBF16, 1, 2>(a, st) : launch_fwd_t<OpBF16, 2, 2>(a, st);
 }
 
 // The DiT trunk: one fused launch per layer (input projection rides in the first, the final layer in the last).
@@ -571,6 +579,29 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
     HIP_TRY(hipEventRecord(h->fork_ev, st));
     for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(h->side[g - 1], h->fork_ev, 0));
   }
+  // Tail split (round 4): two 64-token workgroups share a CU, so a launch runs in rounds of 2 x CUs tiles and its last, partial round
+  // leaves slots empty (768 tiles = 1 024 cells x 3 forwards: 1.5 rounds; 384 tiles = 512 cells: 0.75).  The tiles of the partial
+  // round that would run with an empty neighbour slot are launched as 32-token tiles instead (the NTT = 1 instantiation, on a side
+  // stream beside the 64-token launch): r <= CUs tiles become 2 r half tiles (one short round of pairs instead of a round of lone
+  // workgroups); r > CUs: 2 CUs - r of them are halved so that every slot is taken.  A cell's result does not depend on the tile
+  // shape that carried it (same k order, same per-token LayerNorm / softmax arithmetic: bit-identical, tested).
+  // MEASURED SLOWER (profiles/r4o_ab_tail_split.txt: 1 024 cells x 3 forwards 0.415 -> 0.366 of peak, 512 cells 0.366 -> 0.357, 1 000
+  // cells 0.412 -> 0.363, 300 cells 0.332 -> 0.293): a 32-token tile streams twice the weight bytes per token, and that stream is what
+  // the kernel waits for (dit_forward.hpp, SCLDM_PROXY); lone workgroups of the partial round already run ~1.5x faster.  Off by default.
+  int tail_full = 0;
+  if (h->tail_split && G == 1 && ntt == 2 && ft == 2 && (prec == SCLDM_PREC_BF16 || prec == SCLDM_PREC_FP16)) {
+    const int slots = 2 * h->n_cu, r = tiles_all % slots;
+    if (r > 0) tail_full = r <= slots / 2 ? r : slots - r;
+  }
+  const int n64 = tiles_all - tail_full;
+  const int n32 = tail_full > 0 ? cdiv((long long)n_fwd * 16 - (long long)n64 * 64, 32) : 0;
+  if (tail_full > 0 && n64 > 0) {
+    if (!h->side[0]) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->side[0], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->join_ev[0], hipEventDisableTiming));
+    }
+    if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  }
   a.tile0 = 0;
   a.grid_tiles = 0;
   // layers per launch: the residual stays in registers between the layers of a launch (fewer hand-off round trips and
@@ -597,14 +628,34 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
       HIP_TRY(hipEventRecord(e0, st));
     }
     int rc = SCLDM_OK;
-    for (int g = 0; g < G && rc == SCLDM_OK; ++g) {
-      hipStream_t sg = g == 0 ? st : h->side[g - 1];
-      if (G > 1) {
-        a.tile0 = gt0[g];
-        a.grid_tiles = gt0[g + 1] - gt0[g];
+    if (tail_full > 0) {
+      hipStream_t s1 = st;
+      if (n64 > 0) {
+        HIP_TRY(hipEventRecord(h->fork_ev, st));
+        HIP_TRY(hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
+        a.tile0 = 0;
+        a.grid_tiles = n64;
+        rc = launch_fwd(prec, 2, ft, a, st);
+        s1 = h->side[0];
       }
-      rc = launch_fwd(prec, ntt, ft, a, sg);
-    }
+      a.tile0 = 2 * n64;
+      a.grid_tiles = n32;
+      if (rc == SCLDM_OK) rc = launch_fwd(prec, 1, ft, a, s1);
+      if (n64 > 0) {
+        HIP_TRY(hipEventRecord(h->join_ev[0], h->side[0]));
+        HIP_TRY(hipStreamWaitEvent(st, h->join_ev[0], 0));
+      }
+      a.tile0 = 0;
+      a.grid_tiles = 0;
+    } else
+      for (int g = 0; g < G && rc == SCLDM_OK; ++g) {
+        hipStream_t sg = g == 0 ? st : h->side[g - 1];
+        if (G > 1) {
+          a.tile0 = gt0[g];
+          a.grid_tiles = gt0[g + 1] - gt0[g];
+        }
+        rc = launch_fwd(prec, ntt, ft, a, sg);
+      }
     if (rc != SCLDM_OK) return rc;
     if (e1) HIP_TRY(hipEventRecord(e1, st));
   }

@@ -32,6 +32,8 @@ struct scldm_dit {
   bool adaln_exact = false;  // SCLDM_ADALN_EXACT: adaln_mfma_kernel (exact fp32) for every precision policy (A/B)
   bool adaln_valu = false;   // SCLDM_ADALN_VALU: adaln_all_kernel instead of adaln_mfma_kernel (A/B)
   int cfg1_direct = 0;  // SCLDM_OPT_CFG1_DIRECT (scldm_dit_set_option)
+  int tail_split = 0;   // SCLDM_OPT_TAIL_SPLIT: the partial last round of a trunk launch runs as 32-token tiles (api.hip: trunk; measured slower)
+  int n_cu = 256;       // compute units of the device (rounds of 2 x n_cu tiles)
   int groups;      // tile groups per layer launch (SCLDM_GROUPS, read once at create)
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
   int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)

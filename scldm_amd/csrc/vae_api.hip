@@ -123,7 +123,7 @@ int upload(void** dev, int* cap, const std::vector<T>& v) {
 int scldm_vae_refresh(scldm_vae* h, bool force, hipStream_t st) {
   const scldm_vae_config& c = h->cfg;
   if (force) vae_set_word_kernel<<<1, 1, 0, st>>>(h->d_dirty + 1, 1);
-  vae_fingerprint_kernel<<<dim3(h->n_fp, 8), 256, 0, st>>>((const VaeFpSrc*)h->d_fp_src, h->d_fp_state);
+  vae_fingerprint_kernel<<<dim3(h->n_fp, 64), 256, 0, st>>>((const VaeFpSrc*)h->d_fp_src, h->d_fp_state);
   vae_fp_compare_kernel<<<1, 1, 0, st>>>(h->d_fp_state, h->d_dirty);
   vae_pack_jobs_kernel<<<h->n_jobs * kVaeJobBlocks, 256, 0, st>>>((const VaePackJob*)h->d_jobs, h->n_jobs, h->d_dirty);
   enc_qfrag_kernel<<<1, 64, 0, st>>>(h->q_ind, h->q_eln_w, h->q_eln_b, h->q_ewq, h->frag_enc_q, c.layernorm_eps, h->d_dirty);

@@ -185,6 +185,12 @@ __global__ void transpose_kernel(const float* __restrict__ W, int R, int C, floa
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < R * C) WT[(i % C) * R + (i / C)] = W[i];
 }
+// the same for up to 34 matrices of one shape in ONE launch (blockIdx.y = matrix; WT of matrix m at dst + m * R * C... stride given)
+struct TransposeJobs { const float* src[34]; };
+__global__ void transpose_many_kernel(const TransposeJobs j, int R, int C, float* __restrict__ dst, long stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < R * C) dst[(size_t)blockIdx.y * stride + (i % C) * R + (i / C)] = j.src[blockIdx.y][i];
+}
 // Encoder queries (cell-independent): qn = LN_1q(inducing points), Q = c_attn_q qn  (layers.py:312-313,326; 248-253)
 __global__ __launch_bounds__(64) void enc_q_fwd_kernel(const float* __restrict__ ind, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                        const float* __restrict__ wq, float eps, float* __restrict__ Q) {
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(64) void enc_pool_bwd_kernel(const EncPoolBwdArgs a
 // Partial reduction: dst[i] (+)= sum_p part[p * stride + off + i]   (index order: deterministic)
 // =================================================================================================================================
 struct RedJob { float* dst; int off, n, accumulate; int rows, ld_src, ld_dst; };   // rows > 1: a [rows][ld_src] block copied to [rows][ld_dst] (n = cols)
-constexpr int kMaxRedJobs = 24;
+constexpr int kMaxRedJobs = 96;   // (3 KB of kernel arguments; a cell side of 8 layers is 76-84 jobs: one launch)
 struct RedArgs { const float* part; int n_part; long stride; int n_jobs; RedJob job[kMaxRedJobs]; };
 // sum over the partials of one element, eight independent running sums (memory-level parallelism; fixed order: deterministic)
 __device__ __forceinline__ float sum_partials(const float* __restrict__ src, int n_part, long stride) {

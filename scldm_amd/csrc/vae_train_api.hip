@@ -191,10 +191,11 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   // ---- transposed c_proj copies (the streaming SwiGLU reads columns of c_proj as rows): enc cross, dec cross, enc layers, dec layers
   auto wct = [&](int i) { return k.wct + (size_t)i * kHP * 32; };
   {
-    auto tr = [&](const float* W, int i) { transpose_kernel<<<cdiv(32 * H, 256), 256, 0, st>>>(W, 32, H, wct(i)); };
-    tr(w->enc_cross.cproj, 0);
-    tr(w->dec_cross.cproj, 1);
-    for (int l = 0; l < L; ++l) { tr(w->enc_blocks[l].cproj, 2 + l); tr(w->dec_blocks[l].cproj, 2 + L + l); }
+    TransposeJobs tj{};     // slots: enc cross, dec cross, enc layers, dec layers (one launch)
+    tj.src[0] = w->enc_cross.cproj;
+    tj.src[1] = w->dec_cross.cproj;
+    for (int l = 0; l < L; ++l) { tj.src[2 + l] = w->enc_blocks[l].cproj; tj.src[2 + L + l] = w->dec_blocks[l].cproj; }
+    transpose_many_kernel<<<dim3(cdiv(32 * H, 256), 2 + 2 * L), 256, 0, st>>>(tj, 32, H, k.wct, (long)kHP * 32);
     enc_q_fwd_kernel<<<1, 64, 0, st>>>(w->inducing_points, w->enc_cross.ln1q_w, w->enc_cross.ln1q_b, w->enc_cross.attn_q, eps, k.Q);
     LAUNCH_CHECK();
   }

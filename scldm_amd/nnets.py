@@ -224,6 +224,7 @@ class DiT(nn.Module):
         # scalar-t forward_with_cfg skip the unconditional forward of the second half (2B instead of 3B sample-forwards per
         # evaluation: 1.5 x the cells/s at the reference's default guidance of dentate_gyrus / parse1m).
         self.guidance1_direct = False
+        self.tail_split = None          # SCLDM_OPT_TAIL_SPLIT (None: the library default, off - measured slower): 32-token tiles for a partial last round
         self._handle = None
         self._weights_key = None
         self._ws = None
@@ -304,6 +305,8 @@ class DiT(nn.Module):
             with torch.cuda.device(self.pos_embed.device):
                 _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
         L.scldm_dit_set_option(self._handle, _lib.OPT_CFG1_DIRECT, int(bool(getattr(self, "guidance1_direct", False))))
+        if getattr(self, "tail_split", None) is not None:
+            L.scldm_dit_set_option(self._handle, _lib.OPT_TAIL_SPLIT, int(bool(self.tail_split)))
         if self.precision == "fp16" and self.__dict__.get("_fp16_checked") != self._weights_key:
             # once per (re)load: the fp16 stream's range report (one stream synchronisation).  `.data` updates that are picked up
             # by the fingerprint re-pack are not re-checked: call fp16_weight_report() after such an update if in doubt.
