@@ -1106,6 +1106,296 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
   for (int idx = tid; idx < 32 * kHP; idx += kThreads) P[DP_WC + idx] = a.head_w[idx / kHP] * R[idx % kHP];
 }
 
+// =================================================================================================================================
+// The same kernel with its heavy contractions on the matrix pipe (exact fp32: v_mfma_f32_16x16x4_f32, the step's 16 genes on one
+// axis).  The version above is LDS-bandwidth bound: every wave re-reads each weight piece for its four genes.  Here a step has five
+// phases separated by workgroup barriers:
+//   1  per gene (16 lanes each, as above): LN_1q, q, attention, c_proj, LN_2 -> rows QN, QQ, AO, PP, H2
+//   A  a | b = W1 h2 | W2 h2 as 16 x 16 tiles D[gene][hidden unit] (wave w: unit tiles w, w + 4), SwiGLU gradient in place -> rows DA, DB
+//   B  d h2 = W1^T da + W2^T db: D[gene][feature], wave = (feature half, matrix); the two matrices' partials are added by the reader
+//   2  per gene: LN_2 backward, d y, d ao, attention backward, d q, LN_1q backward, dE[gene] atomics -> rows DY, DAO, DQQ, DS
+//   C  weight gradients as D[out][in] += sum_genes dy[gene][out] x[gene][in]: 8 + 2 tiles of 16 x 16 per wave (d W1, d W2, d Wq, d Wp,
+//      dK and dV of one head), accumulators in 40 registers across the whole gene range
+// An MFMA reads one scalar per lane and operand: 2 x 256 B of LDS per 2 048 FLOP.
+// =================================================================================================================================
+constexpr int M_DL = G_FLOATS, M_C0 = M_DL + 16, M_FLOATS = M_C0 + 96;
+constexpr int M_BYTES = M_FLOATS * 4;
+static_assert(M_BYTES <= 80 * 1024, "two workgroups per CU");
+__device__ __forceinline__ f32x4 mfma16(float x, float y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, chunk = blockIdx.x, cell = blockIdx.y, nch = gridDim.x;
+  const int wave = tid >> 6, li = tid & 15, g4 = (tid & 63) >> 4;      // MFMA roles: lane = (li, g4)
+  constexpr float kScale = 0.35355339059327373f;   // 1 / sqrt(8)
+  const int H = a.mlp.H;
+  {
+    RowCopy<32> cq, cp;
+    RowCopy<96> c1, c2;
+    cq.load(a.wq, 32, tid); cp.load(a.wp, 32, tid); c1.load(a.mlp.w1, H, tid); c2.load(a.mlp.w2, H, tid);
+    cq.store(S + G_WQ, tid); cp.store(S + G_WP, tid); c1.store(S + G_W1, tid); c2.store(S + G_W2, tid);
+    for (int idx = tid; idx < kT * 64; idx += kThreads) S[G_KV + (idx >> 6) * kP64 + (idx & 63)] = a.kv[(size_t)cell * (kT * 64) + idx];
+    if (tid < 96) {      // c0[u] = sum_i Wc[i][u] w_head[i]
+      float s = 0.f;
+      if (tid < H)
+        for (int i = 0; i < 32; ++i) s = fmaf(a.mlp.wct[tid * 32 + i], a.head_w[i], s);
+      S[M_C0 + tid] = s;
+    }
+  }
+  const float l1w0 = a.ln1q_w[j], l1w1 = a.ln1q_w[j + 16], l1b0 = a.ln1q_b[j], l1b1 = a.ln1q_b[j + 16];
+  const float l2w0 = a.ln2_w[j], l2w1 = a.ln2_w[j + 16], l2b0 = a.ln2_b[j], l2b1 = a.ln2_b[j + 16];
+  const float hw0 = a.head_w[j], hw1 = a.head_w[j + 16];
+  __syncthreads();
+  f32x4 gw1[3] = {kZero4, kZero4, kZero4}, gw2[3] = {kZero4, kZero4, kZero4}, gq = kZero4, gp = kZero4, gk = kZero4, gv = kZero4;
+  float cacc[2] = {0.f, 0.f};   // c[u] partials of this lane's gene quad, hidden-unit tiles wave, wave + 4
+  float vs[10];                 // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each)
+#pragma unroll
+  for (int i = 0; i < 10; ++i) vs[i] = 0.f;
+  const int h = j >> 2, jq = j & 3;
+  const int begin = chunk * a.tiles * 64, end = min(a.G, begin + a.tiles * 64);
+  for (int g0 = begin; g0 < end; g0 += 16) {
+    const int g = g0 + tok;
+    const bool valid = g < end;
+    const size_t gi = (size_t)cell * a.G + (valid ? g : end - 1);
+    const long long gene = a.genes[gi];
+    const float dlog = valid ? a.dl[gi] : 0.f;
+    if (j == 0) S[M_DL + tok] = dlog;
+    const float* e = a.emb + (size_t)gene * 32;
+    const float q00 = e[j], q01 = e[j + 16];
+    const Ln n1 = ln_own(q00, q01, a.eps);
+    S[G_QN + tok * kP + j] = fmaf(n1.h0, l1w0, l1b0);
+    S[G_QN + tok * kP + j + 16] = fmaf(n1.h1, l1w1, l1b1);
+    tsync();
+    lin32<32>(S + G_WQ, S + G_QN + tok * kP, j, [&](int, int o, float v) { S[G_QQ + tok * kP + o] = v; });
+    tsync();
+    float p[4];
+    {
+      const f32x4 qa = *v4(S + G_QQ + tok * kP + 8 * h), qb = *v4(S + G_QQ + tok * kP + 8 * h + 4);
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        p[kk] = (dot4(qa, *v4(K)) + dot4(qb, *v4(K + 4))) * kScale;
+        mx = fmaxf(mx, p[kk]);
+      }
+      mx = quad_max(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
+      const float inv = 1.0f / quad_sum(l);
+      f32x4 aa = kZero4, ab = kZero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        p[kk] *= inv;
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        aa = fma4(p[kk], *v4(V), aa);
+        ab = fma4(p[kk], *v4(V + 4), ab);
+      }
+      aa = quad_sum4(aa);
+      ab = quad_sum4(ab);
+      if (jq < 2) *v4(S + G_AO + tok * kP + 8 * h + 4 * jq) = jq == 0 ? aa : ab;
+      *v4(S + G_PP + tok * kP64 + h * 16 + 4 * jq) = f32x4{p[0], p[1], p[2], p[3]};
+    }
+    tsync();
+    float y0 = q00, y1 = q01;
+    lin32<32>(S + G_WP, S + G_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) y0 += v; else y1 += v; });
+    const Ln n2 = ln_own(y0, y1, a.eps);
+    S[G_H2 + tok * kP + j] = fmaf(n2.h0, l2w0, l2b0);
+    S[G_H2 + tok * kP + j + 16] = fmaf(n2.h1, l2w1, l2b1);
+    __syncthreads();
+    // ---- phase A: a | b tiles D[gene 4 g4 + r][unit 16 ot + li], SwiGLU gradient in place
+    {
+      float hk[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) hk[s] = S[G_H2 + li * kP + 4 * s + g4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ot = wave + 4 * q;
+        if (ot < 6) {
+          f32x4 aa = kZero4, bb = kZero4;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            aa = mfma16(hk[s], S[G_W1 + (16 * ot + li) * kP + 4 * s + g4], aa);
+            bb = mfma16(hk[s], S[G_W2 + (16 * ot + li) * kP + 4 * s + g4], bb);
+          }
+          const float c0u = S[M_C0 + 16 * ot + li];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tk = 4 * g4 + r;
+            const float dl = S[M_DL + tk], sg = sigm(aa[r]), sa = aa[r] * sg, dh = dl * c0u;
+            cacc[q] = fmaf(dl, sa * bb[r], cacc[q]);
+            S[G_DA + tk * kQ + 16 * ot + li] = dh * bb[r] * (sg * (1.0f + aa[r] * (1.0f - sg)));
+            S[G_DB + tk * kQ + 16 * ot + li] = dh * sa;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase B: d h2 partials, wave = (feature half it, matrix); W1's go to the TX rows, W2's to the DQQ rows (free until phase 2)
+    {
+      const int it = wave & 1, mtx = wave >> 1;
+      const float* Wm = S + (mtx ? G_W2 : G_W1);
+      const float* Dm = S + (mtx ? G_DB : G_DA);
+      f32x4 acc = kZero4;
+#pragma unroll 8
+      for (int s = 0; s < 24; ++s) acc = mfma16(Dm[li * kQ + 4 * s + g4], Wm[(4 * s + g4) * kP + 16 * it + li], acc);
+      float* Pt = S + (mtx ? G_DQQ : G_TX);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[(4 * g4 + r) * kP + 16 * it + li] = acc[r];
+    }
+    __syncthreads();
+    // ---- phase 2: per gene
+    float d0, d1;
+    {
+      const float t0 = S[G_TX + tok * kP + j] + S[G_DQQ + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16] + S[G_DQQ + tok * kP + j + 16];
+      vs[4] = fmaf(t0, n2.h0, vs[4]); vs[5] = fmaf(t1, n2.h1, vs[5]); vs[6] += t0; vs[7] += t1;
+      vs[8] = fmaf(dlog, y0, vs[8]); vs[9] = fmaf(dlog, y1, vs[9]);
+      ln_back(n2, t0 * l2w0, t1 * l2w1, d0, d1);
+      d0 = fmaf(dlog, hw0, d0);
+      d1 = fmaf(dlog, hw1, d1);
+    }
+    S[G_DY + tok * kP + j] = d0;
+    S[G_DY + tok * kP + j + 16] = d1;
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<32>(S + G_WP, S + G_DY + tok * kP, j, acc);
+      acc = half_sum4(acc);
+      if (j < 8) *v4(S + G_DAO + tok * kP + 4 * j) = acc;
+    }
+    tsync();
+    {
+      const f32x4 da = *v4(S + G_DAO + tok * kP + 8 * h), db = *v4(S + G_DAO + tok * kP + 8 * h + 4);
+      float dp[4], dg = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        dp[kk] = dot4(da, *v4(V)) + dot4(db, *v4(V + 4));
+        dg = fmaf(p[kk], dp[kk], dg);
+      }
+      dg = quad_sum(dg);
+      f32x4 qa = kZero4, qb = kZero4, dsv;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float ds = p[kk] * (dp[kk] - dg) * kScale;
+        dsv[kk] = ds;
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        qa = fma4(ds, *v4(K), qa);
+        qb = fma4(ds, *v4(K + 4), qb);
+      }
+      qa = quad_sum4(qa);
+      qb = quad_sum4(qb);
+      if (jq < 2) *v4(S + G_DQQ + tok * kP + 8 * h + 4 * jq) = jq == 0 ? qa : qb;
+      *v4(S + G_DS + tok * kP64 + h * 16 + 4 * jq) = dsv;
+    }
+    tsync();
+    {
+      f32x4 acc = kZero4;
+      lin32_t_acc<32>(S + G_WQ, S + G_DQQ + tok * kP, j, acc);
+      acc = half_sum4(acc);
+      if (j < 8) *v4(S + G_TX + tok * kP + 4 * j) = acc;
+    }
+    tsync();
+    {
+      const float t0 = S[G_TX + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16];
+      vs[0] = fmaf(t0, n1.h0, vs[0]); vs[1] = fmaf(t1, n1.h1, vs[1]); vs[2] += t0; vs[3] += t1;
+      float o0, o1;
+      ln_back(n1, t0 * l1w0, t1 * l1w1, o0, o1);
+      if (valid && dlog != 0.f) {
+        float* ge = a.g_emb + (size_t)gene * 32;
+        atomicAdd(ge + j, d0 + o0);
+        atomicAdd(ge + j + 16, d1 + o1);
+      }
+    }
+    __syncthreads();
+    // ---- phase C: weight gradients, D[out 16 ot + 4 g4 + r][in 16 it + li] += sum_genes dy[gene][out] x[gene][in]
+    {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int idx = wave + 4 * n, ot = idx >> 1, it = idx & 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int tk = 4 * s + g4;
+          const float x = S[G_H2 + tk * kP + 16 * it + li];
+          gw1[n] = mfma16(S[G_DA + tk * kQ + 16 * ot + li], x, gw1[n]);
+          gw2[n] = mfma16(S[G_DB + tk * kQ + 16 * ot + li], x, gw2[n]);
+        }
+      }
+      const int ot = wave >> 1, it = wave & 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int tk = 4 * s + g4;
+        gq = mfma16(S[G_DQQ + tk * kP + 16 * ot + li], S[G_QN + tk * kP + 16 * it + li], gq);
+        gp = mfma16(S[G_DY + tk * kP + 16 * ot + li], S[G_AO + tk * kP + 16 * it + li], gp);
+        // head `wave` of the cell's keys: D[key 4 g4 + r][column 16 (wave >> 1) + li], useful where (li >> 3) == (wave & 1)
+        gk = mfma16(S[G_DS + tk * kP64 + wave * 16 + li], S[G_QQ + tk * kP + 16 * (wave >> 1) + li], gk);
+        gv = mfma16(S[G_PP + tk * kP64 + wave * 16 + li], S[G_DAO + tk * kP + 16 * (wave >> 1) + li], gv);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- one partial per workgroup
+  float* P = a.part + (size_t)(cell * nch + chunk) * DP_SIZE;
+  {
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int idx = wave + 4 * n, ot = idx >> 1, it = idx & 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[DP_W1 + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gw1[n][r];
+        P[DP_W2 + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gw2[n][r];
+      }
+    }
+    const int ot = wave >> 1, it = wave & 1;
+    float* DK = a.dkv_part + (size_t)(cell * nch + chunk) * (kT * 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      P[DP_WQ + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gq[r];
+      P[DP_WP + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gp[r];
+      if ((li >> 3) == (wave & 1)) {
+        DK[(4 * g4 + r) * 64 + 16 * (wave >> 1) + li] = gk[r];
+        DK[(4 * g4 + r) * 64 + 32 + 16 * (wave >> 1) + li] = gv[r];
+      }
+    }
+  }
+  // the 16 gene slots' running sums R[slot][10 values][16 lanes]; c partials RC[g4][96 units] of every wave's tiles
+  float* R = S;
+  float* RC = S + 16 * 10 * 16;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) R[(tok * 10 + i) * 16 + j] = vs[i];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (wave + 4 * q < 6) RC[g4 * 96 + 16 * (wave + 4 * q) + li] = cacc[q];
+  __syncthreads();
+  float sum = 0.f;
+  const int vi = tid >> 4;
+  if (vi < 10) {
+#pragma unroll
+    for (int t = 0; t < kT; ++t) sum += R[(t * 10 + vi) * 16 + j];
+  }
+  float cu = 0.f;
+  if (tid < 96) cu = (RC[tid] + RC[96 + tid]) + (RC[192 + tid] + RC[288 + tid]);
+  __syncthreads();
+  float* C = S;            // c[u]
+  float* HD = S + 128;     // sum dlogit * y
+  if (tid < 96) C[tid] = cu;
+  if (vi < 10) {
+    const int f = j + 16 * (vi & 1);
+    if (vi < 2) P[DP_LN1QW + f] = sum;
+    else if (vi < 4) P[DP_LN1QB + f] = sum;
+    else if (vi < 6) P[DP_LN2W + f] = sum;
+    else if (vi < 8) P[DP_LN2B + f] = sum;
+    else HD[f] = sum;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float s2 = HD[tid];
+    for (int u = 0; u < H; ++u) s2 = fmaf(a.mlp.wct[u * 32 + tid], C[u], s2);
+    P[DP_HEADW + tid] = s2;
+  }
+  for (int idx = tid; idx < 32 * kHP; idx += kThreads) P[DP_WC + idx] = a.head_w[idx / kHP] * C[idx % kHP];
+}
+
 }  // namespace wide
 }  // namespace vtrain
 }  // namespace scldm
