@@ -142,9 +142,27 @@ __global__ __launch_bounds__(256) void vae_fingerprint_kernel(const VaeFpSrc* __
   const long long lo = (long long)blockIdx.y * chunk, hi = lo + chunk < s.n ? lo + chunk : s.n;
   if (lo >= s.n) return;
   unsigned long long hsum = 0;
-  for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) {
-    const unsigned long long v = s.p[pos];
+  auto mix = [&](unsigned long long v, long long pos) {
     hsum += (v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1 + blockIdx.x * 7919ll)) * 0xBF58476D1CE4E5B9ull ^ (v << 29);
+  };
+  // (a thread's loop is a chain of dependent HBM round trips unless several loads are in flight: 16-byte loads, two per iteration;
+  // chunk boundaries are multiples of 256 words, so only the tensor's base address decides the alignment)
+  if ((reinterpret_cast<size_t>(s.p) & 15) == 0) {
+    const uint4* p4 = reinterpret_cast<const uint4*>(s.p);
+    const long long q_lo = lo / 4, q_hi = hi / 4;      // whole 16-byte groups of [lo, hi)
+    long long q = q_lo + threadIdx.x;
+    for (; q + 256 < q_hi; q += 512) {
+      const uint4 u = p4[q], w = p4[q + 256];
+      mix(u.x, 4 * q); mix(u.y, 4 * q + 1); mix(u.z, 4 * q + 2); mix(u.w, 4 * q + 3);
+      mix(w.x, 4 * (q + 256)); mix(w.y, 4 * (q + 256) + 1); mix(w.z, 4 * (q + 256) + 2); mix(w.w, 4 * (q + 256) + 3);
+    }
+    if (q < q_hi) {
+      const uint4 u = p4[q];
+      mix(u.x, 4 * q); mix(u.y, 4 * q + 1); mix(u.z, 4 * q + 2); mix(u.w, 4 * q + 3);
+    }
+    for (long long pos = 4 * q_hi + threadIdx.x; pos < hi; pos += 256) mix(s.p[pos], pos);   // the last 0-3 words
+  } else {
+    for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) mix(s.p[pos], pos);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
