@@ -138,7 +138,10 @@ struct VaeFpSrc { const uint32_t* p; long long n; };
 __global__ __launch_bounds__(256) void vae_fingerprint_kernel(const VaeFpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
   const VaeFpSrc s = src[blockIdx.x];
   if (s.n <= 0) return;
-  const long long chunk = ((s.n + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+  // (at least 2 048 words per workgroup: the ~170 small tensors are one workgroup = ONE atomic each - same-address 64-bit atomics
+  // serialise at ~20 ns, and 2 400 of them were most of this kernel's 53 us)
+  long long chunk = ((s.n + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+  if (chunk < 2048) chunk = 2048;
   const long long lo = (long long)blockIdx.y * chunk, hi = lo + chunk < s.n ? lo + chunk : s.n;
   if (lo >= s.n) return;
   unsigned long long hsum = 0;
@@ -166,7 +169,10 @@ __global__ __launch_bounds__(256) void vae_fingerprint_kernel(const VaeFpSrc* __
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
+  __shared__ unsigned long long wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = hsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 // state[0] = accumulator of this pass, state[1] = fingerprint of the packed copies; dirty[0] = re-pack?, dirty[1] = force
 __global__ void vae_fp_compare_kernel(unsigned long long* __restrict__ state, int* __restrict__ dirty) {
