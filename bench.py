@@ -607,6 +607,16 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
     return rec
 
 
+def kernel_source_sha256():
+    """fingerprint of the fused layer kernel's sources (the PMC summary records the one it was collected on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("dit_forward.hpp", "common.hpp"):
+        with open(os.path.join(ROOT, "scldm_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 _T0 = time.perf_counter()
 
 
@@ -741,7 +751,12 @@ def main():
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; see the file's note)
                 with open(pmc) as f:
                     pj = json.load(f)
-                if pj.get("layers_per_launch", rl["layers_per_launch"]) == rl["layers_per_launch"]:
+                sha = kernel_source_sha256()
+                if pj.get("layers_per_launch", rl["layers_per_launch"]) != rl["layers_per_launch"]:
+                    traffic_src = "stale: profiles/pmc_dit_forward_kernel.json was collected with another number of layers per launch"
+                elif pj.get("kernel_source_sha256") not in (None, sha):
+                    traffic_src = "stale: the kernel sources changed after profiles/pmc_dit_forward_kernel.json was collected (tools/pmc_summary.py)"
+                else:
                     traffic, traffic_src = pj.get("hbm_bytes_per_launch"), "profiles/pmc_dit_forward_kernel.json"
             rl["traffic"], rl["traffic_source"] = traffic, traffic_src
             rl["traffic_ratio"] = (traffic / rl["algorithmic_hbm_bytes_per_launch"]) if traffic else None

@@ -2,6 +2,7 @@
 // sequencing of the kernels in vae_train.hpp.  The forward is the inference path (mcab.hpp) with two extra outputs; the backward
 // reads the parameters LIVE from the caller's tensors (PyTorch layouts) and writes every gradient in the same layout.
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "vae_handle.hpp"
@@ -209,18 +210,19 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ea.dz_a = k.dz_dec; ea.dz_b = dz; ea.dao = k.dao; ea.dgq = k.dgq; ea.part = k.p_ecell;
   ea.B = B; ea.n_lat = nl; ea.n_layer = L; ea.eps = eps;
   const bool wd = cell_wide();
-  {
-    static const int attr = [] {
-      int rc = 0;
+  {   // (the attribute is per device: a process that drives several GPUs sets it on each)
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
       for (const void* f : {(const void*)wide::enc_cell_fwd_kernel, (const void*)wide::enc_cell_bwd_kernel, (const void*)wide::dec_cell_fwd_kernel,
                             (const void*)wide::dec_cell_bwd_kernel})
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES) != hipSuccess) rc = 1;
-      if (hipFuncSetAttribute((const void*)wide::enc_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::PB_BYTES) != hipSuccess) rc = 1;
-      if (hipFuncSetAttribute((const void*)wide::dec_gene_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::G_BYTES) != hipSuccess) rc = 1;
-      if (hipFuncSetAttribute((const void*)wide::dec_gene_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::M_BYTES) != hipSuccess) rc = 1;
-      return rc;
-    }();
-    if (attr) return fail(SCLDM_ERR_HIP, "hipFuncSetAttribute (LDS size of the VAE training kernels) failed");
+        HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES));
+      HIP_TRY(hipFuncSetAttribute((const void*)wide::enc_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::PB_BYTES));
+      HIP_TRY(hipFuncSetAttribute((const void*)wide::dec_gene_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::G_BYTES));
+      HIP_TRY(hipFuncSetAttribute((const void*)wide::dec_gene_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::M_BYTES));
+      if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+    }
   }
   if (wd) {
     wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(ea);

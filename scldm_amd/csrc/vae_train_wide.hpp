@@ -1236,9 +1236,16 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
       const int it = wave & 1, mtx = wave >> 1;
       const float* Wm = S + (mtx ? G_W2 : G_W1);
       const float* Dm = S + (mtx ? G_DB : G_DA);
-      f32x4 acc = kZero4;
-#pragma unroll 8
-      for (int s = 0; s < 24; ++s) acc = mfma16(Dm[li * kQ + 4 * s + g4], Wm[(4 * s + g4) * kP + 16 * it + li], acc);
+      // k slot (s, g4) <-> hidden unit u = 16 (s >> 2) + 4 g4 + (s & 3): the two weight rows a 32-lane group reads are 4 rows = 16 banks
+      // apart (4 s + g4 would put them 4 banks apart: two-way conflicts); two accumulator chains keep the pipe fed
+      f32x4 acc = kZero4, acc2 = kZero4;
+#pragma unroll 6
+      for (int s = 0; s < 24; s += 2) {
+        const int u0 = 16 * (s >> 2) + 4 * g4 + (s & 3), u1 = u0 + 1;
+        acc = mfma16(Dm[li * kQ + u0], Wm[u0 * kP + 16 * it + li], acc);
+        acc2 = mfma16(Dm[li * kQ + u1], Wm[u1 * kP + 16 * it + li], acc2);
+      }
+      acc += acc2;
       float* Pt = S + (mtx ? G_DQQ : G_TX);
 #pragma unroll
       for (int r = 0; r < 4; ++r) Pt[(4 * g4 + r) * kP + 16 * it + li] = acc[r];
@@ -1315,7 +1322,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
         const int idx = wave + 4 * n, ot = idx >> 1, it = idx & 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int tk = 4 * s + g4;
+          const int tk = s + 4 * g4;       // (k slot <-> gene: rows 4 apart = 16 banks apart within a 32-lane group: conflict-free)
           const float x = S[G_H2 + tk * kP + 16 * it + li];
           gw1[n] = mfma16(S[G_DA + tk * kQ + 16 * ot + li], x, gw1[n]);
           gw2[n] = mfma16(S[G_DB + tk * kQ + 16 * ot + li], x, gw2[n]);
@@ -1324,7 +1331,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
       const int ot = wave >> 1, it = wave & 1;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int tk = 4 * s + g4;
+        const int tk = s + 4 * g4;
         gq = mfma16(S[G_DQQ + tk * kP + 16 * ot + li], S[G_QN + tk * kP + 16 * it + li], gq);
         gp = mfma16(S[G_DY + tk * kP + 16 * ot + li], S[G_AO + tk * kP + 16 * it + li], gp);
         // head `wave` of the cell's keys: D[key 4 g4 + r][column 16 (wave >> 1) + li], useful where (li >> 3) == (wave & 1)

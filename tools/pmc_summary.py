@@ -2,7 +2,7 @@
 """Fold the per-pass PMC listings of tools/collect_evidence.sh (gpurun_out/<tag>_pmc_*.txt) into one JSON summary of the fused
 DiT kernel: profiles/<tag>_pmc_dit_forward_kernel.json and profiles/pmc_dit_forward_kernel.json (the file bench.py reads
 `roofline.traffic` from).   usage: tools/pmc_summary.py <tag> [layers_per_launch]"""
-import json, os, re, sys
+import hashlib, json, os, re, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -29,6 +29,9 @@ out = {
     "write_bytes_per_launch": None if write_kb is None else write_kb * 1024,
     "hbm_bytes_per_launch": None if fetch_kb is None or write_kb is None else 2 * fetch_kb * 1024 + write_kb * 1024,
     "algorithmic_hbm_bytes_per_launch": alg,
+    # bench.py reports `roofline.traffic` from this file only while the kernel's sources are the ones that were profiled
+    "kernel_source_sha256": hashlib.sha256(b"".join(open(os.path.join(root, "scldm_amd", "csrc", f), "rb").read()
+                                                    for f in ("dit_forward.hpp", "common.hpp"))).hexdigest(),
     "sq_counters_per_launch": {k: v for k, v in vals.items() if k.startswith("SQ_") or k.startswith("GRBM") or k.startswith("TCC")},
     "note": f"round {tag}: separate rocprofv3 --pmc passes (SQ set 1; SQ set 2 + GRBM; FETCH_SIZE; WRITE_SIZE + TCC hit/miss) with --kernel-trace only, "
             "tools/rocprof_pmc.sh over tests/perf/dit_profile.py (default bench workload, 6 evaluations, all launches averaged: the first launch of an "
