@@ -75,6 +75,9 @@ extern "C" void scldm_vae_destroy(scldm_vae* h) {
   void* more[] = {h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty};
   for (void* p : more)
     if (p) (void)hipFree(p);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (hipEvent_t e : {h->ev_fork, h->ev_gene, h->ev_join})
+    if (e) (void)hipEventDestroy(e);
   delete h;
 }
 

@@ -29,6 +29,10 @@ struct scldm_vae {
   int* d_dirty;                 // [0] re-pack?, [1] force
   // sources of the two derived tables (enc_qfrag_kernel, dec_qtab_kernel)
   const float *q_ind, *q_eln_w, *q_eln_b, *q_ewq, *q_dln_w, *q_dln_b, *q_dwq;
+  // training backward: the recompute forwards of the 16-token sides and the per-gene partial reduction run on a second stream
+  // beside the per-gene backward (created on first use by scldm_vae_train_backward)
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_gene, ev_join;
 };
 
 // vae_api.hip internals used by the training entry points: TransformerVAE.encode that also leaves the pooling's attention output

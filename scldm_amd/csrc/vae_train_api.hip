@@ -55,7 +55,7 @@ bool gene_wide() {
 }
 
 struct Ws {
-  float *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
+  float *kv_fwd, *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
   int tilesD, chunksD, tilesE, chunksE, quads, cparts;
   size_t bytes;
 };
@@ -67,6 +67,7 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   split_tiles(G, B, &w.tilesD, &w.chunksD, gene_wide() ? 1024 : 2048);
   split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? 1024 : 2048);   // (the second version's workgroups are four waves)
   w.quads = cdiv(B, 4);
+  w.kv_fwd = k.take((size_t)B * 48 * 64);   // the forward's decode left the cells' K | V here ((B, 16, 64) floats at offset 0: vae_decode_impl)
   w.wct = k.take((size_t)(2 + 2 * L) * kHP * 32);
   w.Q = k.take(512);
   w.dQ = k.take(512);
@@ -224,24 +225,40 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
       if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
   }
+  // The recompute forwards of the two 16-token sides (B workgroups each) only feed the cell-side backward kernels: they run on a second
+  // stream beside the head and per-gene backward, which take the cells' K | V from the buffer the forward's decode left behind.
+  static const bool overlap = [] { const char* e = getenv("SCLDM_VAE_TRAIN_OVERLAP"); return !(e && e[0] == '0'); }();
+  hipStream_t s2 = st;
+  if (overlap) {
+    if (!h->side) {
+      HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_gene, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    s2 = h->side;
+    HIP_TRY(hipEventRecord(h->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(s2, h->ev_fork, 0));
+  }
   if (wd) {
-    wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(ea);
-  } else enc_cell_fwd_kernel<<<k.quads, 64, 0, st>>>(ea);
+    wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, s2>>>(ea);
+  } else enc_cell_fwd_kernel<<<k.quads, 64, 0, s2>>>(ea);
   LAUNCH_CHECK();
   DecCellTrainArgs da{};
   da.z = z; da.w_in = w->dec_latent_w; da.blocks = blocks_of(w->dec_blocks, L, wct(2 + L), H);
   da.cln1_w = w->dec_cross.ln1_w; da.cln1_b = w->dec_cross.ln1_b; da.wkv = w->dec_cross.attn_kv;
   da.xsave = k.xs_dec; da.kv = k.kv; da.dkv_part = k.p_dkv; da.chunks = k.chunksD; da.dz = k.dz_dec; da.part = k.p_dcell;
   da.B = B; da.n_lat = nl; da.n_layer = L; da.eps = eps;
-  if (wd) wide::dec_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(da);
-  else if (nl <= 16) dec_cell_fwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
-  else dec_cell_fwd_kernel<32><<<k.quads, 64, 0, st>>>(da);
+  if (wd) wide::dec_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, s2>>>(da);
+  else if (nl <= 16) dec_cell_fwd_kernel<16><<<k.quads, 64, 0, s2>>>(da);
+  else dec_cell_fwd_kernel<32><<<k.quads, 64, 0, s2>>>(da);
   LAUNCH_CHECK();
+  if (overlap) HIP_TRY(hipEventRecord(h->ev_join, s2));
   // ---- NB head, then the per-gene decoder chain
   head_bwd_kernel<<<B, 256, 0, st>>>(mu, theta, dmu, dtheta, library_size, genes, G, 1.0f / c.nb_temperature, k.dl, g_theta, k.bsum);
   LAUNCH_CHECK();
   DecBwdArgs ga{};
-  ga.genes = genes; ga.emb = w->gene_embedding; ga.dl = k.dl; ga.kv = k.kv;
+  ga.genes = genes; ga.emb = w->gene_embedding; ga.dl = k.dl; ga.kv = overlap ? k.kv_fwd : k.kv;
   ga.ln1q_w = w->dec_cross.ln1q_w; ga.ln1q_b = w->dec_cross.ln1q_b; ga.wq = w->dec_cross.attn_q; ga.wp = w->dec_cross.attn_proj;
   ga.ln2_w = w->dec_cross.ln2_w; ga.ln2_b = w->dec_cross.ln2_b; ga.head_w = w->head_w;
   ga.mlp = mlp_of(w->dec_cross.w1, w->dec_cross.w2, wct(1), H);
@@ -251,6 +268,10 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   else if (gene_wide()) wide::dec_gene_bwd_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::G_BYTES, st>>>(ga);
   else dec_gene_bwd_kernel<<<dim3(k.chunksD, B), 64, 0, st>>>(ga);
   LAUNCH_CHECK();
+  if (overlap) {
+    HIP_TRY(hipEventRecord(h->ev_gene, st));
+    HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+  }
   if (wd) wide::dec_cell_bwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, st>>>(da);
   else if (nl <= 16) dec_cell_bwd_kernel<16><<<k.quads, 64, 0, st>>>(da);
   else dec_cell_bwd_kernel<32><<<k.quads, 64, 0, st>>>(da);
@@ -282,10 +303,13 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     j.vec(G_(gc.ln2_w), DP_LN2W, 32);
     j.vec(G_(gc.ln2_b), DP_LN2B, 32);
     j.vec(G_(g->head_w), DP_HEADW, 32);
-    if ((rc = j.run(k.p_gene, B * k.chunksD, DP_SIZE, st))) return rc;
+    // (on the second stream, beside the cell-side backward kernels: it only needs the per-gene kernel's partials)
+    if (overlap) HIP_TRY(hipStreamWaitEvent(s2, h->ev_gene, 0));
+    if ((rc = j.run(k.p_gene, B * k.chunksD, DP_SIZE, s2))) return rc;
     Jobs jb;
     jb.vec(G_(g->head_b), 0, 1);
-    if ((rc = jb.run(k.bsum, B, 1, st))) return rc;
+    if ((rc = jb.run(k.bsum, B, 1, s2))) return rc;
+    if (overlap) HIP_TRY(hipEventRecord(h->ev_fork, s2));   // (re-used as the final join)
   }
   {
     Jobs j;   // decoder cell side
@@ -325,6 +349,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
                                        G_(g->enc_cross.attn_q), G_(g->enc_cross.ln1q_w), G_(g->enc_cross.ln1q_b), G_(g->inducing_points));
     LAUNCH_CHECK();
   }
+  if (overlap) HIP_TRY(hipStreamWaitEvent(st, h->ev_fork, 0));
   return SCLDM_OK;
 }
 
