@@ -240,6 +240,15 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     HIP_TRY(hipEventRecord(h->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s2, h->ev_fork, 0));
   }
+  // whatever path leaves this function, the caller's stream waits for everything the second stream was given (the caller frees the
+  // workspace in stream order of `st` only)
+  struct JoinSide {
+    scldm_vae* h; hipStream_t st; bool on;
+    ~JoinSide() {
+      if (!on) return;
+      if (hipEventRecord(h->ev_fork, h->side) == hipSuccess) (void)hipStreamWaitEvent(st, h->ev_fork, 0);
+    }
+  } join_side{h, st, overlap};
   if (wd) {
     wide::enc_cell_fwd_kernel<<<B, wide::kThreads, wide::LDS_BYTES, s2>>>(ea);
   } else enc_cell_fwd_kernel<<<k.quads, 64, 0, s2>>>(ea);
@@ -309,7 +318,6 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     Jobs jb;
     jb.vec(G_(g->head_b), 0, 1);
     if ((rc = jb.run(k.bsum, B, 1, s2))) return rc;
-    if (overlap) HIP_TRY(hipEventRecord(h->ev_fork, s2));   // (re-used as the final join)
   }
   {
     Jobs j;   // decoder cell side
@@ -349,8 +357,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
                                        G_(g->enc_cross.attn_q), G_(g->enc_cross.ln1q_w), G_(g->enc_cross.ln1q_b), G_(g->inducing_points));
     LAUNCH_CHECK();
   }
-  if (overlap) HIP_TRY(hipStreamWaitEvent(st, h->ev_fork, 0));
-  return SCLDM_OK;
+  return SCLDM_OK;   // (join_side: `st` waits for the second stream)
 }
 
 extern "C" int scldm_nb_loglik(const float* x, const float* mu, const float* theta, float eps, float* out, size_t n, void* stream_) {
