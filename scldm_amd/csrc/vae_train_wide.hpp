@@ -139,7 +139,11 @@ __device__ __forceinline__ void copy_small(float* __restrict__ dst, const float*
 }
 
 // ---- the three contractions -----------------------------------------------------------------------------------------------------------
-// y[o] = W[o][:] . x for o = j, j + 16, ...: f(m, o, value)
+// y[o] = W[o][:] . x for o = j, j + 16, ...: f(m, o, value).  k-outer with the next k piece of every output row requested before
+// this piece's FMAs (one wave per SIMD: nothing else hides the LDS latency; SCLDM_VAE_LIN_PIPE=0 = one output row at a time).
+#ifndef SCLDM_VAE_LIN_PIPE
+#define SCLDM_VAE_LIN_PIPE 1
+#endif
 template <int OUT, class F>
 __device__ __forceinline__ void lin32(const float* __restrict__ W, const float* __restrict__ xrow, int j, F f) {
   f32x4 x[8];
@@ -159,6 +163,40 @@ __device__ __forceinline__ void lin32(const float* __restrict__ W, const float* 
     f(m, o, s0 + s1);
   }
 }
+// the cell-side kernels' form (one wave per SIMD, registers to spare): all output rows advance together
+template <int OUT, class F>
+__device__ __forceinline__ void lin32p(const float* __restrict__ W, const float* __restrict__ xrow, int j, F f) {
+#if SCLDM_VAE_LIN_PIPE
+  constexpr int NO = OUT / 16;
+  f32x4 x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = v4(xrow)[q];
+  f32x4 wc[NO], wn[NO];
+  float s[NO];
+#pragma unroll
+  for (int m = 0; m < NO; ++m) { wc[m] = *v4(W + (j + 16 * m) * kP); s[m] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (q < 7) {
+#pragma unroll
+      for (int m = 0; m < NO; ++m) wn[m] = *v4(W + (j + 16 * m) * kP + 4 * (q + 1));
+    }
+#pragma unroll
+    for (int m = 0; m < NO; ++m) {
+      s[m] = fmaf(wc[m][0], x[q][0], s[m]); s[m] = fmaf(wc[m][1], x[q][1], s[m]);
+      s[m] = fmaf(wc[m][2], x[q][2], s[m]); s[m] = fmaf(wc[m][3], x[q][3], s[m]);
+    }
+    if (q < 7) {
+#pragma unroll
+      for (int m = 0; m < NO; ++m) wc[m] = wn[m];
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < NO; ++m) f(m, j + 16 * m, s[m]);
+#else
+  lin32<OUT>(W, xrow, j, f);
+#endif
+}
 // acc[c] += sum over the rows o with ((o >> 3) & 1) == (j >> 3) of W[o][4 (j & 7) + c] dy[o]   (finish with half_sum4)
 template <int OUT>
 __device__ __forceinline__ void lin32_t_acc(const float* __restrict__ W, const float* __restrict__ dyrow, int j, f32x4& acc) {
@@ -172,6 +210,37 @@ __device__ __forceinline__ void lin32_t_acc(const float* __restrict__ W, const f
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = fma4(d[e], *v4(W + (o0 + e) * kP + 4 * ib), acc);
     }
+}
+// the cell-side kernels' form: the next group's five loads are requested before this group's FMAs, two accumulator chains
+template <int OUT>
+__device__ __forceinline__ void lin32_t_accp(const float* __restrict__ W, const float* __restrict__ dyrow, int j, f32x4& acc) {
+#if SCLDM_VAE_LIN_PIPE
+  const int ib = j & 7, hf = j >> 3;
+  constexpr int NG = OUT / 8;          // groups of four output rows: o0 = 16 (t >> 1) + 8 hf + 4 (t & 1)
+  f32x4 dc = *v4(dyrow + 8 * hf), wc[4], dn = dc, wn[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { wc[e] = *v4(W + (8 * hf + e) * kP + 4 * ib); wn[e] = wc[e]; }
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    if (t + 1 < NG) {
+      const int o1 = 16 * ((t + 1) >> 1) + 8 * hf + 4 * ((t + 1) & 1);
+      dn = *v4(dyrow + o1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wn[e] = *v4(W + (o1 + e) * kP + 4 * ib);
+    }
+    acc = fma4(dc[0], wc[0], acc);
+    acc2 = fma4(dc[1], wc[1], acc2);
+    acc = fma4(dc[2], wc[2], acc);
+    acc2 = fma4(dc[3], wc[3], acc2);
+    dc = dn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wc[e] = wn[e];
+  }
+  acc += acc2;
+#else
+  lin32_t_acc<OUT>(W, dyrow, j, acc);
+#endif
 }
 // dW[o][i] = sum_t DY[t][o] X[t][i] for o = tid >> 3 (+ 32 m), i = 4 (tid & 7) .. + 3; stored at dst[o * ld_o + i * ld_i]
 template <int OUT>
@@ -238,7 +307,7 @@ __device__ __forceinline__ void block_front(const BlockW& w, float* __restrict__
   S[A_HN + tok * kP + j] = fmaf(b.n1.h0, w.ln1_w[j], w.ln1_b[j]);
   S[A_HN + tok * kP + j + 16] = fmaf(b.n1.h1, w.ln1_w[j + 16], w.ln1_b[j + 16]);
   tsync();
-  lin32<96>(S + W_QKV, S + A_HN + tok * kP, j, [&](int, int o, float v) { S[A_QKV + tok * kQ + o] = v; });
+  lin32p<96>(S + W_QKV, S + A_HN + tok * kP, j, [&](int, int o, float v) { S[A_QKV + tok * kQ + o] = v; });
   __syncthreads();
   {
     const int h = j >> 1, kh = j & 1;
@@ -265,7 +334,7 @@ __device__ __forceinline__ void block_front(const BlockW& w, float* __restrict__
     if (kh == 0) *v4(S + A_AO + tok * kP + 4 * h) = ao;
   }
   tsync();
-  lin32<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = b.x0 + v; else b.m1 = b.x1 + v; });
+  lin32p<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = b.x0 + v; else b.m1 = b.x1 + v; });
   b.n2 = ln_own(b.m0, b.m1, eps);
   S[A_H2 + tok * kP + j] = fmaf(b.n2.h0, w.ln2_w[j], w.ln2_b[j]);
   S[A_H2 + tok * kP + j + 16] = fmaf(b.n2.h1, w.ln2_w[j + 16], w.ln2_b[j + 16]);
@@ -275,13 +344,13 @@ __device__ __forceinline__ void block_front(const BlockW& w, float* __restrict__
 // SwiGLU forward from H2: returns MLP(h2) for the lane's two features (through A_DH2 as the exchange row)
 __device__ __forceinline__ void mlp_forward(float* __restrict__ S, int tok, int j, float& y0, float& y1) {
   float a[6], g[6];
-  lin32<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
-  lin32<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
+  lin32p<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
+  lin32p<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
 #pragma unroll
   for (int m = 0; m < 6; ++m) S[A_HID + tok * kQ + j + 16 * m] = a[m] * sigm(a[m]) * g[m];
   tsync();
   f32x4 acc = kZero4;
-  lin32_t_acc<96>(S + W_CT, S + A_HID + tok * kQ, j, acc);
+  lin32_t_accp<96>(S + W_CT, S + A_HID + tok * kQ, j, acc);
   acc = half_sum4(acc);
   if (j < 8) *v4(S + A_DH2 + tok * kP + 4 * j) = acc;
   tsync();
@@ -294,9 +363,9 @@ __device__ __forceinline__ void mlp_forward(float* __restrict__ S, int tok, int 
 // the gradient w.r.t. the LN_2 input INCLUDING the residual path (d0 / d1 updated in place).
 __device__ __forceinline__ void mlp_back(float* __restrict__ S, int DM, const float* __restrict__ ln2_w, const Ln& n2, int tok, int j, float& d0, float& d1) {
   float a[6], g[6];
-  lin32<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
-  lin32<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
-  lin32<96>(S + W_CT, S + DM + tok * kP, j, [&](int m, int o, float dh) {
+  lin32p<96>(S + W_1, S + A_H2 + tok * kP, j, [&](int m, int, float v) { a[m] = v; });
+  lin32p<96>(S + W_2, S + A_H2 + tok * kP, j, [&](int m, int, float v) { g[m] = v; });
+  lin32p<96>(S + W_CT, S + DM + tok * kP, j, [&](int m, int o, float dh) {
     const float s = sigm(a[m]), sa = a[m] * s;
     S[A_HID + tok * kQ + o] = sa * g[m];
     S[A_DA + tok * kQ + o] = dh * g[m] * (s * (1.0f + a[m] * (1.0f - s)));
@@ -304,8 +373,8 @@ __device__ __forceinline__ void mlp_back(float* __restrict__ S, int DM, const fl
   });
   tsync();
   f32x4 acc = kZero4;
-  lin32_t_acc<96>(S + W_1, S + A_DA + tok * kQ, j, acc);
-  lin32_t_acc<96>(S + W_2, S + A_DB + tok * kQ, j, acc);
+  lin32_t_accp<96>(S + W_1, S + A_DA + tok * kQ, j, acc);
+  lin32_t_accp<96>(S + W_2, S + A_DB + tok * kQ, j, acc);
   acc = half_sum4(acc);
   if (j < 8) *v4(S + A_DH2 + tok * kP + 4 * j) = acc;
   tsync();
@@ -325,7 +394,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
   tsync();
   {
     f32x4 acc = kZero4;
-    lin32_t_acc<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
+    lin32_t_accp<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DAO + tok * kP + 4 * j) = acc;
   }
@@ -370,7 +439,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
   tsync();
   {
     f32x4 acc = kZero4;
-    lin32_t_acc<96>(S + W_QKV, S + A_DQKV + tok * kQ, j, acc);
+    lin32_t_accp<96>(S + W_QKV, S + A_DQKV + tok * kQ, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
   }
@@ -457,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_fwd_kernel(const DecCellTra
   S[A_X + tok * kP + j + 16] = zn1;
   __syncthreads();
   BlockState b;
-  lin32<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.x0 = v; else b.x1 = v; });
+  lin32p<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.x0 = v; else b.x1 = v; });
   float* XS = a.xsave + ((size_t)cell * (L + 1) * kT + tok) * 32;
   for (int l = 0; l < L; ++l) {
     XS[(size_t)l * kT * 32 + j] = b.x0;
@@ -474,7 +543,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_fwd_kernel(const DecCellTra
   S[A_HN + tok * kP + j + 16] = fmaf(n.h1, a.cln1_w[j + 16], a.cln1_b[j + 16]);
   tsync();
   float* kv = a.kv + ((size_t)cell * kT + tok) * 64;
-  lin32<64>(S + W_E1, S + A_HN + tok * kP, j, [&](int, int o, float v) { kv[o] = v; });
+  lin32p<64>(S + W_E1, S + A_HN + tok * kP, j, [&](int, int o, float v) { kv[o] = v; });
 }
 
 __global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTrainArgs a) {
@@ -510,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTra
   __syncthreads();
   {
     f32x4 acc = kZero4;
-    lin32_t_acc<64>(S + W_E1, S + A_DQKV + tok * kQ, j, acc);
+    lin32_t_accp<64>(S + W_E1, S + A_DQKV + tok * kQ, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
   }
@@ -545,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTra
   S[A_X + tok * kP + j + 16] = zn1;
   {
     f32x4 acc = kZero4;
-    lin32_t_acc<32>(S + W_E2, S + DM + tok * kP, j, acc);
+    lin32_t_accp<32>(S + W_E2, S + DM + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
   }
@@ -592,7 +661,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_fwd_kernel(const EncCellTra
   LayerCopy lc;
   if (L > 0) lc.load(a.blocks.b[0], tid);
   BlockState b;
-  lin32<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = a.ind[tok * 32 + j] + v; else b.m1 = a.ind[tok * 32 + j + 16] + v; });
+  lin32p<32>(S + W_P, S + A_AO + tok * kP, j, [&](int m, int, float v) { if (m == 0) b.m0 = a.ind[tok * 32 + j] + v; else b.m1 = a.ind[tok * 32 + j + 16] + v; });
   float* ys = a.ysave + ((size_t)cell * kT + tok) * 32;
   ys[j] = b.m0;
   ys[j + 16] = b.m1;
@@ -637,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
   float d0, d1;
   {
     float zl0 = 0.f, zl1 = 0.f, zn0, zn1, rz;
-    lin32<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) zl0 = v; else zl1 = v; });
+    lin32p<32>(S + W_E2, S + A_X + tok * kP, j, [&](int m, int, float v) { if (m == 0) zl0 = v; else zl1 = v; });
     latent_ln(zl0, zl1, a.n_lat, j, a.eps, zn0, zn1, rz);
     const bool in0 = j < a.n_lat, in1 = j + 16 < a.n_lat;
     const size_t zi = ((size_t)cell * kT + tok) * a.n_lat;
@@ -649,7 +718,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
     S[A_DX1 + tok * kP + j + 16] = in1 ? rz * (g1 - sa - zn1 * sb) : 0.f;
     tsync();
     f32x4 acc = kZero4;
-    lin32_t_acc<32>(S + W_E2, S + A_DX1 + tok * kP, j, acc);
+    lin32_t_accp<32>(S + W_E2, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
     tsync();
@@ -693,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
   tsync();
   {
     f32x4 acc = kZero4;
-    lin32_t_acc<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
+    lin32_t_accp<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);                                    // d ao[4 (j & 7) .. + 3]
     if (j < 8) {
       *v4(a.dao + ((size_t)cell * kT + tok) * 32 + 4 * j) = acc;
