@@ -369,7 +369,7 @@ int scldm_nb_sample(const float* mu, const float* theta, float* out, size_t n, u
  * -log_nb_positive(counts, mu, theta), models.py:243, src/scldm/distributions.py:6-42).  fp32.
  *   forward : (mu, theta, z) = TransformerVAE.forward(counts, genes, library_size, counts_subset, genes_subset) - the inference
  *             kernels - and leaves in `saved` what the backward cannot recompute cheaply (the pooling's attention output and
- *             log-sum-exp); uses the packed weights of the last scldm_vae_load_weights (call it after every optimiser step).
+ *             log-sum-exp) or should not wait for (the decoder's per-cell K | V); `ws` need not survive the call; uses the packed weights of the last scldm_vae_load_weights (call it after every optimiser step).
  *   backward: given d loss / d mu, d theta (B, G; either may be NULL) and optionally d loss / d z (B, 16, n_lat), writes d loss / d
  *             parameter for EVERY tensor named in `g` (same struct and layouts as scldm_vae_weights, pointers writable; overwritten,
  *             not accumulated; enc_pos_embed is ignored: frozen in the reference, nnets.py:103-106).  Parameters are read LIVE from

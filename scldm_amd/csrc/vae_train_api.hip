@@ -32,12 +32,13 @@ void split_tiles(int n_tok, int B, int* tiles, int* chunks, int wgs = 2048) {
   *chunks = cdiv(per_cell, *tiles);
 }
 
-struct Saved { float *pooled, *lse2; size_t bytes; };
+struct Saved { float *pooled, *lse2, *kv; size_t bytes; };
 Saved carve_saved(int B, void* base) {
   Carver c{reinterpret_cast<char*>(base)};
   Saved s;
   s.pooled = c.take((size_t)B * kT * 32);
   s.lse2 = c.take((size_t)B * 64);
+  s.kv = c.take((size_t)B * kT * 64);   // K | V of the cells' latent tokens (the decode's plain (B, 16, 64) copy), for the per-gene backward
   s.bytes = c.off;
   return s;
 }
@@ -55,7 +56,7 @@ bool gene_wide() {
 }
 
 struct Ws {
-  float *kv_fwd, *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
+  float *wct, *Q, *dQ, *xs_enc, *xs_dec, *ysave, *kv, *dl, *dz_dec, *dao, *dgq, *bsum, *p_gene, *p_dkv, *p_dcell, *p_ecell, *p_pool;
   int tilesD, chunksD, tilesE, chunksE, quads, cparts;
   size_t bytes;
 };
@@ -67,7 +68,6 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   split_tiles(G, B, &w.tilesD, &w.chunksD, gene_wide() ? 1024 : 2048);
   split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? 1024 : 2048);   // (the second version's workgroups are four waves)
   w.quads = cdiv(B, 4);
-  w.kv_fwd = k.take((size_t)B * 48 * 64);   // the forward's decode left the cells' K | V here ((B, 16, 64) floats at offset 0: vae_decode_impl)
   w.wct = k.take((size_t)(2 + 2 * L) * kHP * 32);
   w.Q = k.take(512);
   w.dQ = k.take(512);
@@ -167,7 +167,12 @@ extern "C" int scldm_vae_train_forward(scldm_vae* h, const float* counts_subset,
   Saved s = carve_saved(B, saved_);
   int rc = scldm_vae_encode_ex(h, counts_subset, genes_subset, B, S, z, SCLDM_PREC_FP32, s.pooled, s.lse2, st);
   if (rc) return rc;
-  return scldm_vae_decode(h, z, genes, library_size, B, G, mu, theta, SCLDM_PREC_FP32, ws, stream_);
+  rc = scldm_vae_decode(h, z, genes, library_size, B, G, mu, theta, SCLDM_PREC_FP32, ws, stream_);
+  if (rc) return rc;
+  // the decode's fp32 route leaves the cells' plain K | V at the start of its workspace (vae_api.hip: vae_decode_impl): keep a copy in
+  // `saved` so that the per-gene backward does not wait for the recompute forward (4 KB per cell)
+  HIP_TRY(hipMemcpyAsync(s.kv, ws, (size_t)B * kT * 64 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SCLDM_OK;
 }
 
 extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w, const scldm_vae_weights* g, const float* counts_subset,
@@ -226,7 +231,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
     }
   }
   // The recompute forwards of the two 16-token sides (B workgroups each) only feed the cell-side backward kernels: they run on a second
-  // stream beside the head and per-gene backward, which take the cells' K | V from the buffer the forward's decode left behind.
+  // stream beside the head and per-gene backward, which take the cells' K | V from the copy the forward left in `saved`.
   static const bool overlap = [] { const char* e = getenv("SCLDM_VAE_TRAIN_OVERLAP"); return !(e && e[0] == '0'); }();
   hipStream_t s2 = st;
   if (overlap) {
@@ -267,7 +272,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   head_bwd_kernel<<<B, 256, 0, st>>>(mu, theta, dmu, dtheta, library_size, genes, G, 1.0f / c.nb_temperature, k.dl, g_theta, k.bsum);
   LAUNCH_CHECK();
   DecBwdArgs ga{};
-  ga.genes = genes; ga.emb = w->gene_embedding; ga.dl = k.dl; ga.kv = overlap ? k.kv_fwd : k.kv;
+  ga.genes = genes; ga.emb = w->gene_embedding; ga.dl = k.dl; ga.kv = overlap ? sv.kv : k.kv;
   ga.ln1q_w = w->dec_cross.ln1q_w; ga.ln1q_b = w->dec_cross.ln1q_b; ga.wq = w->dec_cross.attn_q; ga.wp = w->dec_cross.attn_proj;
   ga.ln2_w = w->dec_cross.ln2_w; ga.ln2_b = w->dec_cross.ln2_b; ga.head_w = w->head_w;
   ga.mlp = mlp_of(w->dec_cross.w1, w->dec_cross.w2, wct(1), H);
