@@ -6,6 +6,7 @@
 // (:91-94), SelfAttention (:143-158), MLP (:161-174), FinalLayerDit (:397-401), TimestepEmbedder (:351-364),
 // DiT.forward (src/scldm/nnets.py:273-297).  The reference gets its gradients from torch autograd.
 #pragma once
+#include <type_traits>
 #include "../../include/scldm_hip.h"
 #include "common.hpp"
 
@@ -265,29 +266,35 @@ struct TileLoaderBF {
 #pragma unroll
         for (int i = 0; i < 8; ++i) rs[e] += f[g * kFPT + e][i];
   }
-  __device__ __forceinline__ void store(__bf16* __restrict__ S /* [BM][kLDH] */) const {
+  // E = __bf16 or _Float16: the 16-bit type the operands are rounded to while staged
+  template <typename E>
+  __device__ __forceinline__ void store(E* __restrict__ S /* [BM][kLDH] */) const {
+    typedef __attribute__((ext_vector_type(8))) E Ex8;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < kSlots; ++j) {
-      bf16x8 v;
+      Ex8 v;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[j][i];
+      for (int i = 0; i < 8; ++i) v[i] = (E)f[j][i];
       if constexpr (KC) {
         const int item = tid + 256 * j;
-        *reinterpret_cast<bf16x8*>(S + (item / kKG) * kLDH + (item % kKG) * 8) = v;
+        *reinterpret_cast<Ex8*>(S + (item / kKG) * kLDH + (item % kKG) * 8) = v;
       } else {
         const int g = j / kFPT, e = j % kFPT;
-        *reinterpret_cast<bf16x8*>(S + ((tid & 63) * kFPT + e) * kLDH + ((tid >> 6) + 4 * g) * 8) = v;
+        *reinterpret_cast<Ex8*>(S + ((tid & 63) * kFPT + e) * kLDH + ((tid >> 6) + 4 * g) * 8) = v;
       }
     }
   }
 };
 
-template <int WTM, int WTN, bool A_KC, bool B_KC>
+// F16: fp16 operands (10 mantissa bits = the reference's TF32 class; v_mfma_f32_32x32x16_f16) instead of bf16 - same rate, same staging
+template <int WTM, int WTN, bool A_KC, bool B_KC, bool F16 = false>
 __global__ __launch_bounds__(256) void hgemm_kernel(GemmArgs g) {
   constexpr int BM = 64 * WTM, BN = 64 * WTN;
+  using E = typename std::conditional<F16, _Float16, __bf16>::type;
+  typedef __attribute__((ext_vector_type(8))) E Ex8;
   extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-  __bf16* const smem = reinterpret_cast<__bf16*>(gemm_smem);
+  E* const smem = reinterpret_cast<E*>(gemm_smem);
   auto As = [&](int b) { return smem + b * (BM * kLDH); };
   auto Bs = [&](int b) { return smem + 2 * BM * kLDH + b * (BN * kLDH); };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
@@ -320,19 +327,22 @@ __global__ __launch_bounds__(256) void hgemm_kernel(GemmArgs g) {
       la.load(g.A, g.sam, g.sak, m0, g.M, k0 + kBKH, kend);
       lb.load(g.B, g.sbn, g.sbk, n0, g.N, k0 + kBKH, kend);
     }
-    const __bf16* __restrict__ as = As(buf) + (wm * 32 * WTM + (lane & 31)) * kLDH + (lane >> 5) * 8;
-    const __bf16* __restrict__ bs = Bs(buf) + (wn * 32 * WTN + (lane & 31)) * kLDH + (lane >> 5) * 8;
+    const E* __restrict__ as = As(buf) + (wm * 32 * WTM + (lane & 31)) * kLDH + (lane >> 5) * 8;
+    const E* __restrict__ bs = Bs(buf) + (wn * 32 * WTN + (lane & 31)) * kLDH + (lane >> 5) * 8;
 #pragma unroll
     for (int kk = 0; kk < kBKH; kk += 16) {
-      bf16x8 a[WTM], b[WTN];
+      Ex8 a[WTM], b[WTN];
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * kLDH + kk);
+      for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const Ex8*>(as + i * 32 * kLDH + kk);
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * kLDH + kk);
+      for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const Ex8*>(bs + j * 32 * kLDH + kk);
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WTN; ++j) {
+          if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
     }
     if (more) {
       if constexpr (!A_KC) if (want_rs) la.add_rowsum(rs);

@@ -123,11 +123,11 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base, bool fused_path) {
 }
 
 // ---- GEMM dispatch --------------------------------------------------------------------------------------------
-template <bool BF, int WTM, int WTN, bool A_KC, bool B_KC>
-int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
+template <int BF, int WTM, int WTN, bool A_KC, bool B_KC>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {   // BF: 0 exact fp32, 1 bf16 operands, 2 fp16 operands
   static std::atomic<bool> attr_set[kMaxDevices];   // the attribute is per device (and per function): one flag each
   constexpr int smem = BF ? hgemm_smem_bytes<WTM, WTN>() : gemm_smem_bytes<WTM, WTN>();
-  auto kern = BF ? hgemm_kernel<WTM, WTN, A_KC, B_KC> : sgemm_kernel<WTM, WTN, A_KC, B_KC>;
+  auto kern = BF == 2 ? hgemm_kernel<WTM, WTN, A_KC, B_KC, true> : BF == 1 ? hgemm_kernel<WTM, WTN, A_KC, B_KC, false> : sgemm_kernel<WTM, WTN, A_KC, B_KC>;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev].load(std::memory_order_acquire)) {
@@ -141,7 +141,7 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t st) {
 }
 
 // C[M,N] (ldc) (+)= A(m,k) B(n,k) (+ bias[n]); element strides as in train.hpp.  `part` = split-K scratch.
-thread_local bool g_bf16 = false;   // operand precision of the GEMMs of the call in progress (SCLDM_PREC_*)
+thread_local int g_bf16 = 0;   // operand precision of the GEMMs of the call in progress: 0 exact fp32, 1 bf16, 2 fp16 (the fused fp16 route)
 
 int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, long sbn, long sbk, float* C, long ldc, int M,
          int N, int K, const float* bias, bool accumulate, float* part, size_t part_floats, float* rowsum_out = nullptr) {
@@ -174,8 +174,9 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
 #define SCLDM_GEMM_CASE(BF, WT)                                                                                             \
   (a_kc ? (b_kc ? launch_gemm<BF, WT, WT, true, true>(g, splits, st) : launch_gemm<BF, WT, WT, true, false>(g, splits, st)) \
         : (b_kc ? launch_gemm<BF, WT, WT, false, true>(g, splits, st) : launch_gemm<BF, WT, WT, false, false>(g, splits, st)))
-  if (g_bf16) rc = big ? SCLDM_GEMM_CASE(true, 2) : SCLDM_GEMM_CASE(true, 1);
-  else rc = big ? SCLDM_GEMM_CASE(false, 2) : SCLDM_GEMM_CASE(false, 1);
+  if (g_bf16 == 2) rc = big ? SCLDM_GEMM_CASE(2, 2) : SCLDM_GEMM_CASE(2, 1);
+  else if (g_bf16) rc = big ? SCLDM_GEMM_CASE(1, 2) : SCLDM_GEMM_CASE(1, 1);
+  else rc = big ? SCLDM_GEMM_CASE(0, 2) : SCLDM_GEMM_CASE(0, 1);
 #undef SCLDM_GEMM_CASE
   if (rc != SCLDM_OK) return rc;
   if (splits > 1) {
@@ -715,7 +716,10 @@ inline int train_precision(const scldm_dit* h, int n, int precision) {
 int check_common(const scldm_dit* h, const scldm_dit_weights* w, int n, int precision, const void* saved, const void* ws) {
   if (!h || !w || !saved || !ws) return fail(SCLDM_ERR_SHAPE, "null argument");
   if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
-  g_bf16 = precision == SCLDM_PREC_BF16;   // (fp16: the GEMMs outside the fused layers are exact fp32)
+  // (fp16 reaches here only on the fused route - train_precision maps it to fp32 elsewhere: its conditioning / adaLN GEMMs run on
+  // fp16 operands too, the arithmetic class of the whole step; SCLDM_TRAIN_FP16_EXACT_SMALL=1 keeps them exact fp32)
+  static const bool f16_exact = [] { const char* e = getenv("SCLDM_TRAIN_FP16_EXACT_SMALL"); return e && e[0] == '1'; }();
+  g_bf16 = precision == SCLDM_PREC_BF16 ? 1 : (precision == SCLDM_PREC_FP16 && !f16_exact) ? 2 : 0;
   if (n < 1) return fail(SCLDM_ERR_SHAPE, "n must be >= 1");
   const scldm_dit_config& c = h->cfg;
   const int hd = c.n_head > 0 ? c.n_embed / c.n_head : 0;
