@@ -190,6 +190,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->join_ev[g]) (void)hipEventDestroy(h->join_ev[g]);
   }
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  if (h->bwd_pack_ev) (void)hipEventDestroy(h->bwd_pack_ev);
   if (h->cond_stream) (void)hipStreamDestroy(h->cond_stream);
   for (hipEvent_t ev : {h->ev_cond[0], h->ev_cond[1], h->ev_free[0], h->ev_free[1], h->ev_ready})
     if (ev) (void)hipEventDestroy(ev);

@@ -152,7 +152,8 @@ struct PackJob {
   long long d_off;      // element offset added to the destination index (layer: start of the layer's stream)
 };
 // prec_mask: bit p set = pack the streams of precision p (kPackLayer / kPackFinal jobs of other precisions are skipped - the
-// training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set (bit 9: as fp16 instead of bf16).
+// training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set (bit 9: as fp16 instead of bf16); bit 10: ONLY
+// the kPackLayerBwd jobs (the training step's second launch: the backward stream is packed beside the forward, not ahead of it).
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int n_jobs, const int* __restrict__ dirty,
                                                         unsigned prec_mask, int* __restrict__ fp16_stats = nullptr) {
   if (dirty && *dirty == 0) return;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   const PackJob& j = jobs[lo];
   const long long idx = (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
   if (idx >= j.n) return;
+  if ((prec_mask & 0x400u) && j.kind != kPackLayerBwd) return;
   switch (j.kind) {
     case kPackCopy:
       reinterpret_cast<float*>(j.d)[idx] = j.s[0][idx];

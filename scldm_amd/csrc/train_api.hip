@@ -966,6 +966,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     if (use_fused) TRY(fused::to_tile(k.dx, fs.dx, n, st));
   }
   if (use_fused) {
+    TRY(fused::backward_join(h, st));
     TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision));
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }

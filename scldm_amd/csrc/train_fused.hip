@@ -549,6 +549,7 @@ int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
       HIP_TRY(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming));
     }
   if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  if (!h->bwd_pack_ev) HIP_TRY(hipEventCreateWithFlags(&h->bwd_pack_ev, hipEventDisableTiming));
   return SCLDM_OK;
 }
 int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precision) {
@@ -558,10 +559,18 @@ int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precis
   // forked here, joined by prepare_join() before the first consumer of a packed copy.
   HIP_TRY(hipEventRecord(h->fork_ev, st));            // everything queued so far (the previous step's optimizer update) comes first
   HIP_TRY(hipStreamWaitEvent(h->side[0], h->fork_ev, 0));
+  // Two launches over the same job table: what the FORWARD reads first (its weight stream, biases, stacked adaLN copies - the main
+  // stream waits for these in prepare_join()), then the backward weight stream, which runs beside the adaLN GEMM and the recording
+  // forward and is awaited by the first backward layer (backward_join).  Measured +-0 (2.46 ms per step either way at 1 024 cells: the
+  // conditioning chain on the main stream takes as long as the whole pack), so the default stays ONE launch; SCLDM_TRAIN_PACK_SPLIT=1.
   // bit 9: the backward stream is packed as fp16 (same buffer: it is re-packed every step, in the step's operand type)
-  rc = scldm_run_pack(h, true, (1u << precision) | 0x100u | (precision == SCLDM_PREC_FP16 ? 0x200u : 0u), h->side[0]);
+  static const bool split = [] { const char* e = getenv("SCLDM_TRAIN_PACK_SPLIT"); return e && e[0] == '1'; }();
+  const unsigned bwd_bits = 0x100u | (precision == SCLDM_PREC_FP16 ? 0x200u : 0u);
+  rc = scldm_run_pack(h, true, (1u << precision) | (split ? 0u : bwd_bits), h->side[0]);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(h->join_ev[0], h->side[0]));
+  if (split && (rc = scldm_run_pack(h, true, bwd_bits | 0x400u, h->side[0]))) return rc;
+  HIP_TRY(hipEventRecord(h->bwd_pack_ev, h->side[0]));
   return SCLDM_OK;
 }
 // side stream k (created on first use) ordered after everything queued on `st` so far / `st` ordered after side stream k
@@ -583,6 +592,10 @@ int join_side(scldm_dit* h, hipStream_t st, int k) {
 }
 int prepare_join(scldm_dit* h, hipStream_t st) {
   HIP_TRY(hipStreamWaitEvent(st, h->join_ev[0], 0));
+  return SCLDM_OK;
+}
+int backward_join(scldm_dit* h, hipStream_t st) {   // the backward weight stream of this step is packed
+  if (h->bwd_pack_ev) HIP_TRY(hipStreamWaitEvent(st, h->bwd_pack_ev, 0));
   return SCLDM_OK;
 }
 

@@ -41,7 +41,8 @@ bool eligible(const scldm_dit* h, int n, int precision);   // shape, precision (
 // refresh the packed forward (bf16) and backward weight streams from the live parameters
 int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st);   // pack-job tables, side streams, events (no kernel work)
 int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precision);   // forks the re-pack (of that precision's streams) onto a side stream
-int prepare_join(scldm_dit* h, hipStream_t st);                           // `st` waits for it (before the first packed copy is read)
+int prepare_join(scldm_dit* h, hipStream_t st);
+int backward_join(scldm_dit* h, hipStream_t st);                           // `st` waits for it (before the first packed copy is read)
 // trunk forward (input projection .. final layer) with the record; mod = (n, mod_w) adaLN vectors
 int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st, int precision);
 // plain [T][256] fp32 <-> tile layout
