@@ -197,3 +197,54 @@ def test_the_selectable_earlier_kernel_versions_pass_the_same_gates(env):
     r = subprocess.run(cmd, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "8 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("n_layer,n_lat,pos,multiple_of", [(3, 24, False, 32), (1, 7, True, 8), (10, 32, True, 4)])
+def test_gradients_match_oracle_on_other_model_shapes(n_layer, n_lat, pos, multiple_of):
+    """The kernels take up to 16 trunk layers, latent widths up to 32 and SwiGLU hidden widths up to 96; the reference's config is one
+    point of that family (8 layers, 16 wide, hidden 88, positional encoding).  Others: a latent width above 16 (the second feature of a
+    lane is inside the latent LayerNorm), an odd width, no positional encoding, hidden 96 (no zero-padded units), 1 and 10 layers."""
+    from scldm_amd.layers import InputTransformerVAE
+    from scldm_amd.nnets import Decoder, Encoder
+    from scldm_amd.stochastic_layers import NegativeBinomialTransformerLayer
+    from scldm_amd.vae import TransformerVAE
+    n_genes, B, S, G = 300, 6, 90, 150
+    enc = Encoder(n_layer=n_layer, n_inducing_points=16, n_embed=32, n_embed_latent=n_lat, n_head=8, n_head_cross=4, dropout=0.0, bias=False,
+                  multiple_of=multiple_of, layernorm_eps=1e-8, norm_layer="layernorm", positional_encoding=pos)
+    dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=n_lat, n_head=8, n_head_cross=4, n_layer=n_layer, n_inducing_points=16,
+                  dropout=0.0, bias=False, multiple_of=multiple_of, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
+                  use_adaln=False)
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm", layernorm_eps=1e-8)
+    vae = TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p"))
+    sd = make_state_dict({k: tuple(v.shape) for k, v in vae.state_dict().items()}, 900 + n_layer)
+    vae.load_state_dict(sd, strict=True)
+    vae = vae.cuda().train()
+    cfg = VAEConfig(n_genes=n_genes, n_embed_latent=n_lat, n_layer=n_layer, multiple_of=multiple_of, positional_encoding=pos)
+    rng = np.random.default_rng(n_layer * 10 + n_lat)
+    genes = rng.integers(0, n_genes + 1, (B, G)).astype(np.int64)
+    counts = rng.poisson(0.9, (B, G)).astype(np.float32)
+    genes_s = rng.integers(0, n_genes + 1, (B, S)).astype(np.int64)
+    counts_s = rng.poisson(0.9, (B, S)).astype(np.float32)
+    lib = (counts.sum(1, keepdims=True) + 1.0).astype(np.float32)
+    zw = (0.3 * rng.standard_normal((B, 16, n_lat))).astype(np.float32)
+    loss, params, z = hip_step(vae, counts, genes, lib, counts_s, genes_s, z_weight=zw)
+    t = torch.from_numpy
+    loss_o, (mu_o, th_o, z_o), grads = vae_training_grads(sd, cfg, t(counts), t(genes), t(lib), t(counts_s), t(genes_s), z_weight=t(zw))
+    assert abs(float(loss) - float(loss_o)) <= TOL * abs(float(loss_o))
+    assert max_abs_rel(z.cpu(), z_o) < TOL and max_abs_rel(params["mu"].detach().cpu(), mu_o) < TOL
+    wn = float(grads["decoder_head.params.weight"].norm())
+    bad, worst = {}, 0.0
+    for name_, p in vae.named_parameters():
+        if name_ in FROZEN:
+            continue
+        ref = grads[name_]
+        if name_ == BIAS:
+            if not abs(float(p.grad)) <= 1e-3 * wn:
+                bad[name_] = float(p.grad)
+            continue
+        e = max_abs_rel(p.grad.cpu(), ref) if float(ref.abs().max()) > 0 else float(p.grad.abs().max())
+        worst = max(worst, e)
+        if not e < TOL:
+            bad[name_] = e
+    print(f"[parity] VAE training, {n_layer} layers, latent width {n_lat}, pos {pos}, hidden multiple {multiple_of}: worst gradient error {worst:.2e}")
+    assert not bad, bad
