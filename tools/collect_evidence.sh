@@ -19,6 +19,7 @@ ROCPROF_ROWS=16 bash tools/rocprof_stats.sh ${tag}_stats_ditl1024 tests/perf/tra
 timeout 300 python tests/perf/train_scale.py > ${o}_train_scale.txt 2>&1
 timeout 300 python tests/perf/train_scale.py nogc > ${o}_train_scale_nogc.txt 2>&1
 timeout 300 python tests/perf/vae_train_bench.py 32 128 512 > ${o}_vae_train_bench.txt 2>&1
+timeout 300 python tests/perf/vae_train_host.py 32 >> ${o}_vae_train_bench.txt 2>&1
 ROCPROF_ROWS=12 bash tools/rocprof_stats.sh ${tag}_stats_parse1m bench.py --workload parse1m_b1024_euler100 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > ${o}_parse1m_b1024_kernel_stats.txt 2>&1
 ROCPROF_ROWS=12 bash tools/rocprof_stats.sh ${tag}_stats_train_fp16 bench.py --workload replogle_train_b1024 --precision fp16 --steps 20 --warmup 5 > ${o}_train_fp16_b1024_kernel_stats.txt 2>&1
 timeout 120 python tests/perf/power_probe.py 4096 30 > ${o}_power_probe.txt 2>&1
