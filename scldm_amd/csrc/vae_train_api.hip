@@ -65,8 +65,13 @@ Ws carve_ws(const scldm_vae* h, int B, int S, int G, void* base) {
   const int L = c.n_layer;
   Carver k{reinterpret_cast<char*>(base)};
   Ws w;
-  split_tiles(G, B, &w.tilesD, &w.chunksD, gene_wide() ? 1024 : 2048);
-  split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? 1024 : 2048);   // (the second version's workgroups are four waves)
+  // (the second version's workgroups are four waves, two per CU: one full round of 512 measured best at batch 32 - per-gene kernel
+  // 606 us against 633-645 us with 1 024-4 096 workgroups, pooling 123 us against 130-138 us - and equal at batch 512;
+  // SCLDM_VAE_GENE_WGS / SCLDM_VAE_POOL_WGS override the target counts)
+  static const int wgs_d = [] { const char* e = getenv("SCLDM_VAE_GENE_WGS"); return e ? atoi(e) : 512; }();
+  static const int wgs_e = [] { const char* e = getenv("SCLDM_VAE_POOL_WGS"); return e ? atoi(e) : 512; }();
+  split_tiles(G, B, &w.tilesD, &w.chunksD, gene_wide() ? wgs_d : 2048);
+  split_tiles(S, B, &w.tilesE, &w.chunksE, gene_wide() ? wgs_e : 2048);
   w.quads = cdiv(B, 4);
   w.wct = k.take((size_t)(2 + 2 * L) * kHP * 32);
   w.Q = k.take(512);
