@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
 // position-dependent, order-independent (wrapping) sum - tensor blockIdx.x is split over kFpSplit workgroups.  A partial
 // `.data` write (a few rows of a class table, a masked update) therefore always moves it; the pass reads the parameters once
 // (39 MB for the base DiT: ~10 us, against >= 300 us for the smallest forward).
-constexpr int kFpSplit = 8;
+// Round 4: 32 workgroups per tensor (at least 2 048 words each), 16-byte loads with two in flight, one atomic per workgroup - with 8
+// workgroups of scalar loads a thread's loop was ~190 dependent HBM round trips on the largest tensors and the pass took 62-68 us,
+// which every Python-level forward_with_cfg (the dopri5 sampler: 110 per solve) pays.
+constexpr int kFpSplit = 32;
 struct FpSrc {
   const uint32_t* p;
   long long n;
@@ -222,17 +225,37 @@ struct FpSrc {
 __global__ __launch_bounds__(256) void fingerprint_kernel(const FpSrc* __restrict__ src, unsigned long long* __restrict__ acc) {
   const FpSrc s = src[blockIdx.x];
   if (s.n <= 0) return;
-  const long long chunk = ((s.n + kFpSplit - 1) / kFpSplit + 255) / 256 * 256;
+  long long chunk = ((s.n + kFpSplit - 1) / kFpSplit + 255) / 256 * 256;
+  if (chunk < 2048) chunk = 2048;
   const long long lo = (long long)blockIdx.y * chunk, hi = lo + chunk < s.n ? lo + chunk : s.n;
   if (lo >= s.n) return;
   unsigned long long hsum = 0;
-  for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) {
-    const unsigned long long v = s.p[pos];
+  auto mix = [&](unsigned long long v, long long pos) {
     hsum += (v + 0x9E3779B97F4A7C15ull * (unsigned long long)(pos + 1 + blockIdx.x * 7919ll)) * 0xBF58476D1CE4E5B9ull ^ (v << 29);
+  };
+  if ((reinterpret_cast<size_t>(s.p) & 15) == 0) {       // (chunk boundaries are multiples of 256 words: only the base decides)
+    const uint4* p4 = reinterpret_cast<const uint4*>(s.p);
+    const long long q_hi = hi / 4;
+    long long q = lo / 4 + threadIdx.x;
+    for (; q + 256 < q_hi; q += 512) {
+      const uint4 u = p4[q], w = p4[q + 256];
+      mix(u.x, 4 * q); mix(u.y, 4 * q + 1); mix(u.z, 4 * q + 2); mix(u.w, 4 * q + 3);
+      mix(w.x, 4 * (q + 256)); mix(w.y, 4 * (q + 256) + 1); mix(w.z, 4 * (q + 256) + 2); mix(w.w, 4 * (q + 256) + 3);
+    }
+    if (q < q_hi) {
+      const uint4 u = p4[q];
+      mix(u.x, 4 * q); mix(u.y, 4 * q + 1); mix(u.z, 4 * q + 2); mix(u.w, 4 * q + 3);
+    }
+    for (long long pos = 4 * q_hi + threadIdx.x; pos < hi; pos += 256) mix(s.p[pos], pos);
+  } else {
+    for (long long pos = lo + threadIdx.x; pos < hi; pos += 256) mix(s.p[pos], pos);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) hsum += __shfl_xor(hsum, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(acc, hsum);
+  __shared__ unsigned long long wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = hsum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 // state[0] = accumulator of the current pass, state[1] = fingerprint of the packed weights; dirty[0] = re-pack?, dirty[1] = force
 __global__ void set_word_kernel(int* p, int v) { *p = v; }
