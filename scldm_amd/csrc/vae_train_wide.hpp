@@ -90,7 +90,7 @@ __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return fmaf(a[3], b[3]
 __device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 c) { return f32x4{fmaf(s, a[0], c[0]), fmaf(s, a[1], c[1]), fmaf(s, a[2], c[2]), fmaf(s, a[3], c[3])}; }
 __device__ __forceinline__ const f32x4* v4(const float* p) { return reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4* v4(float* p) { return reinterpret_cast<f32x4*>(p); }
-#define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
+__device__ __forceinline__ f32x4 z4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // ---- weight copies into LDS ---------------------------------------------------------------------------------------------------------
 // rows of 32 floats (row-major, contiguous) -> [rows_total][kP]; rows >= rows_valid are zero.  Split into a load half (registers) and
@@ -104,7 +104,7 @@ struct RowCopy {
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       const int idx = tid + n * kThreads, row = idx >> 3;
-      f32x4 v = kZero4;
+      f32x4 v = z4();
       if (idx < ROWS * 8 && row < rows_valid) {
         if (al) v = v4(src)[idx];
         else { const float* s = src + (size_t)idx * 4; v = f32x4{s[0], s[1], s[2], s[3]}; }
@@ -248,7 +248,7 @@ __device__ __forceinline__ void wgrad(const float* __restrict__ DY, int py, cons
   const int i4 = tid & 7, oo = tid >> 3;
   f32x4 acc[OUT / 32];
 #pragma unroll
-  for (int m = 0; m < OUT / 32; ++m) acc[m] = kZero4;
+  for (int m = 0; m < OUT / 32; ++m) acc[m] = z4();
 #pragma unroll 4
   for (int t = 0; t < kT; ++t) {
     const f32x4 xv = *v4(X + t * kP + 4 * i4);
@@ -324,7 +324,7 @@ __device__ __forceinline__ void block_front(const BlockW& w, float* __restrict__
     for (int kk = 0; kk < 8; ++kk) l += __expf(s[kk] - mx);
     l = pair_sum(l);
     const float lse = mx + __logf(l);
-    f32x4 ao = kZero4;
+    f32x4 ao = z4();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       b.p[kk] = __expf(s[kk] - lse);
@@ -349,7 +349,7 @@ __device__ __forceinline__ void mlp_forward(float* __restrict__ S, int tok, int 
 #pragma unroll
   for (int m = 0; m < 6; ++m) S[A_HID + tok * kQ + j + 16 * m] = a[m] * sigm(a[m]) * g[m];
   tsync();
-  f32x4 acc = kZero4;
+  f32x4 acc = z4();
   lin32_t_accp<96>(S + W_CT, S + A_HID + tok * kQ, j, acc);
   acc = half_sum4(acc);
   if (j < 8) *v4(S + A_DH2 + tok * kP + 4 * j) = acc;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void mlp_back(float* __restrict__ S, int DM, const fl
     S[A_DB + tok * kQ + o] = dh * sa;
   });
   tsync();
-  f32x4 acc = kZero4;
+  f32x4 acc = z4();
   lin32_t_accp<96>(S + W_1, S + A_DA + tok * kQ, j, acc);
   lin32_t_accp<96>(S + W_2, S + A_DB + tok * kQ, j, acc);
   acc = half_sum4(acc);
@@ -393,7 +393,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
   S[A_DX1 + tok * kP + j + 16] = d1;
   tsync();
   {
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DAO + tok * kP + 4 * j) = acc;
@@ -409,7 +409,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
       dg = fmaf(b.p[kk], dp[kk], dg);
     }
     dg = pair_sum(dg);
-    f32x4 dq = kZero4;
+    f32x4 dq = z4();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const float ds = b.p[kk] * (dp[kk] - dg) * kTScale;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
   }
   __syncthreads();
   {   // key side: this lane's token is the KEY; queries 8 kh .. 8 kh + 7
-    f32x4 dk = kZero4, dv = kZero4;
+    f32x4 dk = z4(), dv = z4();
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
       const int t = 8 * kh + tt;
@@ -438,7 +438,7 @@ __device__ __forceinline__ void attn_back(const BlockW& w, float* __restrict__ S
   }
   tsync();
   {
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<96>(S + W_QKV, S + A_DQKV + tok * kQ, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTra
   S[A_HN + tok * kP + j + 16] = fmaf(n.h1, a.cln1_w[j + 16], a.cln1_b[j + 16]);
   __syncthreads();
   {
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<64>(S + W_E1, S + A_DQKV + tok * kQ, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kThreads) void dec_cell_bwd_kernel(const DecCellTra
   S[A_X + tok * kP + j] = zn0;
   S[A_X + tok * kP + j + 16] = zn1;
   {
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<32>(S + W_E2, S + DM + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
     S[A_DX1 + tok * kP + j] = in0 ? rz * (g0 - sa - zn0 * sb) : 0.f;          // d zl rows
     S[A_DX1 + tok * kP + j + 16] = in1 ? rz * (g1 - sa - zn1 * sb) : 0.f;
     tsync();
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<32>(S + W_E2, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);
     if (j < 8) *v4(S + A_DHN + tok * kP + 4 * j) = acc;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(kThreads) void enc_cell_bwd_kernel(const EncCellTra
   P[ec_off_ind(L) + tok * 32 + j + 16] = d1;
   tsync();
   {
-    f32x4 acc = kZero4;
+    f32x4 acc = z4();
     lin32_t_accp<32>(S + W_P, S + A_DX1 + tok * kP, j, acc);
     acc = half_sum4(acc);                                    // d ao[4 (j & 7) .. + 3]
     if (j < 8) {
@@ -822,10 +822,10 @@ __global__ __launch_bounds__(kThreads) void enc_pool_bwd_kernel(const EncPoolBwd
   const int begin = chunk * a.tiles * 64, end = min(a.S, begin + a.tiles * 64);
   const int h = j >> 2, iq = j & 3;
   f32x4 gw[8];          // d c_attn[o = (lane >> 3) + 8 m][4 (lane & 7) ..]
-  f32x4 gqa = kZero4, gqb = kZero4;   // dQ[(head, query) = lane][d = 0 .. 7 of that head]
+  f32x4 gqa = z4(), gqb = z4();   // dQ[(head, query) = lane][d = 0 .. 7 of that head]
   float gln = 0.f;      // lanes < 32: LN_1 weight gradient of feature lane; lanes >= 32: bias gradient of feature lane - 32
 #pragma unroll
-  for (int m = 0; m < 8; ++m) gw[m] = kZero4;
+  for (int m = 0; m < 8; ++m) gw[m] = z4();
   for (int s0 = begin + wave * 4; s0 < end; s0 += 16) {
     const int s = s0 + tk;
     const bool valid = s < end;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kThreads) void enc_pool_bwd_kernel(const EncPoolBwd
     {
       const f32x4 ka = *v4(Wv + PW_KV + tk * kP64 + 8 * h), kb = *v4(Wv + PW_KV + tk * kP64 + 8 * h + 4);
       const f32x4 va = *v4(Wv + PW_KV + tk * kP64 + 32 + 8 * h), vb = *v4(Wv + PW_KV + tk * kP64 + 32 + 8 * h + 4);
-      f32x4 dka = kZero4, dkb = kZero4, dva = kZero4, dvb = kZero4;
+      f32x4 dka = z4(), dkb = z4(), dva = z4(), dvb = z4();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = 4 * iq + q;
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kThreads) void enc_pool_bwd_kernel(const EncPoolBwd
     }
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<64>(S + PB_W, Wv + PW_DKV + tk * kP64, j, acc);
       acc = half_sum4(acc);
       if (j < 8) *v4(Wv + PW_TX + tk * kP + 4 * j) = acc;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
   const float l2w0 = a.ln2_w[j], l2w1 = a.ln2_w[j + 16], l2b0 = a.ln2_b[j], l2b1 = a.ln2_b[j + 16];
   const float hw0 = a.head_w[j], hw1 = a.head_w[j + 16];
   __syncthreads();
-  f32x4 gq[1] = {kZero4}, gp[1] = {kZero4}, g1[3] = {kZero4, kZero4, kZero4}, g2[3] = {kZero4, kZero4, kZero4}, gkv = kZero4;
+  f32x4 gq[1] = {z4()}, gp[1] = {z4()}, g1[3] = {z4(), z4(), z4()}, g2[3] = {z4(), z4(), z4()}, gkv = z4();
   float vs[16];       // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each), c (six hidden units)
 #pragma unroll
   for (int i = 0; i < 16; ++i) vs[i] = 0.f;
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
       const float inv = 1.0f / quad_sum(l);
-      f32x4 aa = kZero4, ab = kZero4;
+      f32x4 aa = z4(), ab = z4();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         p[kk] *= inv;
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
     }
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<96>(S + G_W1, S + G_DA + tok * kQ, j, acc);
       lin32_t_acc<96>(S + G_W2, S + G_DB + tok * kQ, j, acc);
       acc = half_sum4(acc);
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
     S[G_DY + tok * kP + j + 16] = d1;
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<32>(S + G_WP, S + G_DY + tok * kP, j, acc);
       acc = half_sum4(acc);
       if (j < 8) *v4(S + G_DAO + tok * kP + 4 * j) = acc;
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
         dg = fmaf(p[kk], dp[kk], dg);
       }
       dg = quad_sum(dg);
-      f32x4 qa = kZero4, qb = kZero4, dsv;
+      f32x4 qa = z4(), qb = z4(), dsv;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const float ds = p[kk] * (dp[kk] - dg) * kScale;
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_kernel(const DecBwdA
     }
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<32>(S + G_WQ, S + G_DQQ + tok * kP, j, acc);
       acc = half_sum4(acc);
       tsync();      // (G_TX of this gene was read above; the fence keeps the store below it)
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
   const float l2w0 = a.ln2_w[j], l2w1 = a.ln2_w[j + 16], l2b0 = a.ln2_b[j], l2b1 = a.ln2_b[j + 16];
   const float hw0 = a.head_w[j], hw1 = a.head_w[j + 16];
   __syncthreads();
-  f32x4 gw1[3] = {kZero4, kZero4, kZero4}, gw2[3] = {kZero4, kZero4, kZero4}, gq = kZero4, gp = kZero4, gk = kZero4, gv = kZero4;
+  f32x4 gw1[3] = {z4(), z4(), z4()}, gw2[3] = {z4(), z4(), z4()}, gq = z4(), gp = z4(), gk = z4(), gv = z4();
   float cacc[2] = {0.f, 0.f};   // c[u] partials of this lane's gene quad, hidden-unit tiles wave, wave + 4
   float vs[10];                 // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each)
 #pragma unroll
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
       const float inv = 1.0f / quad_sum(l);
-      f32x4 aa = kZero4, ab = kZero4;
+      f32x4 aa = z4(), ab = z4();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         p[kk] *= inv;
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
       for (int q = 0; q < 2; ++q) {
         const int ot = wave + 4 * q;
         if (ot < 6) {
-          f32x4 aa = kZero4, bb = kZero4;
+          f32x4 aa = z4(), bb = z4();
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
             aa = mfma16(hk[s], S[G_W1 + (16 * ot + li) * kP + 4 * s + g4], aa);
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
       const float* Dm = S + (mtx ? G_DB : G_DA);
       // k slot (s, g4) <-> hidden unit u = 16 (s >> 2) + 4 g4 + (s & 3): the two weight rows a 32-lane group reads are 4 rows = 16 banks
       // apart (4 s + g4 would put them 4 banks apart: two-way conflicts); two accumulator chains keep the pipe fed
-      f32x4 acc = kZero4, acc2 = kZero4;
+      f32x4 acc = z4(), acc2 = z4();
 #pragma unroll 6
       for (int s = 0; s < 24; s += 2) {
         const int u0 = 16 * (s >> 2) + 4 * g4 + (s & 3), u1 = u0 + 1;
@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
     S[G_DY + tok * kP + j + 16] = d1;
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<32>(S + G_WP, S + G_DY + tok * kP, j, acc);
       acc = half_sum4(acc);
       if (j < 8) *v4(S + G_DAO + tok * kP + 4 * j) = acc;
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
         dg = fmaf(p[kk], dp[kk], dg);
       }
       dg = quad_sum(dg);
-      f32x4 qa = kZero4, qb = kZero4, dsv;
+      f32x4 qa = z4(), qb = z4(), dsv;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const float ds = p[kk] * (dp[kk] - dg) * kScale;
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
     }
     tsync();
     {
-      f32x4 acc = kZero4;
+      f32x4 acc = z4();
       lin32_t_acc<32>(S + G_WQ, S + G_DQQ + tok * kP, j, acc);
       acc = half_sum4(acc);
       if (j < 8) *v4(S + G_TX + tok * kP + 4 * j) = acc;
