@@ -35,7 +35,20 @@ constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
 #ifndef SCLDM_BWD_PF
 #define SCLDM_BWD_PF 8
 #endif
-constexpr int PF = SCLDM_BWD_PF;   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
+constexpr int PF = SCLDM_BWD_PF;
+// Cache policy of the streaming traffic (A/B switches, round 5): the operand-pair stores (written once here, read once by the
+// weight-gradient GEMM) and the record loads (read once per phase) pass through the XCD's 4 MB L2 next to the 2.8 MB backward weight
+// stream that every workgroup of the XCD re-reads.  0 = default policy, 1 = nt, 2 = sc1 (stores: write through, drop the line).
+#ifndef SCLDM_BWD_PAIR_ST
+#define SCLDM_BWD_PAIR_ST 0
+#endif
+#ifndef SCLDM_BWD_REC_NT
+#define SCLDM_BWD_REC_NT 0
+#endif
+// debugging aid: 1 = wait for every vector-memory operation in flight after each group of operand-pair stores
+#ifndef SCLDM_BWD_ST_WAIT
+#define SCLDM_BWD_ST_WAIT 0
+#endif   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
 constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;   // bf16 elements per image row (+16 B pad)
 constexpr int R0_OFF = 0;                                   // h2 image, later h1 image
 constexpr int R1_OFF = R0_OFF + TM * XA_LD * 2;             // dy2 image, later dy1 image
@@ -85,24 +98,70 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Global memory goes through buffer descriptors (round 5): wave-uniform base in SGPRs + ONE per-lane byte offset + immediates.
+// With flat 64-bit addresses hipcc kept one VGPR pair per access alive, spilled them, and reloaded each from scratch in front of
+// its load behind an s_waitcnt vmcnt(0) - the eight loads of a record tile ran one round trip after the other (and every such
+// wait drained the weight ring and the operand-pair stores in flight).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+// destination of an operand-pair tile: rows = tokens (ld elements apart); wave-uniform base pointer (SGPR pair: the token tile's
+// first row and the wave's first column folded in) + this lane's row / half offset in `voff` (bytes) -> global_store ... saddr.
+// (Round 5: MUBUF stores with an SGPR soffset gave run-to-run different operand arrays on MI355X - the store data registers were
+// re-used by VALU writes two issue slots later, a hazard hipcc does not pad for - so stores take the global saddr form.)
+typedef __attribute__((address_space(1))) char gchar;       // global address space: a pointer rebuilt from integers is generic (flat_store) otherwise
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+typedef __attribute__((address_space(1))) f32x4 g_f32x4;
+struct PairDst {
+  gchar* base;
+  unsigned voff;   // (c32 * ld + 8 * hh) * 2
+  bool on;
+};
+__device__ __forceinline__ gchar* uniform_ptr(const void* p) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return (gchar*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void pair_store(const PairDst& d, unsigned imm, const u32x4 v) {
+  g_u32x4* gp = (g_u32x4*)(d.base + (d.voff + imm));
+#if SCLDM_BWD_PAIR_ST == 1
+  __builtin_nontemporal_store(v, gp);
+#else
+  *gp = v;
+#endif
+}
 // quads q (q0) and q+1 (q1) of a 32-feature tile -> 16 bytes per lane (features f8 + 8*hh .. +7 of the lane's token), stored
-// to the LDS image row and, when grow != nullptr, to the same position of the plain global operand array
-__device__ __forceinline__ void put_pair(E* lrow, E* grow, int f8, int hh, const Quad& q0, const Quad& q1) {
+// to the LDS image row and, when g.on, to the same position of the plain global operand array
+__device__ __forceinline__ void put_pair(E* lrow, const PairDst& g, int f8, int hh, const Quad& q0, const Quad& q1) {
   union { Quad q; unsigned u[2]; } a, b;
   a.q = q0; b.q = q1;
   halfwave_pair(a.u[0], b.u[0]);
   halfwave_pair(a.u[1], b.u[1]);
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const u32x4 v = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
   if (lrow) *reinterpret_cast<u32x4*>(lrow + f8 + 8 * hh) = v;
-  if (grow) *reinterpret_cast<u32x4*>(grow + f8 + 8 * hh) = v;
+  if (g.on) pair_store(g, (unsigned)f8 * 2u, v);
 }
-// a whole accumulator tile (32 features x 32 tokens of token tile tt) -> image / operand array columns [col0, col0 + 32)
-__device__ __forceinline__ void put_tile(const float (&t)[16], E* lrow, E* grow, int col0, int hh) {
+// a whole accumulator tile (32 features x 32 tokens of token tile tt) -> image columns [col0, col0 + 32) / operand array columns
+// [g's first column, + 32)
+__device__ __forceinline__ void put_tile(const float (&t)[16], E* lrow, const PairDst& g, int col0, int hh) {
 #pragma unroll
-  for (int q = 0; q < 4; q += 2)
-    put_pair(lrow, grow, col0 + q * 8, hh, OP::pack4(t[q * 4 + 0], t[q * 4 + 1], t[q * 4 + 2], t[q * 4 + 3]),
-             OP::pack4(t[q * 4 + 4], t[q * 4 + 5], t[q * 4 + 6], t[q * 4 + 7]));
+  for (int q = 0; q < 4; q += 2) {
+    union { Quad q; unsigned u[2]; } a, b;
+    a.q = OP::pack4(t[q * 4 + 0], t[q * 4 + 1], t[q * 4 + 2], t[q * 4 + 3]);
+    b.q = OP::pack4(t[q * 4 + 4], t[q * 4 + 5], t[q * 4 + 6], t[q * 4 + 7]);
+    halfwave_pair(a.u[0], b.u[0]);
+    halfwave_pair(a.u[1], b.u[1]);
+    const u32x4 v = u32x4{a.u[0], a.u[1], b.u[0], b.u[1]};
+    if (lrow) *reinterpret_cast<u32x4*>(lrow + col0 + q * 8 + 8 * hh) = v;
+    if (g.on) pair_store(g, (unsigned)(q * 8) * 2u, v);
+  }
+#if SCLDM_BWD_ST_WAIT
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
 }
 
 // accumulator tile X^T[row = acc_row(r, hh)][col = c32] -> the wave's transpose scratch T[row][col]
@@ -158,31 +217,53 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   WStream<OP, PF, 1> ws;
   ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
 
-  // record / gradient tiles in the 4-wave forward kernel's layout: forward wave = wave >> 1, its feature tile = wave & 1
-  auto tile_off = [&](int tt, int q) { return ((size_t)((tile * 4 + (wave >> 1)) * 16 + (tt * 2 + (wave & 1)) * 4 + q) * 64 + lane) * 4; };
-  auto load_f32 = [&](const float* base, float (&dst)[NTT][16]) {
+  // record / gradient tiles in the 4-wave forward kernel's layout [tile][fwd wave = wave >> 1][quad (tt*2 + ft)*4 + q][lane][4],
+  // ft = wave & 1: a quad is 1 KB (fp32) / 512 B (16-bit) contiguous per wave; the descriptors start at this wave's first quad
+  const size_t quad0 = (size_t)((tile * 4 + (wave >> 1)) * 16 + (wave & 1) * 4) * 64;   // in lane-quads of 4 elements
+  const __amdgpu_buffer_rsrc_t r_xin = uniform_rsrc(a.x_in + quad0 * 4), r_dx = uniform_rsrc(a.dx + quad0 * 4);
+  const __amdgpu_buffer_rsrc_t r_y1 = uniform_rsrc(a.y1 + quad0 * 4), r_y2 = uniform_rsrc(a.y2 + quad0 * 4);
+  const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u;
+  auto load_f32 = [&](const __amdgpu_buffer_rsrc_t r, float (&dst)[NTT][16]) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 t4 = *reinterpret_cast<const f32x4*>(base + tile_off(tt, q));
+        union { u32x4 u; f32x4 f; } t4;
+        t4.u = __builtin_amdgcn_raw_buffer_load_b128(r, lane16 + q * 1024, tt * 8192, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = t4[i];
+        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = t4.f[i];
       }
   };
-  auto load_bf16 = [&](const E* base, float (&dst)[NTT][16]) {   // (a 16-bit record array of the operand type)
+  gchar* const p_dx = uniform_ptr(a.dx + quad0 * 4);
+  auto store_dx = [&](const float (&src)[NTT][16]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(g_f32x4*)(p_dx + (lane16 + (unsigned)(tt * 8192 + q * 1024))) = f32x4{src[tt][q * 4], src[tt][q * 4 + 1], src[tt][q * 4 + 2], src[tt][q * 4 + 3]};
+  };
+  auto load_bf16 = [&](const __amdgpu_buffer_rsrc_t r, float (&dst)[NTT][16]) {   // (a 16-bit record array of the operand type)
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const Quad t4 = *reinterpret_cast<const Quad*>(base + tile_off(tt, q));
+        union { u32x2 u; Quad h; } t4;
+        t4.u = __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + q * 512, tt * 4096, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = (float)t4[i];
+        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = (float)t4.h[i];
       }
+  };
+  // operand-pair destinations: [token][ld] 16-bit arrays; this wave writes columns first + [0, 32) of token tile tt
+  const unsigned pv256 = (unsigned)(c32 * kD + 8 * hh) * 2u, pv768 = (unsigned)(c32 * 3 * kD + 8 * hh) * 2u;
+  static_assert(kBwdChunks * kBwdChunk == 3 * kD, "the hidden operand arrays share the dqkv row pitch");
+  auto pair_dst = [&](const E* base, int ld, int tt, int first) {
+    return PairDst{uniform_ptr(base + (size_t)(tok0 + tt * 32) * ld + first), ld == kD ? pv256 : pv768, true};
   };
   // adaLN vector `vec` of the lane's sample, the four features of register quad q
   auto mod4 = [&](int tt, int vec, int q) { return OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + vec * kD + fb + q * 8 + hh * 4); };
   // sum over the 16 tokens of each sample of a per-(feature, token) quantity -> dmod[sample][vec][feature]
+  gchar* const p_dmod = uniform_ptr(a.dmod + (size_t)smp0 * a.mod_stride + a.mod_off + fb);
+  const unsigned dmod_voff = (unsigned)((sp * a.mod_stride + hh * 4) * 4);
   auto dmod_store = [&](const float (&v)[NTT][16], int vec) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -190,9 +271,10 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[r] = row16_sum(v[tt][r]);
       if ((c32 & 15) == 0 && smp0 + tt * 2 + sp < a.n) {
-        float* dst = a.dmod + (size_t)(smp0 + tt * 2 + sp) * a.mod_stride + a.mod_off + vec * kD + fb + hh * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dst + q * 8) = f32x4{tot[q * 4], tot[q * 4 + 1], tot[q * 4 + 2], tot[q * 4 + 3]};
+        for (int q = 0; q < 4; ++q)
+          *(g_f32x4*)(p_dmod + (dmod_voff + (unsigned)(((tt * 2) * a.mod_stride + vec * kD + q * 8) * 4))) =
+              f32x4{tot[q * 4], tot[q * 4 + 1], tot[q * 4 + 2], tot[q * 4 + 3]};
       }
     }
   };
@@ -228,7 +310,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     lds_barrier();   // RED may be rewritten by the next reduction
   };
   // y = LN(v) * S + shift (S = 1 + scale, staged) -> LDS image + operand array
-  auto ln_modulate = [&](const float (&v)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v, int sh_v, E* img, E* gout) {
+  auto ln_modulate = [&](const float (&v)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v, int sh_v, E* img, const E* gout) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const float nmr = -mean[tt] * rstd[tt];
@@ -239,7 +321,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[q * 4 + i] = fmaf(fmaf(v[tt][q * 4 + i], rstd[tt], nmr), sc[i], sh[i]);
       }
-      put_tile(y, img + (tt * 32 + c32) * XA_LD, gout + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+      put_tile(y, img + (tt * 32 + c32) * XA_LD, pair_dst(gout, kD, tt, fb), fb, hh);
     }
   };
   // backward of y = LN(x) * S + shift given dh = d y (accumulator tiles): dres += d x; dmod[sc_v] = sum_t dh xhat, dmod[sh_v] = sum_t dh
@@ -352,13 +434,13 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   float xr[NTT][16];    // x_mid: stays in registers across the MLP chunks (the LayerNorm-2 backward needs it again)
   {
   float dxr[NTT][16];
-  load_f32(a.dx, dxr);
+  load_f32(r_dx, dxr);
   lds_barrier();
 
   // ================= MLP branch: x_out = x_mid + a5 * c_proj(silu(w1 h2) * (w2 h2)),  h2 = LN(x_mid) (1 + a3) + a4 =================
   {
     float t[NTT][16];
-    load_bf16(a.y2, t);   // y2
+    load_bf16(r_y2, t);   // y2
     // d a5 = sum_t d x_out * y2;  d y2 = a5 * d x_out -> image R1 + operand array
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -372,12 +454,12 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
           t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
         }
       }
-      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, a.e_dy2 + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, pair_dst(a.e_dy2, kD, tt, fb), fb, hh);
     }
     dmod_store(t, 5);
     // x_mid = x_in + a2 * y1
-    load_f32(a.x_in, xr);
-    load_bf16(a.y1, t);
+    load_f32(r_xin, xr);
+    load_bf16(r_y1, t);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -414,10 +496,10 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
         da[r] = d * bv * (s * fmaf(av, 1.0f - s, 1.0f));
         db[r] = d * sl;
       }
-      const size_t grow = (size_t)(tok0 + tt * 32 + c32) * (kBwdChunks * kBwdChunk) + c * kBwdChunk;
-      put_tile(da, R2 + (tt * 32 + c32) * DADB_LD, a.e_da + grow, fb, hh);
-      put_tile(db, R2 + (tt * 32 + c32) * DADB_LD + kBwdChunk, a.e_db + grow, fb, hh);
-      put_tile(hid, nullptr, a.e_hid + grow, fb, hh);
+      const int first = c * kBwdChunk + fb;
+      put_tile(da, R2 + (tt * 32 + c32) * DADB_LD, pair_dst(a.e_da, 3 * kD, tt, first), fb, hh);
+      put_tile(db, R2 + (tt * 32 + c32) * DADB_LD + kBwdChunk, pair_dst(a.e_db, 3 * kD, tt, first), fb, hh);
+      put_tile(hid, nullptr, pair_dst(a.e_hid, 3 * kD, tt, first), fb, hh);
     }
     if (c == 0) BWD_STAMP(4);
     lds_barrier();
@@ -431,14 +513,14 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   float mean1[NTT], rstd1[NTT];
   {
   float dxr[NTT][16];
-  load_f32(a.dx, dxr);
+  load_f32(r_dx, dxr);
   ln_backward(dh[0], xr, mean2, rstd2, 3, 4, dxr);
 
   BWD_STAMP(8);
   // ================= attention branch: x_mid = x_in + a2 * (c_proj(attention(c_attn(h1))) + b),  h1 = LN(x_in) (1 + a0) + a1 =================
   {
     float t[NTT][16];
-    load_bf16(a.y1, t);
+    load_bf16(r_y1, t);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float dy[16];
@@ -451,17 +533,13 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
           t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
         }
       }
-      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, a.e_dy1 + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);   // d y1 (R1's last reader was chunk 2's d hid pass)
+      put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, pair_dst(a.e_dy1, kD, tt, fb), fb, hh);   // d y1 (R1's last reader was chunk 2's d hid pass)
     }
     dmod_store(t, 2);
   }
   // d x_mid waits in a.dx for the LayerNorm-1 backward at the end
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(a.dx + tile_off(tt, q)) = f32x4{dxr[tt][q * 4], dxr[tt][q * 4 + 1], dxr[tt][q * 4 + 2], dxr[tt][q * 4 + 3]};
-  load_f32(a.x_in, xr);
+  store_dx(dxr);
+  load_f32(r_xin, xr);
   ln_stats(xr, mean1, rstd1);
   ln_modulate(xr, mean1, rstd1, 0, 1, R0, a.e_h1);   // h1 (R0's last readers were chunk 2's a / b passes)
   }
@@ -539,7 +617,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       float o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ot[r];
-      put_tile(o, nullptr, a.e_ao + (size_t)(tok0 + tt * 32 + c32) * kD, fb, hh);
+      put_tile(o, nullptr, pair_dst(a.e_ao, kD, tt, fb), fb, hh);
     }
     // dP^T[key][query] = V dAO^T;  dS = P (dP - sum_key P dP) / sqrt(d)
     f32x16 dpt = OP::mma(VF[tt][0], GF[tt][0], zero16);
@@ -562,14 +640,13 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     masked_frags(ds, dSh);
     float o[16];
     E* lrow = DQKV + (tt * 32 + c32) * DQKV_LD;
-    E* grow = a.e_dqkv + (size_t)(tok0 + tt * 32 + c32) * (3 * kD);
     // dQ^T[d][query] = K^T dS^T
     {
       f32x16 dq = OP::mma(KT[tt][0], dSh[0], zero16);
       dq = OP::mma(KT[tt][1], dSh[1], dq);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dq[r];
-      put_tile(o, lrow, grow, fb, hh);
+      put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, fb), fb, hh);
     }
     // dK^T[d][key] = Q^T dS
     Frag T1[2];
@@ -583,7 +660,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       dk = OP::mma(QT[tt][1], T1[1], dk);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dk[r];
-      put_tile(o, lrow, grow, kD + fb, hh);
+      put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, kD + fb), kD + fb, hh);
     }
     // dV^T[d][key] = dAO^T P
     tr_write_own(TR, p, sp, c32, hh);
@@ -596,7 +673,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       dv = OP::mma(GT[tt][1], T1[1], dv);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dv[r];
-      put_tile(o, lrow, grow, 2 * kD + fb, hh);
+      put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, 2 * kD + fb), 2 * kD + fb, hh);
     }
   }
   BWD_STAMP(11);
@@ -605,15 +682,11 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   BWD_STAMP(12);
   // d x_in = d x_mid + LN1-backward(d h1);  d a0, d a1
   float dxr[NTT][16];
-  load_f32(a.x_in, xr);
-  load_f32(a.dx, dxr);
+  load_f32(r_xin, xr);
+  load_f32(r_dx, dxr);
   ln_backward(dh[0], xr, mean1, rstd1, 0, 1, dxr);
 
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<f32x4*>(a.dx + tile_off(tt, q)) = f32x4{dxr[tt][q * 4], dxr[tt][q * 4 + 1], dxr[tt][q * 4 + 2], dxr[tt][q * 4 + 3]};
+  store_dx(dxr);
   BWD_STAMP(13);
 #undef BWD_STAMP
 }
