@@ -165,24 +165,42 @@ def sync(device):
         torch.cuda.synchronize()
 
 
-def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world):
+def run_steps(m, wl, z2, cond2, scales, steps, dist_on, world, bmax=None):
+    """`steps` sampling passes; for N > 1 each followed by the path's single collective: an all-gather of the generated latents
+    (1 KB per cell).  Ranks may hold different numbers of cells (a strong-scaling split of a global batch that N does not divide):
+    every rank then contributes [unconditional | guided] blocks padded to `bmax` cells, as scldm_amd.sampling.sample_latents_sharded does."""
     out = None
     for _ in range(steps):
         out = m.sample_ode_cfg(z2, cond2, scales, wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1, wl["method"])
         if dist_on:
             import torch.distributed as dist
+            b = out.shape[0] // 2
+            if bmax is not None and bmax != b:
+                pad = torch.zeros((2, bmax) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
+                pad[0, :b] = out[:b]
+                pad[1, :b] = out[b:]
+                out = pad.view((2 * bmax,) + tuple(out.shape[1:]))
             gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), device=out.device, dtype=out.dtype)
             dist.all_gather_into_tensor(gathered, out)  # the single collective of the path: generated latents, 1 KB per cell
             out = gathered
     return out
 
 
+def shard_cells(wl, world, rank):
+    """(cells of this rank, cells of the largest rank): a weak-scaling workload gives every rank wl['B'] cells; a strong-scaling one
+    splits wl['B'] GLOBAL cells like scldm_amd.sampling.shard_bounds (the first B % world ranks get one extra cell)."""
+    if not wl.get("strong"):
+        return wl["B"], wl["B"]
+    base, rem = divmod(wl["B"], world)
+    return base + (1 if rank < rem else 0), base + (1 if rem else 0)
+
+
 def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_blocks):
     """`steps` timed steps bracketed by barrier + synchronize on both sides; returns (seconds: max over ranks, block timing,
     last output, inputs).  A strong-scaling workload gives every rank B / world of its cells."""
-    B = wl["B"] // world if wl.get("strong") else wl["B"]
+    B, bmax = shard_cells(wl, world, rank)
     z2, cond2, scales = make_inputs(wl, B, device, seed=1234 + rank)
-    run_steps(m, wl, z2, cond2, scales, warmup, dist_on, world)
+    run_steps(m, wl, z2, cond2, scales, warmup, dist_on, world, bmax)
     if time_blocks:
         m.block_timing(True)
     if dist_on:
@@ -190,7 +208,7 @@ def time_workload(m, wl, device, steps, warmup, dist_on, world, rank, time_block
         dist.barrier()
     sync(device)
     t0 = time.perf_counter()
-    out = run_steps(m, wl, z2, cond2, scales, steps, dist_on, world)
+    out = run_steps(m, wl, z2, cond2, scales, steps, dist_on, world, bmax)
     sync(device)
     if dist_on:
         dist.barrier()
@@ -233,14 +251,15 @@ def cross_rank_check(m, wl, out, B, device, world, rank, n_check=8):
     rec = {"checked_rank": None, "cells": 0, "bit_equal": None}
     if rank == 0:
         r = world - 1 if world > 1 else 0
+        B, bmax = shard_cells(wl, world, r)          # the checked rank's shard (it may be one cell shorter than rank 0's)
         n = min(n_check, B)
         z2, cond2, scales = make_inputs(wl, B, device, seed=1234 + r)
         idx = torch.cat([torch.arange(n), torch.arange(B, B + n)]).to(device)
         zs, cs = z2[idx], {k: v[idx] for k, v in cond2.items()}
         steps = wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1
         local = m.sample_ode_cfg(zs, cs, scales, steps, wl["method"])
-        block = out[r * 2 * B:(r + 1) * 2 * B]
-        got = torch.cat([block[:n], block[B:B + n]])
+        block = out[r * 2 * bmax:(r + 1) * 2 * bmax]
+        got = torch.cat([block[:n], block[bmax:bmax + n]])
         rec = {"checked_rank": r, "cells": n, "bit_equal": bool(torch.equal(local, got)),
                "max_abs_diff": float((local - got).abs().max())}
         if not rec["bit_equal"]:
@@ -467,12 +486,13 @@ def precision_path(wl, device, prec, steps, warmup, ref_cells=64):
     return rec
 
 
-def cpu_baseline(m, wl, target_s=6.0):
+def cpu_baseline(m, wl, target_s=3.0):
     """The CPU oracle (plain-torch fp32 restatement of the reference, validated against it in tests/) timed on this box's host
     cores over a bounded sample of the SAME workload: the full number of CFG evaluations on a reduced cell count (chosen from a
-    short calibration so that one solve takes about `target_s` seconds), warm-up 1 solve, median of 3 - measured, not
-    extrapolated.  Thread count: the fastest of 16 / 32 / 64 threads (or all host threads when there are fewer) in a short
-    calibration; `cores` reports the count actually used, `host_cores` what the box has."""
+    short probe so that one solve takes about `target_s` seconds), warm-up 1 solve, median of 3 - measured, not extrapolated.
+    Thread count is FIXED (round 5: the per-box calibration picked 16 threads on one box and 32 on the next and the number swung
+    2x between rounds): `value` / `cores` are the 16-thread figure, `value_32_threads` the same sample on 32 threads (both capped at
+    the host's thread count).  Larger OpenMP teams on these 1.5k-row GEMMs are pathological (256 threads: seconds per cell-evaluation)."""
     from oracle.dit import DiTConfig, dit_forward_with_cfg
     from oracle.transport import sample_ode_fixed
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -487,34 +507,31 @@ def cpu_baseline(m, wl, target_s=6.0):
         return time.perf_counter() - t0
 
     all_cores = os.cpu_count() or 1
-    tried = {}
-    # team sizes: 16, 32, 64 and all host threads when there are at most 64 of them - an oversubscribed OpenMP team on these
-    # 1.5k-row GEMMs is pathological (256 threads of the GPU boxes' EPYC 9575F host: 3-18 s per cell-evaluation against 1-3 ms
-    # with 16-32, measured in round 2), so larger teams are not even probed
-    cand = {min(all_cores, 16), min(all_cores, 32), min(all_cores, 64)}
-    for nt in sorted(cand):                             # small teams first: they bound what "slow" means
+    t16, t32 = min(all_cores, 16), min(all_cores, 32)
+    torch.set_num_threads(t16)
+    solve(2, 2)                                         # first touch
+    per_cell_eval = solve(32, 3) / (32 * 2)             # seconds per cell per evaluation on the 16-thread team
+    cells = int(min(512, max(8, target_s / (per_cell_eval * n_evals))))
+    res = {}
+    for nt in sorted({t16, t32}):
         torch.set_num_threads(nt)
-        probe = solve(2, 2) / 2                         # 2 cells x 1 evaluation: first touch + a cheap look at this team size
-        if tried and probe > 8 * min(tried.values()):   # oversubscribed OpenMP team (e.g. 256 threads on 1.5k-row GEMMs): seconds
-            tried[nt] = probe                           # per cell-evaluation - recorded, not calibrated further
-            continue
-        tried[nt] = solve(32, 3) / (32 * 2)             # seconds per cell per evaluation
-    threads = min(tried, key=tried.get)
-    torch.set_num_threads(threads)
-    cells = int(min(512, max(8, target_s / (tried[threads] * n_evals))))
-    solve(cells, steps)                                 # warm-up solve
-    times = [solve(cells, steps) for _ in range(3)]
-    med = statistics.median(times)
+        solve(cells, steps)                             # warm-up solve
+        times = [solve(cells, steps) for _ in range(3)]
+        res[nt] = (statistics.median(times), times)
+    torch.set_num_threads(t16)
     cpu_model = platform.processor() or ""
     try:
         with open("/proc/cpuinfo") as f:
             cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu_model)
     except OSError:
         pass
-    return {"value": cells / med, "unit": "cells/s", "cores": threads, "host_cores": all_cores, "kind": "port", "cpu": cpu_model,
-            "sample": f"{cells} cells x all {n_evals} CFG evaluations ({wl['method']}), fp32 torch CPU ops on {threads} threads "
-                      f"(calibration, s per cell-evaluation by thread count: {', '.join(f'{k}: {v:.4f}' for k, v in sorted(tried.items()))}), "
-                      f"median of 3 solves ({', '.join(f'{t:.2f}' for t in times)} s) after one warm-up solve; measured, not extrapolated"}
+    med, times = res[t16]
+    rec = {"value": cells / med, "unit": "cells/s", "cores": t16, "host_cores": all_cores, "kind": "port", "cpu": cpu_model,
+           "sample": f"{cells} cells x all {n_evals} CFG evaluations ({wl['method']}), fp32 torch CPU ops on a fixed team of {t16} threads, "
+                     f"median of 3 solves ({', '.join(f'{t:.2f}' for t in times)} s) after one warm-up solve; measured, not extrapolated"}
+    if t32 != t16:
+        rec["value_32_threads"] = cells / res[t32][0]
+    return rec
 
 
 def mfma_ceiling_record():
@@ -619,6 +636,141 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
     return rec
 
 
+def synthetic_vocabulary_encoder(vocab, strategy, seed=3):
+    """Size-factor statistics of a made-up vocabulary encoder with the attributes LatentDiffusion._sample_log_size_factors reads
+    (src/scldm/models.py:473-597): per-label (independent) or per joint class mean / std of the log library size."""
+    import random
+    from types import SimpleNamespace
+    rnd = random.Random(seed)
+    names = sorted(vocab)
+    if strategy == "joint" and len(names) > 1:
+        import itertools
+        toks = {"_".join(map(str, idx)): "c" + "_".join(map(str, idx)) for idx in itertools.product(*[range(vocab[k]) for k in names])}
+        mu = {c: rnd.uniform(6.5, 9.0) for c in toks.values()}
+        sd = {c: rnd.uniform(0.1, 0.5) for c in toks.values()}
+        return SimpleNamespace(joint_key="joint", joint_components=names, joint_idx_2_classes=toks,
+                               mu_size_factor={"joint": mu}, sd_size_factor={"joint": sd}, size_factor_condition_key=None)
+    k = names[0]
+    return SimpleNamespace(size_factor_condition_key=k, mu_size_factor={k: {i: rnd.uniform(6.5, 9.0) for i in range(vocab[k])}},
+                           sd_size_factor={k: {i: rnd.uniform(0.1, 0.5) for i in range(vocab[k])}})
+
+
+def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
+    """What one `predict_step` of the reference delivers (src/scldm/models.py:707-819 + _utils.py:192-197), end to end on the device
+    path: size factors drawn on device (SizeFactorSampler) -> noise -> fused CFG ODE -> MCAB decode (fp32) with the negative-binomial
+    draw fused in -> CSR assembly on device -> host arrays (indptr / indices / data of the 2B generated rows + the 2B latents).
+    cells/s = requested cells / wall time of the whole chain (median of `reps` after one warm-up), with the device time of each stage."""
+    from scldm_amd.datamodule import dense_to_csr
+    from scldm_amd.sampling import SizeFactorSampler, sample_latents
+    wl = dict(WORKLOADS[wl_name])
+    B = wl["B"]
+    m = make_model(wl, precision, device)
+    vae = make_vae(n_genes, device)
+    vae.precision = "fp32"
+    smp = SizeFactorSampler(synthetic_vocabulary_encoder(wl["vocab"], wl["strategy"]), wl["strategy"], device)
+    g = torch.Generator().manual_seed(21)
+    cond = {k: torch.randint(0, v, (B,), generator=g).to(device) for k, v in wl["vocab"].items()}
+    scales = {k: wl["scale"] for k in wl["vocab"]}
+    genes2 = torch.arange(n_genes, device=device).repeat(2 * B, 1)
+    steps = wl["evals"] + 1 if wl["method"] == "euler" else wl["evals"] // 2 + 1
+
+    def once(ev=None):
+        rec = (lambda i: ev[i].record()) if ev else (lambda i: None)
+        rec(0)
+        sf = smp.sample(cond, B)
+        z0 = torch.randn((B, 16, 16), device=device)
+        rec(1)
+        z = sample_latents(m, z0, cond, scales, steps, wl["method"])
+        rec(2)
+        lib = torch.exp(sf).view(-1, 1)
+        counts = vae.decode_sample(z, genes2, torch.cat([lib, lib], dim=0))
+        rec(3)
+        indptr, indices, data = dense_to_csr(counts)
+        rec(4)
+        host = (indptr.cpu(), indices.cpu(), data.cpu(), z.cpu())
+        rec(5)
+        return host
+    once()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        host = once()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = statistics.median(ts)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    once(ev)
+    torch.cuda.synchronize()
+    stage = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
+    nnz = int(host[2].numel())
+    return {"workload": wl_name, "cells": B, "generated_rows": 2 * B, "n_genes": n_genes, "cfg_evaluations": wl["evals"], "method": wl["method"],
+            "dit_precision": precision, "decode_precision": "fp32", "cells_per_s": B / dt, "ms": 1e3 * dt, "ms_each": [round(1e3 * t, 3) for t in ts],
+            "stage_ms": {"size_factors_and_noise": stage[0], "ode": stage[1], "decode_and_nb_draw": stage[2], "csr_assembly": stage[3],
+                         "device_to_host": stage[4]},
+            "nnz_fraction": nnz / (2 * B * n_genes), "host_bytes": sum(int(t.numel()) * t.element_size() for t in host),
+            "path": "SizeFactorSampler.sample -> sample_latents (scldm_sample_ode) -> TransformerVAE.decode_sample -> dense_to_csr -> .cpu()"}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the stdout line: the contract's keys + the scalars a reader needs, <= 6 KB; everything else goes to profiles/bench_last.json
+# --------------------------------------------------------------------------------------------------------------------
+def _dig(d, *path, default=None):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def compact_line(result):
+    keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "dit_fwd_tflops_per_gpu", "dit_fwd_mfma_frac", "roofline", "cpu_baseline", "per_rank_ms_per_step",
+            "allgather_ms", "cross_rank_check", "strong_scaling", "train_tflops_per_gpu", "final_loss", "data_parallel")
+    out = {k: result[k] for k in keep if k in result}
+    if isinstance(out.get("cpu_baseline"), dict) and len(out["cpu_baseline"].get("sample", "")) > 420:
+        out["cpu_baseline"] = dict(out["cpu_baseline"], sample=out["cpu_baseline"]["sample"][:417] + "...")
+    sc = {}
+    def put(key, *path):
+        v = _dig(result, *path)
+        if v is not None:
+            sc[key] = round(v, 6) if isinstance(v, float) else v
+    # the same workload at the reference's arithmetic class (fp16 = TF32's mantissa) and at the <= 1e-4 parity precision (bf16x3)
+    put("fp16_cells_per_s", "reference_class_path", "cells_per_s"); put("fp16_frac", "reference_class_path", "roofline", "frac")
+    put("fp16_err_vs_fp32", "reference_class_path", "err_fp16_vs_fp32", "max_abs_over_max_ref")
+    put("bf16x3_cells_per_s", "parity_path", "cells_per_s"); put("bf16x3_frac", "parity_path", "roofline", "frac")
+    put("bf16x3_err_vs_fp32", "parity_path", "err_bf16x3_vs_fp32", "max_abs_over_max_ref")
+    put("bf16_err_vs_fp32", "parity_path", "err_bf16_vs_fp32", "max_abs_over_max_ref")
+    put("bf16_cells_per_s", "throughput_path", "cells_per_s"); put("bf16_frac", "throughput_path", "roofline", "frac")
+    for w in result.get("other_workloads", []) or []:
+        tag = {"dentate_b512_euler50": "b512", "parse1m_b1024_euler100": "b1024", "hlca_b2048_heun100": "hlca_b2048_heun100",
+               "parse1m_b8192_euler100_strong": "b8192"}.get(w["workload"], w["workload"])
+        sc[f"cells_per_s_{tag}"] = round(w["cells_per_s"], 1)
+        sc[f"frac_{tag}"] = round(w["dit_fwd_mfma_frac"], 4)
+    put("dopri5_cells_per_s", "default_sampler", "cells_per_s"); put("dopri5_frac", "default_sampler", "dit_fwd_mfma_frac")
+    put("dopri5_cfg_evaluations", "default_sampler", "cfg_evaluations")
+    put("with_decode_cells_per_s", "with_vae_decode", "cells_per_s")
+    put("decode_fp32_rows_per_s", "with_vae_decode", "decode_only_fp32", "rows_per_s"); put("decode_fp32_frac", "with_vae_decode", "decode_only_fp32", "roofline", "frac")
+    put("decode_bf16_rows_per_s", "with_vae_decode", "decode_only_bf16", "rows_per_s"); put("decode_bf16_frac", "with_vae_decode", "decode_only_bf16", "roofline", "frac")
+    put("encode_fp32_cells_per_s", "with_vae_encode", "dentate_fp32", "cells_per_s"); put("encode_fp32_frac", "with_vae_encode", "dentate_fp32", "roofline", "frac")
+    put("encode_bf16_cells_per_s", "with_vae_encode", "dentate_bf16", "cells_per_s"); put("encode_bf16_frac", "with_vae_encode", "dentate_bf16", "roofline", "frac")
+    put("e2e_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "cells_per_s")
+    put("e2e_ms_dentate512", "generation_end_to_end", "dentate_b512_euler50", "ms")
+    put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
+    put("e2e_ms_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "ms")
+    put("train_ms", "training_step", "ms_per_step"); put("train_cells_per_s", "training_step", "cells_per_s"); put("train_tflops", "training_step", "tflops")
+    put("train_fp16_ms", "training_step_fp16", "ms_per_step"); put("train_b256_ms", "training_step_b256", "ms_per_step")
+    put("train_ditl_b1024_tflops", "training_step_ditl_b1024", "tflops"); put("train_ditl_b256_tflops", "training_step_ditl", "tflops")
+    put("ditl_sampling_tflops", "ditl_sampling", "tflops")
+    put("vae_train_b32_ms", "vae_training_step", "b32", "ms_per_step"); put("vae_train_b512_ms", "vae_training_step", "b512", "ms_per_step")
+    put("guidance1_direct_cells_per_s", "guidance1_direct", "cells_per_s")
+    put("mfma_sustained_normal_tflops", "mfma_sustained_ceiling", "normal_tflops")
+    put("strong_scaling_cells_per_s", "strong_scaling", "cells_per_s"); put("strong_scaling_ms", "strong_scaling", "ms_per_step")
+    out.update(sc)
+    out["details"] = "profiles/bench_last.json (every record behind these scalars; written by this run)"
+    return out
+
+
 def kernel_source_sha256():
     """fingerprint of the fused layer kernel's sources (the PMC summary records the one it was collected on)"""
     import hashlib
@@ -645,7 +797,18 @@ def emit(result, rank):
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(result), flush=True)  # the one JSON line
+        try:   # the long per-workload records: next to the profiles, not on stdout (the driver keeps an 8 KB tail)
+            if os.environ.get("BENCH_FAKE") == "1":
+                raise OSError("BENCH_FAKE run: no details file")
+            os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+            with open(os.path.join(ROOT, "profiles", "bench_last.json"), "w") as f:
+                json.dump(result, f, indent=1)
+        except OSError as e:
+            note(f"profiles/bench_last.json not written: {e}")
+        line = json.dumps(compact_line(result))
+        if len(line) > 6144:
+            note(f"stdout line is {len(line)} bytes (> 6 KB)")
+        print(line, flush=True)  # the one JSON line
 
 
 def main():
@@ -656,6 +819,7 @@ def main():
     ap.add_argument("--workload", default="dentate_b4096_euler100", choices=sorted(WORKLOADS) + sorted(TRAIN_WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "bf16x3", "fp32"])
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--global-cells", type=int, default=0, help="override the GLOBAL cell count of the strong-scaling leg (N > 1)")
     ap.add_argument("--evals", type=int, default=0, help="override the number of CFG evaluations (profiling only; not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short extra-workload measurements")
@@ -826,6 +990,14 @@ def main():
             note("decode done")
             result["with_vae_encode"] = encode_record(device)
             note("encode done")
+            try:   # configs[1] as the reference's predict_step delivers it, and the configs[3] per-GPU shard
+                result["generation_end_to_end"] = {
+                    "dentate_b512_euler50": generation_end_to_end("dentate_b512_euler50", 17002, device, args.precision),
+                    "parse1m_b1024_euler100": generation_end_to_end("parse1m_b1024_euler100", 2000, device, args.precision)}
+            except Exception as e:   # an extra: never takes the headline line down
+                result["generation_end_to_end"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            note("end-to-end generation done")
             tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
             torch.cuda.empty_cache()
             tprec = "bf16" if args.precision in ("bf16", "fp16") else "fp32"
@@ -842,6 +1014,10 @@ def main():
                                                 "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dth / 10) / 1e12, "dtype": "fp16",
                                                 "path": "fused route, fp16 operands (10 mantissa bits = the reference's TF32 training arithmetic), "
                                                         "device-side loss scaling of the backward"}
+            torch.cuda.empty_cache()
+            d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1)   # the small-batch step (host / launch bound)
+            result["training_step_b256"] = {"workload": "replogle_train_b1024 at 256 cells", "cells_per_s": 256 / (d256 / 20), "ms_per_step": 1e3 * d256 / 20,
+                                            "dtype": tprec}
             note("training step done")
             try:
                 result["vae_training_step"] = vae_training_record(device)
@@ -883,10 +1059,15 @@ def main():
     if dist_on and not args.no_extra and args.workload == "dentate_b4096_euler100":
         # N > 1: the strong-scaling leg north_star names (parse1m, 8192 cells global = 8192 / N per GPU), every rank takes part
         w2 = dict(WORKLOADS["parse1m_b8192_euler100_strong"])
+        if args.global_cells:
+            w2["B"] = args.global_cells
         m2 = make_model(w2, args.precision, device)
-        d2, _, _, (_, _, _, B2) = time_workload(m2, w2, device, 1, 1, dist_on, world, rank, time_blocks=False)
+        d2, _, out2, (_, _, _, B2) = time_workload(m2, w2, device, 1, 1, dist_on, world, rank, time_blocks=False)
         result["strong_scaling"] = {"workload": "parse1m_b8192_euler100_strong", "global_cells": w2["B"], "cells_per_gpu": B2,
-                                    "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2, "scaling": "strong"}
+                                    "cells_per_gpu_by_rank": [shard_cells(w2, world, r)[0] for r in range(world)],
+                                    "gathered_rows": int(out2.shape[0]) if out2 is not None else None,
+                                    "cells_per_s": w2["B"] / d2, "ms_per_step": 1e3 * d2, "scaling": "strong",
+                                    "cross_rank_check": cross_rank_check(m2, w2, out2, B2, device, world, rank)}
         if not fake:
             # BASELINE configs[4] under the same launch: the data-parallel training step (bucketed gradient all-reduce overlapped with
             # the backward) on the base shape and on the DiT-L shape, 1 024 / 256 cells per GPU

@@ -111,6 +111,18 @@ int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
  * than 10 mantissa bits) and the non-zero values packed. */
 int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream);
 
+/* Overflow guard of the fp16 (loss-scaled) training backward - the counterpart of torch.cuda.amp.GradScaler's found_inf for the
+ * reference's trainer (experiments/scripts/train_ldm.py: the reference trains in TF32 and needs none; fp16 operands have TF32's
+ * mantissa but 5 exponent bits).  The last launch of scldm_dit_train_backward counts the non-finite values among ALL gradients it
+ * produced; when there are any, the NEXT backward lowers its loss scale by one more power of two (the headroom recovers one step
+ * per 2 000 clean backwards), and - if the caller registered one with scldm_dit_train_set_found_inf - a device float is set to 1.0
+ * (reset to 0.0 at the start of every fp16 backward) so that an optimizer can skip the step without a host read (torch's fused
+ * Adam/AdamW take it as `optimizer.found_inf`).  scldm_dit_train_fp16_state synchronises `stream` and reports the loss scale S of
+ * the last backward, its non-finite count, the headroom (<= 0, powers of two below the nominal scale) and the number of
+ * backwards that overflowed so far. */
+int scldm_dit_train_fp16_state(scldm_dit* h, float* scale, long long* nonfinite_last, int* headroom, long long* overflow_steps, void* stream);
+int scldm_dit_train_set_found_inf(scldm_dit* h, float* found_inf /* device, caller-owned, may be NULL */);
+
 /* Labels outside [0, vocab] (or == vocab without a null row) are clamped by the conditioning kernels and counted in a
  * device-side sticky counter instead of reading another class's table (the reference's nn.Embedding raises).  This call
  * synchronises `stream`, returns the count since the last call in *count and resets it. */
@@ -181,7 +193,7 @@ int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ulabels, int 
 #define SCLDM_OPT_TAIL_SPLIT 2
 int scldm_dit_set_option(scldm_dit* h, int option, int value);
 
-/* DiT layers one fused-kernel launch runs (4 by default, SCLDM_LPL=1..4: the residual stays in registers between them; 0 for a
+/* DiT layers one fused-kernel launch runs (8 by default, SCLDM_LPL=1..8: the residual stays in registers between them; 0 for a
  * handle outside the fused shape family).  bench.py uses it to state the algorithmic FLOPs of a launch. */
 int scldm_dit_layers_per_launch(const scldm_dit* h);
 

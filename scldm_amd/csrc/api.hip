@@ -158,6 +158,8 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (e == hipSuccess) e = alloc((void**)&h->d_plan, 8);
   if (e == hipSuccess) e = alloc((void**)&h->d_fp16_stats, 16);
   if (e == hipSuccess) e = hipMemset(h->d_fp16_stats, 0, 16);
+  if (e == hipSuccess) e = alloc((void**)&h->d_ls, 64);
+  if (e == hipSuccess) e = hipMemset(h->d_ls, 0, 64);
   if (e == hipSuccess) e = alloc((void**)&h->label_err, 4);
   if (e == hipSuccess) e = hipMemset(h->label_err, 0, 4);
   if (e == hipSuccess) e = alloc((void**)&h->d_fp_state, 16);
@@ -181,7 +183,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
     if (h->wfinal[p]) (void)hipFree(h->wfinal[p]);
   }
   void* ptrs[] = {h->ada_x3, h->w0t, h->b0, h->w2t, h->b2, h->emb, h->ada_t, h->ada_b, h->in_wt, h->in_w, h->in_b, h->pos, h->fin_b, h->b_qkv,
-                  h->b_proj, h->label_err, h->d_plan, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->wt16, h->d_cast_jobs, h->ada16, h->ada_ball};
+                  h->b_proj, h->label_err, h->d_plan, h->d_ls, h->d_fp16_stats, h->d_jobs, h->d_fp_src, h->d_fp_state, h->d_dirty, h->bwd_stream, h->d_tjobs, h->iota, h->w16, h->wt16, h->d_cast_jobs, h->ada16, h->ada_ball};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
@@ -369,6 +371,26 @@ extern "C" int scldm_dit_refresh_weights(scldm_dit* h, void* stream_) {
   if (!h) return fail(SCLDM_ERR_SHAPE, "null handle");
   if (!h->loaded) return fail(SCLDM_ERR_STATE, "scldm_dit_load_weights has not been called");
   return run_pack(h, false, (hipStream_t)stream_);
+}
+
+extern "C" int scldm_dit_train_fp16_state(scldm_dit* h, float* scale, long long* nonfinite_last, int* headroom, long long* overflow_steps, void* stream_) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "scldm_dit_train_fp16_state: null handle");
+  hipStream_t st = (hipStream_t)stream_;
+  unsigned v[16] = {0};
+  HIP_TRY(hipMemcpyAsync(v, h->d_ls, sizeof(v), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float S;
+  memcpy(&S, &v[0], 4);
+  if (scale) *scale = S;
+  if (nonfinite_last) *nonfinite_last = (long long)(int)v[2];
+  if (headroom) *headroom = (int)v[3];
+  if (overflow_steps) *overflow_steps = (long long)(int)v[7];
+  return SCLDM_OK;
+}
+extern "C" int scldm_dit_train_set_found_inf(scldm_dit* h, float* found_inf) {
+  if (!h) return fail(SCLDM_ERR_SHAPE, "scldm_dit_train_set_found_inf: null handle");
+  h->found_inf = found_inf;
+  return SCLDM_OK;
 }
 
 extern "C" int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream_) {

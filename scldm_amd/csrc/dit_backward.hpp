@@ -46,6 +46,35 @@ constexpr int PF = SCLDM_BWD_PF;
 #define SCLDM_BWD_REC_NT 0
 #endif
 // debugging aid: 1 = wait for every vector-memory operation in flight after each group of operand-pair stores
+// which phases request their global reads ahead of use (bit 0: kernel start, bit 1: LayerNorm-2 backward, bit 2: before the K = 768 pass)
+#ifndef SCLDM_BWD_HOIST
+#define SCLDM_BWD_HOIST 10
+#endif
+// 1: the LayerNorm reductions alternate between two LDS buffers and need ONE barrier each; 0: one buffer, two barriers
+#ifndef SCLDM_BWD_RED2
+#define SCLDM_BWD_RED2 1
+#endif
+// 1: the weight ring is parked (not refilled) across the attention core, whose operand fragments are the kernel's register peak
+#ifndef SCLDM_BWD_PARK
+#define SCLDM_BWD_PARK 1
+#endif
+// 1: d x_mid stays in 32 registers from the LayerNorm-2 backward to the LayerNorm-1 backward (one 64 KB store and one load per tile less)
+#ifndef SCLDM_BWD_KEEP_DX
+#define SCLDM_BWD_KEEP_DX 1
+#endif
+// 1: x_in stays in registers from the LayerNorm-1 forward recompute to the LayerNorm-1 backward as well
+#ifndef SCLDM_BWD_KEEP_XIN
+#define SCLDM_BWD_KEEP_XIN 1
+#endif
+// 1: d x_out stays in registers across the SwiGLU chunks too (needs KEEP_DX: the gradient is then read once and written once per layer)
+#ifndef SCLDM_BWD_KEEP_DXOUT
+#define SCLDM_BWD_KEEP_DXOUT 1
+#endif
+// 1: x_in stays in registers across the SwiGLU chunks as well (x_mid is a temporary of phases 1-2 and of the LayerNorm-2 backward):
+// the record's residual is then read once per layer
+#ifndef SCLDM_BWD_KEEP_XIN_MLP
+#define SCLDM_BWD_KEEP_XIN_MLP 1
+#endif
 #ifndef SCLDM_BWD_ST_WAIT
 #define SCLDM_BWD_ST_WAIT 0
 #endif   // k-steps of weight-ring run-ahead: one wave gets two MFMAs (64 cycles) out of a fragment, an L2 round trip is ~10 of those
@@ -62,8 +91,8 @@ static_assert(TR_OFF + NW * TR_BYTES <= R_END && TR_OFF % 8 == 0, "transpose scr
 constexpr int MOD_OFF = R_END;
 constexpr int MOD_BYTES = NS * kModBlock * 2;               // fp16 copies of the six adaLN vectors of the tile's samples
 constexpr int RED_OFF = MOD_OFF + MOD_BYTES;
-constexpr int RED_BYTES = 2 * NW * TM * 4;
-constexpr int BIAS_OFF = RED_OFF + RED_BYTES;
+constexpr int RED_BYTES = 2 * NW * TM * 4;                  // one reduction (two values per token and wave); TWO buffers, used alternately:
+constexpr int BIAS_OFF = RED_OFF + 2 * RED_BYTES;           // a reduction's readers are past the NEXT reduction's barrier before its buffer is written again
 constexpr int LDS_BYTES = BIAS_OFF + 3 * kD * 4;
 
 struct BwdArgs {
@@ -164,23 +193,40 @@ __device__ __forceinline__ void put_tile(const float (&t)[16], E* lrow, const Pa
 #endif
 }
 
-// accumulator tile X^T[row = acc_row(r, hh)][col = c32] -> the wave's transpose scratch T[row][col]
-__device__ __forceinline__ void tr_write(E* T, const f32x16& x, int c32, int hh) {
+// LDS byte offsets above 64 KB do not fit a ds instruction's 16-bit immediate: hipcc then builds ONE address register per
+// access (base + constant), keeps all of them alive for the next use of the same address and spills them (round 5: 40 of the
+// kernel's 50 spilled registers were such addresses).  An offset that went through opaque() is a plain register to the compiler:
+// region base + lane part are added once, every access is that register + a small immediate.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// accumulator tile X^T[row = acc_row(r, hh)][col = c32] -> the wave's transpose scratch T[row][col]; T = scratch + (4 hh * TR_LD + c32)
+__device__ __forceinline__ void tr_write(E* T, const f32x16& x) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) T[acc_row(r, hh) * TR_LD + c32] = (E)x[r];
+  for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2)) * TR_LD] = (E)x[r];
+}
+// the same from the two packed operand fragments of a tile (F[h][j] = accumulator register 8 h + j, already rounded to E)
+__device__ __forceinline__ void tr_write_frags(E* T, const Frag (&F)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) T[((j & 3) + 8 * (2 * h + (j >> 2))) * TR_LD] = F[h][j];
 }
 // the query's eight own-sample values (keys 16 sp + acc_row(i, hh)) -> T[key][query]; the other sample's keys are zero
-__device__ __forceinline__ void tr_write_own(E* T, const float (&v)[8], int sp, int c32, int hh) {
+__device__ __forceinline__ void tr_write_own(E* T, const float (&v)[8], int sp) {
+  E* own = T + 16 * sp * TR_LD;
+  E* other = T + 16 * (1 - sp) * TR_LD;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    T[(16 * sp + acc_row(i, hh)) * TR_LD + c32] = (E)v[i];
-    T[(16 * (1 - sp) + acc_row(i, hh)) * TR_LD + c32] = (E)0.f;
+    own[((i & 3) + 8 * (i >> 2)) * TR_LD] = (E)v[i];
+    other[((i & 3) + 8 * (i >> 2)) * TR_LD] = (E)0.f;
   }
 }
 // fragment h (columns 16h .. 16h+15 as the k axis) of row c32, k slots in the accumulator's row order (slot (hh, j) <-> column
 // 16h + (j&3) + 8 (j>>2) + 4 hh): the order pack8() gives the register-built partner operand
-__device__ __forceinline__ Frag tr_read(const E* T, int c32, int hh, int h) {
-  const E* p = T + c32 * TR_LD + 16 * h + 4 * hh;
+__device__ __forceinline__ Frag tr_read(const E* T, int h) {   // T = scratch + (c32 * TR_LD + 4 hh)
+  const E* p = T + 16 * h;
   const Quad a = *reinterpret_cast<const Quad*>(p), b = *reinterpret_cast<const Quad*>(p + 8);
   Frag f;
 #pragma unroll
@@ -196,7 +242,6 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   E* DQKV = reinterpret_cast<E*>(smem);
   using ModE = OP::ModE;
   ModE* MOD = reinterpret_cast<ModE*>(smem + MOD_OFF);
-  float* RED = reinterpret_cast<float*>(smem + RED_OFF);
   float* BIAS = reinterpret_cast<float*>(smem + BIAS_OFF);
 
   const int tid = threadIdx.x;
@@ -206,7 +251,18 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   const int tile = blockIdx.x;
   const int tok0 = tile * TM, smp0 = tile * NS;
   const int fb = wave * 32;   // first feature / head dimension owned by this wave
-  E* TR = reinterpret_cast<E*>(smem + TR_OFF + wave * TR_BYTES);
+  // Every lane-dependent address below is rebuilt AT ITS USE SITE from a laundered lane id (lane_now()): hipcc otherwise hoists
+  // the address arithmetic of the whole kernel above the SwiGLU loop, spills the results there and reloads each behind an
+  // s_waitcnt vmcnt(0) that drains the record loads in flight (round 5).  A handful of VALU operations per phase instead.
+  auto lane_now = [&]() { return opaque(lane); };
+  // reduction scratch [buffer][2][wave][token]: this lane's write slot (own wave) / first read slot (wave 0)
+  auto red_w = [&]() { return reinterpret_cast<float*>(smem + opaque(RED_OFF + (wave * TM + (lane_now() & 31)) * 4)); };
+  auto red_r = [&]() { return reinterpret_cast<const float*>(smem + opaque(RED_OFF + (lane_now() & 31) * 4)); };
+  constexpr int RED0 = 0, RED1 = SCLDM_BWD_RED2 ? RED_BYTES / 4 : 0;   // float offset of the two buffers
+  auto mod_base = [&]() {
+    const int l = lane_now();
+    return reinterpret_cast<const ModE*>(smem + opaque(MOD_OFF + (((l & 31) >> 4) * kModBlock + fb + (l >> 5) * 4) * (int)sizeof(ModE)));
+  };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #define BWD_STAMP(i)                                                                                                        \
@@ -214,16 +270,19 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * NW + wave) * 16 + (i)] = __builtin_readcyclecounter();             \
   } while (0)
   BWD_STAMP(0);
-  WStream<OP, PF, 1> ws;
-  ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
+  WStream<OP, PF, 1> ws;   // the weight ring is requested at the end of phase 2 and parked across every phase without a GEMM pass (SCLDM_BWD_PARK)
+  constexpr bool kPark = SCLDM_BWD_PARK && PF <= 8;
+  if (!kPark) ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
 
   // record / gradient tiles in the 4-wave forward kernel's layout [tile][fwd wave = wave >> 1][quad (tt*2 + ft)*4 + q][lane][4],
   // ft = wave & 1: a quad is 1 KB (fp32) / 512 B (16-bit) contiguous per wave; the descriptors start at this wave's first quad
   const size_t quad0 = (size_t)((tile * 4 + (wave >> 1)) * 16 + (wave & 1) * 4) * 64;   // in lane-quads of 4 elements
   const __amdgpu_buffer_rsrc_t r_xin = uniform_rsrc(a.x_in + quad0 * 4), r_dx = uniform_rsrc(a.dx + quad0 * 4);
   const __amdgpu_buffer_rsrc_t r_y1 = uniform_rsrc(a.y1 + quad0 * 4), r_y2 = uniform_rsrc(a.y2 + quad0 * 4);
-  const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u;
+  // (opaque: with provably disjoint bits hipcc turns `lane16 + q * 1024` into an OR, which it does not fold into the instruction's
+  // immediate offset - one address register per access again)
   auto load_f32 = [&](const __amdgpu_buffer_rsrc_t r, float (&dst)[NTT][16]) {
+    const unsigned lane16 = (unsigned)opaque(lane_now() * 16);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -236,35 +295,39 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   };
   gchar* const p_dx = uniform_ptr(a.dx + quad0 * 4);
   auto store_dx = [&](const float (&src)[NTT][16]) {
+    const unsigned lane16 = (unsigned)opaque(lane_now() * 16);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *(g_f32x4*)(p_dx + (lane16 + (unsigned)(tt * 8192 + q * 1024))) = f32x4{src[tt][q * 4], src[tt][q * 4 + 1], src[tt][q * 4 + 2], src[tt][q * 4 + 3]};
   };
-  auto load_bf16 = [&](const __amdgpu_buffer_rsrc_t r, float (&dst)[NTT][16]) {   // (a 16-bit record array of the operand type)
+  // a 16-bit record array of the operand type: requested as packed pairs (16 registers in flight), widened where it is used
+  auto load_16 = [&](const __amdgpu_buffer_rsrc_t r, u32x2 (&raw)[NTT][4]) {
+    const unsigned lane8 = (unsigned)opaque(lane_now() * 8);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        union { u32x2 u; Quad h; } t4;
-        t4.u = __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + q * 512, tt * 4096, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[tt][q * 4 + i] = (float)t4.h[i];
-      }
+      for (int q = 0; q < 4; ++q) raw[tt][q] = __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + q * 512, tt * 4096, 0);
+  };
+  auto widen = [&](const u32x2 (&raw)[NTT][4], int tt, int q, int i) {
+    union { u32x2 u; Quad h; } t4;
+    t4.u = raw[tt][q];
+    return (float)t4.h[i];
   };
   // operand-pair destinations: [token][ld] 16-bit arrays; this wave writes columns first + [0, 32) of token tile tt
-  const unsigned pv256 = (unsigned)(c32 * kD + 8 * hh) * 2u, pv768 = (unsigned)(c32 * 3 * kD + 8 * hh) * 2u;
   static_assert(kBwdChunks * kBwdChunk == 3 * kD, "the hidden operand arrays share the dqkv row pitch");
   auto pair_dst = [&](const E* base, int ld, int tt, int first) {
-    return PairDst{uniform_ptr(base + (size_t)(tok0 + tt * 32) * ld + first), ld == kD ? pv256 : pv768, true};
+    const int l = lane_now();
+    return PairDst{uniform_ptr(base + (size_t)(tok0 + tt * 32) * ld + first), (unsigned)opaque(((l & 31) * ld + 8 * (l >> 5)) * 2), true};
   };
   // adaLN vector `vec` of the lane's sample, the four features of register quad q
-  auto mod4 = [&](int tt, int vec, int q) { return OP::load_mod4(MOD + (tt * 2 + sp) * kModBlock + vec * kD + fb + q * 8 + hh * 4); };
+  auto mod4 = [&](const ModE* mb, int tt, int vec, int q) { return OP::load_mod4(mb + tt * 2 * kModBlock + vec * kD + q * 8); };
   // sum over the 16 tokens of each sample of a per-(feature, token) quantity -> dmod[sample][vec][feature]
   gchar* const p_dmod = uniform_ptr(a.dmod + (size_t)smp0 * a.mod_stride + a.mod_off + fb);
-  const unsigned dmod_voff = (unsigned)((sp * a.mod_stride + hh * 4) * 4);
   auto dmod_store = [&](const float (&v)[NTT][16], int vec) {
+    const int ld = lane_now();
+    const unsigned dmod_voff = (unsigned)opaque(((((ld & 31) >> 4)) * a.mod_stride + (ld >> 5) * 4) * 4);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float tot[16];
@@ -279,7 +342,9 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     }
   };
   // LayerNorm statistics of every token of the tile (one sweep; fp32): in-lane sums -> half-wave exchange -> 8-way LDS combine
-  auto ln_stats = [&](const float (&v)[NTT][16], float (&mean)[NTT], float (&rstd)[NTT]) {
+  auto ln_stats = [&](const float (&v)[NTT][16], float (&mean)[NTT], float (&rstd)[NTT], int RED) {
+    float* const RED_W = red_w();
+    const float* const RED_R = red_r();
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float s = 0.f, ss = 0.f;
@@ -291,8 +356,8 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       s = xor32_sum(s);
       ss = xor32_sum(ss);
       if (hh == 0) {
-        RED[wave * TM + tt * 32 + c32] = s;
-        RED[NW * TM + wave * TM + tt * 32 + c32] = ss;
+        RED_W[RED + tt * 32] = s;
+        RED_W[RED + NW * TM + tt * 32] = ss;
       }
     }
     lds_barrier();
@@ -301,23 +366,26 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       float m = 0.f, e2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        m += RED[w * TM + tt * 32 + c32];
-        e2 += RED[NW * TM + w * TM + tt * 32 + c32];
+        m += RED_R[RED + w * TM + tt * 32];
+        e2 += RED_R[RED + NW * TM + w * TM + tt * 32];
       }
       mean[tt] = m * (1.0f / kD);
       rstd[tt] = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean[tt], mean[tt], e2 * (1.0f / kD)), 0.f) + a.eps);
     }
+#if !SCLDM_BWD_RED2
     lds_barrier();   // RED may be rewritten by the next reduction
+#endif
   };
   // y = LN(v) * S + shift (S = 1 + scale, staged) -> LDS image + operand array
   auto ln_modulate = [&](const float (&v)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v, int sh_v, E* img, const E* gout) {
+    const ModE* const mb = mod_base();
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       const float nmr = -mean[tt] * rstd[tt];
       float y[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 sc = mod4(tt, sc_v, q), sh = mod4(tt, sh_v, q);
+        const f32x4 sc = mod4(mb, tt, sc_v, q), sh = mod4(mb, tt, sh_v, q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) y[q * 4 + i] = fmaf(fmaf(v[tt][q * 4 + i], rstd[tt], nmr), sc[i], sh[i]);
       }
@@ -326,7 +394,10 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
   };
   // backward of y = LN(x) * S + shift given dh = d y (accumulator tiles): dres += d x; dmod[sc_v] = sum_t dh xhat, dmod[sh_v] = sum_t dh
   auto ln_backward = [&](const f32x16 (&dh)[NTT], const float (&x)[NTT][16], const float (&mean)[NTT], const float (&rstd)[NTT], int sc_v,
-                         int sh_v, float (&dres)[NTT][16]) {
+                         int sh_v, float (&dres)[NTT][16], int RED) {
+    float* const RED_W = red_w();
+    const float* const RED_R = red_r();
+    const ModE* const mb = mod_base();
     float t1[NTT][16];
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -334,7 +405,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 sc = mod4(tt, sc_v, q);
+        const f32x4 sc = mod4(mb, tt, sc_v, q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = q * 4 + i;
@@ -347,8 +418,8 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       s1 = xor32_sum(s1);
       s2 = xor32_sum(s2);
       if (hh == 0) {
-        RED[wave * TM + tt * 32 + c32] = s1;
-        RED[NW * TM + wave * TM + tt * 32 + c32] = s2;
+        RED_W[RED + tt * 32] = s1;
+        RED_W[RED + NW * TM + tt * 32] = s2;
       }
     }
     dmod_store(t1, sc_v);
@@ -363,15 +434,15 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        s1 += RED[w * TM + tt * 32 + c32];
-        s2 += RED[NW * TM + w * TM + tt * 32 + c32];
+        s1 += RED_R[RED + w * TM + tt * 32];
+        s2 += RED_R[RED + NW * TM + w * TM + tt * 32];
       }
       s1 *= (1.0f / kD);
       s2 *= (1.0f / kD);
       const float nmr = -mean[tt] * rstd[tt];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 sc = mod4(tt, sc_v, q);
+        const f32x4 sc = mod4(mb, tt, sc_v, q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = q * 4 + i;
@@ -380,13 +451,16 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
         }
       }
     }
+#if !SCLDM_BWD_RED2
     lds_barrier();
+#endif
   };
-  auto bias_tile = [&](const float* brow) {
+  auto bias_tile = [&](int p) {   // bias of c_attn rows p * 256 + fb .. + 31 as an initial accumulator tile
+    const float* const BIAS_R = reinterpret_cast<const float*>(smem + opaque(BIAS_OFF + (fb + (lane_now() >> 5) * 4) * 4));
     f32x16 t;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + q * 8 + hh * 4);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(BIAS_R + p * kD + q * 8);
 #pragma unroll
       for (int i = 0; i < 4; ++i) t[q * 4 + i] = b4[i];
     }
@@ -412,78 +486,114 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     F[1] = hi_half.f;
   };
 
-  // ---- stage the adaLN vectors (scales as 1 + scale) and the c_attn bias ----
+  // ---- phase 1: every global read of the phase is requested up front (one round trip, not one per use): the adaLN vectors and
+  // the c_attn bias (staged to LDS), d x_out, y2, x_in, y1 ----
+  constexpr int kModLd = NS * kModBlock / 4 / NT;   // 3 float4 per thread
+  static_assert(NS * kModBlock / 4 % NT == 0, "whole float4 per thread");
+  f32x4 mstage[kModLd], bstage = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < kModLd; ++j) {
+    const int idx = tid + NT * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)min(smp0 + sl, a.n - 1) * a.mod_stride + a.mod_off + w4 * 4);
+  }
+  if (tid < 3 * kD / 4) bstage = *reinterpret_cast<const f32x4*>(a.b_qkv + tid * 4);
+  // The residual x and its gradient are NOT kept in registers across the GEMM phases (the up-projection tiles, the operand
+  // fragments of the attention core and the weight ring need them): each phase re-reads what it needs from the record / from
+  // a.dx (L2-resident, 64 KB per tile).
+  float mean2[NTT], rstd2[NTT];
+  float xr[NTT][16];    // x_mid in phases 1-2, x_in from the LayerNorm-2 backward on
+#if SCLDM_BWD_KEEP_DXOUT
+  static_assert(SCLDM_BWD_KEEP_DX, "KEEP_DXOUT extends KEEP_DX");
+  float dxr[NTT][16];
+#endif
   {
-    constexpr int kModLd = NS * kModBlock / 4 / NT;   // 3 float4 per thread
-    static_assert(NS * kModBlock / 4 % NT == 0, "whole float4 per thread");
+  auto stage_mod = [&]() {
 #pragma unroll
     for (int j = 0; j < kModLd; ++j) {
-      const int idx = tid + NT * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
-      f32x4 m = *reinterpret_cast<const f32x4*>(a.mod + (size_t)min(smp0 + sl, a.n - 1) * a.mod_stride + a.mod_off + w4 * 4);
+      const int idx = tid + NT * j, w4 = idx % (kModBlock / 4);
       const int vec = w4 / (kD / 4);
+      f32x4 m = mstage[j];
       if (vec == 0 || vec == 3) m += 1.0f;
       OP::store_mod4(MOD + (size_t)idx * 4, m);
     }
-    if (tid < 3 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + tid * 4) = *reinterpret_cast<const f32x4*>(a.b_qkv + tid * 4);
-  }
-  // The residual x and its gradient are NOT kept in registers across the GEMM phases (the up-projection tiles, the operand
-  // fragments of the attention core and the weight ring need them): each phase re-reads what it needs from the record / from
-  // a.dx (L2-resident, 64 KB per tile) - the compiler otherwise parks the same values in scratch, whose traffic shares the
-  // in-order vmcnt queue with the weight ring.
-  float mean2[NTT], rstd2[NTT];
-  float xr[NTT][16];    // x_mid: stays in registers across the MLP chunks (the LayerNorm-2 backward needs it again)
-  {
+    if (tid < 3 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + tid * 4) = bstage;
+  };
+#if !SCLDM_BWD_KEEP_DXOUT
   float dxr[NTT][16];
+#endif
+  u32x2 y2raw[NTT][4], y1raw[NTT][4];
+#if !(SCLDM_BWD_HOIST & 8)
+  stage_mod();
+#endif
   load_f32(r_dx, dxr);
+  load_16(r_y2, y2raw);
+#if SCLDM_BWD_HOIST & 1
+  load_f32(r_xin, xr);
+  load_16(r_y1, y1raw);
+#endif
+#if SCLDM_BWD_HOIST & 8
+  stage_mod();
+#endif
   lds_barrier();
 
   // ================= MLP branch: x_out = x_mid + a5 * c_proj(silu(w1 h2) * (w2 h2)),  h2 = LN(x_mid) (1 + a3) + a4 =================
   {
+    const ModE* const mb = mod_base();
     float t[NTT][16];
-    load_bf16(r_y2, t);   // y2
     // d a5 = sum_t d x_out * y2;  d y2 = a5 * d x_out -> image R1 + operand array
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float dy[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 g = mod4(tt, 5, q);
+        const f32x4 g = mod4(mb, tt, 5, q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           dy[q * 4 + i] = g[i] * dxr[tt][q * 4 + i];
-          t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
+          t[tt][q * 4 + i] = widen(y2raw, tt, q, i) * dxr[tt][q * 4 + i];
         }
       }
       put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, pair_dst(a.e_dy2, kD, tt, fb), fb, hh);
     }
     dmod_store(t, 5);
     // x_mid = x_in + a2 * y1
+#if !(SCLDM_BWD_HOIST & 1)
     load_f32(r_xin, xr);
-    load_bf16(r_y1, t);
+    load_16(r_y1, y1raw);
+#endif
+#if SCLDM_BWD_KEEP_XIN_MLP
+    float xm[NTT][16];
+#else
+    float (&xm)[NTT][16] = xr;
+#endif
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 g = mod4(tt, 2, q);
+        const f32x4 g = mod4(mb, tt, 2, q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xr[tt][q * 4 + i] = fmaf(g[i], t[tt][q * 4 + i], xr[tt][q * 4 + i]);
+        for (int i = 0; i < 4; ++i) xm[tt][q * 4 + i] = fmaf(g[i], widen(y1raw, tt, q, i), xr[tt][q * 4 + i]);
       }
-  }
   BWD_STAMP(1);
-  ln_stats(xr, mean2, rstd2);
-  ln_modulate(xr, mean2, rstd2, 3, 4, R0, a.e_h2);
+  ln_stats(xm, mean2, rstd2, RED0);
+  ln_modulate(xm, mean2, rstd2, 3, 4, R0, a.e_h2);
   }
+  }
+  if (kPark) ws.init(reinterpret_cast<const Frag*>(a.w_stream) + (size_t)wave * kBwdUnitsLayer * 64, lane);
   lds_barrier();   // h2 and dy2 images complete
   BWD_STAMP(2);
 
   f32x16 dh[1][NTT];   // d h2 (this phase), later d h1
   for (int c = 0; c < kBwdChunks; ++c) {
     f32x16 ad[1][NTT], aa[1][NTT], ab[1][NTT];
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ad, ws, R1, XA_LD, lane);   // d hid^T = c_proj^T d y2 (this wave's 32 hidden units)
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(aa, ws, R0, XA_LD, lane);   // a^T = w1 h2
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ab, ws, R0, XA_LD, lane);   // b^T = w2 h2
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ad, ws, R1, XA_LD, lane_now());   // d hid^T = c_proj^T d y2 (this wave's 32 hidden units)
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(aa, ws, R0, XA_LD, lane_now());   // a^T = w1 h2
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(ab, ws, R0, XA_LD, lane_now());   // b^T = w2 h2
+    // (round 5: the order a, b, [SwiGLU factors in place, hid out], d hid, [da, db out] holds one accumulator tile less but measured
+    //  5 k cycles per chunk SLOWER - two store bursts and two VALU stretches between passes instead of one)
     if (c == 0) BWD_STAMP(3);
     if (c > 0) lds_barrier();   // every wave has finished the previous chunk's d h2 pass over R2
+    const int first = c * kBwdChunk + fb;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float da[16], db[16], hid[16];
@@ -496,7 +606,6 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
         da[r] = d * bv * (s * fmaf(av, 1.0f - s, 1.0f));
         db[r] = d * sl;
       }
-      const int first = c * kBwdChunk + fb;
       put_tile(da, R2 + (tt * 32 + c32) * DADB_LD, pair_dst(a.e_da, 3 * kD, tt, first), fb, hh);
       put_tile(db, R2 + (tt * 32 + c32) * DADB_LD + kBwdChunk, pair_dst(a.e_db, 3 * kD, tt, first), fb, hh);
       put_tile(hid, nullptr, pair_dst(a.e_hid, 3 * kD, tt, first), fb, hh);
@@ -504,77 +613,111 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     if (c == 0) BWD_STAMP(4);
     lds_barrier();
     if (c == 0) BWD_STAMP(5);
-    if (c == 0) gemm_pass<OP, NTT, 1, 32, false, true, PF>(dh, ws, R2, DADB_LD, lane);    // d h2^T (+)= [w1^T | w2^T] [da | db]
-    else gemm_pass<OP, NTT, 1, 32, false, false, PF>(dh, ws, R2, DADB_LD, lane);
+    if (c == 0) gemm_pass<OP, NTT, 1, 32, false, true, PF>(dh, ws, R2, DADB_LD, lane_now());    // d h2^T (+)= [w1^T | w2^T] [da | db]
+    else if (kPark && c == kBwdChunks - 1) gemm_pass<OP, NTT, 1, 32, false, false, PF, kPark>(dh, ws, R2, DADB_LD, lane_now());
+    else gemm_pass<OP, NTT, 1, 32, false, false, PF>(dh, ws, R2, DADB_LD, lane_now());
     if (c == 0) BWD_STAMP(6);
   }
   BWD_STAMP(7);
   // d x_mid = d x_out + LN2-backward(d h2);  d a3, d a4
   float mean1[NTT], rstd1[NTT];
-  {
+#if SCLDM_BWD_KEEP_DX && !SCLDM_BWD_KEEP_DXOUT
   float dxr[NTT][16];
+#endif
+  {
+  // every global read of the two phases is requested here: d x_out (needed at the end of the LayerNorm-2 backward), y1 and x_in.
+  // x_mid = x_in + a2 y1 is REBUILT here instead of living in 32 registers across the SwiGLU chunks (round 5: that loop is the
+  // kernel's register peak, and x_in / y1 are read again for this phase anyway)
+#if !SCLDM_BWD_KEEP_DX
+  float dxr[NTT][16];
+#endif
+  u32x2 y1raw[NTT][4];
+#if !SCLDM_BWD_KEEP_DXOUT
   load_f32(r_dx, dxr);
-  ln_backward(dh[0], xr, mean2, rstd2, 3, 4, dxr);
+#endif
+  load_16(r_y1, y1raw);
+#if !SCLDM_BWD_KEEP_XIN_MLP
+  load_f32(r_xin, xr);
+#endif
+  {
+    const ModE* const mb = mod_base();
+    float xm[NTT][16];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 g = mod4(mb, tt, 2, q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xm[tt][q * 4 + i] = fmaf(g[i], widen(y1raw, tt, q, i), xr[tt][q * 4 + i]);
+      }
+    ln_backward(dh[0], xm, mean2, rstd2, 3, 4, dxr, RED1);
+  }
 
   BWD_STAMP(8);
   // ================= attention branch: x_mid = x_in + a2 * (c_proj(attention(c_attn(h1))) + b),  h1 = LN(x_in) (1 + a0) + a1 =================
   {
+    const ModE* const mb = mod_base();
     float t[NTT][16];
-    load_bf16(r_y1, t);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float dy[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 g = mod4(tt, 2, q);
+        const f32x4 g = mod4(mb, tt, 2, q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           dy[q * 4 + i] = g[i] * dxr[tt][q * 4 + i];
-          t[tt][q * 4 + i] *= dxr[tt][q * 4 + i];
+          t[tt][q * 4 + i] = widen(y1raw, tt, q, i) * dxr[tt][q * 4 + i];
         }
       }
       put_tile(dy, R1 + (tt * 32 + c32) * XA_LD, pair_dst(a.e_dy1, kD, tt, fb), fb, hh);   // d y1 (R1's last reader was chunk 2's d hid pass)
     }
     dmod_store(t, 2);
   }
+#if !SCLDM_BWD_KEEP_DX
   // d x_mid waits in a.dx for the LayerNorm-1 backward at the end
   store_dx(dxr);
-  load_f32(r_xin, xr);
-  ln_stats(xr, mean1, rstd1);
+#endif
+  ln_stats(xr, mean1, rstd1, RED0);
   ln_modulate(xr, mean1, rstd1, 0, 1, R0, a.e_h1);   // h1 (R0's last readers were chunk 2's a / b passes)
   }
+  if (kPark) ws.unpark();
   lds_barrier();
 
   BWD_STAMP(9);
   // q, k, v, d ao of head `wave`: as (token, k = head dim) operands straight from the accumulator tiles, and transposed
   // ((head dim, k = token), through the wave's LDS scratch - R2's tail is free since the last d h2 pass)
+  // (round 5: the transposed copies are made in the core, one tile at a time, from the packed fragments - holding all eight next
+  //  to the four passes' accumulators and the ring was the kernel's register peak)
   Frag QF[NTT][2], KF[NTT][2], VF[NTT][2], GF[NTT][2];
-  Frag QT[NTT][2], KT[NTT][2], VT[NTT][2], GT[NTT][2];
   {
     f32x16 acc[1][NTT];
-    auto both = [&](Frag (&F)[NTT][2], Frag (&T)[NTT][2]) {
+    auto keep = [&](Frag (&F)[NTT][2]) {
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) {
-        to_frags(acc[0][tt], F[tt]);
-        tr_write(TR, acc[0][tt], c32, hh);
-        wave_sync();
-        T[tt][0] = tr_read(TR, c32, hh, 0);
-        T[tt][1] = tr_read(TR, c32, hh, 1);
-        wave_sync();
-      }
+      for (int tt = 0; tt < NTT; ++tt) to_frags(acc[0][tt], F[tt]);
     };
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R1, XA_LD, lane);   // d ao^T = c_proj^T d y1
-    both(GF, GT);
-    f32x16 b = bias_tile(BIAS + 0 * kD + fb);
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
-    both(QF, QT);
-    b = bias_tile(BIAS + 1 * kD + fb);
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
-    both(KF, KT);
-    b = bias_tile(BIAS + 2 * kD + fb);
-    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane, &b);
-    both(VF, VT);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R1, XA_LD, lane_now());   // d ao^T = c_proj^T d y1
+    keep(GF);
+    f32x16 b = bias_tile(0);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane_now(), &b);
+    keep(QF);
+    b = bias_tile(1);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF>(acc, ws, R0, XA_LD, lane_now(), &b);
+    keep(KF);
+    b = bias_tile(2);
+    gemm_pass<OP, NTT, 1, 16, false, true, PF, kPark>(acc, ws, R0, XA_LD, lane_now(), &b);
+    keep(VF);
   }
+  const int l_tr = lane_now();
+  E* const TRW = reinterpret_cast<E*>(smem + opaque(TR_OFF + wave * TR_BYTES + (4 * (l_tr >> 5) * TR_LD + (l_tr & 31)) * 2));   // transpose scratch, write side
+  E* const TRR = reinterpret_cast<E*>(smem + opaque(TR_OFF + wave * TR_BYTES + ((l_tr & 31) * TR_LD + 4 * (l_tr >> 5)) * 2));   // read side
+  auto transposed = [&](const Frag (&F)[2], Frag (&T)[2]) {   // (head dim, k = token) copy of a (token, k = head dim) tile
+    tr_write_frags(TRW, F);
+    wave_sync();
+    T[0] = tr_read(TRR, 0);
+    T[1] = tr_read(TRR, 1);
+    wave_sync();
+  };
   BWD_STAMP(10);
   lds_barrier();   // every wave is done with the h1 / dy1 images: the dqkv image and the transpose scratch may overwrite them
 
@@ -612,8 +755,10 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     masked_frags(p, Ph);
     // O^T[d][query] = V^T P^T (operand for the c_proj weight gradient)
     {
-      f32x16 ot = OP::mma(VT[tt][0], Ph[0], zero16);
-      ot = OP::mma(VT[tt][1], Ph[1], ot);
+      Frag VT[2];
+      transposed(VF[tt], VT);
+      f32x16 ot = OP::mma(VT[0], Ph[0], zero16);
+      ot = OP::mma(VT[1], Ph[1], ot);
       float o[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = ot[r];
@@ -642,49 +787,73 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
     E* lrow = DQKV + (tt * 32 + c32) * DQKV_LD;
     // dQ^T[d][query] = K^T dS^T
     {
-      f32x16 dq = OP::mma(KT[tt][0], dSh[0], zero16);
-      dq = OP::mma(KT[tt][1], dSh[1], dq);
+      Frag KT[2];
+      transposed(KF[tt], KT);
+      f32x16 dq = OP::mma(KT[0], dSh[0], zero16);
+      dq = OP::mma(KT[1], dSh[1], dq);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dq[r];
       put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, fb), fb, hh);
     }
     // dK^T[d][key] = Q^T dS
     Frag T1[2];
-    tr_write_own(TR, ds, sp, c32, hh);
+    tr_write_own(TRW, ds, sp);
     wave_sync();
-    T1[0] = tr_read(TR, c32, hh, 0);
-    T1[1] = tr_read(TR, c32, hh, 1);
+    T1[0] = tr_read(TRR, 0);
+    T1[1] = tr_read(TRR, 1);
     wave_sync();
     {
-      f32x16 dk = OP::mma(QT[tt][0], T1[0], zero16);
-      dk = OP::mma(QT[tt][1], T1[1], dk);
+      Frag QT[2];
+      transposed(QF[tt], QT);
+      f32x16 dk = OP::mma(QT[0], T1[0], zero16);
+      dk = OP::mma(QT[1], T1[1], dk);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dk[r];
       put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, kD + fb), kD + fb, hh);
     }
     // dV^T[d][key] = dAO^T P
-    tr_write_own(TR, p, sp, c32, hh);
+    tr_write_own(TRW, p, sp);
     wave_sync();
-    T1[0] = tr_read(TR, c32, hh, 0);
-    T1[1] = tr_read(TR, c32, hh, 1);
+    T1[0] = tr_read(TRR, 0);
+    T1[1] = tr_read(TRR, 1);
     wave_sync();
     {
-      f32x16 dv = OP::mma(GT[tt][0], T1[0], zero16);
-      dv = OP::mma(GT[tt][1], T1[1], dv);
+      Frag GT[2];
+      transposed(GF[tt], GT);
+      f32x16 dv = OP::mma(GT[0], T1[0], zero16);
+      dv = OP::mma(GT[1], T1[1], dv);
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[r] = dv[r];
       put_tile(o, lrow, pair_dst(a.e_dqkv, 3 * kD, tt, 2 * kD + fb), 2 * kD + fb, hh);
     }
   }
   BWD_STAMP(11);
+  if (kPark) ws.unpark();
   lds_barrier();   // dqkv image complete
-  gemm_pass<OP, NTT, 1, 48, false, true, PF>(dh, ws, DQKV, DQKV_LD, lane);   // d h1^T = c_attn^T d qkv
-  BWD_STAMP(12);
-  // d x_in = d x_mid + LN1-backward(d h1);  d a0, d a1
+  // x_in (and d x_mid) are requested before the K = 768 pass and arrive under it
+#if !SCLDM_BWD_KEEP_DX
   float dxr[NTT][16];
+#endif
+#if (SCLDM_BWD_HOIST & 4) && !SCLDM_BWD_KEEP_XIN
   load_f32(r_xin, xr);
+#endif
+#if SCLDM_BWD_HOIST & 4
+#if !SCLDM_BWD_KEEP_DX
   load_f32(r_dx, dxr);
-  ln_backward(dh[0], xr, mean1, rstd1, 0, 1, dxr);
+#endif
+#endif
+  gemm_pass<OP, NTT, 1, 48, false, true, PF, kPark>(dh, ws, DQKV, DQKV_LD, lane_now());   // d h1^T = c_attn^T d qkv (last pass: the ring ends here)
+  BWD_STAMP(12);
+#if !(SCLDM_BWD_HOIST & 4) && !SCLDM_BWD_KEEP_XIN
+  load_f32(r_xin, xr);
+#endif
+#if !(SCLDM_BWD_HOIST & 4)
+#if !SCLDM_BWD_KEEP_DX
+  load_f32(r_dx, dxr);
+#endif
+#endif
+  // d x_in = d x_mid + LN1-backward(d h1);  d a0, d a1
+  ln_backward(dh[0], xr, mean1, rstd1, 0, 1, dxr, RED1);
 
   store_dx(dxr);
   BWD_STAMP(13);

@@ -228,6 +228,16 @@ struct WStream {
     return u.f;
   }
   __device__ __forceinline__ void advance(int frags) { soff += frags * 64 * (unsigned)sizeof(Frag); }
+  // after a PARK pass: request the PF units the skipped refills would have fetched
+  __device__ __forceinline__ void unpark() {
+    soff -= PF * FT * 64 * (unsigned)sizeof(Frag);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+#pragma unroll
+      for (int ft = 0; ft < FT; ++ft) ring[s][ft] = fetch(ft);
+      advance(FT);
+    }
+  }
   __device__ __forceinline__ void init(const Frag* unit0, int lane) {
     // the descriptor inputs are made provably wave-uniform (a lane-tainted pointer makes hipcc wrap every load in a waterfall loop)
     const unsigned long long b = reinterpret_cast<unsigned long long>(unit0);
@@ -252,7 +262,9 @@ struct WStream {
 // the unrolled body and waits for it two MFMAs later, and issues each ds_read right in front of its consumer):
 //     NTT ds_read_b128 (B fragments of the NEXT k-step)  |  FT*NTT MFMAs (this k-step)  |  FT global loads
 // (refill of the ring slot just consumed = PF k-steps ahead).
-template <typename OP, int NTT, int FT, int KSTEPS, bool SWAP, bool ZERO, int PF>
+// PARK=true: the pass's last ring revolution is not refilled (the offset still advances): the ring registers are free until
+// WStream::unpark() re-requests those PF units (dit_backward.hpp parks the ring across the register-hungry attention core).
+template <typename OP, int NTT, int FT, int KSTEPS, bool SWAP, bool ZERO, int PF, bool PARK = false>
 __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF, FT>& ws,
                                           const typename OP::E* __restrict__ bsm, int ldb, int lane, const f32x16* init = nullptr) {
   // ZERO with init != nullptr: tile (ft, *) starts from init[ft] (a per-row bias tile) instead of zero
@@ -265,7 +277,7 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
   Frag bcur[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) bcur[tt] = *reinterpret_cast<const Frag*>(bbase + tt * 32 * ldb);
-  auto step = [&](int ks, int s, bool first) {
+  auto step = [&](int ks, int s, bool first, bool refill = true) {
     Frag bnext[NTT];
     // B fragments of k-step ks+1 (after the last k-step this reads the row pad / next row: valid LDS, never used)
 #if SCLDM_PROXY & 2    // timing proxy 2 (WRONG RESULTS): the activation fragments are read once per pass - what the LDS fragment reads cost
@@ -284,8 +296,10 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
       }
     }
 #if !(SCLDM_PROXY & 1)   // timing proxy 1 (WRONG RESULTS): the weight ring is never refilled - what the L2 -> VGPR weight stream costs
+    if (refill) {
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.fetch(ft);  // refill the slot just consumed: PF k-steps ahead
+      for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.fetch(ft);  // refill the slot just consumed: PF k-steps ahead
+    }
 #endif
     ws.advance(FT);
 #pragma unroll
@@ -293,19 +307,24 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
     if (OP::kPin) {
       __builtin_amdgcn_sched_group_barrier(0x100, NTT * OP::kFragLoads, 0);       // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, FT * NTT * OP::kMmaOps, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, FT * OP::kFragLoads, 0);        // VMEM read
+      if (refill) __builtin_amdgcn_sched_group_barrier(0x020, FT * OP::kFragLoads, 0);        // VMEM read
     }
   };
   // peeled first ring revolution (so that ZERO needs no accumulator clearing), then the rolled loop
 #if SCLDM_SETPRIO
   __builtin_amdgcn_s_setprio(SCLDM_SETPRIO);
 #endif
+  static_assert(!PARK || (KSTEPS % PF == 0 && KSTEPS >= 2 * PF), "a parking pass has a whole last revolution of its own");
 #pragma unroll
   for (int s = 0; s < (PF < KSTEPS ? PF : KSTEPS); ++s) step(s, s, ZERO && s == 0);
 #pragma unroll 1
-  for (int ks0 = PF; ks0 < KSTEPS; ks0 += PF) {
+  for (int ks0 = PF; ks0 < KSTEPS - (PARK ? PF : 0); ks0 += PF) {
 #pragma unroll
     for (int s = 0; s < PF; ++s) step(ks0 + s, s, false);
+  }
+  if (PARK) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) step(KSTEPS - PF + s, s, false, false);
   }
 #if SCLDM_SETPRIO
   __builtin_amdgcn_s_setprio(0);

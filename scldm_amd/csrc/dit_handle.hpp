@@ -38,6 +38,8 @@ struct scldm_dit {
   int dbg_layer;   // SCLDM_DBG_LAYER (read once at create; -1: middle layer)
   int tab_rows[SCLDM_MAX_CLASSES];  // rows of each class table (vocab + has_null_row)
   int* label_err;  // device: sticky count of clamped out-of-range labels
+  float* d_ls = nullptr;   // device, 16 x 32 bit: loss-scale state of the fp16 backward (train_fused.hip: LossScaleState); persists across steps
+  float* found_inf = nullptr;   // caller-owned device float (scldm_dit_train_set_found_inf): 1.0 after a backward that produced non-finite gradients
   int* d_fp16_stats;  // device: [0] packed fp16 weights beyond +-65504, [1] below the smallest normal, [2] non-zero values packed
   int* d_plan;     // device: [0] t is uniform, [1] conditioning rows of the chosen plan (scldm_dit_forward_cfg, t_stride 2)
   // packing job table + fingerprint state (scldm_dit_load_weights / scldm_dit_refresh_weights)

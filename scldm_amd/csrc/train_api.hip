@@ -706,8 +706,9 @@ int attn_bwd(hipStream_t st, int D, int n_head, long n, const TI* qkv, const flo
 // The split-bf16 policy exists in the fused inference kernel only; on the training / generic entry points a request for it is served by
 // the exact-fp32 GEMM route (same parity class: fp32 products are a superset of bf16x3's accuracy).  fp16 - the reference's own
 // arithmetic class, TF32's mantissa (train_ldm.py:18) - TRAINS on the fused route of the base shape since round 4 (fp16 operands in the
-// recording forward, the fused backward layer and the weight-gradient GEMMs; the small GEMMs around them exact fp32; the backward
-// loss-scaled on device); shapes outside the fused family keep the exact-fp32 route for it.
+// recording forward, the fused backward layer, the weight-gradient GEMMs and - by default - the small conditioning / adaLN GEMMs around
+// them (SCLDM_TRAIN_FP16_EXACT_SMALL=1 keeps those exact fp32, check_common below); the backward loss-scaled on device with an overflow
+// guard (train_fused.hip); shapes outside the fused family keep the exact-fp32 route for it.
 inline int train_precision(const scldm_dit* h, int n, int precision) {
   if (precision == SCLDM_PREC_FP16 && h && fused::eligible(h, n, SCLDM_PREC_FP16)) return SCLDM_PREC_FP16;
   return (precision == SCLDM_PREC_BF16X3 || precision == SCLDM_PREC_FP16) ? SCLDM_PREC_FP32 : precision;
@@ -950,7 +951,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // multiplied by 1 / S at the end (exact: powers of two) - before any gradient-ready event is recorded.
   const bool f16 = use_fused && precision == SCLDM_PREC_FP16;
   if (f16) {
-    TRY(fused::scale_dout(dout, (long)T * din, fs, st));
+    TRY(fused::scale_dout(h, dout, (long)T * din, fs, st));
     dout = fs.dout_s;
   }
   if (edge) {

@@ -448,38 +448,86 @@ __global__ void scatter_ada_kernel(const float* __restrict__ dw_all, const float
 
 
 // ---- loss scaling of the fp16 backward -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void loss_scale_kernel(const float* __restrict__ dout, long n, float* __restrict__ scale) {
+// State (16 x 32 bit on the handle, persists across steps):
+//   [0] S (float, a power of two)   [1] 1 / S   [2] non-finite gradient values of the LAST backward (int)   [3] headroom h <= 0 (int)
+//   [4] clean backwards since the last overflow (int)   [5] max |dout| bits of the running reduction (uint)   [6] block ticket (uint)
+//   [7] backwards that overflowed so far (int)
+// S = 2^(floor(log2(8 / max |dout|)) + h): the nominal scale puts max |S dout| in [8, 16); an intermediate of the backward can still
+// leave the fp16 range - unscale_kernel counts the non-finite gradient values, the next backward lowers h by one (and the
+// caller's found_inf flag lets the optimizer skip the poisoned step), and h recovers one power of two per kHeadroomRecover clean steps.
+constexpr int kLsBlocks = 128, kHeadroomMin = -24, kHeadroomRecover = 2000;
+__global__ __launch_bounds__(1024) void loss_scale_kernel(const float* __restrict__ dout, long n, float* __restrict__ state, float* __restrict__ found_inf) {
   __shared__ float red[16];
+  __shared__ bool last;
+  unsigned* st = reinterpret_cast<unsigned*>(state);
   float m = 0.f;
-  for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(dout[i]));   // (NaN / inf: fmaxf drops NaN, inf is caught below)
+  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n; i += (long)gridDim.x * 1024) m = fmaxf(m, fabsf(dout[i]));   // (fmaxf drops NaN, inf is caught below)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    atomicMax(st + 5, __float_as_uint(m));          // non-negative floats order like their bit patterns
+    __threadfence();
+    last = atomicAdd(st + 6, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    const float mx = __uint_as_float(atomicMax(st + 5, 0u));
+    int h = (int)st[3], clean = (int)st[4];
+    if ((int)st[2] > 0) {                            // the previous backward produced non-finite gradients
+      h = max(h - 1, kHeadroomMin);
+      clean = 0;
+      st[7] = st[7] + 1;
+    } else if (h < 0 && ++clean >= kHeadroomRecover) {
+      ++h;
+      clean = 0;
+    }
     float S = 1.0f;
-    if (m > 0.f && m < 3.0e38f) S = exp2f(fminf(fmaxf(floorf(log2f(8.0f / m)), -24.f), 60.f));
-    scale[0] = S;
-    scale[1] = 1.0f / S;
+    if (mx > 0.f && mx < 3.0e38f) S = exp2f(fminf(fmaxf(floorf(log2f(8.0f / mx)) + (float)h, -24.f), 60.f));
+    state[0] = S;
+    state[1] = 1.0f / S;
+    st[2] = 0u;
+    st[3] = (unsigned)h;
+    st[4] = (unsigned)clean;
+    st[5] = 0u;
+    st[6] = 0u;
+    if (found_inf) *found_inf = 0.f;
   }
 }
 __global__ void scale_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale, float* __restrict__ dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] * scale[0];
 }
-constexpr int kMaxUnscale = 16 * 10 + SCLDM_MAX_CLASSES + 16;
+// every gradient tensor of the fused fp16 backward: 9 per layer + the class tables + 11 of the two ends + dx
+constexpr int kMaxUnscale = kMaxFp16TrainLayers * 9 + SCLDM_MAX_CLASSES + 12;
 struct UnscaleArgs {
   float* p[kMaxUnscale];
   int n[kMaxUnscale];
   int count;
-  const float* scale;
+  float* state;
+  float* found_inf;
 };
 __global__ __launch_bounds__(256) void unscale_kernel(const UnscaleArgs a) {
   float* __restrict__ p = a.p[blockIdx.x];
   const int n = a.n[blockIdx.x];
-  const float inv = a.scale[1];
-  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) p[i] *= inv;
+  const float inv = a.state[1];
+  int bad = 0;
+  for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
+    const float v = p[i] * inv;
+    p[i] = v;
+    bad += !(fabsf(v) <= 3.0e38f);      // inf or NaN
+  }
+  const unsigned long long any = __ballot(bad != 0);
+  if (any) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(reinterpret_cast<int*>(a.state) + 2, bad);
+      if (a.found_inf) *a.found_inf = 1.0f;
+    }
+  }
 }
 
 }  // namespace
@@ -523,7 +571,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.edge_part = c.take<float>(edge_part_floats(h));
   s.dout_s = c.take<float>(T * 32);
-  s.scale = c.take<float>(64);
+  s.scale = h->d_ls;   // (loss-scale state: on the handle, it persists across steps)
   s.bytes = c.off;
   return s;
 }
@@ -880,8 +928,8 @@ int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, fl
   return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16>(h, g, mod, dmod, n, rec, s, st) : backward_layers_t<BwdBF16>(h, g, mod, dmod, n, rec, s, st);
 }
 
-int scale_dout(const float* dout, long n_elem, const Scratch& s, hipStream_t st) {
-  loss_scale_kernel<<<1, 1024, 0, st>>>(dout, n_elem, s.scale);
+int scale_dout(scldm_dit* h, const float* dout, long n_elem, const Scratch& s, hipStream_t st) {
+  loss_scale_kernel<<<(unsigned)std::min<long>(kLsBlocks, cdiv(n_elem, 1024)), 1024, 0, st>>>(dout, n_elem, s.scale, h->found_inf);
   scale_copy_kernel<<<cdiv(n_elem, 256), 256, 0, st>>>(dout, s.scale, s.dout_s, n_elem);
   LAUNCH_CHECK();
   return SCLDM_OK;
@@ -891,8 +939,11 @@ int unscale_grads(scldm_dit* h, const scldm_dit_grads* g, float* dx_out, long dx
   const scldm_dit_config& c = h->cfg;
   const int L = c.n_layer, H = c.hidden_dim, din = c.n_embed_input;
   UnscaleArgs a{};
+  bool full = false;
   auto add = [&](float* p, long n) {
-    if (p && n > 0 && a.count < kMaxUnscale) { a.p[a.count] = p; a.n[a.count] = (int)n; ++a.count; }
+    if (!p || n <= 0) return;
+    if (a.count >= kMaxUnscale) { full = true; return; }   // (a dropped tensor would stay multiplied by S)
+    a.p[a.count] = p; a.n[a.count] = (int)n; ++a.count;
   };
   for (int l = 0; l < L; ++l) {
     add(g->attn_w[l], 3 * kD * kD); add(g->attn_b[l], 3 * kD); add(g->proj_w[l], kD * kD); add(g->proj_b[l], kD);
@@ -903,7 +954,9 @@ int unscale_grads(scldm_dit* h, const scldm_dit_grads* g, float* dx_out, long dx
   add(g->fin_ada_w, 2 * kD * kD); add(g->fin_ada_b, 2 * kD); add(g->t_w0, kD * 256); add(g->t_b0, kD); add(g->t_w2, kD * kD); add(g->t_b2, kD);
   add(g->in_w, (long)kD * din); add(g->in_b, kD); add(g->fin_w, (long)din * kD); add(g->fin_b, din); add(g->pos_embed, 16 * kD);
   add(dx_out, dx_elems);
-  a.scale = s.scale;
+  if (full) return fail(SCLDM_ERR_SHAPE, "fp16 training: more gradient tensors than the un-scale table holds (%d)", kMaxUnscale);
+  a.state = s.scale;
+  a.found_inf = h->found_inf;
   unscale_kernel<<<dim3(a.count, 32), 256, 0, st>>>(a);
   LAUNCH_CHECK();
   return SCLDM_OK;

@@ -30,7 +30,7 @@ struct Scratch {
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
   float* dout_s;    // fp16 policy: the loss-scaled copy of d loss / d output (n x 16 x n_embed_input)
-  float* scale;     // fp16 policy: [0] loss scale S (a power of two), [1] 1 / S - decided on device from max |dout|
+  float* scale;     // fp16 policy: the handle's loss-scale state ([0] S, a power of two decided on device from max |dout|, [1] 1 / S, ...)
   size_t bytes;
 };
 Scratch carve_scratch(const scldm_dit* h, int n, void* base);
@@ -66,8 +66,9 @@ int fork_side(scldm_dit* h, hipStream_t st, int k, hipStream_t* out);
 int join_side(scldm_dit* h, hipStream_t st, int k);
 
 // fp16 policy: loss scaling of the backward.  scale_dout: S = 2^floor(log2(8 / max |dout|)) (device side, no host read), dout_s = S dout;
-// unscale: every tensor of `g` (and dx_out, when given) times 1 / S in one launch over a by-value pointer table.
-int scale_dout(const float* dout, long n_elem, const Scratch& s, hipStream_t st);
+// unscale: every tensor of `g` (and dx_out, when given) times 1 / S in one launch over a by-value pointer table; the same launch counts
+// the non-finite values it meets (overflow guard: the next scale_dout lowers the scale, h->found_inf lets the optimizer skip the step).
+int scale_dout(scldm_dit* h, const float* dout, long n_elem, const Scratch& s, hipStream_t st);
 int unscale_grads(scldm_dit* h, const scldm_dit_grads* g, float* dx_out, long dx_elems, const Scratch& s, hipStream_t st);
 
 // (mod_w, 256) stacked weight gradient + (mod_w) stacked bias gradient -> g->ada_w[l] / ada_b[l] / fin_ada_w / fin_ada_b

@@ -110,7 +110,10 @@ void trunk_jobs(JobList& jl, float* dst, const scldm_vae_block* blocks, int n_la
   }
 }
 template <typename T>
-int upload(void** dev, int* cap, const std::vector<T>& v) {
+int upload(void** dev, int* cap, const std::vector<T>& v, hipStream_t st) {
+  // a pack / fingerprint launch of an earlier refresh may still be reading the table on the caller's (non-blocking) stream: the
+  // null-stream copy below would not wait for it.  Loading weights is a rare path: drain the stream first.
+  HIP_TRY(hipStreamSynchronize(st));
   if ((int)v.size() > *cap) {
     if (*dev) (void)hipFree(*dev);
     *dev = nullptr;
@@ -181,7 +184,7 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   for (const VaePackJob& j : jl.jobs)
     if (!j.src0 || !j.dst || (j.kind == VJ_W12 && !j.src1)) return fail(SCLDM_ERR_SHAPE, "scldm_vae_load_weights: a weight pointer is NULL");
   int rc;
-  if ((rc = upload(&h->d_jobs, &h->jobs_cap, jl.jobs)) || (rc = upload(&h->d_fp_src, &h->fp_cap, jl.fps))) return rc;
+  if ((rc = upload(&h->d_jobs, &h->jobs_cap, jl.jobs, st)) || (rc = upload(&h->d_fp_src, &h->fp_cap, jl.fps, st))) return rc;
   h->n_jobs = (int)jl.jobs.size();
   h->n_fp = (int)jl.fps.size();
   h->q_ind = w->inducing_points; h->q_eln_w = ec.ln1q_w; h->q_eln_b = ec.ln1q_b; h->q_ewq = ec.attn_q;

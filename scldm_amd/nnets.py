@@ -169,9 +169,10 @@ class DiT(nn.Module):
     arithmetic the reference itself runs under `set_float32_matmul_precision("high")`, inference.py:26 - ~1e-3 vs exact fp32,
     like the reference; weights are range-checked against +-65 504 when packed) or "bf16" (8 bits: throughput path); default
     from $SCLDM_PRECISION, else "fp32".  Training: "bf16" and - since round 4 - "fp16" (the reference's own training arithmetic class,
-    train_ldm.py:18) run the fused route of the base shape at the matrix-core rate (fp16: backward loss-scaled on device, the small
-    GEMMs around the fused layers exact fp32); "bf16x3", and "fp16" on shapes outside the fused family (e.g. a DiT-L), are served by the
-    exact-fp32 GEMM route.
+    train_ldm.py:18) run the fused route of the base shape at the matrix-core rate (fp16: the backward is loss-scaled on device with an
+    overflow guard - `fp16_train_state()`, `found_inf_flag()`; the small conditioning / adaLN GEMMs around the fused layers use fp16 operands
+    as well, SCLDM_TRAIN_FP16_EXACT_SMALL=1 keeps those exact fp32); "bf16x3", and "fp16" on shapes outside the fused family (e.g. a
+    DiT-L), are served by the exact-fp32 GEMM route.
 
     The fused inference kernels read PACKED copies of the parameters.  They are refreshed automatically when a parameter's
     storage or torch version counter changes, and an on-device fingerprint of the parameters is re-checked at every call so
@@ -293,6 +294,28 @@ class DiT(nn.Module):
             self._handle = h
         return L, self._handle
 
+    def found_inf_flag(self) -> torch.Tensor:
+        """Device float the fp16 training backward sets to 1.0 when it produced non-finite gradients (reset to 0.0 at the start of every
+        fp16 backward): hand it to an optimizer that understands GradScaler's `found_inf` (torch's fused Adam / AdamW skip the step on
+        device, no host read) - `scldm_amd.training.train_step` does.  The fp16 counterpart of torch.cuda.amp.GradScaler for the
+        reference's trainer (experiments/scripts/train_ldm.py)."""
+        L, h = self._native_handle()
+        flag = self.__dict__.get("_found_inf")
+        if flag is None or flag.device != self.pos_embed.device:
+            flag = self.__dict__["_found_inf"] = torch.zeros((), dtype=torch.float32, device=self.pos_embed.device)
+            _lib.check(L.scldm_dit_train_set_found_inf(h, flag.data_ptr()), "scldm_dit_train_set_found_inf")
+        return flag
+
+    def fp16_train_state(self) -> dict:
+        """Loss-scale state of the fp16 backward (synchronises the current stream): the scale S of the last backward, the number of
+        non-finite gradient values it produced, the headroom (powers of two below the nominal scale, <= 0) and the count of
+        backwards that overflowed so far."""
+        L, h = self._native_handle()
+        S, bad, head, steps = C.c_float(), C.c_longlong(), C.c_int(), C.c_longlong()
+        with torch.cuda.device(self.pos_embed.device):
+            _lib.check(L.scldm_dit_train_fp16_state(h, C.byref(S), C.byref(bad), C.byref(head), C.byref(steps), _stream_ptr()), "scldm_dit_train_fp16_state")
+        return {"scale": S.value, "nonfinite_last": bad.value, "headroom": head.value, "overflow_steps": steps.value}
+
     def _native(self):
         L, _ = self._native_handle()
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -304,9 +327,9 @@ class DiT(nn.Module):
             # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation)
             with torch.cuda.device(self.pos_embed.device):
                 _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
-        L.scldm_dit_set_option(self._handle, _lib.OPT_CFG1_DIRECT, int(bool(getattr(self, "guidance1_direct", False))))
+        _lib.check(L.scldm_dit_set_option(self._handle, _lib.OPT_CFG1_DIRECT, int(bool(getattr(self, "guidance1_direct", False)))), "scldm_dit_set_option")
         if getattr(self, "tail_split", None) is not None:
-            L.scldm_dit_set_option(self._handle, _lib.OPT_TAIL_SPLIT, int(bool(self.tail_split)))
+            _lib.check(L.scldm_dit_set_option(self._handle, _lib.OPT_TAIL_SPLIT, int(bool(self.tail_split))), "scldm_dit_set_option")
         if self.precision == "fp16" and self.__dict__.get("_fp16_checked") != self._weights_key:
             # once per (re)load: the fp16 stream's range report (one stream synchronisation).  `.data` updates that are picked up
             # by the fingerprint re-pack are not re-checked: call fp16_weight_report() after such an update if in doubt.

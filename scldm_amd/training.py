@@ -213,6 +213,9 @@ def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str,
     backward through the HIP kernels with the bucketed gradient all-reduce (mean over ranks) overlapped with it, then
     optimizer.step().  Returns the local loss."""
     optimizer.zero_grad(set_to_none=True)
+    # fp16 training: the backward's overflow flag (non-finite gradients after the loss-scaled backward) makes the optimizer skip the
+    # step - on device for optimizers that take GradScaler's `found_inf` (torch's fused Adam / AdamW), by one host read otherwise
+    found_inf = dit.found_inf_flag() if getattr(dit, "precision", None) == "fp16" and hasattr(dit, "found_inf_flag") else None
     loss = transport.training_losses(dit, x1, {"condition": condition})["loss"].mean()
     if sync is None:
         sync = dit.__dict__.get("_train_step_sync")
@@ -233,5 +236,17 @@ def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str,
             allreduce_gradients(extra, group, bucket_bytes)
     else:
         allreduce_gradients(dit.parameters(), group, bucket_bytes)
-    optimizer.step()
+    if found_inf is None:
+        optimizer.step()
+    else:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(found_inf, op=dist.ReduceOp.MAX, group=group)     # every rank skips the same steps
+        if getattr(optimizer, "_step_supports_amp_scaling", False):
+            optimizer.found_inf, optimizer.grad_scale = found_inf, None
+            try:
+                optimizer.step()
+            finally:
+                del optimizer.found_inf, optimizer.grad_scale
+        elif float(found_inf) == 0.0:
+            optimizer.step()
     return loss.detach()

@@ -63,3 +63,67 @@ def test_world_size_mismatch_fails_loudly():
     r = _run(["--gpus", "4"], {"BENCH_FAKE": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def _strong(extra):
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "16", *extra], {"BENCH_FAKE": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and len(j["per_rank_ms_per_step"]) == 8 and j["allgather_ms"] >= 0
+    assert j["config"]["gathered_rows"] == 8 * 2 * 16 and j["cross_rank_check"]["bit_equal"] is True
+    assert len(json.dumps(j)) <= 6144          # the driver keeps an 8 KB tail of stdout: the line must fit with room to spare
+    return j["strong_scaling"]
+
+
+def test_gpus_8_strong_scaling_splits_8192_cells_evenly():
+    """The first real 8-GPU run (configs[3]: 8 192 cells over 8 ranks) must not die on plumbing: eight gloo ranks of the fake sampler."""
+    s = _strong([])
+    assert s["global_cells"] == 8192 and s["cells_per_gpu_by_rank"] == [1024] * 8 and s["gathered_rows"] == 8 * 2 * 1024
+    assert s["cross_rank_check"]["checked_rank"] == 7 and s["cross_rank_check"]["bit_equal"] is True
+
+
+def test_gpus_8_strong_scaling_pads_uneven_shards():
+    """8 190 cells do not divide by 8: six ranks take 1 024 cells, two take 1 023, every rank's [unconditional | guided] block is
+    padded to 1 024 for the all-gather, and rank 0 verifies the SHORT last shard bit for bit through the padded layout."""
+    s = _strong(["--global-cells", "8190"])
+    assert s["global_cells"] == 8190 and s["cells_per_gpu_by_rank"] == [1024] * 6 + [1023] * 2
+    assert s["gathered_rows"] == 8 * 2 * 1024
+    assert s["cross_rank_check"]["checked_rank"] == 7 and s["cross_rank_check"]["cells"] == 8 and s["cross_rank_check"]["bit_equal"] is True
+
+
+def test_rank_binds_its_device_before_anything_creates_a_handle(monkeypatch):
+    """One process per GPU: rank r must call torch.cuda.set_device(LOCAL_RANK) BEFORE a model (native handle, streams, workspaces)
+    exists - a handle created on device 0 by every rank is the classic first-8-GPU-run failure.  torch.cuda is mocked: this runs on CPU."""
+    import importlib
+    import torch
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    order = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_make_model(*a, **k):
+        order.append(("make_model", None))
+        raise Stop()
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: order.append(("set_device", d)))
+    monkeypatch.setattr(bench, "make_model", fake_make_model)
+    for k in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_FAKE", "BENCH_FORCE_DIST"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "1", "--warmup", "0", "--no-extra", "--no-cpu-baseline"])
+    try:
+        bench.main()
+    except Stop:
+        pass
+    assert order[0] == ("set_device", 5) and order[1] == ("make_model", None), order
+    # and a LOCAL_RANK beyond the visible devices is refused before any device call
+    monkeypatch.setenv("LOCAL_RANK", "9")
+    order.clear()
+    try:
+        bench.main()
+        raise AssertionError("expected SystemExit")
+    except SystemExit as e:
+        assert "LOCAL_RANK 9" in str(e) and not order

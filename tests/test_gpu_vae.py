@@ -128,6 +128,58 @@ def test_sample_cells_harness_matches_oracle_chain():
         sample_cells(dit, vae, {"clusters": cu(lab)}, {"other": 1.0}, B, cu(genes), cu(logsf))
 
 
+def test_generation_chain_with_device_size_factors_matches_oracle_chain():
+    """The end-to-end chain bench.py times as `generation_end_to_end` (reference: LatentDiffusion.predict_step -> sample,
+    src/scldm/models.py:707-819): SizeFactorSampler.sample -> sample_cells (fused CFG Euler + MCAB decode) at 8 cells, (mu, theta)
+    and latents against the oracle chain (oracle size factors with the same eps, oracle DiT + transport, oracle decode); then the
+    counts drawn by the fused decoder go through dense_to_csr and come back as the arrays scipy builds from the same matrix."""
+    from types import SimpleNamespace
+    import scipy.sparse as sp
+    from oracle.dit import DiTConfig, dit_forward_with_cfg
+    from oracle.size_factors import sample_log_size_factors
+    from oracle.transport import sample_ode_fixed
+    from scldm_amd.datamodule import dense_to_csr
+    from scldm_amd.nnets import DiT
+    from scldm_amd.sampling import SizeFactorSampler, sample_cells
+    g, vae, sd_v, cfg_v = build("vae_2000")
+    gd = load_golden("dit_base")
+    kw = golden_json(gd, "kwargs_json")
+    shapes = {k: tuple(v) for k, v in golden_json(gd, "shapes_json").items()}
+    sd_d = make_state_dict(shapes, int(gd["seed"]))
+    dit = DiT(**kw)
+    dit.load_state_dict(sd_d, strict=True)
+    dit = dit.cuda().eval()
+    cfg_d = DiTConfig(class_vocab_sizes=kw["class_vocab_sizes"], condition_strategy=kw["condition_strategy"])
+    rng = np.random.default_rng(17)
+    B, G = 8, 257
+    enc = SimpleNamespace(size_factor_condition_key="clusters", mu_size_factor={"clusters": {i: 6.5 + 0.2 * i for i in range(13)}},
+                          sd_size_factor={"clusters": {i: 0.1 + 0.02 * i for i in range(13)}})        # label 13 has no statistics -> 0
+    z0 = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    lab = np.array([0, 3, 13, 7, 12, 1, 13, 5], dtype=np.int64)
+    eps = rng.standard_normal(B).astype(np.float32)
+    genes = np.stack([rng.permutation(2000)[:G] for _ in range(B)]).astype(np.int64)
+    scales = {"clusters": 1.0}
+    smp = SizeFactorSampler(enc, "mutually_exclusive", "cuda")
+    sf = smp.sample({"clusters": cu(lab)}, B, eps=cu(eps))
+    sf_ref = sample_log_size_factors(enc, "mutually_exclusive", {"clusters": lab}, B, eps)
+    assert np.array_equal(sf.cpu().numpy(), sf_ref)
+    nb, z = sample_cells(dit, vae, {"clusters": cu(lab)}, scales, B, cu(genes), None, num_steps=6, sampling_method="euler", z0=cu(z0),
+                         draw_counts=False, size_factor_sampler=SimpleNamespace(sample=lambda c, b: sf))
+    z2 = torch.from_numpy(np.concatenate([z0, z0]))
+    cond2 = {"clusters": torch.from_numpy(np.concatenate([lab, lab]))}
+    z_ref = sample_ode_fixed(z2, lambda x, t: dit_forward_with_cfg(sd_d, cfg_d, x, t, cond2, scales), 6, "euler")
+    lib = torch.exp(torch.from_numpy(np.concatenate([sf_ref, sf_ref]))).view(-1, 1)
+    mu_ref, th_ref = decode(sd_v, cfg_v, z_ref, torch.from_numpy(np.concatenate([genes, genes])), lib)
+    assert z.shape == (2 * B, 16, 16) and max_abs_rel(z.cpu(), z_ref) < TOL
+    assert max_abs_rel(nb.mu.cpu(), mu_ref) < 2e-4 and max_abs_rel(nb.theta.cpu(), th_ref) < 1e-5
+    assert torch.allclose(nb.mu.sum(1).cpu(), lib.view(-1), rtol=1e-4)          # rows sum to the drawn library size (exp(0) = 1 where no statistics)
+    counts, _ = sample_cells(dit, vae, {"clusters": cu(lab)}, scales, B, cu(genes), sf, num_steps=6, sampling_method="euler", z0=cu(z0))
+    indptr, indices, data = dense_to_csr(counts)
+    ref = sp.csr_matrix(counts.cpu().numpy())
+    assert np.array_equal(indptr.cpu().numpy(), ref.indptr) and np.array_equal(indices.cpu().numpy(), ref.indices)
+    assert np.array_equal(data.cpu().numpy(), ref.data) and counts.shape == (2 * B, G) and (counts >= 0).all()
+
+
 def test_bf16_decode_close_to_fp32():
     """decode with bf16 operands in the per-gene contractions (vae.precision = "bf16"): mu within bf16 noise of the fp32 path,
     rows still sum to the library size, theta identical."""
