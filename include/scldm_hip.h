@@ -111,6 +111,23 @@ int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
  * than 10 mantissa bits) and the non-zero values packed. */
 int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream);
 
+/* State arithmetic of the adaptive Dormand-Prince 5(4) solver - the reference's DEFAULT sampler (src/scldm/models.py:793 ->
+ * transport/transport.py:324-331 -> integrators.py:100-112 -> torchdiffeq.odeint(method="dopri5")) - as four kernels instead of ~40
+ * elementwise launches per step; the step-size control stays on the host (scldm_amd/transport: Sampler._sample_dopri5).  All tensors
+ * fp32, contiguous, `n` elements on the device; `k` / `coef` are HOST arrays of n_k <= 7 device pointers / h-scaled tableau weights.
+ *   scldm_rk_combine: out = y0 + sum_j coef_j k_j (left to right; y0 may be NULL)                      - stage points
+ *   scldm_rk_error:   ws[1022] (double) = mean((sum_j coef_j k_j / (atol + rtol max(|y0|, |y1|)))^2)    - error ratio^2; ws = 8 KB of
+ *                     zero-initialised device memory (block partials + a ticket), summed in a fixed order
+ *   scldm_rk_dense:   coefficients c1..c4 of the quartic interpolant of an accepted step (c0 = y0)
+ *   scldm_rk_poly:    out = c0 + s1 c1 + s2 c2 + s3 c3 + s4 c4                                           - a save point */
+int scldm_rk_combine(float* out, const float* y0, const float* const* k, const float* coef, int n_k, long long n, void* stream);
+int scldm_rk_error(const float* y0, const float* y1, const float* const* k, const float* coef, int n_k, long long n, float atol, float rtol,
+                   void* ws, void* stream);
+int scldm_rk_dense(const float* y0, const float* y1, const float* const* k, const float* mid_coef, int n_k, const float* fa, const float* fb,
+                   float h, float two_h, long long n, float* c1, float* c2, float* c3, float* c4, void* stream);
+int scldm_rk_poly(float* out, const float* c0, const float* c1, const float* c2, const float* c3, const float* c4, float s1, float s2, float s3,
+                  float s4, long long n, void* stream);
+
 /* Overflow guard of the fp16 (loss-scaled) training backward - the counterpart of torch.cuda.amp.GradScaler's found_inf for the
  * reference's trainer (experiments/scripts/train_ldm.py: the reference trains in TF32 and needs none; fp16 operands have TF32's
  * mantissa but 5 exponent bits).  The last launch of scldm_dit_train_backward counts the non-finite values among ALL gradients it

@@ -13,6 +13,7 @@
 #include "dit_aux.hpp"
 #include "dit_forward.hpp"
 #include "dit_handle.hpp"
+#include "ode_rk.hpp"
 
 using namespace scldm;
 
@@ -1043,6 +1044,59 @@ __global__ __launch_bounds__(256, 2) void mfma_ceiling_kernel(const bf16x8* __re
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   if (s == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s;   // keeps the loop alive; never true in practice
 }
+// ---- Dormand-Prince 5(4) state arithmetic (ode_rk.hpp); pointer tables and coefficients are HOST arrays, passed by value ----
+static int rk_args(scldm::rk::CombArgs* a, const float* const* k, const float* coef, int n_k, const char* who) {
+  if (n_k < 0 || n_k > scldm::rk::kMaxK || (n_k && (!k || !coef))) return fail(SCLDM_ERR_SHAPE, "%s: 0..%d stage tensors", who, scldm::rk::kMaxK);
+  a->n_k = n_k;
+  for (int j = 0; j < n_k; ++j) {
+    if (!k[j]) return fail(SCLDM_ERR_SHAPE, "%s: stage tensor %d is NULL", who, j);
+    a->k[j] = k[j];
+    a->c[j] = coef[j];
+  }
+  return SCLDM_OK;
+}
+extern "C" int scldm_rk_combine(float* out, const float* y0, const float* const* k, const float* coef, int n_k, long long n, void* stream_) {
+  if (!out || n < 1 || n % 4) return fail(SCLDM_ERR_SHAPE, "scldm_rk_combine: n must be a positive multiple of 4");
+  scldm::rk::CombArgs a{};
+  int rc = rk_args(&a, k, coef, n_k, "scldm_rk_combine");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scldm::rk::combine_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, out, y0, a, (long)(n / 4));
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_rk_error(const float* y0, const float* y1, const float* const* k, const float* coef, int n_k, long long n, float atol, float rtol,
+                              void* ws, void* stream_) {
+  if (!y0 || !y1 || !ws || n < 1) return fail(SCLDM_ERR_SHAPE, "scldm_rk_error: bad argument");
+  scldm::rk::CombArgs a{};
+  int rc = rk_args(&a, k, coef, n_k, "scldm_rk_error");
+  if (rc) return rc;
+  double* w = reinterpret_cast<double*>(ws);     // [0, 1022) block partials | [1022] mean of squared ratios | [1023] ticket (zero at first use)
+  const unsigned blocks = (unsigned)std::min<long long>(cdiv(n, 256 * 8), 1022);
+  hipLaunchKernelGGL(scldm::rk::error_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, y0, y1, a, (long)n, atol, rtol, w,
+                     reinterpret_cast<unsigned*>(w + 1023), w + 1022);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_rk_dense(const float* y0, const float* y1, const float* const* k, const float* mid_coef, int n_k, const float* fa, const float* fb,
+                              float h, float two_h, long long n, float* c1, float* c2, float* c3, float* c4, void* stream_) {
+  if (!y0 || !y1 || !fa || !fb || !c1 || !c2 || !c3 || !c4 || n < 1) return fail(SCLDM_ERR_SHAPE, "scldm_rk_dense: bad argument");
+  scldm::rk::CombArgs a{};
+  int rc = rk_args(&a, k, mid_coef, n_k, "scldm_rk_dense");
+  if (rc) return rc;
+  hipLaunchKernelGGL(scldm::rk::dense_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream_, y0, y1, a, fa, fb, h, two_h, (long)n, c1,
+                     c2, c3, c4);
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+extern "C" int scldm_rk_poly(float* out, const float* c0, const float* c1, const float* c2, const float* c3, const float* c4, float s1, float s2, float s3,
+                             float s4, long long n, void* stream_) {
+  if (!out || !c0 || !c1 || !c2 || !c3 || !c4 || n < 1 || n % 4) return fail(SCLDM_ERR_SHAPE, "scldm_rk_poly: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(scldm::rk::poly_kernel, dim3((unsigned)cdiv(n / 4, 256)), dim3(256), 0, (hipStream_t)stream_, out, c0, c1, c2, c3, c4, s1, s2, s3, s4,
+                     (long)(n / 4));
+  LAUNCH_CHECK();
+  return SCLDM_OK;
+}
+
 extern "C" int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops) {
   if (!tflops || fill < 0 || fill > 2 || iters < 1) return fail(SCLDM_ERR_SHAPE, "scldm_mfma_sustained_tflops: bad argument");
   const int blocks = 512, launches = 5;   // 2 workgroups of 4 waves per CU

@@ -187,6 +187,75 @@ class Sampler:
                         base = base + (h * wi) * k
                 return base
 
+            # Device state arithmetic (round 5): on a CUDA fp32 state the stage points, the error ratio and the dense output are four
+            # HIP kernels (scldm_rk_*: csrc/ode_rk.hpp) that perform the SAME fp32 operations in the same order as the torch
+            # expressions of the host-composed path below (kept for CPU tensors, i.e. the oracle-side tests): ~40 elementwise
+            # launches per step -> 4, the error ratio still read back once per step.
+            dev = x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0
+            if dev:
+                import ctypes as C
+                import numpy as np
+                from .. import _lib
+                L = _lib.lib()
+                x = x.contiguous()
+                n_el = x.numel()
+                ws = torch.zeros(1024, dtype=torch.float64, device=x.device)
+                f32 = lambda v: float(np.float32(v))
+
+                def _tab(w, ks, h):
+                    pairs = [(k, f32(h * wi)) for wi, k in zip(w, ks) if wi != 0.0]
+                    ptrs = (C.c_void_p * len(pairs))(*[k.data_ptr() for k, _ in pairs])
+                    return ptrs, (C.c_float * len(pairs))(*[c for _, c in pairs]), len(pairs), [k for k, _ in pairs]
+
+                def _st():
+                    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+                def comb(base, w, ks, h):
+                    ks = [k.contiguous() for k in ks]
+                    ptrs, cs, nk, keep = _tab(w, ks, h)
+                    out = torch.empty_like(base)
+                    with torch.cuda.device(x.device):
+                        _lib.check(L.scldm_rk_combine(out.data_ptr(), base.data_ptr(), ptrs, cs, nk, n_el, _st()), "scldm_rk_combine")
+                    return out
+
+                def error_ratio(y0_, y1_, ks, h):
+                    ptrs, cs, nk, keep = _tab(_DP_E, ks, h)
+                    with torch.cuda.device(x.device):
+                        _lib.check(L.scldm_rk_error(y0_.data_ptr(), y1_.data_ptr(), ptrs, cs, nk, n_el, atol, rtol, ws.data_ptr(), _st()), "scldm_rk_error")
+                    return float(ws[1022]) ** 0.5                      # the step's one host read
+
+                def dense_fit(y0_, y1_, ks, h):
+                    ptrs, cs, nk, keep = _tab(_DP_MID, ks, h)
+                    cf = [torch.empty_like(y0_) for _ in range(4)]
+                    with torch.cuda.device(x.device):
+                        _lib.check(L.scldm_rk_dense(y0_.data_ptr(), y1_.data_ptr(), ptrs, cs, nk, ks[0].data_ptr(), ks[6].data_ptr(), f32(h), f32(2 * h),
+                                                    n_el, cf[0].data_ptr(), cf[1].data_ptr(), cf[2].data_ptr(), cf[3].data_ptr(), _st()), "scldm_rk_dense")
+                    return (y0_, *cf)
+
+                def dense_eval(coeff, s_):
+                    out = torch.empty_like(coeff[0])
+                    with torch.cuda.device(x.device):
+                        _lib.check(L.scldm_rk_poly(out.data_ptr(), *[c.data_ptr() for c in coeff], f32(s_), f32(s_ * s_), f32(s_ * s_ * s_),
+                                                   f32(s_ * s_ * s_ * s_), n_el, _st()), "scldm_rk_poly")
+                    return out
+            else:
+                def error_ratio(y0_, y1_, ks, h):
+                    err = sum((h * e) * k for e, k in zip(_DP_E, ks) if e != 0.0)
+                    return _rms(err / (atol + rtol * torch.maximum(y0_.abs(), y1_.abs())))
+
+                def dense_fit(y0_, y1_, ks, h):
+                    ymid = comb(y0_, _DP_MID, ks, h)
+                    fa, fb = ks[0], ks[6]
+                    return (y0_, h * fa, h * (fb - 4 * fa) - 11 * y0_ - 5 * y1_ + 16 * ymid,
+                            h * (5 * fa - 3 * fb) + 18 * y0_ + 14 * y1_ - 32 * ymid, 2 * h * (fb - fa) - 8 * (y1_ + y0_) + 16 * ymid)
+
+                def dense_eval(coeff, s_):
+                    total, sp = coeff[0] + s_ * coeff[1], s_
+                    for cf in coeff[2:]:
+                        sp = sp * s_
+                        total = total + sp * cf
+                    return total
+
             ts = [float(v) for v in torch.linspace(0.0, 1.0, num_steps).double()]   # integrators.py:95, cast as the solver does
             y0 = x
             f0 = f(y0, ts[0])
@@ -211,14 +280,12 @@ class Sampler:
                         yi = comb(y0, a_row, ks, h)
                         ks.append(f(yi, ta + h if c == 1.0 else ta + c * h))
                     y1 = yi                   # the last stage point is the 5th-order solution (FSAL: ks[6] = f(ta + h, y1))
-                    err = sum((h * e) * k for e, k in zip(_DP_E, ks) if e != 0.0)
-                    ratio = _rms(err / (atol + rtol * torch.maximum(y0.abs(), y1.abs())))
+                    if dev:
+                        ks = [k.contiguous() for k in ks]
+                    ratio = error_ratio(y0, y1, ks, h)
                     if ratio <= 1.0:
                         accepted.append((ta, h))
-                        ymid = comb(y0, _DP_MID, ks, h)
-                        fa, fb = ks[0], ks[6]
-                        coeff = (y0, h * fa, h * (fb - 4 * fa) - 11 * y0 - 5 * y1 + 16 * ymid,
-                                 h * (5 * fa - 3 * fb) + 18 * y0 + 14 * y1 - 32 * ymid, 2 * h * (fb - fa) - 8 * (y1 + y0) + 16 * ymid)
+                        coeff = dense_fit(y0, y1, ks, h)
                         t0, t1, y0, f0 = ta, ta + h, y1, ks[6]
                     else:
                         rejected.append((ta, h))
@@ -226,12 +293,7 @@ class Sampler:
                         h = h * 10.0
                     else:
                         h = h * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
-                s_ = (next_t - t0) / (t1 - t0)
-                total, sp = coeff[0] + s_ * coeff[1], s_
-                for cf in coeff[2:]:
-                    sp = sp * s_
-                    total = total + sp * cf
-                out.append(total)
+                out.append(dense_eval(coeff, (next_t - t0) / (t1 - t0)))
             _sample.last_stats = {"evaluations": n_eval, "rejected": len(rejected), "accepted_steps": accepted, "rejected_steps": rejected}
             return torch.stack(out)
 
