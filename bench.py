@@ -283,13 +283,22 @@ def time_allgather(out, B, device, world, reps=5):
     return (time.perf_counter() - t0) / reps
 
 
-def time_training(wl, precision, device, steps, warmup, dist_on, world):
+def make_optimizer(params, lr, kind="native"):
+    """AdamW as the reference's trainer configures it (src/scldm/models.py configure_optimizers): `native` = scldm_amd.optim.AdamW (the
+    same arithmetic in one HIP launch per step), `torch` = torch.optim.AdamW(fused=True)."""
+    if kind == "torch":
+        return torch.optim.AdamW(params, lr=lr, fused=True)
+    from scldm_amd.optim import AdamW
+    return AdamW(params, lr=lr)
+
+
+def time_training(wl, precision, device, steps, warmup, dist_on, world, optimizer="native"):
     """One step = Transport.training_losses forward + HIP backward + gradient all-reduce (N > 1) + fused AdamW on the per-GPU
     batch of synthetic latents (standing in for frozen-VAE output).  Returns seconds for `steps` steps (max over ranks)."""
     from scldm_amd.training import train_step
     from scldm_amd.transport import create_transport
     m = make_model(wl, precision, device).train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+    opt = make_optimizer(m.parameters(), 1e-4, optimizer)
     tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
     g = torch.Generator().manual_seed(3)
     x1 = torch.randn(wl["B"], 16, 16, generator=g).to(device)
@@ -597,7 +606,7 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
         gs = torch.stack([torch.sort(torch.randperm(n_genes, generator=g)[:S]).values for _ in range(B)]).to(device)
         cs = counts.gather(1, gs)
         lib = counts.sum(1, keepdim=True)
-        opt = torch.optim.AdamW(vae.parameters(), lr=1e-3, fused=True)
+        opt = make_optimizer(vae.parameters(), 1e-3)
 
         def step(ev=None):
             opt.zero_grad(set_to_none=True)
@@ -759,6 +768,7 @@ def compact_line(result):
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
     put("e2e_ms_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "ms")
     put("train_ms", "training_step", "ms_per_step"); put("train_cells_per_s", "training_step", "cells_per_s"); put("train_tflops", "training_step", "tflops")
+    put("train_torch_adamw_ms", "training_step_torch_adamw", "ms_per_step")
     put("train_fp16_ms", "training_step_fp16", "ms_per_step"); put("train_b256_ms", "training_step_b256", "ms_per_step")
     put("train_ditl_b1024_tflops", "training_step_ditl_b1024", "tflops"); put("train_ditl_b256_tflops", "training_step_ditl", "tflops")
     put("ditl_sampling_tflops", "ditl_sampling", "tflops")
@@ -875,7 +885,7 @@ def main():
                   "ms_per_step": 1e3 * dt / args.steps,
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                   "config": {"workload": args.workload, "cells_per_gpu": wl["B"], "global_cells": world * wl["B"],
-                             "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "AdamW (fused)",
+                             "class_vocab_sizes": wl["vocab"], "condition_strategy": wl["strategy"], "optimizer": "scldm_amd.optim.AdamW (torch.optim.AdamW arithmetic, one launch)",
                              "parallelism": f"data-parallel x{world}, bucketed in-place gradient all-reduce overlapped with the backward" if dist_on else "single GPU"},
                   "train_tflops_per_gpu": 3 * dit_flops(**{k: v for k, v in wl.get("shape", {}).items() if k != "n_head"}) * wl["B"]
                   / (dt / args.steps) / 1e12, "final_loss": loss, "data_parallel": time_training.info}
@@ -1016,6 +1026,11 @@ def main():
                                                         "device-side loss scaling of the backward"}
             torch.cuda.empty_cache()
             d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1)   # the small-batch step (host / launch bound)
+            torch.cuda.empty_cache()
+            dto, _ = time_training(tw, tprec, device, 10, 5, False, 1, optimizer="torch")
+            result["training_step_torch_adamw"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dto / 10, "dtype": tprec,
+                                                   "optimizer": "torch.optim.AdamW(fused=True) instead of scldm_amd.optim.AdamW"}
+            result["training_step"]["optimizer"] = "scldm_amd.optim.AdamW (torch.optim.AdamW's arithmetic and state_dict, one HIP launch per step)"
             result["training_step_b256"] = {"workload": "replogle_train_b1024 at 256 cells", "cells_per_s": 256 / (d256 / 20), "ms_per_step": 1e3 * d256 / 20,
                                             "dtype": tprec}
             note("training step done")

@@ -111,6 +111,21 @@ int scldm_dit_refresh_weights(scldm_dit* h, void* stream);
  * than 10 mantissa bits) and the non-zero values packed. */
 int scldm_dit_fp16_stats(scldm_dit* h, long long* overflow, long long* subnormal, long long* nonzero, void* stream);
 
+/* AdamW step over every parameter tensor in ONE launch (csrc/optim.hip) - the optimizer of the reference's trainer is
+ * torch.optim.AdamW (src/scldm/models.py configure_optimizers; experiments/configs/training/default.yaml); same arithmetic as torch's
+ * fused AdamW.  `entries` is a HOST array (device pointers inside); `step` a device float holding the number of steps taken so far
+ * (incremented here unless *found_inf != 0, in which case nothing is updated: torch.cuda.amp.GradScaler's protocol and the fp16
+ * backward's overflow flag).  Python binding: scldm_amd.optim.AdamW. */
+typedef struct {
+  float* p;         /* parameter (updated in place) */
+  const float* g;   /* gradient */
+  float* m;         /* exp_avg */
+  float* v;         /* exp_avg_sq */
+  long long n;      /* elements */
+} scldm_adamw_entry;
+int scldm_adamw_step(const scldm_adamw_entry* entries, int count, float* step, const float* found_inf /* may be NULL */, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int maximize, void* stream);
+
 /* State arithmetic of the adaptive Dormand-Prince 5(4) solver - the reference's DEFAULT sampler (src/scldm/models.py:793 ->
  * transport/transport.py:324-331 -> integrators.py:100-112 -> torchdiffeq.odeint(method="dopri5")) - as four kernels instead of ~40
  * elementwise launches per step; the step-size control stays on the host (scldm_amd/transport: Sampler._sample_dopri5).  All tensors

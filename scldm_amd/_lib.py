@@ -35,6 +35,10 @@ class DitWeights(C.Structure):
                [(n, c_void_pp) for n in ("class_emb", "attn_w", "attn_b", "proj_w", "proj_b", "w1", "w2", "cproj", "ada_w", "ada_b")]
 
 
+class AdamwEntry(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_longlong)]
+
+
 class VaeConfig(C.Structure):
     _fields_ = [("n_genes", C.c_int), ("n_embed", C.c_int), ("n_inducing", C.c_int), ("n_embed_latent", C.c_int),
                 ("n_layer", C.c_int), ("n_head", C.c_int), ("n_head_cross", C.c_int), ("hidden_dim", C.c_int),
@@ -78,6 +82,7 @@ def lib() -> C.CDLL:
     L.scldm_dit_destroy.restype = None
     L.scldm_dit_load_weights.argtypes = [C.c_void_p, C.POINTER(DitWeights), C.c_void_p]
     L.scldm_dit_refresh_weights.argtypes = [C.c_void_p, C.c_void_p]
+    L.scldm_adamw_step.argtypes = [C.POINTER(AdamwEntry), C.c_int, C.c_void_p, C.c_void_p] + [C.c_float] * 5 + [C.c_int, C.c_void_p]
     fpp = C.POINTER(C.c_void_p)
     L.scldm_rk_combine.argtypes = [C.c_void_p, C.c_void_p, fpp, c_float_p, C.c_int, C.c_longlong, C.c_void_p]
     L.scldm_rk_error.argtypes = [C.c_void_p, C.c_void_p, fpp, c_float_p, C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
@@ -167,7 +172,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
            "scldm_dit_refresh_weights", "scldm_dit_fp16_stats", "scldm_dit_train_fp16_state", "scldm_dit_train_set_found_inf", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_set_option", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
-           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
+           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_adamw_step", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes", "scldm_dit_train_saved_bytes_for", "scldm_dit_train_workspace_bytes_for",
            "scldm_dit_train_prepare", "scldm_dit_train_set_grad_events", "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_fm_mix", "scldm_fm_loss", "scldm_fm_loss_bwd", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights", "scldm_vae_refresh_weights",
            "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_vae_decode_sample", "scldm_vae_train_saved_bytes", "scldm_vae_train_workspace_bytes", "scldm_vae_train_forward", "scldm_vae_train_backward", "scldm_nb_loglik", "scldm_nb_loglik_bwd", "scldm_nb_sample", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",

@@ -250,3 +250,66 @@ def train_step(dit, transport, optimizer, x1: torch.Tensor, condition: dict[str,
         elif float(found_inf) == 0.0:
             optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """The whole optimisation step - Transport.training_losses -> loss.mean().backward() -> optimizer.step() (models.py:443-470) -
+    captured ONCE in a HIP graph and replayed per mini-batch: one graph launch instead of ~100 kernel launches, the autograd walk,
+    the optimizer's Python and ~2 ms of host time per step (at <= 512 cells per GPU the eager step is host-bound).
+
+    The library's side streams (weight re-pack, the backward's independent tails) fork from and join the capturing stream through
+    events, so they become branches of the graph.  Requirements: a CUDA model in training mode, fixed batch size and label keys, an
+    optimizer whose step is capturable (torch.optim.Adam / AdamW with `fused=True, capturable=True`), single process (the
+    gradient all-reduce of data-parallel training is not captured: use `train_step`).  `t` is drawn on the device inside the
+    graph (Transport.sample), x0 as always.  `__call__(x1, condition)` copies the batch into the graph's static inputs, replays
+    and returns the (static) loss tensor."""
+
+    def __init__(self, dit, transport, optimizer, x1: torch.Tensor, condition: dict[str, torch.Tensor], warmup: int = 3):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("GraphedTrainStep captures a single-process step; data-parallel training uses train_step")
+        if not x1.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs CUDA (ROCm) tensors")
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("the optimizer step is captured in a HIP graph: construct it with capturable=True "
+                                 "(e.g. torch.optim.AdamW(params, fused=True, capturable=True))")
+        self.dit, self.transport, self.optimizer = dit, transport, optimizer
+        self.x1 = x1.detach().clone()
+        self.condition = {k: v.detach().clone() for k, v in condition.items()}
+        self.found_inf = dit.found_inf_flag() if getattr(dit, "precision", None) == "fp16" and hasattr(dit, "found_inf_flag") else None
+        side = torch.cuda.Stream(device=x1.device)
+        side.wait_stream(torch.cuda.current_stream(x1.device))
+        with torch.cuda.stream(side):          # warm-up on a side stream: allocations, lazy handles, pack tables, workspaces
+            for _ in range(max(1, warmup)):
+                self._body()
+        torch.cuda.current_stream(x1.device).wait_stream(side)
+        torch.cuda.synchronize(x1.device)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._body()
+        self.replays = 0
+
+    def _body(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.transport.training_losses(self.dit, self.x1, {"condition": self.condition})["loss"].mean()
+        loss.backward()
+        if self.found_inf is not None and getattr(self.optimizer, "_step_supports_amp_scaling", False):
+            self.optimizer.found_inf, self.optimizer.grad_scale = self.found_inf, None
+            try:
+                self.optimizer.step()
+            finally:
+                del self.optimizer.found_inf, self.optimizer.grad_scale
+        else:
+            self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, x1: torch.Tensor, condition: dict[str, torch.Tensor]) -> torch.Tensor:
+        if x1.shape != self.x1.shape or set(condition) != set(self.condition):
+            raise ValueError(f"GraphedTrainStep was captured for x1 {tuple(self.x1.shape)} and labels {sorted(self.condition)}")
+        self.x1.copy_(x1, non_blocking=True)
+        for k, v in condition.items():
+            self.condition[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss

@@ -86,7 +86,11 @@ class Transport:
     def sample(self, x1: torch.Tensor):
         """x0 ~ N(0, I), t ~ U[0, 1] (transport.py:97-108)."""
         x0 = torch.randn_like(x1)
-        if x1.is_cuda:
+        if x1.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture (scldm_amd.training.GraphedTrainStep) host code does not run again at replay: t comes from
+            # the device generator (whose captured draws advance per replay); same distribution as the reference's CPU draw
+            t = torch.rand((x1.shape[0],), device=x1.device, dtype=x1.dtype)
+        elif x1.is_cuda:
             # same CPU generator draw as the reference's `torch.rand((B,)).to(x1)`, but through pinned memory and an asynchronous
             # copy: a pageable host-to-device copy blocks the host until everything queued on the stream has finished, which
             # serialises the host's kernel enqueueing with the previous step's device work

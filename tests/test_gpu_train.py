@@ -213,6 +213,51 @@ def test_fp16_overflow_is_detected_the_step_is_skipped_and_the_scale_backs_off()
         assert all(torch.equal(q0[k], p.detach()) for k, p in m2.named_parameters())
 
 
+def test_native_adamw_matches_torch_fused_adamw_and_shares_its_state_dict():
+    """scldm_amd.optim.AdamW (one HIP launch per step) against torch.optim.AdamW(fused=True) - the optimizer of the reference's trainer -
+    on tensors of assorted sizes (multiples of 4 and not, a 16-byte-misaligned view), eight steps: parameters and both moments within
+    fp32 rounding; `found_inf` skips an update (and the step count); a state_dict round-trips between the two classes."""
+    from scldm_amd.optim import AdamW
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [(684, 256), (256,), (1536, 256), (3,), (17, 5), (4097,), (2025, 256)]
+    base = [torch.randn(s, device="cuda", generator=gen) * 0.05 for s in shapes]
+    big = torch.randn(1025, device="cuda", generator=gen)
+    def make():
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        ps.append(torch.nn.Parameter(big.clone()[1:]))          # data pointer 4 bytes off a 16-byte boundary
+        return ps
+    pa, pb = make(), make()
+    kw = dict(lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    oa, ob = AdamW(pa, **kw), torch.optim.AdamW(pb, fused=True, **kw)
+    for it in range(8):
+        for x, y in zip(pa, pb):
+            g = torch.randn(x.shape, device="cuda", generator=gen) * (0.1 if it % 2 else 1e-3)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), float((x - y).abs().max())
+        # (the moments are differences of nearby numbers: one ulp of an operand, torch's build contracts a * b + c and this one does not)
+        assert torch.allclose(oa.state[x]["exp_avg"], ob.state[y]["exp_avg"], rtol=1e-5, atol=2e-8), float((oa.state[x]["exp_avg"] - ob.state[y]["exp_avg"]).abs().max())
+        assert torch.allclose(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    assert float(oa.state[pa[0]]["step"]) == float(ob.state[pb[0]]["step"]) == 8.0
+    snap = [x.detach().clone() for x in pa]
+    oa.found_inf = torch.ones((), device="cuda")
+    oa.step()
+    del oa.found_inf
+    assert all(torch.equal(a, b) for a, b in zip(snap, pa)) and float(oa.state[pa[0]]["step"]) == 8.0
+    ob2 = torch.optim.AdamW(pb, fused=True, **kw)
+    ob2.load_state_dict(oa.state_dict())                         # ours -> torch
+    oa2 = AdamW(pa, **kw)
+    oa2.load_state_dict(ob.state_dict())                         # torch -> ours
+    for x, y in zip(pa, pb):
+        g = torch.randn(x.shape, device="cuda", generator=gen)
+        x.grad, y.grad = g.clone(), g.clone()
+    oa2.step(); ob2.step()
+    assert float(oa2.state[pa[0]]["step"]) == 9.0
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=3e-6, atol=1e-7)     # (an update is ~3e-3: 1e-7 is 3e-5 of it)
+
+
 def _bf16_step_vs_oracle(n, n_layer=8, seed=81, fused=None, monkeypatch=None):
     vocab = {"cell_line": 4, "gene": 2024}
     if fused is not None:

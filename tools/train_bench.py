@@ -17,7 +17,11 @@ for p in m.parameters():   # adaLN-Zero init would zero the whole backward: use 
     if p.requires_grad and float(p.detach().abs().sum()) == 0:
         torch.nn.init.normal_(p, std=0.02)
 m.precision = precision
-opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+if os.environ.get("TRAIN_BENCH_TORCH_ADAMW") == "1":
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+else:
+    from scldm_amd.optim import AdamW
+    opt = AdamW(m.parameters(), lr=1e-4)
 tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
 x1 = torch.randn(B, 16, 16, device="cuda")
 cond = {"cell_line": torch.randint(0, 4, (B,), device="cuda"), "gene": torch.randint(0, 2024, (B,), device="cuda")}
