@@ -966,9 +966,36 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(ln_bwd(st, kD, n, k.dh, s.x_last, s.st_f, s.mod, (long)mw, of + kD, of, k.dx, 0, k.dmod));
     if (use_fused) TRY(fused::to_tile(k.dx, fs.dx, n, st));
   }
+  // Fused route, adaLN Linears mod_l = SiLU(c) W_l^T + b_l (round 5): the two products of every layer's slice of dmod - the weight
+  // gradient d W_l = dmod_l^T SiLU(c) (+ row sums = bias gradient) and the running sum d SiLU(c) += dmod_l W_l - are queued on a side
+  // stream as soon as that layer's backward kernel is (the final layer's slice first), so they run beside the layers still being
+  // differentiated instead of as two K = 13 824 / M = 13 824 products in the tail after the last layer (140 us of a 2.2 ms step).
+  // MEASURED SLOWER at 1 024 cells (2.77 against 2.15 ms per step: the small products take workgroup slots - and with them whole CUs'
+  // worth of LDS - from the backward layer, which needs one CU per tile) and +-0 at 256 cells: opt-in, SCLDM_TRAIN_ADA_STREAM=1.
+  static const bool ada_opt = [] { const char* e = getenv("SCLDM_TRAIN_ADA_STREAM"); return e && e[0] == '1'; }();
+  const bool ada_stream = use_fused && ada_opt;
+  hipStream_t s_ada_l = st;
+  auto ada_slice = [&](int l, bool first) -> int {
+    const int width = l < L ? 6 * kD : 2 * kD;
+    const size_t off = (size_t)l * 6 * kD;
+    float* dw_all = fs.ada_dw;
+    float* db_all = fs.ada_dw + (size_t)mw * kD;
+    TRY(gemm(s_ada_l, k.dmod + off, 1, mw, s.sc, 1, kD, dw_all + off * kD, kD, width, kD, n, nullptr, false, nullptr, 0, db_all + off));
+    TRY(gemm(s_ada_l, k.dmod + off, mw, 1, h->ada_t + off, mw, 1, k.dsc, kD, n, kD, width, nullptr, !first, nullptr, 0));
+    return SCLDM_OK;
+  };
   if (use_fused) {
     TRY(fused::backward_join(h, st));
-    TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision));
+    if (ada_stream) {
+      TRY(fused::fork_side(h, st, 1, &s_ada_l));     // (the final layer's dmod slice is complete here)
+      TRY(ada_slice(L, true));
+      TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision, [&](int l) -> int {
+        TRY(fused::fork_side(h, st, 1, &s_ada_l));   // the side stream waits for layer l's kernel
+        return ada_slice(l, false);
+      }));
+    } else {
+      TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision));
+    }
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
   // bf16-source route: dy, dqkv, da, db (consumed only by GEMMs) are bf16 arrays in their slots of the scratch block
@@ -1181,7 +1208,8 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   // disjoint scratch, so the first two go to side streams and the chain stays on `st`.
   hipStream_t s_in = st, s_ada = st;
   if (edge && !dx_out) TRY(fused::fork_side(h, st, 0, &s_in));
-  if (use_fused) TRY(fused::fork_side(h, st, 1, &s_ada));
+  if (use_fused && !ada_stream) TRY(fused::fork_side(h, st, 1, &s_ada));
+  if (ada_stream) s_ada = s_ada_l;
   if (edge) {
     TRY(fused::inproj_backward(h, fs.dx, x, n, g->in_w, g->in_b, g->pos_embed, fs.edge_part, s_in));
   } else {
@@ -1196,10 +1224,15 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     // contiguous (mod_w, D) scratch, scattered to the per-layer gradient tensors by one kernel
     float* dw_all = fs.ada_dw;
     float* db_all = fs.ada_dw + (size_t)mw * kD;
-    // (200 output tiles, K = n: no split-K, so this GEMM needs no partial buffer and can run beside the chain below)
-    TRY(gemm(s_ada, k.dmod, 1, mw, s.sc, 1, kD, dw_all, kD, mw, kD, n, nullptr, false, nullptr, 0, db_all));
-    TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, s_ada));
-    TRY(gemm(st, k.dmod, mw, 1, h->ada_t, mw, 1, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
+    if (ada_stream) {   // every slice's products are queued on the side stream already: scatter, and wait for the running sum
+      TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, s_ada));
+      TRY(fused::join_side(h, st, 1));
+    } else {
+      // (200 output tiles, K = n: no split-K, so this GEMM needs no partial buffer and can run beside the chain below)
+      TRY(gemm(s_ada, k.dmod, 1, mw, s.sc, 1, kD, dw_all, kD, mw, kD, n, nullptr, false, nullptr, 0, db_all));
+      TRY(fused::scatter_ada_grads(h, g, dw_all, db_all, s_ada));
+      TRY(gemm(st, k.dmod, mw, 1, h->ada_t, mw, 1, k.dsc, kD, n, kD, mw, nullptr, false, k.part, k.part_floats));
+    }
   }
   // bf16-source route: one cast of dmod, then d SiLU(c) = dmod W_all as ONE split-K product and the per-layer weight
   // gradients straight into their tensors (column slices of dmod as the m-contiguous A operand, row sums = bias gradients).
@@ -1245,26 +1278,48 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   LAUNCH_CHECK();
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
+  // Fused route (round 5): three independent consumers of d c run beside each other instead of as one chain of ~17 small launches -
+  // the class tables on the input-projection stream (partials in an operand-pair array, free after the last layer), d t_w2 on
+  // the adaLN stream (split-K partials in the fused weight-gradient scratch, free after the last layer), the timestep MLP's data
+  // gradient chain on `st` (the generic split-K scratch).
+  hipStream_t s_emb = st, s_tw2 = st;
+  float* emb_part = k.part;
+  size_t emb_part_floats = k.part_floats;
+  Scratch k_tw2 = k;
+  static const bool tails_serial = [] { const char* e = getenv("SCLDM_TRAIN_TAILS_SERIAL"); return e && e[0] == '1'; }();   // A/B switch
+  const bool par_tails = use_fused && !tails_serial;
+  if (par_tails && edge && !dx_out) {
+    // (partials in the h1 operand-pair array: 8 KB per cell, free since the last layer's weight-gradient launch earlier on `st`)
+    TRY(fused::fork_side(h, st, 0, &s_emb));
+    emb_part = reinterpret_cast<float*>(fs.e_h1);
+    emb_part_floats = (size_t)T_pad * kD / 2;
+  }
+  if (par_tails) {
+    TRY(fused::fork_side(h, st, 1, &s_tw2));
+    k_tw2.part = fs.part;
+    k_tw2.part_floats = fs.part_floats;
+  }
   for (int c = 0; c < cfg.n_classes; ++c) {
     const int64_t* lab = labels ? labels[c] : nullptr;
-    if (n >= 256 && n <= kEmbSeg * kEmbMaxSegs && (size_t)n * kD <= k.part_floats) {
+    if (n >= 256 && n <= kEmbSeg * kEmbMaxSegs && (size_t)n * kD <= emb_part_floats) {
       // training-size batch: two-level sums (a label shared by most samples - the null token - is not one serial chain)
-      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), st));
-      hipLaunchKernelGGL(embed_bwd_seg_partial_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, k.part);
-      hipLaunchKernelGGL(embed_bwd_seg_final_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.part, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), s_emb));
+      hipLaunchKernelGGL(embed_bwd_seg_partial_kernel, dim3(n, kD / 256), dim3(256), 0, s_emb, k.dc, lab, h->tab_rows[c] - 1, n, kD, emb_part);
+      hipLaunchKernelGGL(embed_bwd_seg_final_kernel, dim3(n, kD / 256), dim3(256), 0, s_emb, emb_part, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     } else if (h->tab_rows[c] > n) {   // more table rows than samples: organise the sum by sample (same order, same bits)
-      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), st));
-      hipLaunchKernelGGL(embed_bwd_by_sample_kernel, dim3(n, kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+      HIP_TRY(hipMemsetAsync(g->class_emb[c], 0, (size_t)h->tab_rows[c] * kD * sizeof(float), s_emb));
+      hipLaunchKernelGGL(embed_bwd_by_sample_kernel, dim3(n, kD / 256), dim3(256), 0, s_emb, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     } else {
-      hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, st, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(h->tab_rows[c], kD / 256), dim3(256), 0, s_emb, k.dc, lab, h->tab_rows[c] - 1, n, kD, g->class_emb[c]);
     }
     LAUNCH_CHECK();
   }
-  TRY(linear_wgrad(st, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k, g->t_b2));
+  TRY(linear_wgrad(s_tw2, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k_tw2, g->t_b2));
   TRY(linear_dgrad(st, k.dc, kD, w->t_w2, n, kD, kD, k.dsth, kD, false, k));
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
   LAUNCH_CHECK();
   TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
+  if (s_emb != st && s_emb != s_in) TRY(fused::join_side(h, st, 0));
   if (s_in != st) TRY(fused::join_side(h, st, 0));
   if (s_ada != st) TRY(fused::join_side(h, st, 1));
   if (f16) TRY(fused::unscale_grads(h, g, dx_out, (long)T * din, fs, st));

@@ -567,7 +567,8 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.e_db = c.take<__bf16>(T * kHP);
   s.e_hid = c.take<__bf16>(T * kHP);
   s.e_dy2 = c.take<__bf16>(T * kD);
-  s.part = c.take<float>(part_floats(h));
+  s.part_floats = part_floats(h);
+  s.part = c.take<float>(s.part_floats);
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.edge_part = c.take<float>(edge_part_floats(h));
   s.dout_s = c.take<float>(T * 32);
@@ -819,7 +820,7 @@ struct BwdFP16 {
 
 template <typename BW>
 static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
-                             hipStream_t st) {
+                             hipStream_t st, const std::function<int(int)>& after_layer) {
   using E16 = typename BW::E;
   static bool attr_set[64] = {};   // (per instantiation)
   int dev = 0;
@@ -858,6 +859,10 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     a.dbg = (want_dbg && tiles <= 16384) ? dbg_buf : nullptr;
     BW::launch(tiles, st, a);
     LAUNCH_CHECK();
+    if (after_layer) {
+      const int rc = after_layer(l);
+      if (rc) return rc;
+    }
     if (a.dbg) {
       HIP_TRY(hipStreamSynchronize(st));
       std::vector<unsigned long long> hst((size_t)tiles * BW::NW * 16);
@@ -924,8 +929,9 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
 }
 
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
-                    hipStream_t st, int precision) {
-  return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16>(h, g, mod, dmod, n, rec, s, st) : backward_layers_t<BwdBF16>(h, g, mod, dmod, n, rec, s, st);
+                    hipStream_t st, int precision, const std::function<int(int)>& after_layer) {
+  return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16>(h, g, mod, dmod, n, rec, s, st, after_layer)
+                                      : backward_layers_t<BwdBF16>(h, g, mod, dmod, n, rec, s, st, after_layer);
 }
 
 int scale_dout(scldm_dit* h, const float* dout, long n_elem, const Scratch& s, hipStream_t st) {

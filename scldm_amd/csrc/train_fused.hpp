@@ -2,6 +2,7 @@
 // train_api.hip (conditioning, final layer, input projection: the small GEMM-based pieces) and train_fused.hip (the fused
 // forward with a training record, the fused backward layer, the batched weight-gradient GEMMs).
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 
 #include "dit_handle.hpp"
@@ -30,6 +31,7 @@ struct Scratch {
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
   float* dout_s;    // fp16 policy: the loss-scaled copy of d loss / d output (n x 16 x n_embed_input)
+  size_t part_floats;   // floats behind `part`
   float* scale;     // fp16 policy: the handle's loss-scale state ([0] S, a power of two decided on device from max |dout|, [1] 1 / S, ...)
   size_t bytes;
 };
@@ -50,8 +52,10 @@ int to_tile(const float* plain, float* tile, int n, hipStream_t st);
 int to_plain(const float* tile, float* plain, int n, hipStream_t st);
 // all L layers, last to first: s.dx (tile layout) holds d loss / d x_L on entry and d loss / d x_0 on return; dmod gets the
 // gradients of the layers' adaLN vectors; g receives attn_w/attn_b/proj_w/proj_b/w1/w2/cproj of every layer
+// after_layer(l), when given, runs right after layer l's kernel is queued (its dmod slice is final once that kernel ends): the caller
+// forks the per-layer adaLN products onto a side stream there (round 5)
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
-                    hipStream_t st, int precision);
+                    hipStream_t st, int precision, const std::function<int(int)>& after_layer = {});
 
 // The two ends of the backward as single kernels on the tile layout (n_embed_input 8 / 16 / 32):
 //   final_backward: LayerNorm + Linear of the final layer: dx (tile layout), d(shift, scale) into dmod, d fin_w, d fin_b

@@ -77,4 +77,7 @@ class AdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_step_t", None)
+        # every parameter gets its OWN copy of the step count: torch's optimizers increment the `step` tensor of each parameter, so a
+        # shared tensor loaded there would advance once per parameter per step
+        sd["state"] = {k: {kk: (vv.clone() if kk == "step" and torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
         return sd

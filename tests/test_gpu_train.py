@@ -254,8 +254,8 @@ def test_native_adamw_matches_torch_fused_adamw_and_shares_its_state_dict():
         x.grad, y.grad = g.clone(), g.clone()
     oa2.step(); ob2.step()
     assert float(oa2.state[pa[0]]["step"]) == 9.0
-    for x, y in zip(pa, pb):
-        assert torch.allclose(x, y, rtol=3e-6, atol=1e-7)     # (an update is ~3e-3: 1e-7 is 3e-5 of it)
+    for i, (x, y) in enumerate(zip(pa, pb)):
+        assert torch.allclose(x, y, rtol=3e-6, atol=1e-7), (i, float((x - y).abs().max()))     # (an update is ~3e-3: 1e-7 is 3e-5 of it)
 
 
 def _bf16_step_vs_oracle(n, n_layer=8, seed=81, fused=None, monkeypatch=None):
