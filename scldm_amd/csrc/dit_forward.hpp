@@ -83,14 +83,19 @@ constexpr int kDbgStamps = 32;
 #define SCLDM_MAX_LPL 8
 #endif
 constexpr int kMaxLayersPerLaunch = SCLDM_MAX_LPL;
-constexpr int kMaxLayersPerLaunchRec = 4;
+#ifndef SCLDM_REC_LPL
+#define SCLDM_REC_LPL 4
+#endif
+constexpr int kMaxLayersPerLaunchRec = SCLDM_REC_LPL;   // layer slots of the RECORDING (training) instantiation: 4, or 8 with -DSCLDM_REC_LPL=8
 // 1: every workgroup touches its share of the NEXT layer's weight stream (one 4-byte load per 128-byte line) at the start of a
 // layer, so that the stream's first-touch misses (each XCD's 4 MB L2 holds ~2 layers) are taken a layer ahead of the ring.
 #ifndef SCLDM_L2WARM
 #define SCLDM_L2WARM 0
 #endif
 // Timing proxies (deliberately WRONG results; libx_* experiment builds only): bit 0 no weight-ring refills, bit 1 no activation-fragment
-// LDS reads, bit 2 no SwiGLU transcendental work.  What each costs in time AND clock under the power budget.
+// LDS reads, bit 2 no SwiGLU transcendental work, bit 3 (round 5) the cost model of "two wave groups share one weight ring through LDS":
+// only every SECOND k-step's weight fragments are fetched from L2 (the other group's half) and every k-step reads FT extra 16-byte
+// fragments per lane from LDS (where the shared ring would live), bit 4 the LDS half of that alone (extra reads, full L2 stream).  What each costs in time AND clock under the power budget.
 #ifndef SCLDM_PROXY
 #define SCLDM_PROXY 0
 #endif
@@ -295,8 +300,16 @@ __device__ __forceinline__ void gemm_pass(f32x16 (&acc)[FT][NTT], WStream<OP, PF
         else acc[ft][tt] = OP::mma(ws.ring[s][ft], bcur[tt], first ? (init ? init[ft] : zero) : acc[ft][tt]);
       }
     }
+#if SCLDM_PROXY & 24   // timing proxies 8 / 16 (WRONG RESULTS): FT more fragment reads from LDS per k-step (a weight ring shared through LDS)
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+      typedef __attribute__((ext_vector_type(4))) unsigned px_u32x4;
+      const px_u32x4 extra = *reinterpret_cast<const px_u32x4*>(bbase + ((ft + 1) & (NTT - 1)) * 32 * ldb + ((ks + 2 + ft) & 7) * 16);
+      asm volatile("" ::"v"(extra));
+    }
+#endif
 #if !(SCLDM_PROXY & 1)   // timing proxy 1 (WRONG RESULTS): the weight ring is never refilled - what the L2 -> VGPR weight stream costs
-    if (refill) {
+    if (refill && (!(SCLDM_PROXY & 8) || (ks & 1))) {
 #pragma unroll
       for (int ft = 0; ft < FT; ++ft) ws.ring[s][ft] = ws.fetch(ft);  // refill the slot just consumed: PF k-steps ahead
     }
@@ -1206,7 +1219,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
   if (a.n_here > 2) layer_body(std::integral_constant<int, 2>{});
   if (a.n_here > 3) layer_body(std::integral_constant<int, 3>{});
 #if SCLDM_MAX_LPL > 4
-  if constexpr (!REC) {
+  if constexpr (!REC || SCLDM_REC_LPL == 8) {
     if (a.n_here > 4) layer_body(std::integral_constant<int, 4>{});
     if (a.n_here > 5) layer_body(std::integral_constant<int, 5>{});
     if (a.n_here > 6) layer_body(std::integral_constant<int, 6>{});

@@ -11,7 +11,7 @@ def run(B):
   global host
   wl = dict(bench.TRAIN_WORKLOADS["replogle_train_b1024"]); wl["B"] = B
   m = bench.make_model(wl, "bf16", dev).train()
-  opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
+  opt = bench.make_optimizer(m.parameters(), 1e-4)
   tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
   g = torch.Generator().manual_seed(3)
   x1 = torch.randn(B, 16, 16, generator=g).to(dev)

@@ -5,7 +5,7 @@ tag=${1:-r3}
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 mkdir -p gpurun_out
 o=gpurun_out/$tag
-timeout 1500 python bench.py --steps 20 --warmup 5 > ${o}_bench_default.json 2> ${o}_bench_default.err; tail -c 600 ${o}_bench_default.json; echo
+timeout 1500 python bench.py --steps 20 --warmup 5 > ${o}_bench_default.json 2> ${o}_bench_default.err; tail -c 600 ${o}_bench_default.json; echo; cp profiles/bench_last.json ${o}_bench_default_details.json 2>/dev/null
 timeout 300 python bench.py --precision fp16 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > ${o}_bench_fp16.json 2>/dev/null
 timeout 300 python bench.py --precision bf16x3 --steps 10 --warmup 2 --no-extra --no-cpu-baseline > ${o}_bench_bf16x3.json 2>/dev/null
 timeout 300 python bench.py --precision fp32 --steps 1 --no-extra --no-cpu-baseline > ${o}_bench_fp32.json 2>/dev/null
@@ -31,5 +31,18 @@ cp ${o}_pmc_sq_bf16.txt ${o}_pmc_sq.txt
 bash tools/rocprof_pmc.sh ${tag}_pmc2 "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE" $K tests/perf/dit_profile.py bf16 6 > ${o}_pmc_sq2.txt 2>&1
 bash tools/rocprof_pmc.sh ${tag}_pmc3 "FETCH_SIZE" $K tests/perf/dit_profile.py bf16 6 > ${o}_pmc_fetch.txt 2>&1
 bash tools/rocprof_pmc.sh ${tag}_pmc4 "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" $K tests/perf/dit_profile.py bf16 6 > ${o}_pmc_write.txt 2>&1
+# round 5: the fused training step's kernels (statistics, one-step timeline, four PMC passes over the backward / weight-gradient / recording-forward kernels)
+ROCPROF_ROWS=24 bash tools/rocprof_stats.sh ${tag}_stats_train_bench tools/train_bench.py 1024 25 bf16 > ${o}_train_bench_b1024_kernel_stats.txt 2>&1
+python3 tools/kernel_timeline.py $(find gpurun_out/${tag}_stats_train_bench -name "*kernel_trace.csv" | head -1) 3 > ${o}_train_b1024_timeline.txt 2>&1
+KT="dit_backward|wgrad_bf16|dit_forward"
+bash tools/rocprof_pmc.sh ${tag}_pmct1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "$KT" tools/train_bench.py 1024 8 bf16 > ${o}_pmc_train_sq1.txt 2>&1
+bash tools/rocprof_pmc.sh ${tag}_pmct2 "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU GRBM_GUI_ACTIVE" "$KT" tools/train_bench.py 1024 8 bf16 > ${o}_pmc_train_sq2.txt 2>&1
+bash tools/rocprof_pmc.sh ${tag}_pmct3 "FETCH_SIZE" "$KT" tools/train_bench.py 1024 8 bf16 > ${o}_pmc_train_fetch.txt 2>&1
+bash tools/rocprof_pmc.sh ${tag}_pmct4 "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "$KT" tools/train_bench.py 1024 8 bf16 > ${o}_pmc_train_write.txt 2>&1
+for b in 1024 512 256; do python tools/train_bench.py $b 30 bf16 2>&1 | grep ms/step; done > ${o}_train_bench_sizes.txt
+python tools/train_bench.py 1024 30 fp16 2>&1 | grep ms/step >> ${o}_train_bench_sizes.txt
+TRAIN_BENCH_TORCH_ADAMW=1 python tools/train_bench.py 1024 30 bf16 2>&1 | grep ms/step | sed "s/^/torch AdamW: /" >> ${o}_train_bench_sizes.txt
+python tools/train_graph_bench.py 256 bf16 2>&1 | grep cells >> ${o}_train_bench_sizes.txt
+cp profiles/bench_last.json ${o}_bench_last.json 2>/dev/null
 timeout 2400 python -m pytest tests -m gpu -q -rP 2>&1 | grep -E "^\[parity\]|^\[dopri5|passed|failed|^E  |^FAILED" | cut -c1-400 > ${o}_gpu_tests.txt; tail -2 ${o}_gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" > ${o}_smoke.txt 2>&1; tail -3 ${o}_smoke.txt
