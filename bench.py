@@ -1015,7 +1015,7 @@ def main():
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
-                                                "per layer (DESIGN 4.4a)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.4)"}
+                                                "per layer (DESIGN 4.5)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.6)"}
             if tprec == "bf16":
                 # the same step at the reference's own training precision class (fp16 operands = TF32's mantissa, loss-scaled backward)
                 torch.cuda.empty_cache()
@@ -1048,7 +1048,7 @@ def main():
                         result[key] = {"workload": name, "cells_per_s": tl["B"] / (dtl / 4), "ms_per_step": 1e3 * dtl / 4,
                                        "tflops": 3 * dit_flops(n_embed=1024, n_layer=24) * tl["B"] / (dtl / 4) / 1e12, "dtype": "bf16",
                                        "path": "generic: bf16 operand arrays, LDS-DMA 256-tile GEMMs (bgemm8_kernel) / bgemm_kernel, matrix-core attention, "
-                                               "batched weight gradients beside the chain (DESIGN 4.4b, 4.4c)"}
+                                               "batched weight gradients beside the chain (DESIGN 4.6, HISTORY 4.4b-c)"}
                         torch.cuda.empty_cache()
                     # the same DiT-L shape sampling (generic GEMM route under forward_with_cfg; 20 Euler CFG evaluations, 256 cells)
                     wL = dict(vocab={"cell_line": 4, "gene": 2024}, strategy="joint", B=256, evals=20, method="euler", scale=1.0,

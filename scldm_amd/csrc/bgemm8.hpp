@@ -1,7 +1,7 @@
 // 256 x 256 bf16-source GEMM built around LDS-DMA and a phase-split schedule instead of bgemm256_kernel's register staging:
 // both operands contiguous along k (forward products X W^T, data gradients against the transposed bf16 weight copies) or both
 // contiguous along m (weight gradients: m-contiguous unit images, transposing fragment reads - see the staging / read notes in the
-// body).  DESIGN.md 4.4c; measurements and ablations: tests/perf/gemm_probe.hip, profiles/r3_gemm_probe_*.txt.
+// body).  HISTORY.md 4.4c; measurements and ablations: tests/perf/gemm_probe.hip, profiles/r3_gemm_probe_*.txt.
 //
 // What bgemm256_kernel pays per 64-k stage (8 waves, 32 MFMAs each = 2 048 MFMA cycles per SIMD): 192 KB of fragment reads
 // (768 LDS cycles) AND 64 ds_write_b128 wave-instructions whose VGPR -> LDS transfer costs 13 cycles each (832 cycles, not

@@ -468,7 +468,7 @@ W16 w16_layer(const scldm_dit* h, int l) {
 // rec_y1 / rec_y2): half the bytes in the producing epilogue, in gate_res and in the gate backward
 const bool g_y16 = [] { const char* e = getenv("SCLDM_Y16"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 // (opt-in: measured SLOWER, 46.9 -> 49.3 ms at 1 024 cells - the epilogue of a 256 x 256 tile is the one part of the kernel that nothing
-// overlaps, and the product leaves the group of kernels that run beside the previous layer's batched weight gradient)
+// overlaps, and the product leaves the group of kernels that run beside the previous layer's batched weight gradient; HISTORY.md 4.4c)
 const bool g_fuse_swiglu_bwd = [] { const char* e = getenv("SCLDM_FUSE_SWIGLU_BWD"); return e && atoi(e) != 0; }();
 const bool g_batch_side = [] { const char* e = getenv("SCLDM_BATCH_SIDE"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)
 const bool g_ada_stacked = [] { const char* e = getenv("SCLDM_ADA_STACKED"); return !e || atoi(e) != 0; }();   // A/B switch (read at load)

@@ -1,6 +1,6 @@
 """Training step wall time vs batch size (host-bound if the time does not grow with the batch).
    python tests/perf/train_scale.py            one process, models built one after the other, the previous one released first
-   python tests/perf/train_scale.py nogc       the round-2 behaviour: no explicit release / collection between sizes (see DESIGN 4.4a:
+   python tests/perf/train_scale.py nogc       the round-2 behaviour: no explicit release / collection between sizes (see HISTORY 4.4a:
                                                Python's cyclic collector then frees the previous model - ~30 hipFree, each a device
                                                synchronisation - in the middle of the next size's timed loop)"""
 import gc, os, sys, time
