@@ -292,7 +292,7 @@ def make_optimizer(params, lr, kind="native"):
     return AdamW(params, lr=lr)
 
 
-def time_training(wl, precision, device, steps, warmup, dist_on, world, optimizer="native"):
+def time_training(wl, precision, device, steps, warmup, dist_on, world, optimizer="native", graphed=False):
     """One step = Transport.training_losses forward + HIP backward + gradient all-reduce (N > 1) + fused AdamW on the per-GPU
     batch of synthetic latents (standing in for frozen-VAE output).  Returns seconds for `steps` steps (max over ranks)."""
     from scldm_amd.training import train_step
@@ -303,15 +303,22 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world, optimize
     g = torch.Generator().manual_seed(3)
     x1 = torch.randn(wl["B"], 16, 16, generator=g).to(device)
     cond = {k: torch.randint(0, v, (wl["B"],), generator=g).to(device) for k, v in wl["vocab"].items()}
+    step = lambda: train_step(m, tr, opt, x1, cond)
+    if graphed and not dist_on:
+        # the product's whole-step HIP graph (scldm_amd.training.GraphedTrainStep): forward, backward and optimizer captured once,
+        # one graph launch per mini-batch (the batch is copied into the graph's static inputs every step, as a data loader's would be)
+        from scldm_amd.training import GraphedTrainStep
+        gstep = GraphedTrainStep(m, tr, opt, x1, cond)
+        step = lambda: gstep(x1, cond)
     for _ in range(warmup):
-        train_step(m, tr, opt, x1, cond)
+        step()
     if dist_on:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(m, tr, opt, x1, cond)
+        loss = step()
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -768,7 +775,7 @@ def compact_line(result):
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
     put("e2e_ms_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "ms")
     put("train_ms", "training_step", "ms_per_step"); put("train_cells_per_s", "training_step", "cells_per_s"); put("train_tflops", "training_step", "tflops")
-    put("train_torch_adamw_ms", "training_step_torch_adamw", "ms_per_step")
+    put("train_torch_adamw_ms", "training_step_torch_adamw", "ms_per_step"); put("train_eager_ms", "training_step_eager", "ms_per_step")
     put("train_fp16_ms", "training_step_fp16", "ms_per_step"); put("train_b256_ms", "training_step_b256", "ms_per_step")
     put("train_ditl_b1024_tflops", "training_step_ditl_b1024", "tflops"); put("train_ditl_b256_tflops", "training_step_ditl", "tflops")
     put("ditl_sampling_tflops", "ditl_sampling", "tflops")
@@ -1011,21 +1018,27 @@ def main():
             tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
             torch.cuda.empty_cache()
             tprec = "bf16" if args.precision in ("bf16", "fp16") else "fp32"
-            dtt, _ = time_training(tw, tprec, device, 10, 5, False, 1)
+            dtt, _ = time_training(tw, tprec, device, 20, 5, False, 1, graphed=True)
+            dtt /= 2
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
+                                       "launch": "GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph",
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
                                                 "per layer (DESIGN 4.5)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.6)"}
             if tprec == "bf16":
                 # the same step at the reference's own training precision class (fp16 operands = TF32's mantissa, loss-scaled backward)
                 torch.cuda.empty_cache()
-                dth, _ = time_training(tw, "fp16", device, 10, 5, False, 1)
+                dth, _ = time_training(tw, "fp16", device, 20, 5, False, 1, graphed=True)
+                dth /= 2
                 result["training_step_fp16"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dth / 10), "ms_per_step": 1e3 * dth / 10,
                                                 "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dth / 10) / 1e12, "dtype": "fp16",
                                                 "path": "fused route, fp16 operands (10 mantissa bits = the reference's TF32 training arithmetic), "
                                                         "device-side loss scaling of the backward"}
             torch.cuda.empty_cache()
-            d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1)   # the small-batch step (host / launch bound)
+            dte, _ = time_training(tw, tprec, device, 10, 5, False, 1)
+            result["training_step_eager"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dte / 10, "dtype": tprec,
+                                             "launch": "scldm_amd.training.train_step: eager (~100 kernel launches + autograd + optimizer Python per step)"}
+            d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1, graphed=True)   # the small-batch step
             torch.cuda.empty_cache()
             dto, _ = time_training(tw, tprec, device, 10, 5, False, 1, optimizer="torch")
             result["training_step_torch_adamw"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dto / 10, "dtype": tprec,

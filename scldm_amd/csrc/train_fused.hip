@@ -81,6 +81,11 @@ struct WgradArgs {
   int n_jobs, T, kchunk, splits;
   float* part;
 };
+#ifndef SCLDM_WGRAD_STAGES
+#define SCLDM_WGRAD_STAGES 2
+#endif
+constexpr int kWStages = SCLDM_WGRAD_STAGES;   // register stages in flight per operand (2 or 3)
+static_assert(kWStages == 2 || kWStages == 3, "two or three register stages");
 constexpr int kWK = 64;            // tokens per staged tile
 constexpr int kWLD = 128 + 32;     // bf16 elements per LDS row of a [token][feature] image (320 B: the 8-byte pieces of the transposing
                                    // fragment reads of a 32-lane half - 2 groups x 4 token rows - fall on eight distinct 32-byte bank ranges)
@@ -167,9 +172,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][k][r] = 0.f;
 
-  // Two register stages per operand: the loads of stage i+2 are issued while stage i is multiplied and stage i+1 (requested one
-  // whole iteration earlier) is written to LDS.  Barriers order LDS only (lds_barrier): __syncthreads() would drain the loads in flight.
-  OperandLoader la[2], lb[2];
+  // kWStages register stages per operand: the loads of stage i + kWStages are issued while stage i is multiplied and stage i + 1
+  // (requested kWStages - 1 whole iterations earlier) is written to LDS.  Round 5: 42 % of the kernel's wave cycles are vmcnt waits
+  // (profiles/r5_pmc_train_sq1.txt), but a third stage (-DSCLDM_WGRAD_STAGES=3) measured +-0 (45.4 against 45.2 us): the loads wait on
+  // bandwidth (3.9 TB/s at the fabric with a 66 % L2 hit rate), not on too short a prefetch distance.  Barriers order LDS only
+  // (lds_barrier): __syncthreads() would drain the loads in flight.
+  OperandLoader la[kWStages], lb[kWStages];
   auto make_rsrc = [](const __bf16* p) {
     const unsigned long long b = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
@@ -179,20 +187,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
   const bool want_rs = j.rs_off >= 0 && tn == 0;
   float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int n_it = (t_end - t_beg + kWK - 1) / kWK;
-  la[0].load(ra, j.lda, m0, t_beg);
-  lb[0].load(rb, j.ldb, n0, t_beg);
-  la[1].load(ra, j.lda, m0, t_beg + min(1, n_it - 1) * kWK);
-  lb[1].load(rb, j.ldb, n0, t_beg + min(1, n_it - 1) * kWK);
+#pragma unroll
+  for (int q = 0; q < kWStages; ++q) {
+    la[q].load(ra, j.lda, m0, t_beg + min(q, n_it - 1) * kWK);
+    lb[q].load(rb, j.ldb, n0, t_beg + min(q, n_it - 1) * kWK);
+  }
   if (want_rs) la[0].template add_rowsum<F16>(rs);
   la[0].store(As(0));
   lb[0].store(Bs(0));
   lds_barrier();
   auto iteration = [&](int it, auto slot_tag) {
     constexpr int SLOT = decltype(slot_tag)::value;     // register slot of stage `it` (already in LDS buffer it & 1): free again
+    constexpr int NEXT = (SLOT + 1) % kWStages;         // register slot of stage it + 1
     const int buf = it & 1;
-    // unconditional (the last two iterations re-request the last stage): with the loads under a branch the compiler's waitcnt
+    // unconditional (the last iterations re-request the last stage): with the loads under a branch the compiler's waitcnt
     // pass must assume the path that issued none, and then waits for the NEW stage as well when it needs the old one
-    const int ahead = t_beg + min(it + 2, n_it - 1) * kWK;
+    const int ahead = t_beg + min(it + kWStages, n_it - 1) * kWK;
     la[SLOT].load(ra, j.lda, m0, ahead);
     lb[SLOT].load(rb, j.ldb, n0, ahead);
 #pragma unroll
@@ -217,15 +227,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs g) {
         }
     }
     if (it + 1 < n_it) {
-      if (want_rs) la[SLOT ^ 1].template add_rowsum<F16>(rs);
-      la[SLOT ^ 1].store(As(buf ^ 1));
-      lb[SLOT ^ 1].store(Bs(buf ^ 1));
+      if (want_rs) la[NEXT].template add_rowsum<F16>(rs);
+      la[NEXT].store(As(buf ^ 1));
+      lb[NEXT].store(Bs(buf ^ 1));
     }
     lds_barrier();
   };
-  for (int it = 0; it < n_it; it += 2) {
+  for (int it = 0; it < n_it; it += kWStages) {
     iteration(it, std::integral_constant<int, 0>{});
     if (it + 1 < n_it) iteration(it + 1, std::integral_constant<int, 1>{});
+    if constexpr (kWStages > 2)
+      if (it + 2 < n_it) iteration(it + 2, std::integral_constant<int, 2 % kWStages>{});
   }
   if (want_rs) {   // the 16 threads (tid / 16) that share a feature chunk hold partial sums of the same eight rows
     float* red = reinterpret_cast<float*>(wgrad_smem);   // [16][128]

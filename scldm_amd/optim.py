@@ -52,8 +52,18 @@ class AdamW(torch.optim.Optimizer):
                 prev = next((self.state[p]["step"] for p in ps if "step" in self.state.get(p, {})), None)
                 step_t = group["_step_t"] = torch.zeros((), dtype=torch.float32, device=dev) if prev is None else \
                     torch.as_tensor(float(prev), dtype=torch.float32, device=dev).clone()
-            ent = (_lib.AdamwEntry * len(ps))()
-            for i, p in enumerate(ps):
+            # the pointer table is rebuilt only when a parameter, gradient or state tensor moved (the HIP backward's flat gradient buffer
+            # usually comes back at the same address every step): one pass of data_ptr() calls instead of 84 x the full checks
+            key = (len(ps), sum(p.data_ptr() ^ (p.grad.data_ptr() << 1) for p in ps))
+            cached = group.get("_table")
+            if cached is not None and cached[0] == key:
+                ent = cached[1]
+                ps_build = ()
+            else:
+                ent = (_lib.AdamwEntry * len(ps))()
+                ps_build = ps
+            keep = []
+            for i, p in enumerate(ps_build):
                 if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
                     raise RuntimeError("scldm_amd.optim.AdamW: fp32 CUDA (ROCm) parameters with dense fp32 gradients only; there is no CPU path")
                 st = self.state[p]
@@ -64,7 +74,12 @@ class AdamW(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous() or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
                     raise RuntimeError("scldm_amd.optim.AdamW: parameters and optimizer state must be contiguous")
+                if g is not p.grad:
+                    key = None                       # a temporary contiguous copy: never cache its address
                 ent[i].p, ent[i].g, ent[i].m, ent[i].v, ent[i].n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                keep.append(g)
+            if ps_build:
+                group["_table"] = (key, ent) if key is not None else None
             lr = float(group["lr"])
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):
@@ -73,10 +88,17 @@ class AdamW(torch.optim.Optimizer):
                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "scldm_adamw_step")
         return loss
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:          # the state tensors were replaced: rebuild the pointer table and the shared step count
+            g.pop("_table", None)
+            g.pop("_step_t", None)
+
     def state_dict(self):
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_step_t", None)
+            g.pop("_table", None)
         # every parameter gets its OWN copy of the step count: torch's optimizers increment the `step` tensor of each parameter, so a
         # shared tensor loaded there would advance once per parameter per step
         sd["state"] = {k: {kk: (vv.clone() if kk == "step" and torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
