@@ -188,6 +188,8 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
+  for (int g = 0; g < 2; ++g)
+    if (h->wg_ev[g]) (void)hipEventDestroy(h->wg_ev[g]);
   for (int g = 0; g < 3; ++g) {
     if (h->side[g]) (void)hipStreamDestroy(h->side[g]);
     if (h->join_ev[g]) (void)hipEventDestroy(h->join_ev[g]);

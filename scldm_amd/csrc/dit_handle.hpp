@@ -51,6 +51,7 @@ struct scldm_dit {
   int* d_dirty;    // [0] re-pack flag written by the compare kernel, [1] force flag
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
   hipEvent_t fork_ev, join_ev[3];
+  hipEvent_t wg_ev[2] = {nullptr, nullptr};   // fused training, small batches: layer l's weight-gradient launches (side stream) are done with operand-pair set l & 1
   hipEvent_t bwd_pack_ev = nullptr;   // the training step's backward weight stream is packed (second pack launch of fused::prepare)
   // fused sampler: the conditioning of evaluation e + 1 (timestep rows + adaLN projection: independent of the state z) runs on its own
   // stream beside the trunk of evaluation e, into the other of two buffer sets (scldm_sample_ode)

@@ -31,6 +31,7 @@ namespace {
 constexpr int kSplits = 16;         // most token-axis splits of the weight-gradient GEMMs the partial buffer is sized for
 constexpr int kSplitsDefault = 8;   // measured per layer at 1 024 cells: 4 splits 75 us, 8: 57 us, 16: 64 us + a longer reduction (SCLDM_WGRAD_SPLITS)
 constexpr int kHP = kBwdChunks * kBwdChunk;   // padded hidden width of the operand arrays (768)
+constexpr int kOverlapTiles = 160;            // <= this many 64-token tiles (640 cells): weight gradients of layer l beside the backward of layer l - 1
 
 struct Carver {
   char* base;
@@ -570,6 +571,7 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.handoff = c.take<float>(T * kD);
   s.dx = c.take<float>(T * kD);
   s.ridx = c.take<int32_t>(n);
+  const size_t set_off0 = c.off;
   s.e_h1 = c.take<__bf16>(T * kD);
   s.e_dqkv = c.take<__bf16>(T * 3 * kD);
   s.e_ao = c.take<__bf16>(T * kD);
@@ -579,6 +581,10 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.e_db = c.take<__bf16>(T * kHP);
   s.e_hid = c.take<__bf16>(T * kHP);
   s.e_dy2 = c.take<__bf16>(T * kD);
+  // a second set of the nine arrays for batches whose backward kernel leaves CUs idle: layer l's weight gradients then run on a side
+  // stream beside layer l - 1's backward kernel (backward_layers_t)
+  s.e_set_elems = (c.off - set_off0) / sizeof(__bf16);
+  s.e_set1 = pad4(n) / 4 <= kOverlapTiles ? c.take<__bf16>(s.e_set_elems) : nullptr;
   s.part_floats = part_floats(h);
   s.part = c.take<float>(s.part_floats);
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
@@ -846,7 +852,22 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
   const int tiles = pad4(n) / 4, T = pad4(n) * 16, H = c.hidden_dim;   // the padding tokens carry zero gradients into the operand pairs
   const size_t TD = (size_t)T * kD;
   const size_t bwd_layer_elems = (size_t)BW::NW * kBwdUnitsLayer * 512;
+  // Small batches (round 5): the backward kernel runs one workgroup per tile on its own CU, so at <= 640 cells it leaves a third or more
+  // of the chip idle and layer l's weight-gradient launches can run there: they go to a side stream, the operand pairs alternate
+  // between two sets (a set is rewritten two layers later, behind an event of the launches that read it).  SCLDM_TRAIN_WGRAD_OVERLAP=0
+  // keeps everything on one stream.
+  static const bool overlap_off = [] { const char* e = getenv("SCLDM_TRAIN_WGRAD_OVERLAP"); return e && e[0] == '0'; }();
+  const bool overlap = s.e_set1 != nullptr && !overlap_off && c.n_layer > 1;
+  hipStream_t sw = st;
+  if (overlap) {
+    for (int q = 0; q < 2; ++q)
+      if (!h->wg_ev[q]) HIP_TRY(hipEventCreateWithFlags(&h->wg_ev[q], hipEventDisableTiming));
+  }
+  const ptrdiff_t set_delta = overlap ? s.e_set1 - s.e_h1 : 0;
   for (int l = c.n_layer - 1; l >= 0; --l) {
+    const int set = overlap ? ((c.n_layer - 1 - l) & 1) : 0;
+    const ptrdiff_t sd = set ? set_delta : 0;
+    if (overlap && l < c.n_layer - 2) HIP_TRY(hipStreamWaitEvent(st, h->wg_ev[set], 0));   // this set's previous readers are done
     typename BW::Args a{};
     a.x_in = rec.x + (size_t)l * TD;
     a.y1 = reinterpret_cast<const E16*>(rec.y1) + (size_t)l * TD;
@@ -858,7 +879,7 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     a.mod_off = l * kModBlock;
     a.w_stream = reinterpret_cast<const E16*>(h->bwd_stream) + (size_t)l * bwd_layer_elems;
     a.b_qkv = h->b_qkv + (size_t)l * 768;
-    auto e16 = [](__bf16* p) { return reinterpret_cast<E16*>(p); };   // (16-bit slots; the element type is the step's operand type)
+    auto e16 = [sd](__bf16* p) { return reinterpret_cast<E16*>(p + sd); };   // (16-bit slots; the element type is the step's operand type)
     a.e_h1 = e16(s.e_h1); a.e_dqkv = e16(s.e_dqkv); a.e_ao = e16(s.e_ao); a.e_dy1 = e16(s.e_dy1); a.e_h2 = e16(s.e_h2);
     a.e_da = e16(s.e_da); a.e_db = e16(s.e_db); a.e_hid = e16(s.e_hid); a.e_dy2 = e16(s.e_dy2);
     a.n = n;
@@ -891,12 +912,16 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     WgradArgs wa{};
     ReduceArgs ra{};
     struct Spec { const __bf16* A; int lda; const __bf16* B; int ldb; int M, N; float* dst; float* bias; };
+    if (overlap) {   // the side stream waits for this layer's backward kernel
+      const int rc = fork_side(h, st, 2, &sw);
+      if (rc) return rc;
+    }
     const Spec specs[5] = {
-        {s.e_dqkv, 3 * kD, s.e_h1, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]},
-        {s.e_dy1, kD, s.e_ao, kD, kD, kD, g->proj_w[l], g->proj_b[l]},
-        {s.e_da, kHP, s.e_h2, kD, H, kD, g->w1[l], nullptr},
-        {s.e_db, kHP, s.e_h2, kD, H, kD, g->w2[l], nullptr},
-        {s.e_dy2, kD, s.e_hid, kHP, kD, H, g->cproj[l], nullptr},
+        {s.e_dqkv + sd, 3 * kD, s.e_h1 + sd, kD, 3 * kD, kD, g->attn_w[l], g->attn_b[l]},
+        {s.e_dy1 + sd, kD, s.e_ao + sd, kD, kD, kD, g->proj_w[l], g->proj_b[l]},
+        {s.e_da + sd, kHP, s.e_h2 + sd, kD, H, kD, g->w1[l], nullptr},
+        {s.e_db + sd, kHP, s.e_h2 + sd, kD, H, kD, g->w2[l], nullptr},
+        {s.e_dy2 + sd, kD, s.e_hid + sd, kHP, kD, H, g->cproj[l], nullptr},
     };
     long part_off = 0, first = 0;
     int tile0 = 0, nr = 0;
@@ -928,14 +953,19 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     wa.part = s.part;
     const int splits = cdiv(T, wa.kchunk);
     wa.splits = splits;
-    wgrad_bf16_kernel<BW::kF16><<<tile0 * splits, 256, kWgradLds, st>>>(wa);
+    wgrad_bf16_kernel<BW::kF16><<<tile0 * splits, 256, kWgradLds, sw>>>(wa);
     LAUNCH_CHECK();
     ra.n_jobs = nr;
     ra.splits = splits;
     ra.total = first;
     ra.part = s.part;
-    wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, st>>>(ra);
+    wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, sw>>>(ra);
     LAUNCH_CHECK();
+    if (overlap) HIP_TRY(hipEventRecord(h->wg_ev[set], sw));
+  }
+  if (overlap) {   // every weight gradient is final before the caller's tails / gradient events
+    const int rc = join_side(h, st, 2);
+    if (rc) return rc;
   }
   return SCLDM_OK;
 }

@@ -26,7 +26,10 @@ struct Scratch {
   float* handoff;   // [T*256]
   float* dx;        // [T*256] tile layout
   int32_t* ridx;    // [n]
-  __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;
+  __bf16 *e_h1, *e_dqkv, *e_ao, *e_dy1, *e_h2, *e_da, *e_db, *e_hid, *e_dy2;   // operand-pair set 0
+  __bf16* e_set1;   // second set of the nine arrays (same order and sizes, contiguous), or nullptr: lets layer l's weight gradients run on a
+                    // side stream beside layer l-1's backward kernel when that kernel leaves CUs idle (<= 128 tiles, i.e. <= 512 cells)
+  size_t e_set_elems;   // elements from e_h1 to the end of e_dy2 (= offset of an array in set 1 relative to set 0's, from e_set1 - e_h1)
   float* part;      // split-K partials of one layer's five weight gradients + two bias gradients
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
