@@ -258,6 +258,70 @@ def test_native_adamw_matches_torch_fused_adamw_and_shares_its_state_dict():
         assert torch.allclose(x, y, rtol=3e-6, atol=1e-7), (i, float((x - y).abs().max()))     # (an update is ~3e-3: 1e-7 is 3e-5 of it)
 
 
+def test_fused_training_switches_do_not_change_the_bits(tmp_path):
+    """Round 5's scheduling switches of the fused training step only move launches between streams: the weight gradients of layer l
+    beside the backward kernel of layer l - 1 (two operand-pair sets; on for <= 640 cells), the backward's tails beside each other.
+    Each variant in its own process (the switches are read once per process), base shape, 130 cells x 8 layers, bf16: every gradient
+    bit for bit what the single-stream order gives."""
+    import os, subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gemm_route_child.py")
+    res = {}
+    for name, env in (("default", {}), ("serial", {"SCLDM_TRAIN_WGRAD_OVERLAP": "0", "SCLDM_TRAIN_TAILS_SERIAL": "1"})):
+        out = str(tmp_path / f"{name}.pt")
+        e = {k: v for k, v in os.environ.items() if not k.startswith("SCLDM_TRAIN_")}
+        e.update(env)
+        r = subprocess.run([sys.executable, child, out, "256", "8", "8", "130", "2"], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = torch.load(out)
+    assert set(res["default"]) == set(res["serial"]) and len(res["default"]) > 80
+    for k, v in res["default"].items():
+        assert torch.equal(v, res["serial"][k]), k
+
+
+def test_graphed_train_step_replays_the_eager_step():
+    """scldm_amd.training.GraphedTrainStep: the whole optimisation step captured once in a HIP graph.  With (t, x0) injected through
+    static tensors the graph's replays must produce exactly the parameters the eager step produces from the same start (same kernels,
+    same order within every stream), on a new batch copied into the graph's static inputs, and keep training (loss falls)."""
+    import copy
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import GraphedTrainStep, train_step
+    from scldm_amd.transport import create_transport
+    vocab = {"cell_line": 4, "gene": 2024}
+    m1, sd, cfg = build(vocab, "joint", 8, 91)
+    m1.precision = "bf16"
+    m2 = copy.deepcopy(m1)
+    n = 96
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    t_s, x0_s = torch.rand(n, device="cuda", generator=gen), torch.randn(n, 16, 16, device="cuda", generator=gen)
+    batches = [(torch.randn(n, 16, 16, device="cuda", generator=gen),
+                {"cell_line": torch.randint(0, 4, (n,), device="cuda", generator=gen), "gene": torch.randint(0, 2024, (n,), device="cuda", generator=gen)})
+               for _ in range(3)]
+    def tr():
+        t = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+        t.sample = lambda x1: (t_s, x0_s, x1)
+        return t
+    o1, o2 = AdamW(m1.parameters(), lr=1e-3), AdamW(m2.parameters(), lr=1e-3)
+    g = GraphedTrainStep(m2, tr(), o2, *batches[0], warmup=2)          # (its warm-up steps train m2 on batch 0: do the same eagerly)
+    tr1 = tr()
+    for _ in range(2):
+        train_step(m1, tr1, o1, *batches[0])
+    for k, (p, q) in enumerate(zip(m1.parameters(), m2.parameters())):
+        assert torch.equal(p, q), k                                      # same state after the warm-up steps
+    losses = []
+    for x1, cond in batches + batches:
+        l1 = train_step(m1, tr1, o1, x1, cond)
+        l2 = g(x1, cond).clone()
+        losses.append(float(l2))
+        assert torch.equal(l1, l2)
+    for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), k
+    assert g.replays == 6 and losses[3] < losses[0]
+    with pytest.raises(ValueError):
+        g(batches[0][0][:8], batches[0][1])
+    with pytest.raises(ValueError, match="capturable"):
+        GraphedTrainStep(m1, tr1, torch.optim.AdamW(m1.parameters(), lr=1e-3, fused=True), *batches[0])
+
+
 def _bf16_step_vs_oracle(n, n_layer=8, seed=81, fused=None, monkeypatch=None):
     vocab = {"cell_line": 4, "gene": 2024}
     if fused is not None:
