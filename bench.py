@@ -297,6 +297,9 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world, optimize
     batch of synthetic latents (standing in for frozen-VAE output).  Returns seconds for `steps` steps (max over ranks)."""
     from scldm_amd.training import train_step
     from scldm_amd.transport import create_transport
+    import gc
+    gc.collect()              # a previous record's model must not be finalised (hipFree = device-wide synchronisations) inside this timed loop
+    torch.cuda.synchronize()
     m = make_model(wl, precision, device).train()
     opt = make_optimizer(m.parameters(), 1e-4, optimizer)
     tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
@@ -304,12 +307,18 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world, optimize
     x1 = torch.randn(wl["B"], 16, 16, generator=g).to(device)
     cond = {k: torch.randint(0, v, (wl["B"],), generator=g).to(device) for k, v in wl["vocab"].items()}
     step = lambda: train_step(m, tr, opt, x1, cond)
+    time_training.graphed = False
     if graphed and not dist_on:
         # the product's whole-step HIP graph (scldm_amd.training.GraphedTrainStep): forward, backward and optimizer captured once,
         # one graph launch per mini-batch (the batch is copied into the graph's static inputs every step, as a data loader's would be)
-        from scldm_amd.training import GraphedTrainStep
-        gstep = GraphedTrainStep(m, tr, opt, x1, cond)
-        step = lambda: gstep(x1, cond)
+        try:
+            from scldm_amd.training import GraphedTrainStep
+            gstep = GraphedTrainStep(m, tr, opt, x1, cond)
+            step = lambda: gstep(x1, cond)
+            time_training.graphed = True
+        except Exception as e:   # a capture failure must not take the bench line down: the eager step is timed instead, and said so
+            note(f"GraphedTrainStep failed ({e!r}): timing the eager train_step")
+            torch.cuda.synchronize()
     for _ in range(warmup):
         step()
     if dist_on:
@@ -1022,7 +1031,8 @@ def main():
             dtt /= 2
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
-                                       "launch": "GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph",
+                                       "launch": ("GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph"
+                                                  if time_training.graphed else "eager train_step (graph capture failed: see stderr)"),
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
                                                 "per layer (DESIGN 4.5)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.6)"}
             if tprec == "bf16":
