@@ -232,6 +232,7 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
       HIP_TRY(hipFuncSetAttribute((const void*)wide::enc_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::PB_BYTES));
       HIP_TRY(hipFuncSetAttribute((const void*)wide::dec_gene_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::G_BYTES));
       HIP_TRY(hipFuncSetAttribute((const void*)wide::dec_gene_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::M_BYTES));
+      HIP_TRY(hipFuncSetAttribute((const void*)wide::dec_gene_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wide::M_BYTES));
       if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
   }
@@ -282,8 +283,10 @@ extern "C" int scldm_vae_train_backward(scldm_vae* h, const scldm_vae_weights* w
   ga.ln2_w = w->dec_cross.ln2_w; ga.ln2_b = w->dec_cross.ln2_b; ga.head_w = w->head_w;
   ga.mlp = mlp_of(w->dec_cross.w1, w->dec_cross.w2, wct(1), H);
   ga.g_emb = g_emb; ga.part = k.p_gene; ga.dkv_part = k.p_dkv; ga.G = G; ga.tiles = k.tilesD; ga.eps = eps;
-  static const bool gene_mfma = [] { const char* e = getenv("SCLDM_VAE_GENE_MFMA"); return !(e && e[0] == '0'); }();   // 0: the VALU form
-  if (gene_wide() && gene_mfma) wide::dec_gene_bwd_mfma_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::M_BYTES, st>>>(ga);
+  // 2 (default): every contraction of the per-gene chain on the matrix pipe; 1: the MLP and the weight gradients only; 0: the VALU form
+  static const int gene_mfma = [] { const char* e = getenv("SCLDM_VAE_GENE_MFMA"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2; }();
+  if (gene_wide() && gene_mfma == 2) wide::dec_gene_bwd_mfma2_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::M_BYTES, st>>>(ga);
+  else if (gene_wide() && gene_mfma) wide::dec_gene_bwd_mfma_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::M_BYTES, st>>>(ga);
   else if (gene_wide()) wide::dec_gene_bwd_kernel<<<dim3(k.chunksD, B), wide::kThreads, wide::G_BYTES, st>>>(ga);
   else dec_gene_bwd_kernel<<<dim3(k.chunksD, B), 64, 0, st>>>(ga);
   LAUNCH_CHECK();

@@ -1472,6 +1472,394 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
   for (int idx = tid; idx < 32 * kHP; idx += kThreads) P[DP_WC + idx] = a.head_w[idx / kHP] * C[idx % kHP];
 }
 
+
+// =================================================================================================================================
+// Third generation (round 5): the four 32 x 32 Linears of the per-gene chain - q = Wq LN_1q(e), y = Wp ao, d ao = Wp^T d y,
+// d qn = Wq^T d q - on the matrix pipe as well.  In the kernel above every gene's 16 lanes re-read the whole 32 x 36 weight image
+// for each of them (16 KB of LDS reads per gene: a third of the kernel's LDS cycles, and four dependent chains of 24 16-byte reads
+// per step); here one step's 16 genes are the 16 rows of 16 x 16 x 4 MFMAs: a wave owns (output half, k half) of a product - 4 MFMAs -
+// writes its partial tile to a row set that is free at that point of the step, and the per-gene phase that follows adds the two
+// partials.  Operand reads are LDS-bank aware (ds_read_b32 banks are address mod 32 within 32 lanes, b64 / b128 mod 64):
+//   k along the contiguous axis of BOTH images (q, y, a | b):  lane (li, g4) reads the PAIR of k values 8 p + 2 g4, + 1 as one
+//     ds_read_b64 - row pitch 36 = 4 mod 32 walks 16 rows over 16 distinct 4-bank groups, g4 fills the odd pairs: conflict-free, and
+//     half the LDS instructions of the scalar reads (which were 2-way conflicts: rows li and li + 8 share a bank)
+//   k along the rows of the weight image (d h2, d ao, d qn):  k slot (s, g4) <-> row 16 (s >> 2) + 4 g4 + (s & 3): the B reads of a
+//     32-lane group hit rows 4 apart = 16 banks apart (conflict-free, as before); the A operand's four values of a lane are then
+//     CONSECUTIVE - one ds_read_b128 instead of four 4-way conflicting scalar reads
+// Per step: S0 embeddings, LN_1q | S1 q partials | S2 attention | S3 y partials | S4 LN_2 | A | B | S5 LN_2 backward | S6 d ao
+// partials | S7 attention backward | S8 d qn (two waves, whole k: no free row set is left for a second partial) + C weight gradients |
+// S9 LN_1q backward, dE atomics - separated by workgroup barriers (two workgroups per CU fill each other's waits).
+// =================================================================================================================================
+#ifndef SCLDM_VAE_PHASE_CLOCKS
+#define SCLDM_VAE_PHASE_CLOCKS 0   // 1: one workgroup prints its cycles per phase of dec_gene_bwd_mfma2_kernel (tools only)
+#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// (volatile: keeps hipcc from pairing two of these into one ds_read2_b64, which is serviced 16 lanes at a time with banks mod 32 -
+// 8 LDS cycles and two-way conflicts on this pitch, against 2 + 2 conflict-free)
+// (the LDS address space is spelled out: a volatile access through a generic pointer becomes a flat load)
+typedef const volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
+__device__ __forceinline__ lds_f32x2* v2(const float* p) { return (lds_f32x2*)p; }
+
+__global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const DecBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float S[];
+  const int tid = threadIdx.x, tok = tid >> 4, j = tid & 15, chunk = blockIdx.x, cell = blockIdx.y, nch = gridDim.x;
+  const int wave = tid >> 6, li = tid & 15, g4 = (tid & 63) >> 4;      // MFMA roles: lane = (li, g4)
+  constexpr float kScale = 0.35355339059327373f;   // 1 / sqrt(8)
+  const int H = a.mlp.H;
+  {
+    RowCopy<32> cq, cp;
+    RowCopy<96> c1, c2;
+    cq.load(a.wq, 32, tid); cp.load(a.wp, 32, tid); c1.load(a.mlp.w1, H, tid); c2.load(a.mlp.w2, H, tid);
+    cq.store(S + G_WQ, tid); cp.store(S + G_WP, tid); c1.store(S + G_W1, tid); c2.store(S + G_W2, tid);
+    for (int idx = tid; idx < kT * 64; idx += kThreads) S[G_KV + (idx >> 6) * kP64 + (idx & 63)] = a.kv[(size_t)cell * (kT * 64) + idx];
+    if (tid < 96) {      // c0[u] = sum_i Wc[i][u] w_head[i]
+      float s = 0.f;
+      if (tid < H)
+        for (int i = 0; i < 32; ++i) s = fmaf(a.mlp.wct[tid * 32 + i], a.head_w[i], s);
+      S[M_C0 + tid] = s;
+    }
+  }
+  const float l1w0 = a.ln1q_w[j], l1w1 = a.ln1q_w[j + 16], l1b0 = a.ln1q_b[j], l1b1 = a.ln1q_b[j + 16];
+  const float l2w0 = a.ln2_w[j], l2w1 = a.ln2_w[j + 16], l2b0 = a.ln2_b[j], l2b1 = a.ln2_b[j + 16];
+  const float hw0 = a.head_w[j], hw1 = a.head_w[j + 16];
+  __syncthreads();
+  f32x4 gw1[3] = {z4(), z4(), z4()}, gw2[3] = {z4(), z4(), z4()}, gq = z4(), gp = z4(), gk = z4(), gv = z4();
+  float cacc[2] = {0.f, 0.f};   // c[u] partials of this lane's gene quad, hidden-unit tiles wave, wave + 4
+  float vs[10];                 // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each)
+#pragma unroll
+  for (int i = 0; i < 10; ++i) vs[i] = 0.f;
+  const int h = j >> 2, jq = j & 3;
+  const int half = wave & 1, kh = wave >> 1;     // the small products' roles: (output half, k half)
+  // x W^T with k along both images' rows: partial over input features 16 kh .. + 15 of output half `half`, D[gene 4 g4 + r][16 half + li]
+  auto lin_partial = [&](int x_rows, int w_rows, int dst_rows) {
+    const float* X = S + x_rows + li * kP + 16 * kh + 2 * g4;
+    const float* W = S + w_rows + (16 * half + li) * kP + 16 * kh + 2 * g4;
+    const f32x2 x0 = *v2(X), x1 = *v2(X + 8), w0 = *v2(W), w1 = *v2(W + 8);
+    f32x4 acc = z4();
+    acc = mfma16(x0[0], w0[0], acc);
+    acc = mfma16(x0[1], w0[1], acc);
+    acc = mfma16(x1[0], w1[0], acc);
+    acc = mfma16(x1[1], w1[1], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[dst_rows + (4 * g4 + r) * kP + 16 * half + li] = acc[r];
+  };
+  // dy W with k along the weight image's rows: partial over output rows 16 kq .. + 15, D[gene 4 g4 + r][input 16 it + li]
+  auto lin_t_partial = [&](int dy_rows, int w_rows, int it, int kq, f32x4& acc) {
+    const f32x4 d = *v4(S + dy_rows + li * kP + 16 * kq + 4 * g4);
+    const float* W = S + w_rows + (16 * kq + 4 * g4) * kP + 16 * it + li;
+    acc = mfma16(d[0], W[0], acc);
+    acc = mfma16(d[1], W[kP], acc);
+    acc = mfma16(d[2], W[2 * kP], acc);
+    acc = mfma16(d[3], W[3 * kP], acc);
+  };
+  const int begin = chunk * a.tiles * 64, end = min(a.G, begin + a.tiles * 64);
+#if SCLDM_VAE_PHASE_CLOCKS
+  long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last = __builtin_readcyclecounter();
+#define PHASE_MARK(i) { const long long t_ = __builtin_readcyclecounter(); clk[i] += t_ - last; last = t_; }
+#else
+#define PHASE_MARK(i)
+#endif
+  // this step's gene id, d logit and embedding row were requested one step earlier (the id two steps earlier): S0 no longer waits
+  // for two dependent global loads
+  auto slot = [&](int g0) { return (size_t)cell * a.G + min(g0 + tok, end - 1); };
+  long long gene_nx = a.genes[slot(begin)], gene_n2 = a.genes[slot(begin + 16)];
+  float dl_nx = begin + tok < end ? a.dl[slot(begin)] : 0.f;
+  float e0_nx = a.emb[(size_t)gene_nx * 32 + j], e1_nx = a.emb[(size_t)gene_nx * 32 + j + 16];
+  for (int g0 = begin; g0 < end; g0 += 16) {
+    // ---- S0: embeddings, LN_1q
+    const bool valid = g0 + tok < end;
+    const long long gene = gene_nx;
+    const float dlog = dl_nx, q00 = e0_nx, q01 = e1_nx;
+    gene_nx = gene_n2;
+    e0_nx = a.emb[(size_t)gene_nx * 32 + j];
+    e1_nx = a.emb[(size_t)gene_nx * 32 + j + 16];
+    dl_nx = g0 + 16 + tok < end ? a.dl[slot(g0 + 16)] : 0.f;
+    gene_n2 = a.genes[slot(g0 + 32)];
+    if (j == 0) S[M_DL + tok] = dlog;
+    const Ln n1 = ln_own(q00, q01, a.eps);
+    S[G_QN + tok * kP + j] = fmaf(n1.h0, l1w0, l1b0);
+    S[G_QN + tok * kP + j + 16] = fmaf(n1.h1, l1w1, l1b1);
+    __syncthreads();
+    PHASE_MARK(0);
+    // ---- S1: q partials -> QQ (k half 0), TX (k half 1)
+    lin_partial(G_QN, G_WQ, kh ? G_TX : G_QQ);
+    __syncthreads();
+    PHASE_MARK(1);
+    // ---- S2: attention of the gene over the cell's 16 latent tokens
+    float p[4];
+    {
+      const f32x4 qa = *v4(S + G_QQ + tok * kP + 8 * h) + *v4(S + G_TX + tok * kP + 8 * h);
+      const f32x4 qb = *v4(S + G_QQ + tok * kP + 8 * h + 4) + *v4(S + G_TX + tok * kP + 8 * h + 4);
+      const float qj0 = S[G_QQ + tok * kP + j] + S[G_TX + tok * kP + j], qj1 = S[G_QQ + tok * kP + j + 16] + S[G_TX + tok * kP + j + 16];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        p[kk] = (dot4(qa, *v4(K)) + dot4(qb, *v4(K + 4))) * kScale;
+        mx = fmaxf(mx, p[kk]);
+      }
+      mx = quad_max(mx);
+      float l = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
+      const float inv = 1.0f / quad_sum(l);
+      f32x4 aa = z4(), ab = z4();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        p[kk] *= inv;
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        aa = fma4(p[kk], *v4(V), aa);
+        ab = fma4(p[kk], *v4(V + 4), ab);
+      }
+      aa = quad_sum4(aa);
+      ab = quad_sum4(ab);
+      if (jq < 2) *v4(S + G_AO + tok * kP + 8 * h + 4 * jq) = jq == 0 ? aa : ab;
+      *v4(S + G_PP + tok * kP64 + h * 16 + 4 * jq) = f32x4{p[0], p[1], p[2], p[3]};
+      tsync();     // (the gene's other lanes have read the partial QQ row)
+      S[G_QQ + tok * kP + j] = qj0;            // the whole q: dK's operand in phase C
+      S[G_QQ + tok * kP + j + 16] = qj1;
+    }
+    __syncthreads();
+    PHASE_MARK(2);
+    // ---- S3: c_proj partials -> DY (k half 0), DAO (k half 1)
+    lin_partial(G_AO, G_WP, kh ? G_DAO : G_DY);
+    __syncthreads();
+    PHASE_MARK(3);
+    // ---- S4: residual, LN_2
+    const float y0 = q00 + (S[G_DY + tok * kP + j] + S[G_DAO + tok * kP + j]);
+    const float y1 = q01 + (S[G_DY + tok * kP + j + 16] + S[G_DAO + tok * kP + j + 16]);
+    const Ln n2 = ln_own(y0, y1, a.eps);
+    S[G_H2 + tok * kP + j] = fmaf(n2.h0, l2w0, l2b0);
+    S[G_H2 + tok * kP + j + 16] = fmaf(n2.h1, l2w1, l2b1);
+    __syncthreads();
+    PHASE_MARK(4);
+    // ---- phase A: a | b tiles D[gene 4 g4 + r][unit 16 ot + li], SwiGLU gradient in place
+    {
+      f32x2 hk[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) hk[s] = *v2(S + G_H2 + li * kP + 8 * s + 2 * g4);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ot = wave + 4 * q;
+        if (ot < 6) {
+          f32x4 aa = z4(), bb = z4();
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const f32x2 wa = *v2(S + G_W1 + (16 * ot + li) * kP + 8 * s + 2 * g4), wb = *v2(S + G_W2 + (16 * ot + li) * kP + 8 * s + 2 * g4);
+            aa = mfma16(hk[s][0], wa[0], aa);
+            bb = mfma16(hk[s][0], wb[0], bb);
+            aa = mfma16(hk[s][1], wa[1], aa);
+            bb = mfma16(hk[s][1], wb[1], bb);
+          }
+          const float c0u = S[M_C0 + 16 * ot + li];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tk = 4 * g4 + r;
+            const float dl = S[M_DL + tk], sg = sigm(aa[r]), sa = aa[r] * sg, dh = dl * c0u;
+            cacc[q] = fmaf(dl, sa * bb[r], cacc[q]);
+            S[G_DA + tk * kQ + 16 * ot + li] = dh * bb[r] * (sg * (1.0f + aa[r] * (1.0f - sg)));
+            S[G_DB + tk * kQ + 16 * ot + li] = dh * sa;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    PHASE_MARK(5);
+    // ---- phase B: d h2 partials, wave = (feature half, matrix); W1's go to the TX rows, W2's to the DQQ rows (free until S7)
+    {
+      const float* Wm = S + (kh ? G_W2 : G_W1);
+      const float* Dm = S + (kh ? G_DB : G_DA);
+      f32x4 acc = z4(), acc2 = z4();
+#pragma unroll
+      for (int sq = 0; sq < 6; ++sq) {
+        const f32x4 d = *v4(Dm + li * kQ + 16 * sq + 4 * g4);
+        const float* W = Wm + (16 * sq + 4 * g4) * kP + 16 * half + li;
+        acc = mfma16(d[0], W[0], acc);
+        acc2 = mfma16(d[1], W[kP], acc2);
+        acc = mfma16(d[2], W[2 * kP], acc);
+        acc2 = mfma16(d[3], W[3 * kP], acc2);
+      }
+      acc += acc2;
+      float* Pt = S + (kh ? G_DQQ : G_TX);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[(4 * g4 + r) * kP + 16 * half + li] = acc[r];
+    }
+    __syncthreads();
+    PHASE_MARK(6);
+    // ---- S5: LN_2 backward -> d y
+    float d0, d1;
+    {
+      const float t0 = S[G_TX + tok * kP + j] + S[G_DQQ + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16] + S[G_DQQ + tok * kP + j + 16];
+      vs[4] = fmaf(t0, n2.h0, vs[4]); vs[5] = fmaf(t1, n2.h1, vs[5]); vs[6] += t0; vs[7] += t1;
+      vs[8] = fmaf(dlog, y0, vs[8]); vs[9] = fmaf(dlog, y1, vs[9]);
+      ln_back(n2, t0 * l2w0, t1 * l2w1, d0, d1);
+      d0 = fmaf(dlog, hw0, d0);
+      d1 = fmaf(dlog, hw1, d1);
+    }
+    S[G_DY + tok * kP + j] = d0;
+    S[G_DY + tok * kP + j + 16] = d1;
+    __syncthreads();
+    PHASE_MARK(7);
+    // ---- S6: d ao partials -> DAO (k half 0), TX (k half 1)
+    {
+      f32x4 acc = z4();
+      lin_t_partial(G_DY, G_WP, half, kh, acc);
+      float* Pt = S + (kh ? G_TX : G_DAO);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[(4 * g4 + r) * kP + 16 * half + li] = acc[r];
+    }
+    __syncthreads();
+    PHASE_MARK(8);
+    // ---- S7: attention backward -> d q, d scores; the whole d ao row for phase C
+    {
+      const f32x4 da = *v4(S + G_DAO + tok * kP + 8 * h) + *v4(S + G_TX + tok * kP + 8 * h);
+      const f32x4 db = *v4(S + G_DAO + tok * kP + 8 * h + 4) + *v4(S + G_TX + tok * kP + 8 * h + 4);
+      const float aj0 = S[G_DAO + tok * kP + j] + S[G_TX + tok * kP + j], aj1 = S[G_DAO + tok * kP + j + 16] + S[G_TX + tok * kP + j + 16];
+      float dp[4], dg = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
+        dp[kk] = dot4(da, *v4(V)) + dot4(db, *v4(V + 4));
+        dg = fmaf(p[kk], dp[kk], dg);
+      }
+      dg = quad_sum(dg);
+      f32x4 qa = z4(), qb = z4(), dsv;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float ds = p[kk] * (dp[kk] - dg) * kScale;
+        dsv[kk] = ds;
+        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
+        qa = fma4(ds, *v4(K), qa);
+        qb = fma4(ds, *v4(K + 4), qb);
+      }
+      qa = quad_sum4(qa);
+      qb = quad_sum4(qb);
+      if (jq < 2) *v4(S + G_DQQ + tok * kP + 8 * h + 4 * jq) = jq == 0 ? qa : qb;
+      *v4(S + G_DS + tok * kP64 + h * 16 + 4 * jq) = dsv;
+      tsync();     // (the gene's other lanes have read the partial DAO row)
+      S[G_DAO + tok * kP + j] = aj0;
+      S[G_DAO + tok * kP + j + 16] = aj1;
+    }
+    __syncthreads();
+    PHASE_MARK(9);
+    // ---- S8: d qn = Wq^T d q (waves 0, 1: one input half each, all 32 rows) -> TX; then phase C on every wave
+    if (wave < 2) {
+      f32x4 acc = z4(), acc2 = z4();
+      lin_t_partial(G_DQQ, G_WQ, wave, 0, acc);
+      lin_t_partial(G_DQQ, G_WQ, wave, 1, acc2);
+      acc += acc2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[G_TX + (4 * g4 + r) * kP + 16 * wave + li] = acc[r];
+    }
+    // ---- phase C: weight gradients, D[out 16 ot + 4 g4 + r][in 16 it + li] += sum_genes dy[gene][out] x[gene][in]
+    // (d W1 | d W2 could run in phase B already - measured: B + 1 270 cycles, C - 890: the matrix pipe is shared with the CU's other workgroup)
+    {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int idx = wave + 4 * n, ot = idx >> 1, it = idx & 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int tk = s + 4 * g4;       // (k slot <-> gene: rows 4 apart = 16 banks apart within a 32-lane group: conflict-free)
+          const float x = S[G_H2 + tk * kP + 16 * it + li];
+          gw1[n] = mfma16(S[G_DA + tk * kQ + 16 * ot + li], x, gw1[n]);
+          gw2[n] = mfma16(S[G_DB + tk * kQ + 16 * ot + li], x, gw2[n]);
+        }
+      }
+      const int ot = wave >> 1, it = wave & 1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int tk = s + 4 * g4;
+        gq = mfma16(S[G_DQQ + tk * kP + 16 * ot + li], S[G_QN + tk * kP + 16 * it + li], gq);
+        gp = mfma16(S[G_DY + tk * kP + 16 * ot + li], S[G_AO + tk * kP + 16 * it + li], gp);
+        // head `wave` of the cell's keys: D[key 4 g4 + r][column 16 (wave >> 1) + li], useful where (li >> 3) == (wave & 1)
+        gk = mfma16(S[G_DS + tk * kP64 + wave * 16 + li], S[G_QQ + tk * kP + 16 * (wave >> 1) + li], gk);
+        gv = mfma16(S[G_PP + tk * kP64 + wave * 16 + li], S[G_DAO + tk * kP + 16 * (wave >> 1) + li], gv);
+      }
+    }
+    __syncthreads();
+    PHASE_MARK(10);
+    // ---- S9: LN_1q backward, dE[gene] (runs into the next step's S0: neither touches a row the other does)
+    {
+      const float t0 = S[G_TX + tok * kP + j], t1 = S[G_TX + tok * kP + j + 16];
+      vs[0] = fmaf(t0, n1.h0, vs[0]); vs[1] = fmaf(t1, n1.h1, vs[1]); vs[2] += t0; vs[3] += t1;
+      float o0, o1;
+      ln_back(n1, t0 * l1w0, t1 * l1w1, o0, o1);
+      if (valid && dlog != 0.f) {
+        float* ge = a.g_emb + (size_t)gene * 32;
+        atomicAdd(ge + j, d0 + o0);
+        atomicAdd(ge + j + 16, d1 + o1);
+      }
+    }
+    PHASE_MARK(11);
+  }
+#if SCLDM_VAE_PHASE_CLOCKS
+  if (blockIdx.x == 0 && blockIdx.y == 3 && tid == 0)
+    printf("phase clocks (S0 S1 S2 S3 S4 A B S5 S6 S7 S8+C S9): %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld steps %d\n", clk[0], clk[1], clk[2],
+           clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], clk[11], (end - begin + 15) / 16);
+#endif
+#undef PHASE_MARK
+  __syncthreads();
+  // ---- one partial per workgroup (as dec_gene_bwd_mfma_kernel)
+  float* P = a.part + (size_t)(cell * nch + chunk) * DP_SIZE;
+  {
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int idx = wave + 4 * n, ot = idx >> 1, it = idx & 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[DP_W1 + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gw1[n][r];
+        P[DP_W2 + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gw2[n][r];
+      }
+    }
+    const int ot = wave >> 1, it = wave & 1;
+    float* DK = a.dkv_part + (size_t)(cell * nch + chunk) * (kT * 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      P[DP_WQ + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gq[r];
+      P[DP_WP + (16 * ot + 4 * g4 + r) * 32 + 16 * it + li] = gp[r];
+      if ((li >> 3) == (wave & 1)) {
+        DK[(4 * g4 + r) * 64 + 16 * (wave >> 1) + li] = gk[r];
+        DK[(4 * g4 + r) * 64 + 32 + 16 * (wave >> 1) + li] = gv[r];
+      }
+    }
+  }
+  float* R = S;
+  float* RC = S + 16 * 10 * 16;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) R[(tok * 10 + i) * 16 + j] = vs[i];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+    if (wave + 4 * q < 6) RC[g4 * 96 + 16 * (wave + 4 * q) + li] = cacc[q];
+  __syncthreads();
+  float sum = 0.f;
+  const int vi = tid >> 4;
+  if (vi < 10) {
+#pragma unroll
+    for (int t = 0; t < kT; ++t) sum += R[(t * 10 + vi) * 16 + j];
+  }
+  float cu = 0.f;
+  if (tid < 96) cu = (RC[tid] + RC[96 + tid]) + (RC[192 + tid] + RC[288 + tid]);
+  __syncthreads();
+  float* C = S;            // c[u]
+  float* HD = S + 128;     // sum dlogit * y
+  if (tid < 96) C[tid] = cu;
+  if (vi < 10) {
+    const int f = j + 16 * (vi & 1);
+    if (vi < 2) P[DP_LN1QW + f] = sum;
+    else if (vi < 4) P[DP_LN1QB + f] = sum;
+    else if (vi < 6) P[DP_LN2W + f] = sum;
+    else if (vi < 8) P[DP_LN2B + f] = sum;
+    else HD[f] = sum;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float s2 = HD[tid];
+    for (int u = 0; u < H; ++u) s2 = fmaf(a.mlp.wct[u * 32 + tid], C[u], s2);
+    P[DP_HEADW + tid] = s2;
+  }
+  for (int idx = tid; idx < 32 * kHP; idx += kThreads) P[DP_WC + idx] = a.head_w[idx / kHP] * C[idx % kHP];
+}
+
 }  // namespace wide
 }  // namespace vtrain
 }  // namespace scldm

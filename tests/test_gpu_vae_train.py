@@ -186,11 +186,11 @@ def test_eval_and_no_grad_forward_stay_on_the_inference_path():
     assert not p2["mu"].requires_grad
 
 
-@pytest.mark.parametrize("env", [{"SCLDM_VAE_GENE_MFMA": "0"}, {"SCLDM_VAE_CELL_WIDE": "0", "SCLDM_VAE_GENE_WIDE": "0"}],
-                         ids=["per-gene backward on the VALU", "first-version kernels"])
+@pytest.mark.parametrize("env", [{"SCLDM_VAE_GENE_MFMA": "1"}, {"SCLDM_VAE_GENE_MFMA": "0"}, {"SCLDM_VAE_CELL_WIDE": "0", "SCLDM_VAE_GENE_WIDE": "0"}],
+                         ids=["per-gene backward with only the MLP on the matrix pipe", "per-gene backward on the VALU", "first-version kernels"])
 def test_the_selectable_earlier_kernel_versions_pass_the_same_gates(env):
-    """The backward kernels exist in up to three generations (vae_train.hpp: one token per lane; vae_train_wide.hpp: 16 lanes per
-    token, with the per-gene contractions on the VALU or on fp32 MFMA tiles).  The library reads the selecting environment once per
+    """The backward kernels exist in up to four generations (vae_train.hpp: one token per lane; vae_train_wide.hpp: 16 lanes per
+    token, with the per-gene contractions on the VALU, the MLP's on fp32 MFMA tiles, or - the default - all of them).  The library reads the selecting environment once per
     process, so the earlier generations run the digest and ragged-size gates in a child process - they stay honest A/B baselines."""
     import os, subprocess, sys
     cmd = [sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k", "digests or ragged", "-p", "no:cacheprovider"]
