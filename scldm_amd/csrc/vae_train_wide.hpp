@@ -1562,10 +1562,24 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
   // this step's gene id, d logit and embedding row were requested one step earlier (the id two steps earlier): S0 no longer waits
   // for two dependent global loads
   auto slot = [&](int g0) { return (size_t)cell * a.G + min(g0 + tok, end - 1); };
-  long long gene_nx = a.genes[slot(begin)], gene_n2 = a.genes[slot(begin + 16)];
-  float dl_nx = begin + tok < end ? a.dl[slot(begin)] : 0.f;
-  float e0_nx = a.emb[(size_t)gene_nx * 32 + j], e1_nx = a.emb[(size_t)gene_nx * 32 + j + 16];
-  for (int g0 = begin; g0 < end; g0 += 16) {
+  // The cells of a batch list their genes in the same order, so workgroups of different cells reach the same genes' dE rows at the
+  // same time and their atomics serialise in the L2.  Each cell therefore starts its walk over the chunk's steps at its own offset
+  // (measured: the step's first phase 2 000 -> 1 650 cycles; without any atomics 1 250, 13.5 -> 13.2 ms per batch-512 step).
+  const int nsteps = (end - begin + 15) / 16;
+  const int rot = nsteps > 0 ? (int)(((unsigned)cell * 37u) % (unsigned)nsteps) : 0;
+  auto first_gene = [&](int step) { return begin + 16 * ((step + rot) % nsteps); };
+  long long gene_nx = 0, gene_n2 = 0;
+  float dl_nx = 0.f, e0_nx = 0.f, e1_nx = 0.f;
+  if (nsteps > 0) {
+    const int ga = first_gene(0);
+    gene_nx = a.genes[slot(ga)];
+    gene_n2 = a.genes[slot(first_gene(1))];
+    dl_nx = ga + tok < end ? a.dl[slot(ga)] : 0.f;
+    e0_nx = a.emb[(size_t)gene_nx * 32 + j];
+    e1_nx = a.emb[(size_t)gene_nx * 32 + j + 16];
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    const int g0 = first_gene(step), g1 = first_gene(step + 1);
     // ---- S0: embeddings, LN_1q
     const bool valid = g0 + tok < end;
     const long long gene = gene_nx;
@@ -1573,8 +1587,8 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
     gene_nx = gene_n2;
     e0_nx = a.emb[(size_t)gene_nx * 32 + j];
     e1_nx = a.emb[(size_t)gene_nx * 32 + j + 16];
-    dl_nx = g0 + 16 + tok < end ? a.dl[slot(g0 + 16)] : 0.f;
-    gene_n2 = a.genes[slot(g0 + 32)];
+    dl_nx = g1 + tok < end ? a.dl[slot(g1)] : 0.f;
+    gene_n2 = a.genes[slot(first_gene(step + 2))];
     if (j == 0) S[M_DL + tok] = dlog;
     const Ln n1 = ln_own(q00, q01, a.eps);
     S[G_QN + tok * kP + j] = fmaf(n1.h0, l1w0, l1b0);
@@ -1795,7 +1809,7 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
 #if SCLDM_VAE_PHASE_CLOCKS
   if (blockIdx.x == 0 && blockIdx.y == 3 && tid == 0)
     printf("phase clocks (S0 S1 S2 S3 S4 A B S5 S6 S7 S8+C S9): %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld steps %d\n", clk[0], clk[1], clk[2],
-           clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], clk[11], (end - begin + 15) / 16);
+           clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], clk[11], nsteps);
 #endif
 #undef PHASE_MARK
   __syncthreads();
