@@ -38,7 +38,9 @@ constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
 constexpr int PF = SCLDM_BWD_PF;
 // Cache policy of the streaming traffic (A/B switches, round 5): the operand-pair stores (written once here, read once by the
 // weight-gradient GEMM) and the record loads (read once per phase) pass through the XCD's 4 MB L2 next to the 2.8 MB backward weight
-// stream that every workgroup of the XCD re-reads.  0 = default policy, 1 = nt, 2 = sc1 (stores: write through, drop the line).
+// stream that every workgroup of the XCD re-reads.  0 = default policy, 1 = nt, 2 = sc1 (stores: write through, drop the line),
+// 3 = timing proxy without the stores (98 -> 76 us per launch at 1 024 cells: what the twelve store bursts of a layer cost - vmcnt is
+// in-order, so the weight ring's next wait after a burst is also a wait for the burst's write acknowledgements).
 #ifndef SCLDM_BWD_PAIR_ST
 #define SCLDM_BWD_PAIR_ST 0
 #endif
@@ -157,7 +159,9 @@ __device__ __forceinline__ gchar* uniform_ptr(const void* p) {
 }
 __device__ __forceinline__ void pair_store(const PairDst& d, unsigned imm, const u32x4 v) {
   g_u32x4* gp = (g_u32x4*)(d.base + (d.voff + imm));
-#if SCLDM_BWD_PAIR_ST == 1
+#if SCLDM_BWD_PAIR_ST == 3   // timing proxy: no operand-pair stores at all (weight gradients are garbage)
+  asm volatile("" :: "v"(v), "v"(gp));
+#elif SCLDM_BWD_PAIR_ST == 1
   __builtin_nontemporal_store(v, gp);
 #else
   *gp = v;
