@@ -38,6 +38,8 @@ WORKLOADS = {
     "dentate_b4096_euler100": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=4096, evals=100, method="euler", scale=1.0),
     # BASELINE.json configs[1]
     "dentate_b512_euler50": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=512, evals=50, method="euler", scale=1.0),
+    # a small interactive batch (384 sample-forwards per evaluation = 192 32-token tiles: the launch runs on the 32-token-tile kernel)
+    "dentate_b128_euler50": dict(vocab={"clusters": 14}, strategy="mutually_exclusive", B=128, evals=50, method="euler", scale=1.0),
     # configs[2]: 100 Heun steps = 200 evaluations, guidance 2.0
     "hlca_b2048_heun100": dict(vocab={"cell_type": 50}, strategy="mutually_exclusive", B=2048, evals=200, method="heun", scale=2.0),
     # configs[3] per-GPU shard: 8192 cells over 8 GPUs = 1024 per GPU, joint conditioning
@@ -768,7 +770,7 @@ def compact_line(result):
     put("bf16_err_vs_fp32", "parity_path", "err_bf16_vs_fp32", "max_abs_over_max_ref")
     put("bf16_cells_per_s", "throughput_path", "cells_per_s"); put("bf16_frac", "throughput_path", "roofline", "frac")
     for w in result.get("other_workloads", []) or []:
-        tag = {"dentate_b512_euler50": "b512", "parse1m_b1024_euler100": "b1024", "hlca_b2048_heun100": "hlca_b2048_heun100",
+        tag = {"dentate_b512_euler50": "b512", "dentate_b128_euler50": "b128", "parse1m_b1024_euler100": "b1024", "hlca_b2048_heun100": "hlca_b2048_heun100",
                "parse1m_b8192_euler100_strong": "b8192"}.get(w["workload"], w["workload"])
         sc[f"cells_per_s_{tag}"] = round(w["cells_per_s"], 1)
         sc[f"frac_{tag}"] = round(w["dit_fwd_mfma_frac"], 4)
@@ -983,7 +985,7 @@ def main():
                 result["throughput_path"] = precision_path(wl, device, "bf16", args.steps, args.warmup)
                 note("bf16 throughput path done")
             extra = []
-            for name in ("dentate_b512_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100", "parse1m_b8192_euler100_strong"):
+            for name in ("dentate_b512_euler50", "dentate_b128_euler50", "parse1m_b1024_euler100", "hlca_b2048_heun100", "parse1m_b8192_euler100_strong"):
                 if name == args.workload:
                     continue
                 w2 = dict(WORKLOADS[name])

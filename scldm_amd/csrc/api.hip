@@ -89,6 +89,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_FT")) h->force_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_FT")) h->force_x3_ft = atoi(e);
   if (const char* e = getenv("SCLDM_X3_NTT")) h->force_x3_ntt = atoi(e);
+  if (const char* e = getenv("SCLDM_SMALL_NTT")) h->small_ntt = atoi(e) != 0;
   h->lpl = kMaxLayersPerLaunch;   // layers per fused launch (SCLDM_LPL=1..kMaxLayersPerLaunch for A/B runs)
   if (const char* e = getenv("SCLDM_LPL")) h->lpl = std::min(kMaxLayersPerLaunch, std::max(1, atoi(e)));
   h->groups = 1;
@@ -562,6 +563,11 @@ static int trunk(scldm_dit* h, const float* x, int n_direct, int rep, int n_fwd,
   const size_t es = esize(prec);
   int ntt, ft;
   pick_shape(h, prec, &ntt, &ft);
+  // Small batches (round 5): while 32-token tiles still get a CU each (<= 256 of them = 512 samples), the kernel's walk is what a
+  // launch costs and it is a quarter shorter with half the MFMAs and LDS fragment reads per k-step (163-175 against 212-220 us for the
+  // eight layers at 43-128 cells x 3 CFG branches); beyond that two workgroups share a CU and the doubled weight stream loses
+  // (213 cells: 255 against 228 us).  Same weight stream, same arithmetic per token: bit-identical (SCLDM_SMALL_NTT=0 switches it off).
+  if (h->small_ntt && (prec == SCLDM_PREC_BF16 || prec == SCLDM_PREC_FP16) && ntt == 2 && ft == 2 && (long long)n_fwd * 16 <= 256 * 32) ntt = 1;
   const size_t layer_elems = (size_t)4 * units_per_layer(h->n_chunks[ft - 1], h->half[ft - 1]) * 1024;
   FwdArgs a{};
   a.z = x;

@@ -59,6 +59,7 @@ struct scldm_dit {
   hipEvent_t ev_cond[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_ready = nullptr;
   bool cond_ahead = false;  // SCLDM_COND_AHEAD=1: opt-in (measured +0.5 % at 1 024 joint-conditioned cells, -0.8 % at 512, -0.2 % at 4 096: off)
   int force_ft, force_x3_ft, force_x3_ntt;
+  bool small_ntt = true;   // 32-token tiles for launches of at most 256 of them (SCLDM_SMALL_NTT=0: off)
   unsigned long long* dbg;  // device buffer for phase stamps (debug builds)
   // fused training path (train_fused.hip)
   void* bwd_stream;         // bf16 backward weight stream [layer][8 waves][kBwdUnitsLayer][512] (+ ring slack); allocated on first use

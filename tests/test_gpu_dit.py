@@ -717,6 +717,31 @@ def test_tile_group_launches_are_bit_identical(monkeypatch):
             assert torch.equal(y, ref), (knob, val)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_small_launches_on_32_token_tiles_are_bit_identical(precision, monkeypatch):
+    """Launches of at most 256 32-token tiles (512 samples) run the 32-token-tile instantiation of the fused kernel (a shorter walk
+    while every tile still has a CU to itself).  Same weight stream, same arithmetic per token: the bytes must not depend on it -
+    a cell's result may not change with the size of the batch it is sampled in."""
+    g, m, cfg, sd = build("dit_base", precision)
+    monkeypatch.setenv("SCLDM_SMALL_NTT", "0")             # (read once, when the native handle is created)
+    _, m64, _, _ = build("dit_base", precision)
+    monkeypatch.delenv("SCLDM_SMALL_NTT")
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    with torch.no_grad():
+        for n in (1, 5, 130, 512):
+            x = torch.randn(n, 16, 16, device="cuda", generator=gen)
+            t = torch.rand(n, device="cuda", generator=gen)
+            lab = {"clusters": torch.randint(0, 14, (n,), device="cuda", generator=gen)}
+            assert torch.equal(m(x, t, lab), m64(x, t, lab)), n
+        n = 600                                              # above the threshold: rows of a big launch == the same rows launched alone
+        x = torch.randn(n, 16, 16, device="cuda", generator=gen)
+        t = torch.rand(n, device="cuda", generator=gen)
+        lab = {"clusters": torch.randint(0, 14, (n,), device="cuda", generator=gen)}
+        whole = m(x, t, lab)
+        part = m(x[:100], t[:100], {"clusters": lab["clusters"][:100]})
+        assert torch.equal(whole[:100], part)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # round-2 additions: configurations and boundary behaviour the round-1 review found untested
 # --------------------------------------------------------------------------------------------------------------------
