@@ -31,7 +31,14 @@ using OP = SCLDM_BWD_OP;
 using E = OP::E;
 using Frag = OP::Frag;
 using Quad = OP::Quad;
-constexpr int NTT = 2, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
+// SCLDM_BWD_NTT: 32-token row tiles per workgroup.  2 = the 64-token tile of the forward kernel's record; 1 = half of one (round 5:
+// while 32-token tiles still get a CU each - at most 512 cells - the layer's walk is shorter with half the MFMAs and LDS fragment
+// reads per k-step on the same weight stream; the record and the gradient keep the 64-token geometry, a workgroup reads its half).
+#ifndef SCLDM_BWD_NTT
+#define SCLDM_BWD_NTT 2
+#endif
+constexpr int NTT = SCLDM_BWD_NTT, NW = 8, NT = 64 * NW, TM = 32 * NTT, NS = 2 * NTT;
+static_assert(NTT == 1 || NTT == 2, "the record is laid out in 64-token tiles");
 #ifndef SCLDM_BWD_PF
 #define SCLDM_BWD_PF 8
 #endif
@@ -84,12 +91,13 @@ constexpr int XA_LD = kD + 8, DADB_LD = 2 * kBwdChunk + 8, DQKV_LD = 3 * kD + 8;
 constexpr int R0_OFF = 0;                                   // h2 image, later h1 image
 constexpr int R1_OFF = R0_OFF + TM * XA_LD * 2;             // dy2 image, later dy1 image
 constexpr int R2_OFF = R1_OFF + TM * XA_LD * 2;             // [da | db] image of one chunk
-constexpr int R_END = R2_OFF + TM * DADB_LD * 2;
 constexpr int DQKV_BYTES = TM * DQKV_LD * 2;                // aliases R0..R2 once the q/k/v/dao passes are done
 constexpr int TR_LD = 36;                                   // elements per row of a wave's 32x32 transpose scratch (72 B: conflict-free ds_read_b64)
 constexpr int TR_OFF = DQKV_BYTES;                          // inside R2's tail, behind the dqkv image
 constexpr int TR_BYTES = 32 * TR_LD * 2;
-static_assert(TR_OFF + NW * TR_BYTES <= R_END && TR_OFF % 8 == 0, "transpose scratch must fit behind the dqkv image");
+constexpr int R_END_IMG = R2_OFF + TM * DADB_LD * 2, R_END_TR = TR_OFF + NW * TR_BYTES;
+constexpr int R_END = R_END_IMG > R_END_TR ? R_END_IMG : R_END_TR;   // (64-token tiles: the scratch fits in R2's tail; 32-token tiles: 1 KB past it)
+static_assert(TR_OFF % 8 == 0 && R_END % 16 == 0, "transpose scratch alignment");
 constexpr int MOD_OFF = R_END;
 constexpr int MOD_BYTES = NS * kModBlock * 2;               // fp16 copies of the six adaLN vectors of the tile's samples
 constexpr int RED_OFF = MOD_OFF + MOD_BYTES;
@@ -280,7 +288,9 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 
   // record / gradient tiles in the 4-wave forward kernel's layout [tile][fwd wave = wave >> 1][quad (tt*2 + ft)*4 + q][lane][4],
   // ft = wave & 1: a quad is 1 KB (fp32) / 512 B (16-bit) contiguous per wave; the descriptors start at this wave's first quad
-  const size_t quad0 = (size_t)((tile * 4 + (wave >> 1)) * 16 + (wave & 1) * 4) * 64;   // in lane-quads of 4 elements
+  // (a 32-token tile is half tt = tile & 1 of 64-token tile tile >> 1)
+  const int rec_tile = NTT == 2 ? tile : tile >> 1, rec_tt0 = NTT == 2 ? 0 : tile & 1;
+  const size_t quad0 = (size_t)((rec_tile * 4 + (wave >> 1)) * 16 + (rec_tt0 * 2 + (wave & 1)) * 4) * 64;   // in lane-quads of 4 elements
   const __amdgpu_buffer_rsrc_t r_xin = uniform_rsrc(a.x_in + quad0 * 4), r_dx = uniform_rsrc(a.dx + quad0 * 4);
   const __amdgpu_buffer_rsrc_t r_y1 = uniform_rsrc(a.y1 + quad0 * 4), r_y2 = uniform_rsrc(a.y2 + quad0 * 4);
   // (opaque: with provably disjoint bits hipcc turns `lane16 + q * 1024` into an OR, which it does not fold into the instruction's
@@ -492,12 +502,12 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
 
   // ---- phase 1: every global read of the phase is requested up front (one round trip, not one per use): the adaLN vectors and
   // the c_attn bias (staged to LDS), d x_out, y2, x_in, y1 ----
-  constexpr int kModLd = NS * kModBlock / 4 / NT;   // 3 float4 per thread
-  static_assert(NS * kModBlock / 4 % NT == 0, "whole float4 per thread");
+  constexpr int kModQuads = NS * kModBlock / 4;               // float4s of the tile's adaLN vectors
+  constexpr int kModLd = (kModQuads + NT - 1) / NT;           // 3 per thread (64-token tile), 1.5 (32-token tile: the second one on half the threads)
   f32x4 mstage[kModLd], bstage = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < kModLd; ++j) {
-    const int idx = tid + NT * j, sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
+    const int idx = min(tid + NT * j, kModQuads - 1), sl = idx / (kModBlock / 4), w4 = idx % (kModBlock / 4);
     mstage[j] = *reinterpret_cast<const f32x4*>(a.mod + (size_t)min(smp0 + sl, a.n - 1) * a.mod_stride + a.mod_off + w4 * 4);
   }
   if (tid < 3 * kD / 4) bstage = *reinterpret_cast<const f32x4*>(a.b_qkv + tid * 4);
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(NT, 1) void dit_backward_kernel(const BwdArgs a) {
       const int vec = w4 / (kD / 4);
       f32x4 m = mstage[j];
       if (vec == 0 || vec == 3) m += 1.0f;
-      OP::store_mod4(MOD + (size_t)idx * 4, m);
+      if (kModQuads % NT == 0 || idx < kModQuads) OP::store_mod4(MOD + (size_t)idx * 4, m);
     }
     if (tid < 3 * kD / 4) *reinterpret_cast<f32x4*>(BIAS + tid * 4) = bstage;
   };

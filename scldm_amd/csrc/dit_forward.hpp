@@ -644,8 +644,11 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
         }
   };
   // training record (REC): same lane-linear tile layout as the hand-off buffer
+  static_assert(!REC || NTT <= 2, "the record is laid out in 64-token tiles");
+  const int rec_tile = NTT == 2 ? tile_id : tile_id >> 1, rec_tt0 = NTT == 2 ? 0 : tile_id & 1;
   auto rec_store_x = [&](const float (&src)[FT][NTT][16], int layer_idx) {
-    float* xw = a.rec_x + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
+    // (the record keeps the 64-token-tile geometry whatever this kernel's tile: a 32-token tile is half tt0 of 64-token tile tile_id / 2)
+    float* xw = a.rec_x + (size_t)layer_idx * a.rec_stride + ((size_t)(rec_tile * NW + wave) * (4 * FT * 2) * 64 + (threadIdx.x & 63)) * 4;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -655,11 +658,11 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
           f32x4 t4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) t4[i] = src[ft][tt][q * 4 + i];
-          *reinterpret_cast<f32x4*>(xw + ((tt * FT + ft) * 4 + q) * 256) = t4;
+          *reinterpret_cast<f32x4*>(xw + (((tt + rec_tt0) * FT + ft) * 4 + q) * 256) = t4;
         }
   };
   auto rec_store_y = [&](const f32x16 (&src)[FT][NTT], void* base, int layer_idx) {
-    E* yw = reinterpret_cast<E*>(base) + (size_t)layer_idx * a.rec_stride + ((size_t)(tile_id * NW + wave) * (4 * FT * NTT) * 64 + (threadIdx.x & 63)) * 4;
+    E* yw = reinterpret_cast<E*>(base) + (size_t)layer_idx * a.rec_stride + ((size_t)(rec_tile * NW + wave) * (4 * FT * 2) * 64 + (threadIdx.x & 63)) * 4;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if constexpr (sizeof(E) == 2)   // (the recording instantiations are the 16-bit policies)
-            *reinterpret_cast<Quad*>(yw + ((tt * FT + ft) * 4 + q) * 256) =
+            *reinterpret_cast<Quad*>(yw + (((tt + rec_tt0) * FT + ft) * 4 + q) * 256) =
                 OP::pack4(src[ft][tt][q * 4 + 0], src[ft][tt][q * 4 + 1], src[ft][tt][q * 4 + 2], src[ft][tt][q * 4 + 3]);
         }
   };

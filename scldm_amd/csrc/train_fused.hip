@@ -21,6 +21,19 @@
 #include "dit_backward.hpp"
 #undef SCLDM_BWD_NS
 #undef SCLDM_BWD_OP
+// ... and on 32-token tiles (batches of at most 512 cells)
+#define SCLDM_BWD_NTT 1
+#define SCLDM_BWD_NS bwd32
+#define SCLDM_BWD_OP OpBF16
+#include "dit_backward.hpp"
+#undef SCLDM_BWD_NS
+#undef SCLDM_BWD_OP
+#define SCLDM_BWD_NS bwdh32
+#define SCLDM_BWD_OP OpFP16
+#include "dit_backward.hpp"
+#undef SCLDM_BWD_NS
+#undef SCLDM_BWD_OP
+#undef SCLDM_BWD_NTT
 #include "dit_forward.hpp"
 
 namespace scldm {
@@ -668,15 +681,24 @@ int backward_join(scldm_dit* h, hipStream_t st) {   // the backward weight strea
 
 int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, const Record& rec, const Scratch& s, hipStream_t st, int precision) {
   using L = FwdLayout<OpBF16, 2, 2>;   // (the fp16 policy has the same layout)
+  using L1 = FwdLayout<OpBF16, 1, 2>;
   static_assert(FwdLayout<OpFP16, 2, 2>::LDS_BYTES == L::LDS_BYTES && FwdLayout<OpFP16, 2, 2>::NT == L::NT, "fp16 = the bf16 kernel's shape");
+  static_assert(FwdLayout<OpFP16, 1, 2>::LDS_BYTES == L1::LDS_BYTES && L1::NT == L::NT, "fp16 = the bf16 kernel's shape");
   const bool f16 = precision == SCLDM_PREC_FP16;
-  void (*kern)(const FwdArgs) = f16 ? dit_forward_kernel<OpFP16, 2, 2, true> : dit_forward_kernel<OpBF16, 2, 2, true>;
-  static bool attr_set[2][64] = {};
+  // Small batches: while 32-token tiles still get a CU each, the 32-token-tile instantiation's walk is a quarter shorter (api.hip,
+  // trunk()); it writes the same record (64-token-tile geometry) and the same bits.  SCLDM_TRAIN_SMALL_NTT=0: off.
+  static const bool small_ok = [] { const char* e = getenv("SCLDM_TRAIN_SMALL_NTT"); return !(e && e[0] == '0'); }();
+  const int tiles64 = pad4(n) / 4;
+  const bool small = small_ok && tiles64 <= 128;
+  void (*kern)(const FwdArgs) = small ? (f16 ? dit_forward_kernel<OpFP16, 1, 2, true> : dit_forward_kernel<OpBF16, 1, 2, true>)
+                                      : (f16 ? dit_forward_kernel<OpFP16, 2, 2, true> : dit_forward_kernel<OpBF16, 2, 2, true>);
+  const int lds_bytes = small ? L1::LDS_BYTES : L::LDS_BYTES;
+  static bool attr_set[2][2][64] = {};
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_set[f16][dev]) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L::LDS_BYTES));
-    if (dev >= 0 && dev < 64) attr_set[f16][dev] = true;
+  if (dev < 0 || dev >= 64 || !attr_set[small][f16][dev]) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    if (dev >= 0 && dev < 64) attr_set[small][f16][dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
   if (h->iota_n < n) {   // identity row index, kept on the handle (grown on demand)
@@ -718,7 +740,9 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
   a.rec_y1 = rec.y1;
   a.rec_y2 = rec.y2;
   a.rec_stride = (long)pad4(n) * 16 * kD;
-  const int tiles = pad4(n) / 4;   // the kernel clamps the samples past n to the last real one and never stores their output
+  // (the kernel clamps the samples past n to the last real one and never stores their output; both halves of the last 64-token tile
+  // are launched, so every record row the backward reads is written)
+  const int tiles = small ? 2 * tiles64 : tiles64;
   const int lpl_rec = std::min(h->lpl, kMaxLayersPerLaunchRec);   // the recording instantiation has four layer slots
   for (int i = 0; i < c.n_layer; i += lpl_rec) {
     a.layer = i;
@@ -726,7 +750,7 @@ int forward(scldm_dit* h, const float* x, const float* mod, int n, float* out, c
     a.w_stream = (const char*)h->stream[precision][1] + (size_t)i * layer_elems * 2;
     a.b_qkv = h->b_qkv + (size_t)i * 768;
     a.b_proj = h->b_proj + (size_t)i * 256;
-    kern<<<tiles, L::NT, L::LDS_BYTES, st>>>(a);
+    kern<<<tiles, L::NT, lds_bytes, st>>>(a);
     LAUNCH_CHECK();
   }
   return SCLDM_OK;
@@ -818,22 +842,20 @@ int scatter_ada_grads(scldm_dit* h, const scldm_dit_grads* g, const float* dw_al
 }
 
 namespace {
-struct BwdBF16 {
-  using Args = bwd::BwdArgs;
-  using E = __bf16;
-  static constexpr bool kF16 = false;
-  static constexpr int NW = bwd::NW, NT = bwd::NT, LDS_BYTES = bwd::LDS_BYTES;
-  static void launch(int tiles, hipStream_t st, const Args& a) { bwd::dit_backward_kernel<<<tiles, NT, LDS_BYTES, st>>>(a); }
-  static const void* kernel() { return (const void*)bwd::dit_backward_kernel; }
-};
-struct BwdFP16 {
-  using Args = bwdh::BwdArgs;
-  using E = _Float16;
-  static constexpr bool kF16 = true;
-  static constexpr int NW = bwdh::NW, NT = bwdh::NT, LDS_BYTES = bwdh::LDS_BYTES;
-  static void launch(int tiles, hipStream_t st, const Args& a) { bwdh::dit_backward_kernel<<<tiles, NT, LDS_BYTES, st>>>(a); }
-  static const void* kernel() { return (const void*)bwdh::dit_backward_kernel; }
-};
+#define SCLDM_BWD_POLICY(NAME, NS_, ETYPE, F16)                                                                                          \
+  struct NAME {                                                                                                                         \
+    using Args = NS_::BwdArgs;                                                                                                          \
+    using E = ETYPE;                                                                                                                    \
+    static constexpr bool kF16 = F16;                                                                                                   \
+    static constexpr int NW = NS_::NW, NT = NS_::NT, LDS_BYTES = NS_::LDS_BYTES, TILES_PER_64 = 2 / NS_::NTT;                           \
+    static void launch(int tiles, hipStream_t st, const Args& a) { NS_::dit_backward_kernel<<<tiles, NT, LDS_BYTES, st>>>(a); }         \
+    static const void* kernel() { return (const void*)NS_::dit_backward_kernel; }                                                       \
+  }
+SCLDM_BWD_POLICY(BwdBF16, bwd, __bf16, false);
+SCLDM_BWD_POLICY(BwdFP16, bwdh, _Float16, true);
+SCLDM_BWD_POLICY(BwdBF16Small, bwd32, __bf16, false);   // 32-token tiles (<= 512 cells)
+SCLDM_BWD_POLICY(BwdFP16Small, bwdh32, _Float16, true);
+#undef SCLDM_BWD_POLICY
 }  // namespace
 
 template <typename BW>
@@ -849,7 +871,8 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const scldm_dit_config& c = h->cfg;
-  const int tiles = pad4(n) / 4, T = pad4(n) * 16, H = c.hidden_dim;   // the padding tokens carry zero gradients into the operand pairs
+  // (the padding tokens carry zero gradients into the operand pairs; both halves of the last 64-token tile are launched)
+  const int tiles = pad4(n) / 4 * BW::TILES_PER_64, T = pad4(n) * 16, H = c.hidden_dim;
   const size_t TD = (size_t)T * kD;
   const size_t bwd_layer_elems = (size_t)BW::NW * kBwdUnitsLayer * 512;
   // Small batches (round 5): the backward kernel runs one workgroup per tile on its own CU, so at <= 640 cells it leaves a third or more
@@ -972,6 +995,13 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
 
 int backward_layers(scldm_dit* h, const scldm_dit_grads* g, const float* mod, float* dmod, int n, const Record& rec, const Scratch& s,
                     hipStream_t st, int precision, const std::function<int(int)>& after_layer) {
+  // <= 320 cells: 32-token tiles (the same switch as the recording forward's, SCLDM_TRAIN_SMALL_NTT=0: off).  Measured per launch:
+  // 256 cells 83 -> 71 us; at 512 cells the 256 half tiles take every CU, 93 us either way, and the weight gradients of the next layer
+  // no longer find room beside them (graphed step 1.73 -> 1.75 ms) - so the rule stops where the side-stream overlap needs the CUs.
+  static const bool small_ok = [] { const char* e = getenv("SCLDM_TRAIN_SMALL_NTT"); return !(e && e[0] == '0'); }();
+  if (small_ok && pad4(n) / 4 * 2 <= kOverlapTiles)
+    return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16Small>(h, g, mod, dmod, n, rec, s, st, after_layer)
+                                        : backward_layers_t<BwdBF16Small>(h, g, mod, dmod, n, rec, s, st, after_layer);
   return precision == SCLDM_PREC_FP16 ? backward_layers_t<BwdFP16>(h, g, mod, dmod, n, rec, s, st, after_layer)
                                       : backward_layers_t<BwdBF16>(h, g, mod, dmod, n, rec, s, st, after_layer);
 }

@@ -260,13 +260,14 @@ def test_native_adamw_matches_torch_fused_adamw_and_shares_its_state_dict():
 
 def test_fused_training_switches_do_not_change_the_bits(tmp_path):
     """Round 5's scheduling switches of the fused training step only move launches between streams: the weight gradients of layer l
-    beside the backward kernel of layer l - 1 (two operand-pair sets; on for <= 640 cells), the backward's tails beside each other.
+    beside the backward kernel of layer l - 1 (two operand-pair sets; on for <= 640 cells), the backward's tails beside each other;
+    and the recording forward of <= 512 cells runs on 32-token tiles (same record, same arithmetic per token).
     Each variant in its own process (the switches are read once per process), base shape, 130 cells x 8 layers, bf16: every gradient
     bit for bit what the single-stream order gives."""
     import os, subprocess, sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gemm_route_child.py")
     res = {}
-    for name, env in (("default", {}), ("serial", {"SCLDM_TRAIN_WGRAD_OVERLAP": "0", "SCLDM_TRAIN_TAILS_SERIAL": "1"})):
+    for name, env in (("default", {}), ("serial", {"SCLDM_TRAIN_WGRAD_OVERLAP": "0", "SCLDM_TRAIN_TAILS_SERIAL": "1", "SCLDM_TRAIN_SMALL_NTT": "0"})):
         out = str(tmp_path / f"{name}.pt")
         e = {k: v for k, v in os.environ.items() if not k.startswith("SCLDM_TRAIN_")}
         e.update(env)
