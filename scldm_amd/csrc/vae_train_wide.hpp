@@ -1486,9 +1486,12 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma_kernel(const De
 //   k along the rows of the weight image (d h2, d ao, d qn):  k slot (s, g4) <-> row 16 (s >> 2) + 4 g4 + (s & 3): the B reads of a
 //     32-lane group hit rows 4 apart = 16 banks apart (conflict-free, as before); the A operand's four values of a lane are then
 //     CONSECUTIVE - one ds_read_b128 instead of four 4-way conflicting scalar reads
-// Per step: S0 embeddings, LN_1q | S1 q partials | S2 attention | S3 y partials | S4 LN_2 | A | B | S5 LN_2 backward | S6 d ao
-// partials | S7 attention backward | S8 d qn (two waves, whole k: no free row set is left for a second partial) + C weight gradients |
-// S9 LN_1q backward, dE atomics - separated by workgroup barriers (two workgroups per CU fill each other's waits).
+// The gene's attention over the cell's 16 latent tokens and its backward run on the matrix pipe as well, one head per wave: scores
+// (16 genes x 16 keys, k = 8 head dims) and P V / d P / d S K as 16 x 16 x 4 tiles, softmax and its backward across the 16 lanes of a
+// DPP row in the accumulator layout (lane = key) - before, 16 lanes per gene spent ~190 VALU operations per step on them.
+// Per step: S0 embeddings, LN_1q | S1 q partials | S2 attention | S3 y partials, q summed | S4 LN_2 | A | B | S5 LN_2 backward |
+// S6 d ao (two waves, whole k: the next phase's MFMAs read whole rows) | S7 attention backward | S8 d qn (likewise) + C weight
+// gradients | S9 LN_1q backward, dE atomics - separated by workgroup barriers (two workgroups per CU fill each other's waits).
 // =================================================================================================================================
 #ifndef SCLDM_VAE_PHASE_CLOCKS
 #define SCLDM_VAE_PHASE_CLOCKS 0   // 1: one workgroup prints its cycles per phase of dec_gene_bwd_mfma2_kernel (tools only)
@@ -1497,6 +1500,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // (volatile: keeps hipcc from pairing two of these into one ds_read2_b64, which is serviced 16 lanes at a time with banks mod 32 -
 // 8 LDS cycles and two-way conflicts on this pitch, against 2 + 2 conflict-free)
 // (the LDS address space is spelled out: a volatile access through a generic pointer becomes a flat load)
+__device__ __forceinline__ float row16_max(float v) {   // max over the 16 lanes of a DPP row, in every lane of the row
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false)));   // row_ror:8
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)));
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)));
+}
 typedef const volatile __attribute__((address_space(3))) f32x2 lds_f32x2;
 __device__ __forceinline__ lds_f32x2* v2(const float* p) { return (lds_f32x2*)p; }
 
@@ -1528,7 +1537,6 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
   float vs[10];                 // running sums of this lane's gene slot: ln1q w|b, ln2 w|b, head (two features each)
 #pragma unroll
   for (int i = 0; i < 10; ++i) vs[i] = 0.f;
-  const int h = j >> 2, jq = j & 3;
   const int half = wave & 1, kh = wave >> 1;     // the small products' roles: (output half, k half)
   // x W^T with k along both images' rows: partial over input features 16 kh .. + 15 of output half `half`, D[gene 4 g4 + r][16 half + li]
   auto lin_partial = [&](int x_rows, int w_rows, int dst_rows) {
@@ -1599,44 +1607,42 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
     lin_partial(G_QN, G_WQ, kh ? G_TX : G_QQ);
     __syncthreads();
     PHASE_MARK(1);
-    // ---- S2: attention of the gene over the cell's 16 latent tokens
+    // ---- S2: attention on the matrix pipe, wave = head (16 genes x 16 keys x 8 head dims): scores = q_h K_h^T as two MFMAs (k pairs of
+    // head dims as ds_read_b64; q = the two partials), softmax over the 16 lanes of a DPP row (lane = key), p -> PP rows (phase C's
+    // operand anyway), ao_h = P V_h as four MFMAs whose useful output columns are the head's 8 dims
     float p[4];
     {
-      const f32x4 qa = *v4(S + G_QQ + tok * kP + 8 * h) + *v4(S + G_TX + tok * kP + 8 * h);
-      const f32x4 qb = *v4(S + G_QQ + tok * kP + 8 * h + 4) + *v4(S + G_TX + tok * kP + 8 * h + 4);
-      const float qj0 = S[G_QQ + tok * kP + j] + S[G_TX + tok * kP + j], qj1 = S[G_QQ + tok * kP + j + 16] + S[G_TX + tok * kP + j + 16];
-      float mx = -3.0e38f;
+      const f32x2 q2 = *v2(S + G_QQ + li * kP + 8 * wave + 2 * g4) + *v2(S + G_TX + li * kP + 8 * wave + 2 * g4);
+      const f32x2 k2 = *v2(S + G_KV + li * kP64 + 8 * wave + 2 * g4);
+      f32x4 sc = z4();
+      sc = mfma16(q2[0], k2[0], sc);
+      sc = mfma16(q2[1], k2[1], sc);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
-        p[kk] = (dot4(qa, *v4(K)) + dot4(qb, *v4(K + 4))) * kScale;
-        mx = fmaxf(mx, p[kk]);
+      for (int r = 0; r < 4; ++r) {
+        const float v = sc[r] * kScale, e = __expf(v - row16_max(v));
+        p[r] = e * (1.0f / row16_sum(e));
+        S[G_PP + (4 * g4 + r) * kP64 + 16 * wave + li] = p[r];
       }
-      mx = quad_max(mx);
-      float l = 0.f;
+      tsync();     // (this wave wrote the PP columns it reads)
+      f32x4 ao = z4();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) { p[kk] = __expf(p[kk] - mx); l += p[kk]; }
-      const float inv = 1.0f / quad_sum(l);
-      f32x4 aa = z4(), ab = z4();
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        p[kk] *= inv;
-        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
-        aa = fma4(p[kk], *v4(V), aa);
-        ab = fma4(p[kk], *v4(V + 4), ab);
+      for (int m = 0; m < 2; ++m) {
+        const f32x2 p2 = *v2(S + G_PP + li * kP64 + 16 * wave + 8 * m + 2 * g4);
+        const float* V = S + G_KV + (8 * m + 2 * g4) * kP64 + 32 + 8 * wave + (li & 7);   // (lanes li, li + 8 share an address: no conflict)
+        ao = mfma16(p2[0], V[0], ao);
+        ao = mfma16(p2[1], V[kP64], ao);
       }
-      aa = quad_sum4(aa);
-      ab = quad_sum4(ab);
-      if (jq < 2) *v4(S + G_AO + tok * kP + 8 * h + 4 * jq) = jq == 0 ? aa : ab;
-      *v4(S + G_PP + tok * kP64 + h * 16 + 4 * jq) = f32x4{p[0], p[1], p[2], p[3]};
-      tsync();     // (the gene's other lanes have read the partial QQ row)
-      S[G_QQ + tok * kP + j] = qj0;            // the whole q: dK's operand in phase C
-      S[G_QQ + tok * kP + j + 16] = qj1;
+      if (li < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[G_AO + (4 * g4 + r) * kP + 8 * wave + li] = ao[r];
+      }
     }
     __syncthreads();
     PHASE_MARK(2);
     // ---- S3: c_proj partials -> DY (k half 0), DAO (k half 1)
     lin_partial(G_AO, G_WP, kh ? G_DAO : G_DY);
+    S[G_QQ + tok * kP + j] += S[G_TX + tok * kP + j];               // the whole q: dK's operand in phase C (its partials' last readers
+    S[G_QQ + tok * kP + j + 16] += S[G_TX + tok * kP + j + 16];     // were S2's MFMAs; TX is next written in phase B)
     __syncthreads();
     PHASE_MARK(3);
     // ---- S4: residual, LN_2
@@ -1714,45 +1720,44 @@ __global__ __launch_bounds__(kThreads, 2) void dec_gene_bwd_mfma2_kernel(const D
     S[G_DY + tok * kP + j + 16] = d1;
     __syncthreads();
     PHASE_MARK(7);
-    // ---- S6: d ao partials -> DAO (k half 0), TX (k half 1)
-    {
-      f32x4 acc = z4();
-      lin_t_partial(G_DY, G_WP, half, kh, acc);
-      float* Pt = S + (kh ? G_TX : G_DAO);
+    // ---- S6: d ao = Wp^T d y (waves 0, 1: one input half each, all 32 rows - S7's MFMAs read the whole row, and no row set is free
+    // for a finalised sum of two partials)
+    if (wave < 2) {
+      f32x4 acc = z4(), acc2 = z4();
+      lin_t_partial(G_DY, G_WP, wave, 0, acc);
+      lin_t_partial(G_DY, G_WP, wave, 1, acc2);
+      acc += acc2;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Pt[(4 * g4 + r) * kP + 16 * half + li] = acc[r];
+      for (int r = 0; r < 4; ++r) S[G_DAO + (4 * g4 + r) * kP + 16 * wave + li] = acc[r];
     }
     __syncthreads();
     PHASE_MARK(8);
-    // ---- S7: attention backward -> d q, d scores; the whole d ao row for phase C
+    // ---- S7: attention backward, wave = head: d p = d ao_h V_h^T (two MFMAs), d s = p (d p - sum_keys p d p) / sqrt(8) in the lanes
+    // that hold p, -> DS rows (phase C's operand), d q_h = d S K_h (four MFMAs, 8 useful columns)
     {
-      const f32x4 da = *v4(S + G_DAO + tok * kP + 8 * h) + *v4(S + G_TX + tok * kP + 8 * h);
-      const f32x4 db = *v4(S + G_DAO + tok * kP + 8 * h + 4) + *v4(S + G_TX + tok * kP + 8 * h + 4);
-      const float aj0 = S[G_DAO + tok * kP + j] + S[G_TX + tok * kP + j], aj1 = S[G_DAO + tok * kP + j + 16] + S[G_TX + tok * kP + j + 16];
-      float dp[4], dg = 0.f;
+      const f32x2 a2 = *v2(S + G_DAO + li * kP + 8 * wave + 2 * g4);
+      const f32x2 v2v = *v2(S + G_KV + li * kP64 + 32 + 8 * wave + 2 * g4);
+      f32x4 dp = z4();
+      dp = mfma16(a2[0], v2v[0], dp);
+      dp = mfma16(a2[1], v2v[1], dp);
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float* V = S + G_KV + (4 * jq + kk) * kP64 + 32 + 8 * h;
-        dp[kk] = dot4(da, *v4(V)) + dot4(db, *v4(V + 4));
-        dg = fmaf(p[kk], dp[kk], dg);
+      for (int r = 0; r < 4; ++r) {
+        const float dg = row16_sum(p[r] * dp[r]);
+        S[G_DS + (4 * g4 + r) * kP64 + 16 * wave + li] = p[r] * (dp[r] - dg) * kScale;
       }
-      dg = quad_sum(dg);
-      f32x4 qa = z4(), qb = z4(), dsv;
+      tsync();
+      f32x4 dq = z4();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const float ds = p[kk] * (dp[kk] - dg) * kScale;
-        dsv[kk] = ds;
-        const float* K = S + G_KV + (4 * jq + kk) * kP64 + 8 * h;
-        qa = fma4(ds, *v4(K), qa);
-        qb = fma4(ds, *v4(K + 4), qb);
+      for (int m = 0; m < 2; ++m) {
+        const f32x2 d2 = *v2(S + G_DS + li * kP64 + 16 * wave + 8 * m + 2 * g4);
+        const float* K = S + G_KV + (8 * m + 2 * g4) * kP64 + 8 * wave + (li & 7);
+        dq = mfma16(d2[0], K[0], dq);
+        dq = mfma16(d2[1], K[kP64], dq);
       }
-      qa = quad_sum4(qa);
-      qb = quad_sum4(qb);
-      if (jq < 2) *v4(S + G_DQQ + tok * kP + 8 * h + 4 * jq) = jq == 0 ? qa : qb;
-      *v4(S + G_DS + tok * kP64 + h * 16 + 4 * jq) = dsv;
-      tsync();     // (the gene's other lanes have read the partial DAO row)
-      S[G_DAO + tok * kP + j] = aj0;
-      S[G_DAO + tok * kP + j + 16] = aj1;
+      if (li < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[G_DQQ + (4 * g4 + r) * kP + 8 * wave + li] = dq[r];
+      }
     }
     __syncthreads();
     PHASE_MARK(9);
