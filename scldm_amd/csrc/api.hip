@@ -279,11 +279,12 @@ int scldm_build_pack_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_
     i = 0;
     for (int v : par) j.p[i++] = v;
     j.d_off = d_off;
-    blocks += cdiv(n, 256);
+    const int nb = cdiv(pack_job_threads(kind, n, j.p), 256);
+    blocks += nb;
     jobs.push_back(j);
     if (train) {
       j.first_block = tblocks;
-      tblocks += cdiv(n, 256);
+      tblocks += nb;
       tjobs.push_back(j);
     }
   };

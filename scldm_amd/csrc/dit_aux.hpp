@@ -108,6 +108,50 @@ __device__ __forceinline__ float pack_bwd_val(const float* __restrict__ Wqkv, co
   return Wqkv[(size_t)((v - 64) * 16 + k8) * 256 + frow];
 }
 
+// Store one lane fragment (packed indices idx8 * 8 .. + 7) in the stream's precision: 16-byte stores (round 5: the re-pack runs every
+// training step; one thread per ELEMENT meant a 2-byte store and a full index decode per element: 117 us for the base DiT).
+__device__ __forceinline__ void pack_store8(void* out, long long idx8, const float (&v)[8], int prec, int* fp16_stats = nullptr) {
+  typedef __attribute__((ext_vector_type(4))) unsigned ps_u32x4;
+  if (prec == 0) {
+    float* o = reinterpret_cast<float*>(out) + idx8 * 8;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else if (prec == 1) {
+    union { __bf16 h[8]; ps_u32x4 u; } t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.h[i] = (__bf16)v[i];
+    *reinterpret_cast<ps_u32x4*>(reinterpret_cast<__bf16*>(out) + idx8 * 8) = t.u;
+  } else if (prec == 3) {
+    union { _Float16 h[8]; ps_u32x4 u; } t;
+    int over = 0, sub = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      t.h[i] = (_Float16)v[i];
+      const float av = fabsf(v[i]);
+      over += av > 65504.f;
+      sub += (v[i] != 0.f) && av < 6.103515625e-05f;
+      nz += v[i] != 0.f;
+    }
+    *reinterpret_cast<ps_u32x4*>(reinterpret_cast<_Float16*>(out) + idx8 * 8) = t.u;
+    if (fp16_stats) {   // wave-aggregated counters: one atomic per wave and non-zero counter
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { over += __shfl_xor(over, o); sub += __shfl_xor(sub, o); nz += __shfl_xor(nz, o); }
+      if ((threadIdx.x & 63) == 0) {
+        if (over) atomicAdd(fp16_stats + 0, over);
+        if (sub) atomicAdd(fp16_stats + 1, sub);
+        if (nz) atomicAdd(fp16_stats + 2, nz);
+      }
+    }
+  } else {
+    union { __bf16 h[8]; ps_u32x4 u; } hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) OpBF16x3::split(v[i], hi.h[i], lo.h[i]);
+    __bf16* o = reinterpret_cast<__bf16*>(out) + idx8 * 16;
+    *reinterpret_cast<ps_u32x4*>(o) = hi.u;
+    *reinterpret_cast<ps_u32x4*>(o + 8) = lo.u;
+  }
+}
+
 // Store packed element `idx` (fragment-major: 8 consecutive indices = one lane's 8 k-values) in the stream's precision.
 //   prec 0: fp32   1: bf16   2: split-bf16 (the 8 hi values then the 8 lo values of a lane: 32 bytes per lane-fragment)   3: fp16
 // fp16_stats (prec 3): [0] += values beyond the fp16 range (stored as +-inf), [1] += non-zero values below the smallest normal
@@ -145,12 +189,20 @@ enum PackKind : int { kPackCopy = 0, kPackTranspose = 1, kPackLayer = 2, kPackFi
 struct PackJob {
   int kind;
   int first_block;      // first 256-thread block of this job
-  long long n;          // elements (threads)
+  long long n;          // elements (pack_job_threads(kind, n, p) threads: layer streams take a lane fragment of 8 per thread)
   const float* s[5];    // sources (parameter tensors)
   void* d;              // destination
   int p[6];             // kind-specific: copy -; transpose N,K,ldo,col0; layer H,n_chunks,half,FT,prec; final din,prec
   long long d_off;      // element offset added to the destination index (layer: start of the layer's stream)
 };
+// threads a job needs: the layer streams (forward and backward) handle one lane fragment = 8 consecutive elements per thread; a
+// transpose whose extents are multiples of 32 runs as 32 x 32 tiles through LDS (four elements per thread)
+__host__ __device__ inline bool pack_transpose_tiled(const int* p) { return p[0] % 32 == 0 && p[1] % 32 == 0; }
+__host__ __device__ inline long long pack_job_threads(int kind, long long n, const int* p) {
+  if (kind == kPackLayer || kind == kPackLayerBwd) return n / 8;
+  if (kind == kPackTranspose && pack_transpose_tiled(p)) return n / 4;
+  return n;
+}
 // prec_mask: bit p set = pack the streams of precision p (kPackLayer / kPackFinal jobs of other precisions are skipped - the
 // training step re-packs only what it reads); kPackLayerBwd jobs run when bit 8 is set (bit 9: as fp16 instead of bf16); bit 10: ONLY
 // the kPackLayerBwd jobs (the training step's second launch: the backward stream is packed beside the forward, not ahead of it).
@@ -164,8 +216,21 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   }
   const PackJob& j = jobs[lo];
   const long long idx = (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
-  if (idx >= j.n) return;
   if ((prec_mask & 0x400u) && j.kind != kPackLayerBwd) return;
+  if (j.kind == kPackTranspose && pack_transpose_tiled(j.p)) {   // out[k*ldo + col0 + n] = W[n*K + k], a 32 x 32 tile per block
+    __shared__ float tile[32][33];
+    const int N = j.p[0], K = j.p[1], ldo = j.p[2], col0 = j.p[3];
+    const int b = (int)blockIdx.x - j.first_block, kt = K / 32, n0 = (b / kt) * 32, k0 = (b % kt) * 32;   // (whole block: no early exit before the barrier)
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[r0 + 8 * q][c] = j.s[0][(size_t)(n0 + r0 + 8 * q) * K + k0 + c];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reinterpret_cast<float*>(j.d)[(size_t)(k0 + r0 + 8 * q) * ldo + col0 + n0 + c] = tile[c][r0 + 8 * q];
+    (void)N;
+    return;
+  }
+  if (idx >= pack_job_threads(j.kind, j.n, j.p)) return;
   switch (j.kind) {
     case kPackCopy:
       reinterpret_cast<float*>(j.d)[idx] = j.s[0][idx];
@@ -188,17 +253,21 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
     }
     case kPackLayerBwd: {   // bit 9: the step's operand type is fp16 (same 16-bit stream, re-packed every training step)
       if (!(prec_mask & 0x100u)) return;
-      const float v = pack_bwd_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0]);
-      if (prec_mask & 0x200u) reinterpret_cast<_Float16*>(j.d)[j.d_off + idx] = (_Float16)v;
-      else reinterpret_cast<__bf16*>(j.d)[j.d_off + idx] = (__bf16)v;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = pack_bwd_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx * 8 + e, j.p[0]);
+      pack_store8(j.d, j.d_off / 8 + idx, v, (prec_mask & 0x200u) ? 3 : 1);
       break;
     }
     case kPackLayer:
       if (!((prec_mask >> j.p[4]) & 1u)) return;
-      pack_store(j.d, j.d_off + idx,
-                 pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx, j.p[0], j.p[1], j.p[2], j.p[3],
-                                (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW1Scale : 1.0f, (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW2Scale : 1.0f),
-                 j.p[4], fp16_stats);
+      {
+        const float s1 = (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW1Scale : 1.0f, s2 = (j.p[4] == 1 || j.p[4] == 3) ? OpBF16::kW2Scale : 1.0f;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pack_layer_val(j.s[0], j.s[1], j.s[2], j.s[3], j.s[4], idx * 8 + e, j.p[0], j.p[1], j.p[2], j.p[3], s1, s2);
+        pack_store8(j.d, j.d_off / 8 + idx, v, j.p[4], fp16_stats);
+      }
       break;
     case kPackFinal: {  // final_layer.linear (din,256) -> 16 fragments of a 32-row tile (rows >= din zero): ((ks*64 + l)*8 + j)
       if (!((prec_mask >> j.p[1]) & 1u)) return;
