@@ -149,7 +149,9 @@ int gemm(hipStream_t st, const float* A, long sam, long sak, const float* B, lon
   const bool a_kc = sak == 1, b_kc = sbk == 1;
   if ((!a_kc && sam != 1) || (!b_kc && sbn != 1)) return fail(SCLDM_ERR_SHAPE, "gemm: operand needs a unit stride");
   // 128x128 tiles whenever both extents fill them (arithmetic intensity); split-K restores the workgroup count
-  const bool big = M >= 128 && N >= 128;
+  // ... unless they would leave most of the chip idle on a short product (the conditioning MLP's 1 024 x 256 x 256 Linears: 16 tiles
+  // of 128 = 27 us of latency; 64 tiles of 64 finish in a third of that)
+  const bool big = M >= 128 && N >= 128 && !((long)cdiv(M, 128) * cdiv(N, 128) < 48 && K <= 1024);
   const long tiles = big ? (long)cdiv(M, 128) * cdiv(N, 128) : (long)cdiv(M, 64) * cdiv(N, 64);
   int splits = 1;
   // split K only when the output tiles alone cannot fill the GPU: a 200-tile, K = 1 024 product (the stacked adaLN weight
