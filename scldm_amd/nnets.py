@@ -594,7 +594,7 @@ class DiT(nn.Module):
                     raise ValueError(f"Condition '{c}' length ({lab.shape[0]}) must match batch size ({n})")
                 lab = lab.to(device=dev, dtype=torch.long)
                 if drop_mask is not None:
-                    lab = lab.masked_fill(drop_mask, self.class_vocab_sizes[c])   # null token where dropped (one launch)
+                    lab = torch.where(drop_mask, self.class_vocab_sizes[c], lab)   # null token where dropped (ONE launch: masked_fill clones first)
                 lab = lab.contiguous()
                 keep.append(lab)
                 ptrs.append(lab.data_ptr())
