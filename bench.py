@@ -411,9 +411,11 @@ def throughput_and_latency(fn, calls=20, repeats=3):
 
 def decode_inclusive(m, wl, device, n_genes=17002):
     """Same sampling pass followed by the MCAB decode of all 2B latents to NB parameters (dentate_gyrus gene count), and the
-    decode alone at both VAE precisions with its roofline (fp32-MFMA peak for the parity path, bf16 peak for the bf16 one)."""
+    decode alone at every VAE precision with its roofline (fp32-MFMA peak for the parity path, the 16-bit peak for fp16 / bf16).
+    The chain's decode runs in the reference's arithmetic class (fp16 operands = TF32's mantissa, experiments/scripts/inference.py:26)
+    when the DiT runs a 16-bit policy, exact fp32 otherwise."""
     vae = make_vae(n_genes, device)
-    vae.precision = "bf16" if m.precision in ("bf16", "fp16") else "fp32"   # bf16 run: bf16-operand decode as well
+    vae.precision = chain_prec = "fp16" if m.precision in ("bf16", "fp16") else "fp32"
     B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
     w2 = dict(wl); w2["B"] = B
     z2, cond2, scales = make_inputs(w2, B, device, seed=7)
@@ -428,10 +430,10 @@ def decode_inclusive(m, wl, device, n_genes=17002):
     for _ in range(3):
         t0 = time.perf_counter(); once(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     dt = statistics.median(ts)
-    rec = {"cells_per_gpu": B, "n_genes": n_genes, "cells_per_s": B / dt,
+    rec = {"cells_per_gpu": B, "n_genes": n_genes, "cells_per_s": B / dt, "decode_precision": chain_prec,
            "note": "sampling + MCAB decode of the 2B latents to (mu, theta); decode rates count decoded rows"}
     flops_row = n_genes * MCAB_DECODE_FLOPS_PER_GENE + 3.3e6
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp16", "bf16"):
         vae.precision = prec
         dd, lat = throughput_and_latency(lambda: vae.decode(z2, genes, lib), calls=8)
         ach = 2 * B * flops_row / dd / 1e12
@@ -439,7 +441,66 @@ def decode_inclusive(m, wl, device, n_genes=17002):
                                       "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK[prec] / 1e12, "unit": "TFLOP/s",
                                                    "frac": ach / (PEAK[prec] / 1e12),
                                                    "hbm_out_GBps": 2 * B * n_genes * 8 / dd / 1e9}}
-    rec["decode_only_cells_per_s"] = rec[f"decode_only_{'bf16' if m.precision in ('bf16', 'fp16') else 'fp32'}"]["rows_per_s"]
+    rec["decode_only_cells_per_s"] = rec[f"decode_only_{chain_prec}"]["rows_per_s"]
+    return rec
+
+
+def mcab_roofline(device, rows=8192, cells=4096, n_genes=17002, S=6147, calls=6):
+    """`roofline`-style blocks for the MCAB kernels at the shapes profiles/r6_mcab_* were taken at (decode 8 192 rows x 17 002
+    genes, encode 4 096 cells x 6 147 tokens: the dentate_gyrus sizes at the north-star batch), per precision policy: algorithmic
+    FLOPs per launch / mean launch duration from HIP events around each kernel on its launch stream (scldm_vae_kernel_timing), the
+    same figure `rocprofv3 --kernel-trace --stats` of tests/perf/mcab_profile.py gives; `traffic` = HBM bytes per launch from the
+    committed PMC passes (profiles/pmc_mcab.json: FETCH_SIZE doubled per the guide + WRITE_SIZE, KB -> bytes).
+    Algorithmic work: dec_gene_kernel 23 104 FLOP per decoded gene; enc_pool_kernel 6 528 FLOP per pooled token; the
+    16-token trunks 3.3 / 1.5 MFLOP per cell.  Algorithmic HBM bytes: decode = logits out 4 B + theta out 4 B + gene id in 8 B per
+    gene (tables are L2-resident), encode = count 4 B + gene id 8 B per token."""
+    vae = make_vae(n_genes, device)
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(rows, 16, 16, generator=g).to(device)
+    genes = torch.arange(n_genes, device=device).repeat(rows, 1)
+    lib = torch.full((rows, 1), 3000.0, device=device)
+    sgenes = torch.stack([torch.randperm(n_genes, generator=g)[:S] for _ in range(8)]).repeat(cells // 8, 1).to(device)
+    counts = torch.poisson(torch.full((cells, S), 1.5), generator=g).to(device)
+    pmc = {}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mcab.json")) as f:
+            pmc = json.load(f)
+    except Exception:
+        pass
+    work = {  # kernel -> (algorithmic FLOPs per launch, algorithmic HBM bytes per launch, bound)
+        "dec_gene": (rows * n_genes * MCAB_DECODE_FLOPS_PER_GENE, rows * n_genes * 16.0),
+        "dec_cell": (rows * 3.3e6, rows * (16 * 16 * 4 + 48 * 64 * 4.0)),
+        "dec_finalize": (rows * n_genes * 4.0, rows * n_genes * 8.0),
+        "enc_pool": (cells * S * MCAB_ENCODE_FLOPS_PER_GENE, cells * S * 12.0),
+        "enc_cell": (cells * 1.5e6, cells * (16 * 32 * 4 + 16 * 16 * 4.0)),
+    }
+    rec = {"decode_rows": rows, "encode_cells": cells, "n_genes": n_genes, "tokens_per_cell": S}
+    for prec in ("fp32", "fp16", "bf16"):
+        vae.precision = prec
+        vae.decode(z, genes, lib); vae.encode(counts, sgenes); torch.cuda.synchronize()
+        vae.kernel_timing(True)
+        for _ in range(calls):
+            vae.decode(z, genes, lib)
+            vae.encode(counts, sgenes)
+        t = vae.kernel_timing()
+        vae.kernel_timing(False)
+        out = {}
+        for k, (n, ms) in t.items():
+            if not n:
+                continue
+            fl, by = work[k]
+            us = 1e3 * ms / n
+            hbm_bound = k == "dec_finalize"
+            peak = 8000.0 if hbm_bound else PEAK[prec if k in ("dec_gene", "enc_pool") else "fp32"] / 1e12   # the cell trunks are exact fp32 in every policy
+            ach = by / (us * 1e-6) / 1e9 if hbm_bound else fl / (us * 1e-6) / 1e12
+            traffic = (pmc.get(prec, {}).get(k, {}) or {}).get("hbm_bytes_per_launch")
+            out[k] = {"bound": "hbm" if hbm_bound else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                      "frac": ach / peak, "launches": n, "avg_launch_us": us, "algorithmic_flops_per_launch": fl,
+                      "algorithmic_hbm_bytes_per_launch": by, "traffic": traffic,
+                      "traffic_ratio": (traffic / by) if traffic else None}
+        rec[prec] = out
+    rec["dominant_kernel"] = "dec_gene_kernel"
+    rec["traffic_source"] = "profiles/pmc_mcab.json" if pmc else None
     return rec
 
 
@@ -467,7 +528,7 @@ def encode_record(device, batches=(1024, 4096)):
             genes = torch.stack([torch.randperm(n_genes, generator=g)[:S] for _ in range(8)]).repeat(cells // 8, 1).to(device)
             counts = torch.poisson(torch.full((cells, S), 1.5), generator=g).to(device)
             flops = cells * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6)
-            for prec in ("fp32", "bf16"):
+            for prec in ("fp32", "fp16", "bf16"):
                 vae.precision = prec
                 # throughput: 20 calls back to back between two synchronisations (the headline's protocol; a sub-millisecond call
                 # timed alone is mostly launch ramp, host enqueue and drain: reported beside it as a latency)
@@ -684,7 +745,7 @@ def synthetic_vocabulary_encoder(vocab, strategy, seed=3):
 
 def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     """What one `predict_step` of the reference delivers (src/scldm/models.py:707-819 + _utils.py:192-197), end to end on the device
-    path: size factors drawn on device (SizeFactorSampler) -> noise -> fused CFG ODE -> MCAB decode (fp32) with the negative-binomial
+    path: size factors drawn on device (SizeFactorSampler) -> noise -> fused CFG ODE -> MCAB decode (fp16 operands beside a 16-bit DiT, else fp32) with the negative-binomial
     draw fused in -> CSR assembly on device -> host arrays (indptr / indices / data of the 2B generated rows + the 2B latents).
     cells/s = requested cells / wall time of the whole chain (median of `reps` after one warm-up), with the device time of each stage."""
     from scldm_amd.datamodule import dense_to_csr
@@ -693,7 +754,8 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     B = wl["B"]
     m = make_model(wl, precision, device)
     vae = make_vae(n_genes, device)
-    vae.precision = "fp32"
+    # the decode runs in the reference's arithmetic class (TF32 mantissa = fp16 operands) beside a 16-bit DiT, exact fp32 otherwise
+    vae.precision = "fp16" if precision in ("bf16", "fp16") else "fp32"
     smp = SizeFactorSampler(synthetic_vocabulary_encoder(wl["vocab"], wl["strategy"]), wl["strategy"], device)
     g = torch.Generator().manual_seed(21)
     cond = {k: torch.randint(0, v, (B,), generator=g).to(device) for k, v in wl["vocab"].items()}
@@ -732,7 +794,7 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     stage = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     nnz = int(host[2].numel())
     return {"workload": wl_name, "cells": B, "generated_rows": 2 * B, "n_genes": n_genes, "cfg_evaluations": wl["evals"], "method": wl["method"],
-            "dit_precision": precision, "decode_precision": "fp32", "cells_per_s": B / dt, "ms": 1e3 * dt, "ms_each": [round(1e3 * t, 3) for t in ts],
+            "dit_precision": precision, "decode_precision": vae.precision, "cells_per_s": B / dt, "ms": 1e3 * dt, "ms_each": [round(1e3 * t, 3) for t in ts],
             "stage_ms": {"size_factors_and_noise": stage[0], "ode": stage[1], "decode_and_nb_draw": stage[2], "csr_assembly": stage[3],
                          "device_to_host": stage[4]},
             "nnz_fraction": nnz / (2 * B * n_genes), "host_bytes": sum(int(t.numel()) * t.element_size() for t in host),
@@ -778,9 +840,14 @@ def compact_line(result):
     put("dopri5_cfg_evaluations", "default_sampler", "cfg_evaluations")
     put("with_decode_cells_per_s", "with_vae_decode", "cells_per_s")
     put("decode_fp32_rows_per_s", "with_vae_decode", "decode_only_fp32", "rows_per_s"); put("decode_fp32_frac", "with_vae_decode", "decode_only_fp32", "roofline", "frac")
+    put("decode_fp16_rows_per_s", "with_vae_decode", "decode_only_fp16", "rows_per_s"); put("decode_fp16_frac", "with_vae_decode", "decode_only_fp16", "roofline", "frac")
     put("decode_bf16_rows_per_s", "with_vae_decode", "decode_only_bf16", "rows_per_s"); put("decode_bf16_frac", "with_vae_decode", "decode_only_bf16", "roofline", "frac")
     put("encode_fp32_cells_per_s", "with_vae_encode", "dentate_fp32", "cells_per_s"); put("encode_fp32_frac", "with_vae_encode", "dentate_fp32", "roofline", "frac")
+    put("encode_fp16_cells_per_s", "with_vae_encode", "dentate_fp16", "cells_per_s"); put("encode_fp16_frac", "with_vae_encode", "dentate_fp16", "roofline", "frac")
     put("encode_bf16_cells_per_s", "with_vae_encode", "dentate_bf16", "cells_per_s"); put("encode_bf16_frac", "with_vae_encode", "dentate_bf16", "roofline", "frac")
+    for prec in ("fp32", "fp16"):
+        put(f"mcab_dec_gene_{prec}_frac", "mcab_roofline", prec, "dec_gene", "frac"); put(f"mcab_dec_gene_{prec}_us", "mcab_roofline", prec, "dec_gene", "avg_launch_us")
+        put(f"mcab_enc_pool_{prec}_frac", "mcab_roofline", prec, "enc_pool", "frac"); put(f"mcab_enc_pool_{prec}_us", "mcab_roofline", prec, "enc_pool", "avg_launch_us")
     put("e2e_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "cells_per_s")
     put("e2e_ms_dentate512", "generation_end_to_end", "dentate_b512_euler50", "ms")
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
@@ -1018,6 +1085,11 @@ def main():
             note("decode done")
             result["with_vae_encode"] = encode_record(device)
             note("encode done")
+            try:
+                result["mcab_roofline"] = mcab_roofline(device)
+            except Exception as e:  # noqa: BLE001
+                result["mcab_roofline"] = {"error": repr(e)}
+            note("mcab roofline done")
             try:   # configs[1] as the reference's predict_step delivers it, and the configs[3] per-GPU shard
                 result["generation_end_to_end"] = {
                     "dentate_b512_euler50": generation_end_to_end("dentate_b512_euler50", 17002, device, args.precision),

@@ -391,8 +391,12 @@ int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, in
 
 /* TransformerVAE.decode (vae.py:71-87) up to the distribution parameters: z (B,16,n_lat), genes (B,G) int64,
  * library_size (B) -> mu (B,G) = softmax_G(logit / t) * library_size, theta (B,G) = exp(theta_emb[genes]). */
-/* precision: SCLDM_PREC_FP32 = exact-fp32 MFMA chain (parity path); SCLDM_PREC_BF16 = bf16 operands for the per-gene
- * MCAB / SwiGLU contractions (fp32 accumulate, softmax, LayerNorm, logits), about 3x the decode rate. */
+/* precision (encode, decode, decode_sample): SCLDM_PREC_FP32 = exact-fp32 MFMA chain (parity path, <= 1e-4);
+ * SCLDM_PREC_FP16 = fp16 operands for the per-gene MCAB / SwiGLU contractions (10 mantissa bits = TF32, the arithmetic class the
+ * reference runs CrossAttention / MLP in under set_float32_matmul_precision("high"): experiments/scripts/inference.py:26,
+ * src/scldm/layers.py:248-264,305-330), fp32 accumulate / softmax / LayerNorm / NB head, operands saturated at +-65 504;
+ * SCLDM_PREC_BF16 = the same with bf16 operands (8 bits: narrower than the reference).  Both 16-bit policies run about 3x the fp32
+ * decode rate; the 16-token cell trunks stay exact fp32 in every policy.  Other values: SCLDM_ERR_SHAPE. */
 int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
                      float* theta, int precision, void* ws, void* stream);
 
@@ -403,6 +407,21 @@ int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const f
  * reproducible for a given (seed, B, G), independent of the launch geometry.  RNG-dependent: outside the bit-parity claim. */
 int scldm_vae_decode_sample(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G,
                             float* counts, unsigned long long seed, int precision, void* ws, void* stream);
+
+/* Measurement hook for bench.py (the MCAB counterpart of scldm_dit_block_timing): when enabled, every launch of an MCAB kernel by
+ * scldm_vae_encode / _decode / _decode_sample is bracketed by HIP events on the stream it is launched on (up to 64 launches per
+ * kernel kind, later ones are not recorded); scldm_vae_kernel_timing drains one kind (synchronises on its events) and returns the
+ * number of recorded launches and their summed duration. */
+enum {
+  SCLDM_VAE_K_ENC_POOL = 0,   /* enc_pool_kernel: MCAB pooling over the S input genes of a cell */
+  SCLDM_VAE_K_ENC_CELL = 1,   /* enc_cell_kernel: c_proj + MLP + 16-token trunk + latent head */
+  SCLDM_VAE_K_DEC_CELL = 2,   /* dec_cell_kernel: latent input + 16-token trunk + K | V of the unpooling */
+  SCLDM_VAE_K_DEC_GENE = 3,   /* dec_gene_kernel: MCAB unpooling + SwiGLU + NB-head logit per decoded gene */
+  SCLDM_VAE_K_DEC_FINAL = 4   /* dec_finalize(_sample)_kernel: softmax over genes x library size (+ the NB draw) */
+};
+#define SCLDM_VAE_KERNEL_KINDS 5
+void scldm_vae_kernel_timing_enable(scldm_vae* h, int enable);
+int scldm_vae_kernel_timing(scldm_vae* h, int kind, int* n_launches, double* total_ms);
 
 /* The same draw from explicit parameter tensors: out[i] ~ NB(mu[i], theta[i]), i < n  (NegativeBinomial(mu, theta).sample()). */
 int scldm_nb_sample(const float* mu, const float* theta, float* out, size_t n, unsigned long long seed, void* stream);

@@ -10,7 +10,7 @@ from dataclasses import dataclass
 
 import torch
 
-from .dit import layer_norm, linear, mlp, silu  # noqa: F401
+from .dit import layer_norm, linear, matmul, mlp, silu  # noqa: F401
 
 
 @dataclass
@@ -44,9 +44,11 @@ def cross_attention(sd: dict, prefix: str, x: torch.Tensor, q: torch.Tensor, n_h
     k = k.view(B, S, n_head, hd).transpose(1, 2)
     v = v.view(B, S, n_head, hd).transpose(1, 2)
     qq = qq.view(B, M, n_head, hd).transpose(1, 2)
-    s = (qq @ k.transpose(-1, -2)) / math.sqrt(hd)
+    # (through dit.matmul: under `matmul_operand_bits(10)` both attention products round their operands like every Linear - the
+    # reference's TF32 arithmetic class, experiments/scripts/inference.py:26; exact otherwise)
+    s = matmul(qq, k.transpose(-1, -2)) / math.sqrt(hd)
     p = torch.softmax(s, dim=-1)
-    y = (p @ v).transpose(1, 2).reshape(B, M, D)
+    y = matmul(p, v).transpose(1, 2).reshape(B, M, D)
     return linear(y, sd[f"{prefix}.c_proj.weight"], sd.get(f"{prefix}.c_proj.bias"))
 
 

@@ -18,6 +18,7 @@
 #pragma once
 #include "common.hpp"
 #include "nb_sample.hpp"
+#include <type_traits>
 
 namespace scldm {
 
@@ -31,6 +32,41 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// Operand policy of the per-gene contractions (common.hpp): OpF32 = the exact chain; OpBF16 / OpFP16 = 16-bit operands, fp32
+// accumulate.  OpFP16 carries TF32's 10 mantissa bits - the arithmetic class the reference runs MCAB in
+// (torch.set_float32_matmul_precision("high"): experiments/scripts/inference.py:26, train.py:18) - at the bf16 MFMA rate.
+// What fp16 gives up against TF32 is exponent range.  Weights and the per-cell K / V fragments are converted once per workgroup
+// and SATURATE at +-65 504 (mcab_pack8_sat); the per-tile activation operands (LayerNorm outputs, softmax probabilities, attention
+// outputs, SwiGLU products of O(1) pre-activations) are converted with one v_cvt_pk_f16_f32 per pair and no clamp - both 16-bit
+// kernels are VALU-bound (profiles/r6_mcab_*: VALU ~96 % busy, matrix pipe 14-18 %), and a v_med3 per element was 13 % of the
+// instruction stream; the DiT's fp16 policy makes the same choice.
+// log1p for the 16-bit operand policies: log(u) c / (u - 1) with u = fl(1 + c) compensates the rounding of 1 + c (the classic
+// HP-15C form), so it is accurate to a few ulp for every c >= 0 - v_log_f32 + v_rcp_f32 + 6 VALU against the ~120 instructions of
+// libm's double-float log1pf, which was a quarter of the VALU-bound pooling kernel's instruction stream (profiles/r6_mcab_*).
+// The exact-fp32 policy keeps log1pf (parity path; that kernel is matrix-pipe-bound).
+__device__ __forceinline__ float log1p_fast(float c) {
+  const float u = 1.0f + c, d = u - 1.0f;
+  const float l = __builtin_amdgcn_logf(u) * 0.6931471805599453f;     // v_log_f32 is log2
+  return d == 0.f ? c : l * (c * __builtin_amdgcn_rcpf(d));
+}
+
+template <class OP> struct McabOp { static constexpr bool k16 = true; using Frag = typename OP::Frag; };
+template <> struct McabOp<OpF32> { static constexpr bool k16 = false; using Frag = bf16x8; };
+template <class OP> __device__ __forceinline__ typename McabOp<OP>::Frag mcab_pack8(const float* v) {
+  if constexpr (std::is_same<OP, OpFP16>::value) return OpFP16::pack8(v);
+  else return OpBF16::pack8(v);
+}
+template <class OP> __device__ __forceinline__ typename McabOp<OP>::Frag mcab_pack8_sat(const float* v) {
+  if constexpr (std::is_same<OP, OpFP16>::value) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_fmed3f(v[i], -65504.f, 65504.f);
+    return OpFP16::pack8(t);
+  } else {
+    return OpBF16::pack8(v);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Fragment packing (run once per weight load).  A "weight fragment" of step j holds, for lane l,
@@ -593,35 +629,43 @@ struct DecGeneArgs {
 #endif
 constexpr int kDecWaves = SCLDM_DEC_WAVES;
 constexpr int kDecThreads = 64 * kDecWaves;
-template <bool BF>
+template <class OP>
 #ifndef SCLDM_DEC_UNROLL
 #define SCLDM_DEC_UNROLL 1   // the six SwiGLU tiles of a gene tile unrolled: the next tile's up-projection MFMAs issue under this tile's SiLU (+2 % fp32 decode)
 #endif
 #ifndef SCLDM_DEC_MINW
 #define SCLDM_DEC_MINW 4
 #endif
-__global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 : 1) : SCLDM_DEC_MINW) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
+__global__ __launch_bounds__(kDecThreads, McabOp<OP>::k16 ? (kDecWaves >= 8 ? kDecWaves / 2 : 1) : SCLDM_DEC_MINW) void dec_gene_kernel(const DecGeneArgs a) {   // two workgroups per CU
+  constexpr bool BF = McabOp<OP>::k16;
+  using H8 = typename McabOp<OP>::Frag;
   constexpr int kWF4 = BF ? 1 : 40 * 64, kKV4 = BF ? 1 : kNI * 16, kWF8 = BF ? 20 * 64 : 1, kKV8 = BF ? 6 * 64 : 1;
   __shared__ f32x4 WF[kWF4];    // fp32: 160 weight fragments, 4 steps per float4 (the 16 c_proj ones in lane-half k order)
   __shared__ f32x4 KVP[kKV4];   // fp32: this cell's K | V, plain [key][64 floats]
-  __shared__ bf16x8 WFh[kWF8];  // bf16: the 160 fragments, 8 steps per 16-byte fragment
-  __shared__ bf16x8 KVh[kKV8];  // bf16: this cell's 48 K/V fragments
+  __shared__ H8 WFh[kWF8];  // 16-bit operands: the 160 fragments, 8 steps per 16-byte fragment
+  __shared__ H8 KVh[kKV8];  // 16-bit operands: this cell's 48 K/V fragments
   __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
   __shared__ float RED[kDecWaves][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hh = lane >> 5;
   const int cell = blockIdx.y, chunk = blockIdx.x;
   if constexpr (BF) {
-    auto cvt = [&](const float* src, bf16x8* dst, int nfrag8) {
+    // (the conversion also folds constants the VALU-bound chain would otherwise multiply by per element: the K fragments carry
+    // log2(e), so the softmax is exp2(s - m); the SwiGLU up-projection rows carry -log2(e) (w1 units, tile rows 0-15) and
+    // -1 / log2(e) (w2 units, rows 16-31), so silu(a) b = a' b' / (1 + 2^a') - the DiT kernel's form, common.hpp kW1Scale)
+    auto cvt = [&](const float* src, H8* dst, int nfrag8, auto scale_of) {
       for (int i = tid; i < nfrag8 * 64; i += kDecThreads) {
         const int f = i >> 6, l = i & 63;
         const f32x4 lo = reinterpret_cast<const f32x4*>(src)[(2 * f) * 64 + l], hi = reinterpret_cast<const f32x4*>(src)[(2 * f + 1) * 64 + l];
-        float t[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        dst[i] = OpBF16::pack8(t);
+        const float sc = scale_of(f, l);
+        float t[8] = {lo[0] * sc, lo[1] * sc, lo[2] * sc, lo[3] * sc, hi[0] * sc, hi[1] * sc, hi[2] * sc, hi[3] * sc};
+        dst[i] = mcab_pack8_sat<OP>(t);
       }
     };
-    cvt(a.wfrag, WFh, 20);
-    cvt(a.kvfrag + (size_t)cell * 48 * 64, KVh, 6);
+    // weight fragments of 8 steps: 0-1 c_proj | 2-13 w12 (six tiles x two) | 14-19 wc
+    cvt(a.wfrag, WFh, 20, [](int f, int l) { return (f >= 2 && f < 14) ? ((l & 31) < 16 ? -1.4426950408889634f : -0.6931471805599453f) : 1.0f; });
+    // K / V fragments of 8 steps: 0-1 K | 2-5 V
+    cvt(a.kvfrag + (size_t)cell * 48 * 64, KVh, 6, [](int f, int) { return f < 2 ? 1.4426950408889634f : 1.0f; });
   } else {
     for (int i = tid; i < 40 * 64; i += kDecThreads)
       WF[i] = i < 4 * 64 ? reinterpret_cast<const f32x4*>(a.wfrag_cproj_halves)[i] : reinterpret_cast<const f32x4*>(a.wfrag)[i];
@@ -630,9 +674,9 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
   if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
   __syncthreads();
   // acc += F[steps step0 .. step0+7] (A operand, from LDS) x x[0..7] (B operand, accumulator-order registers)
-  auto mm8 = [&](const f32x4* F4, const bf16x8* F8, int step0, const float* x, f32x16 acc) {
+  auto mm8 = [&](const f32x4* F4, const H8* F8, int step0, const float* x, f32x16 acc) {
     if constexpr (BF) {
-      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(F8[(step0 >> 3) * 64 + lane], OpBF16::pack8(x), acc, 0, 0, 0);
+      return OP::mma(F8[(step0 >> 3) * 64 + lane], mcab_pack8<OP>(x), acc);
     } else {
 #pragma unroll
       for (int g4 = 0; g4 < 2; ++g4) {
@@ -670,6 +714,7 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
         st[t] = mm8(nullptr, KVh, 8 * t, q + 8 * t, zero16());
       }
       // softmax over the 16 keys of each head: 8 keys in-lane (registers 8hl..8hl+7) + 8 in the other half-wave
+      float inv_h[4];
   #pragma unroll
       for (int t = 0; t < 2; ++t)
   #pragma unroll
@@ -681,14 +726,13 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
           float sum = 0.f;
   #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const float p = __expf(st[t][8 * hl + i] - m);
+            const float p = __builtin_amdgcn_exp2f(st[t][8 * hl + i] - m);   // scores are in log2 units (K carries log2 e)
             st[t][8 * hl + i] = p;
             sum += p;
           }
-          sum = xor32_sum(sum);
-          const float inv = __builtin_amdgcn_rcpf(sum);   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
-  #pragma unroll
-          for (int i = 0; i < 8; ++i) st[t][8 * hl + i] *= inv;
+          // P stays un-normalised (in (0, 1]: the same relative operand precision); 1 / sum scales this head's 8 output features
+          // after P V - 16 multiplies per lane instead of 32
+          inv_h[2 * t + hl] = __builtin_amdgcn_rcpf(xor32_sum(sum));   // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division
         }
       // O^T[f][gene] = Vblk^T P^T
       f32x16 ot = zero16();
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
       {
         float ov[16];
   #pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = ot[r];
+        for (int r = 0; r < 16; ++r) ov[r] = ot[r] * inv_h[r >> 2];   // register r <-> feature acc_row(r, hh) = 8 (r >> 2) + ...: head r >> 2
         yt = mm8(WF, WFh, 0, ov, yt);
         yt = mm8(WF, WFh, 8, ov + 8, yt);
       }
@@ -782,10 +826,19 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
     for (int r = 0; r < 16; ++r) { const float d = y[r] - mean; ss += d * d; }
     const float rstd = __builtin_amdgcn_rsqf(xor32_sum(ss) * (1.0f / kE) + a.eps);
     float yn[16];
+    if constexpr (BF) {
+      const float nmr = -mean * rstd;     // (y - mean) rstd as one fma, then the affine fma
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = acc_row(r, hh);
-      yn[r] = (y[r] - mean) * rstd * VEC[f] + VEC[kE + f];
+      for (int r = 0; r < 16; ++r) {
+        const int f = acc_row(r, hh);
+        yn[r] = fmaf(fmaf(y[r], rstd, nmr), VEC[f], VEC[kE + f]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = acc_row(r, hh);
+        yn[r] = (y[r] - mean) * rstd * VEC[f] + VEC[kE + f];
+      }
     }
     // SwiGLU: six tiles of 16 hidden units, each consumed by the down-projection as soon as it exists
     f32x16 mo = zero16();
@@ -799,7 +852,10 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
       ht = mm8(WF, WFh, 16 + 16 * u + 8, yn + 8, ht);
       float hv[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];   // x * v_rcp(1 + v_exp(-x)): 4 VALU ops, not ~15
+      for (int r = 0; r < 8; ++r) {
+        if constexpr (BF) hv[r] = OP::swiglu(ht[r], ht[r + 8]);   // pre-scaled rows: a' b' / (1 + 2^a')
+        else hv[r] = silu_f(ht[r]) * ht[r + 8];                   // x * v_rcp(1 + v_exp(-x)): 4 VALU ops, not ~15
+      }
       mo = mm8(WF, WFh, 16 + 16 * kHTiles + 8 * u, hv, mo);
     }
     // NB head: logit = w . (y + mlp) + b
@@ -840,27 +896,51 @@ __global__ __launch_bounds__(kDecThreads, BF ? (kDecWaves >= 8 ? kDecWaves / 2 :
   }
 }
 
-// mu = softmax_G(logit) * library_size  (stochastic_layers.py:115)
+// Merge of a cell's per-chunk (max, sum exp) partials, by every wave on its own (lane = chunk, then a butterfly): no LDS, no barrier.
+// Round 5 had thread 0 of every 1 024-element workgroup walk the chunks serially (17-28 dependent expf) in front of a barrier:
+// the HBM-bound normalisation pass ran at 2.6 TB/s (profiles/r6a_mcab_decode_*: 0.42 ms for 8 192 x 17 002).
+__device__ __forceinline__ void dec_merge_partials(const float* __restrict__ part, int cell, int n_chunks, float& M, float& S) {
+  const int lane = threadIdx.x & 63;
+  float m = -3.0e38f, s = 0.f;
+  for (int c = lane; c < n_chunks; c += 64) {
+    const float pm = part[((size_t)cell * n_chunks + c) * 2], ps = part[((size_t)cell * n_chunks + c) * 2 + 1];
+    const float nm = fmaxf(m, pm);
+    s = s * expf(m - nm) + ps * expf(pm - nm);
+    m = nm;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
+    const float nm = fmaxf(m, om);
+    s = s * expf(m - nm) + os * expf(om - nm);      // (commutative up to the order of one add: both partners form the same two products)
+    m = nm;
+  }
+  M = m;
+  S = s;
+}
+
+// mu = softmax_G(logit) * library_size  (stochastic_layers.py:115), in place.  16-byte accesses on the 16-byte-aligned body of the
+// row (rows start at cell * G floats: any alignment), the 0-3 leading and trailing elements by workgroup 0.
 __global__ __launch_bounds__(256) void dec_finalize_kernel(float* __restrict__ mu, const float* __restrict__ part,
                                                            const float* __restrict__ library, int G, int n_chunks) {
-  __shared__ float MS[2];
   const int cell = blockIdx.y;
-  if (threadIdx.x == 0) {
-    float M = -3.0e38f, S = 0.f;
-    for (int c = 0; c < n_chunks; ++c) {
-      const float m = part[((size_t)cell * n_chunks + c) * 2], s = part[((size_t)cell * n_chunks + c) * 2 + 1];
-      const float nm = fmaxf(M, m);
-      S = S * expf(M - nm) + s * expf(m - nm);
-      M = nm;
-    }
-    MS[0] = M;
-    MS[1] = library[cell] / S;
+  float M, S;
+  dec_merge_partials(part, cell, n_chunks, M, S);
+  const float scale = library[cell] / S;
+  float* row = mu + (size_t)cell * G;
+  const int head = min(G, (int)((4 - ((reinterpret_cast<size_t>(row) >> 2) & 3)) & 3));
+  const int nvec = (G - head) >> 2;
+  f32x4* v = reinterpret_cast<f32x4*>(row + head);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+    f32x4 x = v[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = expf(x[e] - M) * scale;
+    v[i] = x;
   }
-  __syncthreads();
-  const float M = MS[0], scale = MS[1];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < G; i += gridDim.x * 256) {
-    float* p = mu + (size_t)cell * G + i;
-    *p = expf(*p - M) * scale;
+  if (blockIdx.x == 0) {
+    const int t = threadIdx.x, tail0 = head + 4 * nvec;
+    if (t < head) row[t] = expf(row[t] - M) * scale;
+    if (tail0 + t < G) row[tail0 + t] = expf(row[tail0 + t] - M) * scale;
   }
 }
 
@@ -870,21 +950,10 @@ __global__ __launch_bounds__(256) void dec_finalize_sample_kernel(float* __restr
                                                                   const float* __restrict__ library, const int64_t* __restrict__ genes,
                                                                   const float* __restrict__ theta_emb, int G, int n_chunks,
                                                                   unsigned long long seed) {
-  __shared__ float MS[2];
   const int cell = blockIdx.y;
-  if (threadIdx.x == 0) {
-    float M = -3.0e38f, S = 0.f;
-    for (int c = 0; c < n_chunks; ++c) {
-      const float m = part[((size_t)cell * n_chunks + c) * 2], s = part[((size_t)cell * n_chunks + c) * 2 + 1];
-      const float nm = fmaxf(M, m);
-      S = S * expf(M - nm) + s * expf(m - nm);
-      M = nm;
-    }
-    MS[0] = M;
-    MS[1] = library[cell] / S;
-  }
-  __syncthreads();
-  const float M = MS[0], scale = MS[1];
+  float M, S;
+  dec_merge_partials(part, cell, n_chunks, M, S);
+  const float scale = library[cell] / S;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < G; i += gridDim.x * 256) {
     const size_t e = (size_t)cell * G + i;
     const float mu = expf(out[e] - M) * scale;
@@ -934,8 +1003,10 @@ struct EncPoolArgs {
 // 1.33 rounds of the chip's 768 slots - the second round a third full.  Six waves per cell (two cells per CU, 512 slots) make it two
 // full rounds of cells that each finish in 4/6 of the time; the gene tiles are dealt round-robin over the waves and merged in wave
 // order at the end, so NW changes the summation order of the online softmax merge (not its value beyond fp32 rounding).
-template <bool BF, int NW = 4>
-__global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(const EncPoolArgs a) {
+template <class OP, int NW = 4>
+__global__ __launch_bounds__(64 * NW, McabOp<OP>::k16 ? SCLDM_ENC_MINW : 2) void enc_pool_kernel(const EncPoolArgs a) {
+  constexpr bool BF = McabOp<OP>::k16;
+  using H8 = typename McabOp<OP>::Frag;
   __shared__ f32x4 KF[4 * 64], VF[4 * 64], QF[4 * 64];
   __shared__ float VEC[2 * kE];
   __shared__ float MRG[NW][2][64][18];  // per wave, per column tile, per lane: m, l, O[16]
@@ -954,12 +1025,12 @@ __global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_ker
   const int n_tiles = (a.S + 31) / 32;
   // bf16 operands: the weight / query fragments are the same for every tile - packed once (eight consecutive fp32 steps = the
   // 16 k-values of one bf16 MFMA in the same order: fragment of steps [s0, s0+8))
-  bf16x8 kf16[2], vf16[2], qf16[2];
+  H8 kf16[2], vf16[2], qf16[2];
   if constexpr (BF) {
     auto frag8 = [&](const f32x4* F, int s0) {
       const f32x4 lo = F[(s0 >> 2) * 64 + lane], hi = F[((s0 >> 2) + 1) * 64 + lane];
       float t8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      return OpBF16::pack8(t8);
+      return mcab_pack8_sat<OP>(t8);
     };
 #pragma unroll
     for (int h8 = 0; h8 < 2; ++h8) { kf16[h8] = frag8(KF, 8 * h8); vf16[h8] = frag8(VF, 8 * h8); qf16[h8] = frag8(QF, 8 * h8); }
@@ -1002,7 +1073,7 @@ __global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_ker
       c_nxt = c_n2;
     } else {
       const long long g = a.genes[idx_of(tile)];
-      const float lc = valid ? log1pf(a.counts[idx_of(tile)]) : 0.f;
+      const float lc = valid ? log1p_fast(a.counts[idx_of(tile)]) : 0.f;    // (this branch is the 16-bit policies')
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const f32x4 e4 = *reinterpret_cast<const f32x4*>(a.emb + (size_t)g * kE + qd * 8 + hh * 4);
@@ -1021,9 +1092,9 @@ __global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_ker
     if constexpr (BF) {
 #pragma unroll
       for (int h8 = 0; h8 < 2; ++h8) {
-        const bf16x8 xf = OpBF16::pack8(x + 8 * h8);
-        kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf16[h8], xf, kt, 0, 0, 0);   // K^T[feature][gene]
-        vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, vf16[h8], vt, 0, 0, 0);   // V[gene][d]
+        const H8 xf = mcab_pack8<OP>(x + 8 * h8);
+        kt = OP::mma(kf16[h8], xf, kt);   // K^T[feature][gene]
+        vt = OP::mma(xf, vf16[h8], vt);   // V[gene][d]
       }
     } else {
 #pragma unroll
@@ -1043,7 +1114,7 @@ __global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_ker
     for (int t = 0; t < 2; ++t) {
       f32x16 sc = zero16();
       if constexpr (BF) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(ktv + 8 * t), qf16[t], sc, 0, 0, 0);  // S[gene][(hl, q)]
+        sc = OP::mma(mcab_pack8<OP>(ktv + 8 * t), qf16[t], sc);  // S[gene][(hl, q)]
       } else {
 #pragma unroll
         for (int g4 = 0; g4 < 2; ++g4) {
@@ -1074,8 +1145,8 @@ __global__ __launch_bounds__(64 * NW, BF ? SCLDM_ENC_MINW : 2) void enc_pool_ker
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) pv[r] = sc[r];
-        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(vtv), OpBF16::pack8(pv), O[t], 0, 0, 0);
-        O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(OpBF16::pack8(vtv + 8), OpBF16::pack8(pv + 8), O[t], 0, 0, 0);
+        O[t] = OP::mma(mcab_pack8<OP>(vtv), mcab_pack8<OP>(pv), O[t]);
+        O[t] = OP::mma(mcab_pack8<OP>(vtv + 8), mcab_pack8<OP>(pv + 8), O[t]);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t] = mfma2(vt[r], sc[r], O[t]);  // O^T[d][(hl, q)] += V^T P

@@ -99,10 +99,10 @@ extern "C" int scldm_adamw_step(const scldm_adamw_entry* e, int count, float* st
   if (!e || count < 1 || !step) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_step: bad argument");
   hipStream_t st = (hipStream_t)stream_;
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step, found_inf);
-  for (int i0 = 0; i0 < count; i0 += kMaxTensors) {
+  for (int i0 = 0, i = 0; i0 < count; i0 = i) {   // (i0 = the first entry this launch has not consumed: empty tensors are skipped, never re-visited)
     AdamArgs a{};
     int blocks = 0, k = 0;
-    for (int i = i0; i < count && k < kMaxTensors; ++i) {
+    for (i = i0; i < count && k < kMaxTensors; ++i) {
       if (e[i].n <= 0) continue;
       if (!e[i].p || !e[i].g || !e[i].m || !e[i].v) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_step: tensor %d has a NULL pointer", i);
       if (e[i].n > 0x7fffffffLL) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_step: tensor %d has more than 2^31 elements", i);

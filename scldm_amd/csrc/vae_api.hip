@@ -78,7 +78,51 @@ extern "C" void scldm_vae_destroy(scldm_vae* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   for (hipEvent_t e : {h->ev_fork, h->ev_gene, h->ev_join})
     if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < SCLDM_VAE_KERNEL_KINDS; ++k)
+    for (int i = 0; i < h->tev_made[k]; ++i) (void)hipEventDestroy(h->tev[k][i]);
   delete h;
+}
+
+// ---- measurement hook: event pairs around the MCAB kernel launches (include/scldm_hip.h) -------------------------------------------
+namespace {
+struct KernelTimer {   // records on construction and destruction when the handle's hook is on and there is room
+  scldm_vae* h; int kind; hipStream_t st; bool on;
+  KernelTimer(scldm_vae* h_, int kind_, hipStream_t st_) : h(h_), kind(kind_), st(st_), on(false) {
+    if (!h->timing || h->tev_used[kind] + 2 > 2 * 64) return;
+    while (h->tev_made[kind] < h->tev_used[kind] + 2) {
+      if (hipEventCreate(&h->tev[kind][h->tev_made[kind]]) != hipSuccess) return;
+      ++h->tev_made[kind];
+    }
+    on = hipEventRecord(h->tev[kind][h->tev_used[kind]], st) == hipSuccess;
+  }
+  ~KernelTimer() {
+    if (!on) return;
+    (void)hipEventRecord(h->tev[kind][h->tev_used[kind] + 1], st);
+    h->tev_used[kind] += 2;
+  }
+};
+}  // namespace
+
+extern "C" void scldm_vae_kernel_timing_enable(scldm_vae* h, int enable) {
+  if (!h) return;
+  h->timing = enable != 0;
+  for (int k = 0; k < SCLDM_VAE_KERNEL_KINDS; ++k) h->tev_used[k] = 0;
+}
+extern "C" int scldm_vae_kernel_timing(scldm_vae* h, int kind, int* n_launches, double* total_ms) {
+  if (!h || kind < 0 || kind >= SCLDM_VAE_KERNEL_KINDS) return fail(SCLDM_ERR_SHAPE, "scldm_vae_kernel_timing: bad argument");
+  double tot = 0;
+  int n = 0;
+  for (int i = 0; i + 1 < h->tev_used[kind]; i += 2) {
+    HIP_TRY(hipEventSynchronize(h->tev[kind][i + 1]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, h->tev[kind][i], h->tev[kind][i + 1]));
+    tot += ms;
+    ++n;
+  }
+  if (n_launches) *n_launches = n;
+  if (total_ms) *total_ms = tot;
+  h->tev_used[kind] = 0;
+  return SCLDM_OK;
 }
 
 // ---- weight (re-)packing: one job table, one launch (mcab.hpp: vae_pack_jobs_kernel) -------------------------------------------
@@ -223,7 +267,8 @@ int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes,
                         float* lse2, hipStream_t st) {
   int rc = vae_ready(h);
   if (rc) return rc;
-  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16)
+    return fail(SCLDM_ERR_SHAPE, "unsupported MCAB precision %d (fp32, bf16, fp16)", precision);
   if (B <= 0 || S <= 0 || !counts || !genes || !z || !pooled) return fail(SCLDM_ERR_SHAPE, "bad argument");
   const scldm_vae_config& c = h->cfg;
   EncPoolArgs p;
@@ -232,11 +277,18 @@ int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes,
   p.kfrag = h->frag_enc_k; p.vfrag = h->frag_enc_v; p.qfrag = h->frag_enc_q;
   p.pooled = pooled; p.lse2 = lse2; p.S = S; p.eps = c.layernorm_eps;
   static const int enc_nw = getenv("SCLDM_ENC_WAVES") ? atoi(getenv("SCLDM_ENC_WAVES")) : 4;   // waves per cell of the bf16-operand pooling kernel (A/B: 4 | 6 | 8)
+  {
+  KernelTimer kt(h, SCLDM_VAE_K_ENC_POOL, st);
   if (precision == SCLDM_PREC_BF16) {
-    if (enc_nw == 6) enc_pool_kernel<true, 6><<<B, 384, 0, st>>>(p);
-    else if (enc_nw == 8) enc_pool_kernel<true, 8><<<B, 512, 0, st>>>(p);
-    else enc_pool_kernel<true><<<B, 256, 0, st>>>(p);
-  } else enc_pool_kernel<false><<<B, 256, 0, st>>>(p);
+    if (enc_nw == 6) enc_pool_kernel<OpBF16, 6><<<B, 384, 0, st>>>(p);
+    else if (enc_nw == 8) enc_pool_kernel<OpBF16, 8><<<B, 512, 0, st>>>(p);
+    else enc_pool_kernel<OpBF16><<<B, 256, 0, st>>>(p);
+  } else if (precision == SCLDM_PREC_FP16) {   // TF32's mantissa: the reference's own arithmetic class for MCAB
+    if (enc_nw == 6) enc_pool_kernel<OpFP16, 6><<<B, 384, 0, st>>>(p);
+    else if (enc_nw == 8) enc_pool_kernel<OpFP16, 8><<<B, 512, 0, st>>>(p);
+    else enc_pool_kernel<OpFP16><<<B, 256, 0, st>>>(p);
+  } else enc_pool_kernel<OpF32><<<B, 256, 0, st>>>(p);
+  }
   LAUNCH_CHECK();
   EncCellArgs e;
   e.pooled = pooled; e.ind = h->small + S_ENC_IND; e.proj_frag = h->frag_cell + F_ENC_PROJ;
@@ -245,7 +297,7 @@ int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes,
   e.pos = c.positional_encoding ? h->small + S_ENC_POS : nullptr;
   e.trunk = h->enc_trunk; e.lat_frag = h->frag_cell + F_ENC_LAT; e.z = z;
   e.B = B; e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.eps = c.layernorm_eps;
-  enc_cell_kernel<<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
+  { KernelTimer kt(h, SCLDM_VAE_K_ENC_CELL, st); enc_cell_kernel<<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e); }
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -261,7 +313,8 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
                            float* theta, bool draw, unsigned long long seed, int precision, void* ws_, void* stream_) {
   int rc = vae_ready(h);
   if (rc) return rc;
-  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16) return fail(SCLDM_ERR_SHAPE, "unknown precision %d", precision);
+  if (precision != SCLDM_PREC_FP32 && precision != SCLDM_PREC_BF16 && precision != SCLDM_PREC_FP16)
+    return fail(SCLDM_ERR_SHAPE, "unsupported MCAB precision %d (fp32, bf16, fp16)", precision);
   if (B <= 0 || G <= 0 || !z || !genes || !library_size || !mu || (!theta && !draw) || !ws_) return fail(SCLDM_ERR_SHAPE, "bad argument");
   hipStream_t st = (hipStream_t)stream_;
   const scldm_vae_config& c = h->cfg;
@@ -271,8 +324,11 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   d.z = z; d.lat_frag = h->frag_cell + F_DEC_LAT; d.trunk = h->dec_trunk;
   d.ca_ln1_w = h->small + S_DEC_LN1W; d.ca_ln1_b = h->small + S_DEC_LN1B; d.kv_frag = h->frag_cell + F_DEC_KV;
   d.kvfrag = kv; d.B = B; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.eps = c.layernorm_eps;
-  if (precision == SCLDM_PREC_BF16) dec_cell_kernel<false><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
-  else dec_cell_kernel<true><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+  {
+    KernelTimer kt(h, SCLDM_VAE_K_DEC_CELL, st);
+    if (precision != SCLDM_PREC_FP32) dec_cell_kernel<false><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+    else dec_cell_kernel<true><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+  }
   LAUNCH_CHECK();
   const int nch = dec_chunks(G);
   DecGeneArgs g;
@@ -280,11 +336,18 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
   g.logits = mu; g.theta = draw ? nullptr : theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
   g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
-  if (precision == SCLDM_PREC_BF16) dec_gene_kernel<true><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
-  else dec_gene_kernel<false><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
+  {
+    KernelTimer kt(h, SCLDM_VAE_K_DEC_GENE, st);
+    if (precision == SCLDM_PREC_BF16) dec_gene_kernel<OpBF16><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
+    else if (precision == SCLDM_PREC_FP16) dec_gene_kernel<OpFP16><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
+    else dec_gene_kernel<OpF32><<<dim3(nch, B), kDecThreads, 0, st>>>(g);
+  }
   LAUNCH_CHECK();
-  if (draw) dec_finalize_sample_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, genes, h->theta, G, nch, seed);
-  else dec_finalize_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, G, nch);
+  {
+    KernelTimer kt(h, SCLDM_VAE_K_DEC_FINAL, st);
+    if (draw) dec_finalize_sample_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, genes, h->theta, G, nch, seed);
+    else dec_finalize_kernel<<<dim3(cdiv(G, 256 * 16), B), 256, 0, st>>>(mu, part, library_size, G, nch);   // four 16-byte groups per thread
+  }
   LAUNCH_CHECK();
   return SCLDM_OK;
 }

@@ -33,6 +33,10 @@ struct scldm_vae {
   // beside the per-gene backward (created on first use by scldm_vae_train_backward)
   hipStream_t side;
   hipEvent_t ev_fork, ev_gene, ev_join;
+  // measurement hook (scldm_vae_kernel_timing_enable): HIP event pairs around each MCAB kernel launch, per kernel kind
+  bool timing;
+  hipEvent_t tev[SCLDM_VAE_KERNEL_KINDS][2 * 64];
+  int tev_made[SCLDM_VAE_KERNEL_KINDS], tev_used[SCLDM_VAE_KERNEL_KINDS];
 };
 
 // vae_api.hip internals used by the training entry points: TransformerVAE.encode that also leaves the pooling's attention output

@@ -303,7 +303,12 @@ class DiT(nn.Module):
         flag = self.__dict__.get("_found_inf")
         if flag is None or flag.device != self.pos_embed.device:
             flag = self.__dict__["_found_inf"] = torch.zeros((), dtype=torch.float32, device=self.pos_embed.device)
+            self.__dict__["_found_inf_handle"] = None
+        if self.__dict__.get("_found_inf_handle") != h.value:
+            # (re-)register with THIS handle: a copy / unpickled module, or a handle re-created after .to(device), starts with none
+            # (a stale cached flag left the copy's overflow guard silently off)
             _lib.check(L.scldm_dit_train_set_found_inf(h, flag.data_ptr()), "scldm_dit_train_set_found_inf")
+            self.__dict__["_found_inf_handle"] = h.value
         return flag
 
     def fp16_train_state(self) -> dict:
@@ -377,7 +382,7 @@ class DiT(nn.Module):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
         for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_grad_segs", "_pos_idx", "_param_list", "_prepared_key", "_grad_sync",
-                  "_train_step_sync", "_fp16_checked"):
+                  "_train_step_sync", "_fp16_checked", "_found_inf", "_found_inf_handle"):   # (_found_inf is registered with the handle that does not travel)
             state.pop(k, None)
         return state
 

@@ -54,9 +54,12 @@ class AdamW(torch.optim.Optimizer):
                     torch.as_tensor(float(prev), dtype=torch.float32, device=dev).clone()
             # the pointer table is rebuilt only when a parameter, gradient or state tensor moved (the HIP backward's flat gradient buffer
             # usually comes back at the same address every step): one pass of data_ptr() calls instead of 84 x the full checks
-            key = (len(ps), sum(p.data_ptr() ^ (p.grad.data_ptr() << 1) for p in ps))
+            # (an exact, order-sensitive key: a checksum can collide when the allocator hands equal-sized blocks back in another order)
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
             cached = group.get("_table")
-            if cached is not None and cached[0] == key:
+            if cached is not None and cached[0] == key and all(
+                    self.state[p]["exp_avg"].data_ptr() == cached[2][i][0] and self.state[p]["exp_avg_sq"].data_ptr() == cached[2][i][1]
+                    for i, p in enumerate(ps)):
                 ent = cached[1]
                 ps_build = ()
             else:
@@ -79,7 +82,8 @@ class AdamW(torch.optim.Optimizer):
                 ent[i].p, ent[i].g, ent[i].m, ent[i].v, ent[i].n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
                 keep.append(g)
             if ps_build:
-                group["_table"] = (key, ent) if key is not None else None
+                group["_table"] = (key, ent, [(self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps]) \
+                    if key is not None else None
             lr = float(group["lr"])
             b1, b2 = group["betas"]
             with torch.cuda.device(dev):

@@ -95,7 +95,10 @@ class TransformerVAE(nn.Module):
         self.decoder_head = decoder_head
         self.input_layer = input_layer
         self._handle = None
-        self.precision = "fp32"   # "bf16" = bf16 operands for the per-gene contractions of encode / decode (fp32 everything else)
+        # operand policy of the per-gene contractions of encode / decode / decode_sample (the cell trunks, LayerNorms, softmax and
+        # the NB head are fp32 in every policy): "fp32" = exact (parity path); "fp16" = TF32's mantissa, the arithmetic class the
+        # reference itself runs MCAB in (set_float32_matmul_precision("high"), experiments/scripts/inference.py:26); "bf16" = 8 bits
+        self.precision = "fp32"
         self._weights_key = None
         self._weights_fp = None
         self.check_weight_fingerprint = True
@@ -193,6 +196,22 @@ class TransformerVAE(nn.Module):
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         return self._ws.data_ptr()
+
+    KERNEL_KINDS = ("enc_pool", "enc_cell", "dec_cell", "dec_gene", "dec_finalize")
+
+    def kernel_timing(self, enable: bool | None = None):
+        """Measurement hook (bench.py): `kernel_timing(True / False)` switches HIP-event pairs around every MCAB kernel launch on /
+        off; `kernel_timing()` drains them and returns {kernel: (launches, total ms)} (scldm_vae_kernel_timing)."""
+        L, h = self._native()
+        if enable is not None:
+            L.scldm_vae_kernel_timing_enable(h, int(enable))
+            return None
+        out = {}
+        for k, name in enumerate(self.KERNEL_KINDS):
+            n, ms = C.c_int(), C.c_double()
+            _lib.check(L.scldm_vae_kernel_timing(h, k, C.byref(n), C.byref(ms)), "scldm_vae_kernel_timing")
+            out[name] = (n.value, ms.value)
+        return out
 
     def __del__(self):
         try:

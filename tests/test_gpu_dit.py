@@ -550,13 +550,51 @@ def test_training_mode_label_dropout_matches_oracle_mixture():
     assert 35 <= dropped <= 62  # Binomial(64, 0.8)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_headline_workload_vs_oracle(prec):
+    """VERDICT r5 next #5a: the BENCH workload itself (`dentate_b4096_euler100`: bench.py's own make_model / make_inputs / seed, 4 096
+    cells x 100 CFG Euler evaluations = 12 288 sample-forwards per evaluation) against the float32 oracle chain on 8 cells spread over
+    the batch.  fp16 (the reference's arithmetic class) within 1.5 x the TF32-operand oracle on the same cells; bf16 (the dtype
+    BASELINE.json names, narrower than the reference) <= 3e-2."""
+    import bench
+    from oracle.dit import matmul_operand_bits
+    wl = bench.WORKLOADS["dentate_b4096_euler100"]
+    B, steps = wl["B"], wl["evals"] + 1
+    m = bench.make_model(wl, prec, torch.device("cuda:0"))
+    z2, cond2, scales = bench.make_inputs(wl, B, torch.device("cuda:0"), seed=1234)     # rank 0's inputs in time_workload
+    out = m.sample_ode_cfg(z2, cond2, scales, steps, wl["method"])
+    assert out.shape == (2 * B, 16, 16) and torch.isfinite(out).all()
+    idx = torch.tensor([0, 63, 64, 1000, 2047, 2048, 3333, B - 1])          # tile edges, both halves of the batch, the last cell
+    rows = torch.cat([idx, idx + B]).cuda()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = DiTConfig(class_vocab_sizes=wl["vocab"], condition_strategy=wl["strategy"])
+    zs, cs = z2[rows].cpu(), {k: v[rows].cpu() for k, v in cond2.items()}
+    f32 = lambda xx, tt: dit_forward_with_cfg(sd, cfg, xx, tt, cs, scales)
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(min(16, n_thr))
+    try:
+        ref = sample_ode_fixed(zs, f32, steps, wl["method"])
+        with matmul_operand_bits(10):
+            e_tf32 = max_abs_rel(sample_ode_fixed(zs, f32, steps, wl["method"]), ref)
+    finally:
+        torch.set_num_threads(n_thr)
+    err = max_abs_rel(out[rows].cpu(), ref)
+    print(f"[parity] headline workload dentate_b4096_euler100 [{prec}] 8 cells of 4096 vs float32 oracle chain: {err:.3e}   "
+          f"TF32-operand oracle {e_tf32:.3e}")
+    if prec == "fp16":
+        assert err <= TF32_FACTOR * e_tf32, (err, e_tf32)
+    else:
+        assert err < TOL_BF16, err
+
+
 @pytest.mark.parametrize("vocab,strategy,B,method,steps,scale", [
-    ({"cell_type": 50}, "mutually_exclusive", 2048, "heun", 3, 2.0),                 # BASELINE configs[2] shape (hlca)
-    ({"cell_type": 18, "cytokine": 91}, "joint", 1024, "euler", 4, 1.0),              # configs[3] per-GPU shard (parse1m)
+    ({"cell_type": 50}, "mutually_exclusive", 2048, "heun", 101, 2.0),               # BASELINE configs[2] (hlca): 100 Heun steps
+    ({"cell_type": 18, "cytokine": 91}, "joint", 1024, "euler", 101, 1.0),            # configs[3] per-GPU shard (parse1m): 100 Euler
 ])
 def test_fused_sampler_full_size_properties(vocab, strategy, B, method, steps, scale):
-    """At BASELINE batch sizes: the fused bf16 sampler is bit-repeatable, sharding the batch gives the same cells
-    (cells are independent), and a handful of cells agree with the oracle chain."""
+    """At BASELINE batch sizes AND trajectory lengths (100 Heun steps = 200 CFG evaluations at guidance 2.0; 100 Euler evaluations):
+    the fused bf16 sampler is bit-repeatable, sharding the batch gives the same cells (cells are independent), and a handful of
+    cells agree with the oracle chain."""
     from scldm_amd.nnets import DiT
     from scldm_amd.sampling import sample_latents, shard_bounds
     kw = dict(n_embed=256, n_embed_input=16, n_layer=8, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm",

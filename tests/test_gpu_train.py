@@ -213,6 +213,40 @@ def test_fp16_overflow_is_detected_the_step_is_skipped_and_the_scale_backs_off()
         assert all(torch.equal(q0[k], p.detach()) for k, p in m2.named_parameters())
 
 
+def test_deepcopy_after_an_fp16_step_keeps_its_own_overflow_guard():
+    """a copy (EMA-style deepcopy, unpickled checkpoint) of a DiT that already trained in fp16 must register ITS flag with
+    ITS new native handle - a stale cached flag left the copy's overflow guard silently off."""
+    import copy
+    from scldm_amd.training import train_step
+    from scldm_amd.transport import create_transport
+    vocab = {"cell_line": 4, "gene": 2024}
+    m, sd, cfg = build(vocab, "joint", 8, 85)
+    m.precision = "fp16"
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    n = 37
+    x1 = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    cond = {"cell_line": torch.randint(0, 4, (n,), device="cuda", generator=gen), "gene": torch.randint(0, 2024, (n,), device="cuda", generator=gen)}
+    train_step(m, tr, torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True), x1, cond)
+    flag0 = m.found_inf_flag()
+    m2 = copy.deepcopy(m)
+    assert "_found_inf" not in m2.__dict__
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3, fused=True)
+    for _ in range(8):
+        with torch.no_grad():
+            for blk in m2.blocks:
+                blk.mlp.c_proj.weight.mul_(10.0)
+                blk.mlp.w1.weight.mul_(3.0)
+        before = {k: p.detach().clone() for k, p in m2.named_parameters()}
+        train_step(m2, tr, opt2, x1, cond)
+        if m2.fp16_train_state()["nonfinite_last"] > 0:
+            break
+    assert m2.fp16_train_state()["nonfinite_last"] > 0
+    flag2 = m2.found_inf_flag()
+    assert flag2.data_ptr() != flag0.data_ptr() and float(flag2) == 1.0 and float(flag0) == 0.0
+    assert all(torch.equal(before[k], p.detach()) for k, p in m2.named_parameters()), "the copy must skip its poisoned step"
+
+
 def test_native_adamw_matches_torch_fused_adamw_and_shares_its_state_dict():
     """scldm_amd.optim.AdamW (one HIP launch per step) against torch.optim.AdamW(fused=True) - the optimizer of the reference's trainer -
     on tensors of assorted sizes (multiples of 4 and not, a 16-byte-misaligned view), eight steps: parameters and both moments within

@@ -336,3 +336,75 @@ def test_decode_sample_fuses_decode_and_draw():
         acc += vae.decode_sample(z, genes, lib, seed=100 + s)
     rel = (acc.sum(1) / 64 - lib.view(-1)).abs() / lib.view(-1)
     assert float(rel.max()) < 0.05
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# precision = "fp16": the reference's own arithmetic class for MCAB (TF32 operands under set_float32_matmul_precision("high"):
+# experiments/scripts/inference.py:26, train.py:18; src/scldm/layers.py:248-264,305-330).  Gate = the DiT's: the error against the
+# exact-fp32 reference output must not exceed 1.5 x the error of the ORACLE run with every matmul operand rounded to 10 mantissa
+# bits, on the same inputs.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _tf32_gate(err_fp16, err_tf32, what):
+    print(f"[parity] {what}: fp16-operand kernels {err_fp16:.3e}   TF32-operand oracle {err_tf32:.3e}   ratio {err_fp16 / err_tf32:.2f} (gate 1.5)")
+    assert err_fp16 <= 1.5 * err_tf32, (what, err_fp16, err_tf32)
+
+
+@pytest.mark.parametrize("name", ["vae_small", "vae_2000"])
+def test_fp16_policy_within_the_tf32_operand_oracle_on_reference_goldens(name):
+    from oracle.dit import matmul_operand_bits
+    g, vae, sd, cfg = build(name)
+    t = torch.from_numpy
+    with matmul_operand_bits(10):
+        z_tf = encode(sd, cfg, t(g["counts_subset"]), t(g["genes_subset"]))
+        mu_tf, _ = decode(sd, cfg, t(g["z"]), t(g["genes"]), t(g["library_size"]))
+        mu_tf_r, _ = decode(sd, cfg, t(g["zrand"]), t(g["genes"]), t(g["library_size"]))
+    vae.precision = "fp16"
+    z = vae.encode(cu(g["counts"]), cu(g["genes"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
+    _tf32_gate(max_abs_rel(z.cpu(), g["z"]), max_abs_rel(z_tf, g["z"]), f"{name} encode")
+    nb = vae.decode(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]))
+    _tf32_gate(max_abs_rel(nb.mu.cpu(), g["mu"]), max_abs_rel(mu_tf, g["mu"]), f"{name} decode mu")
+    assert max_abs_rel(nb.theta.cpu(), g["theta"]) < 1e-5      # theta = exp(table[gene]): no contraction, exact in every policy
+    nb_r = vae.decode(cu(g["zrand"]), cu(g["genes"]), cu(g["library_size"]))
+    _tf32_gate(max_abs_rel(nb_r.mu.cpu(), g["mu_rand"]), max_abs_rel(mu_tf_r, g["mu_rand"]), f"{name} decode mu (random latents)")
+    assert torch.allclose(nb.mu.sum(1).cpu(), t(g["library_size"][:, 0]), rtol=1e-4)
+    # the fused draw takes the same policy, is reproducible, and has the decode's mean
+    c1 = vae.decode_sample(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]), seed=5)
+    assert torch.equal(c1, vae.decode_sample(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]), seed=5)) and (c1 >= 0).all()
+    # fp16 is strictly closer to the reference than bf16 on the same inputs
+    vae.precision = "bf16"
+    e_bf = max_abs_rel(vae.decode(cu(g["z"]), cu(g["genes"]), cu(g["library_size"])).mu.cpu(), g["mu"])
+    assert max_abs_rel(nb.mu.cpu(), g["mu"]) < e_bf
+
+
+def test_fp16_policy_hlca_size_within_the_tf32_operand_oracle():
+    """The largest MCAB configuration of the reference (G = 27 997, S = 10 186), 3 cells, fp16 operands against the exact oracle,
+    gated by the TF32-operand oracle; rows sum to the library size; bit-repeatable."""
+    from oracle.dit import matmul_operand_bits
+    G, S, B = 27997, 10186, 3
+    vae, sd, cfg = _fresh_vae(G, 91)
+    rng = np.random.default_rng(17)
+    genes = np.tile(np.arange(G, dtype=np.int64), (B, 1))
+    counts = rng.poisson(0.5, (B, G)).astype(np.float32)
+    sub = np.stack([np.sort(rng.permutation(G)[:S]) for _ in range(B)])
+    lib = counts.sum(1, keepdims=True) + 1
+    cs, gs = np.take_along_axis(counts, sub, 1), np.take_along_axis(genes, sub, 1)
+    t = torch.from_numpy
+    z_ref = encode(sd, cfg, t(cs), t(gs))
+    mu_ref, _ = decode(sd, cfg, z_ref, t(genes), t(lib))
+    with matmul_operand_bits(10):
+        z_tf = encode(sd, cfg, t(cs), t(gs))
+        mu_tf, _ = decode(sd, cfg, z_ref, t(genes), t(lib))
+    vae.precision = "fp16"
+    z = vae.encode(cu(cs), cu(gs))
+    _tf32_gate(max_abs_rel(z.cpu(), z_ref), max_abs_rel(z_tf, z_ref), "hlca encode (S=10186)")
+    nb = vae.decode(z_ref.cuda(), cu(genes), cu(lib))
+    _tf32_gate(max_abs_rel(nb.mu.cpu(), mu_ref), max_abs_rel(mu_tf, mu_ref), "hlca decode mu (G=27997)")
+    assert torch.allclose(nb.mu.sum(1), cu(lib[:, 0]), rtol=2e-4)
+    assert torch.equal(vae.decode(z_ref.cuda(), cu(genes), cu(lib)).mu, nb.mu) and torch.equal(vae.encode(cu(cs), cu(gs)), z)
+
+
+def test_unknown_vae_precision_raises():
+    g, vae, sd, cfg = build("vae_small")
+    vae.precision = "bf16x3"       # a DiT-only policy
+    with pytest.raises(RuntimeError, match="precision"):
+        vae.decode(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]))
