@@ -97,10 +97,13 @@ def decoder(sd: dict, cfg: VAEConfig, z: torch.Tensor, gene_emb: torch.Tensor) -
 
 
 def nb_head(sd: dict, cfg: VAEConfig, h: torch.Tensor, genes: torch.Tensor, library_size: torch.Tensor):
-    """NegativeBinomialTransformerLayer.forward, shared_theta=True,
-    src/scldm/stochastic_layers.py:102-116."""
-    mu = linear(h, sd["decoder_head.params.weight"], sd["decoder_head.params.bias"]).squeeze(-1)
-    theta = torch.exp(sd["decoder_head.theta.weight"][genes.long()]).squeeze(-1)
+    """NegativeBinomialTransformerLayer.forward, both theta variants, src/scldm/stochastic_layers.py:102-116."""
+    if "decoder_head.theta.weight" in sd:
+        mu = linear(h, sd["decoder_head.params.weight"], sd["decoder_head.params.bias"]).squeeze(-1)
+        theta = torch.exp(sd["decoder_head.theta.weight"][genes.long()]).squeeze(-1)
+    else:   # shared_theta=False: params is Linear(n_embed, 2), theta = exp of its second output (stochastic_layers.py:94-96,109-112)
+        mu, theta = torch.chunk(linear(h, sd["decoder_head.params.weight"], sd["decoder_head.params.bias"]), 2, dim=-1)
+        mu, theta = mu.squeeze(-1), torch.exp(theta).squeeze(-1)
     mu = torch.softmax(mu / cfg.nb_temperature, dim=1) * library_size
     return mu, theta
 

@@ -608,7 +608,9 @@ struct DecGeneArgs {
   const float* wfrag;     // packed c_proj (16 steps) | w12 (6*16) | wc (6*8) fragments = 160*64 floats
   const float* wfrag_cproj_halves;   // fp32 path: the 16 c_proj fragments with k in lane-half order (pack_frag32_halves_kernel)
   const float* ln2_w; const float* ln2_b;  // decoder_cross_attention.ln_2
-  const float* head_w; const float* head_b;  // decoder_head.params (1,32), (1)
+  const float* head_w; const float* head_b;  // decoder_head.params (1,32), (1): the mu logit
+  const float* head_w2;   // unshared theta (stochastic_layers.py:94-96,109-111: params is Linear(32, 2), theta = exp of its second
+                          // output): row 1 of the weight, its bias is head_b[1]; nullptr = shared theta (the gene-indexed table)
   float* logits;          // (B, G)  (aliases mu)
   float* theta;           // (B, G), or nullptr when the caller only wants drawn counts (scldm_vae_decode_sample)
   float* part;            // (B, n_chunks, 2): running (max, sum exp) of logit / temperature per chunk
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(kDecThreads, McabOp<OP>::k16 ? (kDecWaves >= 8 ? kD
   __shared__ f32x4 KVP[kKV4];   // fp32: this cell's K | V, plain [key][64 floats]
   __shared__ H8 WFh[kWF8];  // 16-bit operands: the 160 fragments, 8 steps per 16-byte fragment
   __shared__ H8 KVh[kKV8];  // 16-bit operands: this cell's 48 K/V fragments
-  __shared__ float VEC[3 * kE];   // ln2_w | ln2_b | head_w
+  __shared__ float VEC[4 * kE];   // ln2_w | ln2_b | head_w | head_w row 1 (unshared theta)
   __shared__ float RED[kDecWaves][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hh = lane >> 5;
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(kDecThreads, McabOp<OP>::k16 ? (kDecWaves >= 8 ? kD
       WF[i] = i < 4 * 64 ? reinterpret_cast<const f32x4*>(a.wfrag_cproj_halves)[i] : reinterpret_cast<const f32x4*>(a.wfrag)[i];
     for (int i = tid; i < kNI * 16; i += kDecThreads) KVP[i] = reinterpret_cast<const f32x4*>(a.kvfrag + (size_t)cell * (kNI * 64))[i];
   }
-  if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; }
+  if (tid < kE) { VEC[tid] = a.ln2_w[tid]; VEC[kE + tid] = a.ln2_b[tid]; VEC[2 * kE + tid] = a.head_w[tid]; VEC[3 * kE + tid] = a.head_w2 ? a.head_w2[tid] : 0.f; }
   __syncthreads();
   // acc += F[steps step0 .. step0+7] (A operand, from LDS) x x[0..7] (B operand, accumulator-order registers)
   auto mm8 = [&](const f32x4* F4, const H8* F8, int step0, const float* x, f32x16 acc) {
@@ -863,9 +865,15 @@ __global__ __launch_bounds__(kDecThreads, McabOp<OP>::k16 ? (kDecWaves >= 8 ? kD
 #pragma unroll
     for (int r = 0; r < 16; ++r) lg += (y[r] + mo[r]) * VEC[2 * kE + acc_row(r, hh)];
     lg = (xor32_sum(lg) + hb) * a.inv_temp;
+    float th = 0.f;
+    if (a.head_w2) {   // (wave-uniform) unshared theta: the head's second output
+#pragma unroll
+      for (int r = 0; r < 16; ++r) th += (y[r] + mo[r]) * VEC[3 * kE + acc_row(r, hh)];
+      th = expf(xor32_sum(th) + a.head_b[1]);
+    }
     if (valid && hh == 0) {
       a.logits[(size_t)cell * a.G + gi] = lg;
-      if (a.theta) a.theta[(size_t)cell * a.G + gi] = expf(a.theta_emb[g]);
+      if (a.theta) a.theta[(size_t)cell * a.G + gi] = a.head_w2 ? th : expf(a.theta_emb[g]);
     }
     if (valid) {  // online (max, sum exp) per lane; both half-waves carry the same value, count it once at the end
       const float nm = fmaxf(run_m, lg);
@@ -948,8 +956,9 @@ __global__ __launch_bounds__(256) void dec_finalize_kernel(float* __restrict__ m
 // mu and theta stay in registers.  Element index for the RNG = cell * G + gene position.
 __global__ __launch_bounds__(256) void dec_finalize_sample_kernel(float* __restrict__ out, const float* __restrict__ part,
                                                                   const float* __restrict__ library, const int64_t* __restrict__ genes,
-                                                                  const float* __restrict__ theta_emb, int G, int n_chunks,
-                                                                  unsigned long long seed) {
+                                                                  const float* __restrict__ theta_emb, const float* __restrict__ theta_rows,
+                                                                  int G, int n_chunks, unsigned long long seed) {
+  // theta_rows (B, G): per-element dispersions written by dec_gene_kernel (unshared theta); nullptr = exp(theta_emb[gene])
   const int cell = blockIdx.y;
   float M, S;
   dec_merge_partials(part, cell, n_chunks, M, S);
@@ -957,7 +966,7 @@ __global__ __launch_bounds__(256) void dec_finalize_sample_kernel(float* __restr
   for (int i = blockIdx.x * 256 + threadIdx.x; i < G; i += gridDim.x * 256) {
     const size_t e = (size_t)cell * G + i;
     const float mu = expf(out[e] - M) * scale;
-    const float theta = expf(theta_emb[genes[e]]);
+    const float theta = theta_rows ? theta_rows[e] : expf(theta_emb[genes[e]]);
     out[e] = nb_draw(seed, e, mu, theta);
   }
 }

@@ -26,7 +26,7 @@ enum : int {
   S_ENC_IND = S_ENC_CP + 32 * 128, S_ENC_POS = S_ENC_IND + 512, S_ENC_LAT = S_ENC_POS + 512,    // (n_lat<=32, 32)
   S_DEC_LAT = S_ENC_LAT + 1024, S_DEC_LN1W = S_DEC_LAT + 1024, S_DEC_LN1B = S_DEC_LN1W + 32,
   S_DEC_KV = S_DEC_LN1B + 32, S_DEC_LN2W = S_DEC_KV + 64 * 32, S_DEC_LN2B = S_DEC_LN2W + 32,
-  S_HEAD_W = S_DEC_LN2B + 32, S_HEAD_B = S_HEAD_W + 32, S_TOTAL = S_HEAD_B + 32
+  S_HEAD_W = S_DEC_LN2B + 32, S_HEAD_B = S_HEAD_W + 32, S_HEAD_W2 = S_HEAD_B + 32, S_TOTAL = S_HEAD_W2 + 32
 };
 
 
@@ -198,7 +198,8 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
   jl.copy(s + S_ENC_PROJ, ec.attn_proj, 1024); jl.copy(s + S_ENC_W1, ec.w1, H * 32); jl.copy(s + S_ENC_W2, ec.w2, H * 32); jl.copy(s + S_ENC_CP, ec.cproj, 32 * H);
   jl.copy(s + S_ENC_IND, w->inducing_points, 512); jl.copy(s + S_ENC_LAT, w->enc_latent_w, nl * 32); jl.copy(s + S_DEC_LAT, w->dec_latent_w, 32 * nl);
   jl.copy(s + S_DEC_LN1W, dc.ln1_w, 32); jl.copy(s + S_DEC_LN1B, dc.ln1_b, 32); jl.copy(s + S_DEC_KV, dc.attn_kv, 64 * 32);
-  jl.copy(s + S_DEC_LN2W, dc.ln2_w, 32); jl.copy(s + S_DEC_LN2B, dc.ln2_b, 32); jl.copy(s + S_HEAD_W, w->head_w, 32); jl.copy(s + S_HEAD_B, w->head_b, 1);
+  jl.copy(s + S_DEC_LN2W, dc.ln2_w, 32); jl.copy(s + S_DEC_LN2B, dc.ln2_b, 32); jl.copy(s + S_HEAD_W, w->head_w, 32); jl.copy(s + S_HEAD_B, w->head_b, w->theta ? 1 : 2);
+  if (!w->theta) jl.copy(s + S_HEAD_W2, w->head_w + 32, 32);   // unshared theta: decoder_head.params is Linear(32, 2) (stochastic_layers.py:94-96)
   if (c.positional_encoding) jl.copy(s + S_ENC_POS, w->enc_pos_embed, 512);
   // MFMA fragments
   float* fc = h->frag_cell;
@@ -223,7 +224,7 @@ extern "C" int scldm_vae_load_weights(scldm_vae* h, const scldm_vae_weights* w, 
     jl.src(cr->cproj, (long long)32 * H);
   }
   jl.src(w->inducing_points, 512); jl.src(w->enc_latent_w, (long long)nl * 32); jl.src(w->dec_latent_w, (long long)32 * nl);
-  jl.src(w->head_w, 32); jl.src(w->head_b, 1); jl.src(w->gene_embedding, (long long)(c.n_genes + 1) * 32);
+  jl.src(w->head_w, w->theta ? 32 : 64); jl.src(w->head_b, w->theta ? 1 : 2); jl.src(w->gene_embedding, (long long)(c.n_genes + 1) * 32);
   if (c.positional_encoding) jl.src(w->enc_pos_embed, 512);
   for (const VaePackJob& j : jl.jobs)
     if (!j.src0 || !j.dst || (j.kind == VJ_W12 && !j.src1)) return fail(SCLDM_ERR_SHAPE, "scldm_vae_load_weights: a weight pointer is NULL");
@@ -260,7 +261,9 @@ extern "C" size_t scldm_vae_workspace_bytes(const scldm_vae* h, int B, int G) {
   size_t kv = align256((size_t)B * 48 * 64 * 4);
   size_t part = align256((size_t)B * dec_chunks(G > 0 ? G : 1) * 2 * 4);
   size_t pooled = align256((size_t)B * 16 * 32 * 4);
-  return kv + part + pooled;
+  // unshared theta: scldm_vae_decode_sample keeps the (B, G) dispersions of dec_gene_kernel here for the fused draw
+  size_t theta_rows = (h->loaded && !h->theta) ? align256((size_t)B * (G > 0 ? G : 1) * 4) : 0;
+  return kv + part + pooled + theta_rows;
 }
 
 int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes, int B, int S, float* z, int precision, float* pooled,
@@ -334,7 +337,11 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   DecGeneArgs g;
   g.genes = genes; g.emb = h->emb; g.qtab = h->qtab; g.theta_emb = h->theta; g.kvfrag = kv; g.wfrag = h->frag_dec; g.wfrag_cproj_halves = h->frag_dec_halves;
   g.ln2_w = h->small + S_DEC_LN2W; g.ln2_b = h->small + S_DEC_LN2B; g.head_w = h->small + S_HEAD_W; g.head_b = h->small + S_HEAD_B;
-  g.logits = mu; g.theta = draw ? nullptr : theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
+  const bool unshared = h->theta == nullptr;
+  g.head_w2 = unshared ? h->small + S_HEAD_W2 : nullptr;
+  float* theta_rows = (unshared && draw) ? (float*)((char*)ws_ + align256((size_t)B * 48 * 64 * 4) + align256((size_t)B * dec_chunks(G) * 2 * 4) +
+                                                    align256((size_t)B * 16 * 32 * 4)) : nullptr;
+  g.logits = mu; g.theta = draw ? theta_rows : theta; g.part = part; g.G = G; g.n_chunks = nch; g.tiles_per_wave = kDecTilesPerWave;
   g.eps = c.layernorm_eps; g.inv_temp = 1.0f / c.nb_temperature;
   {
     KernelTimer kt(h, SCLDM_VAE_K_DEC_GENE, st);
@@ -345,7 +352,7 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   LAUNCH_CHECK();
   {
     KernelTimer kt(h, SCLDM_VAE_K_DEC_FINAL, st);
-    if (draw) dec_finalize_sample_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, genes, h->theta, G, nch, seed);
+    if (draw) dec_finalize_sample_kernel<<<dim3(cdiv(G, 256 * 4), B), 256, 0, st>>>(mu, part, library_size, genes, h->theta, theta_rows, G, nch, seed);
     else dec_finalize_kernel<<<dim3(cdiv(G, 256 * 16), B), 256, 0, st>>>(mu, part, library_size, G, nch);   // four 16-byte groups per thread
   }
   LAUNCH_CHECK();

@@ -168,6 +168,8 @@ extern "C" int scldm_vae_train_forward(scldm_vae* h, const float* counts_subset,
   if (!h || !counts_subset || !genes_subset || !genes || !library_size || !mu || !theta || !z || !saved_ || !ws)
     return fail(SCLDM_ERR_SHAPE, "null argument");
   if (B < 1 || S < 1 || G < 1) return fail(SCLDM_ERR_SHAPE, "need B, S, G >= 1");
+  if (h->loaded && !h->theta)
+    return fail(SCLDM_ERR_STATE, "the training backward is built for the shared-theta NB head (vae_base.yaml:62); the unshared head decodes only");
   hipStream_t st = (hipStream_t)stream_;
   Saved s = carve_saved(B, saved_);
   int rc = scldm_vae_encode_ex(h, counts_subset, genes_subset, B, S, z, SCLDM_PREC_FP32, s.pooled, s.lse2, st);

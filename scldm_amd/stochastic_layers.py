@@ -1,4 +1,4 @@
-"""Output head of the VAE with the reference's API (src/scldm/stochastic_layers.py:76-116), shared-theta variant."""
+"""Output head of the VAE with the reference's API (src/scldm/stochastic_layers.py:76-116), shared- and unshared-theta variants."""
 from __future__ import annotations
 
 import torch
@@ -6,18 +6,25 @@ import torch.nn as nn
 
 
 class NegativeBinomialTransformerLayer(nn.Module):
-    """Parameter container: `theta` Embedding(n_genes+1, 1) (initialised to ones) and `params` Linear(n_embed, 1).
-    mu = softmax_G(params(h) / t) * library_size and theta = exp(theta[genes]) are computed by scldm_vae_decode."""
+    """Parameter container with the reference's two variants (stochastic_layers.py:89-96):
+      shared_theta=True  (vae_base.yaml `negative_binomial_shared_theta`): `theta` Embedding(n_genes+1, 1) initialised to ones and
+                         `params` Linear(n_embed, 1); theta = exp(theta[genes]);
+      shared_theta=False (`negative_binomial_unshared_theta`): `theta` is None and `params` is Linear(n_embed, 2); theta = exp of the
+                         head's second output, per cell and gene (stochastic_layers.py:109-111).
+    mu = softmax_G(params(h)[..., 0] / t) * library_size.  Both are computed inside scldm_vae_decode (dec_gene_kernel); the training
+    backward (TransformerVAE.forward under autograd) is built for the shared-theta head only."""
 
     def __init__(self, *, n_genes: int, shared_theta: bool = False, n_embed: int | None = None, norm_layer: str = "layernorm",
                  layernorm_eps: float = 1e-8, eps_: float = 1e-6, t: float = 1.0):
         super().__init__()
-        if not shared_theta:
-            raise NotImplementedError("only the shared-theta head (decoder_name negative_binomial_shared_theta, vae_base.yaml:62) is built")
         self.shared_theta = shared_theta
-        self.theta = nn.Embedding(n_genes + 1, 1)
-        nn.init.ones_(self.theta.weight)
-        self.params = nn.Linear(n_embed, 1, bias=True)
+        if shared_theta:
+            self.theta = nn.Embedding(n_genes + 1, 1)
+            nn.init.ones_(self.theta.weight)
+            self.params = nn.Linear(n_embed, 1, bias=True)
+        else:
+            self.theta = None
+            self.params = nn.Linear(n_embed, 2, bias=True)
         self.eps_ = eps_
         self.t = t
 

@@ -176,7 +176,8 @@ class TransformerVAE(nn.Module):
         w = _lib.VaeWeights(gene_embedding=dp(self.input_layer.gene_embedding.weight), inducing_points=dp(enc.ca_layer.inducing_points),
                             enc_pos_embed=dp(enc.pos_embed) if enc.pos_embed is not None else None,
                             enc_latent_w=dp(enc.encoder_latent_input[0].weight), dec_latent_w=dp(dec.decoder_latent_input[1].weight),
-                            theta=dp(self.decoder_head.theta.weight), head_w=dp(self.decoder_head.params.weight),
+                            theta=dp(self.decoder_head.theta.weight) if self.decoder_head.theta is not None else None,   # NULL = unshared theta
+                            head_w=dp(self.decoder_head.params.weight),
                             head_b=dp(self.decoder_head.params.bias), enc_cross=cross(enc.ca_layer),
                             dec_cross=cross(dec.decoder_cross_attention), enc_blocks=eb, dec_blocks=db)
         return w, (eb, db)
@@ -303,6 +304,9 @@ class TransformerVAE(nn.Module):
                                  f"{tuple(gs.shape)}, {tuple(g.shape)}, {tuple(library_size.shape)}")
             if self.precision != "fp32":
                 raise NotImplementedError("TransformerVAE training runs in fp32 (precision='fp32')")
+            if self.decoder_head.theta is None:
+                raise NotImplementedError("the HIP training backward is built for the shared-theta NB head (vae_base.yaml:62); "
+                                          "the unshared-theta head (stochastic_layers.py:94-96) decodes only")
             params = tuple(self.parameters())
             mu, theta, z = _VAETrainFn.apply(self, cs, gs, g, lib, *params)
             return {"mu": mu, "theta": theta}, z

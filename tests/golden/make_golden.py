@@ -380,15 +380,17 @@ def gen_init():
 
 
 VAE_CASES = {"vae_small": (dict(n_genes=60), 50, 20, 2, 201), "vae_2000": (dict(n_genes=2000), 2000, 2000, 2, 202)}
+# round 6: decoder_name negative_binomial_unshared_theta (stochastic_layers.py:94-96): params Linear(32, 2), no theta table
+LATE_VAE_CASES = {"vae_unshared": (dict(n_genes=300, shared_theta=False), 300, 120, 3, 203)}
 
 
-def gen_vae(name, n_genes, G, S, B, seed):
+def gen_vae(name, n_genes, G, S, B, seed, shared_theta=True):
     enc = Encoder(n_layer=8, n_inducing_points=16, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, dropout=0.0,
                   bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", positional_encoding=True)
     dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, n_inducing_points=16,
                   dropout=0.0, bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
                   use_adaln=False)
-    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm",
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=shared_theta, n_embed=32, norm_layer="layernorm",
                                             layernorm_eps=1e-8)
     inp = InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p")
     vae = TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=inp)
@@ -478,8 +480,10 @@ if __name__ == "__main__":
     for name, (Bx, By, D, seed) in MMD_CASES.items():
         gen_mmd(name, Bx, By, D, seed)
     for name, (kw, G, S, B, seed) in VAE_CASES.items():
-        gen_vae(name, kw["n_genes"], G, S, B, seed)
+        gen_vae(name, kw["n_genes"], G, S, B, seed, kw.get("shared_theta", True))
     for name, (kw, B, seed) in LATE_DIT_CASES.items():
         gen_dit(name, kw, B, seed)
     for name, (kw, G, S, B, seed) in VAE_TRAIN_CASES.items():     # (last: everything above stays bit-identical to earlier rounds)
         gen_vae_train(name, kw["n_genes"], G, S, B, seed)
+    for name, (kw, G, S, B, seed) in LATE_VAE_CASES.items():
+        gen_vae(name, kw["n_genes"], G, S, B, seed, kw.get("shared_theta", True))

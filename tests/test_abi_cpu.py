@@ -112,7 +112,7 @@ def test_transport_face_and_training_losses_cpu():
     assert torch.equal(traj[-1], torch.full((2, 3), 0.31640625))
 
 
-def _build_vae(n_genes):
+def _build_vae(n_genes, shared_theta=True):
     from scldm_amd.layers import InputTransformerVAE
     from scldm_amd.nnets import Decoder, Encoder
     from scldm_amd.stochastic_layers import NegativeBinomialTransformerLayer
@@ -122,15 +122,16 @@ def _build_vae(n_genes):
     dec = Decoder(n_genes=n_genes, n_embed=32, n_embed_latent=16, n_head=8, n_head_cross=4, n_layer=8, n_inducing_points=16,
                   dropout=0.0, bias=False, multiple_of=4, layernorm_eps=1e-8, norm_layer="layernorm", shared_embedding=True,
                   use_adaln=False)
-    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=True, n_embed=32, norm_layer="layernorm", layernorm_eps=1e-8)
+    head = NegativeBinomialTransformerLayer(n_genes=n_genes, shared_theta=shared_theta, n_embed=32, norm_layer="layernorm", layernorm_eps=1e-8)
     inp = InputTransformerVAE(n_genes=n_genes, n_embed=32, agg_func="log1p")
     return TransformerVAE(encoder=enc, decoder=dec, decoder_head=head, input_layer=inp)
 
 
-def test_vae_state_dict_is_checkpoint_compatible():
-    g = load_golden("vae_small")
+@pytest.mark.parametrize("name", ["vae_small", "vae_unshared"])
+def test_vae_state_dict_is_checkpoint_compatible(name):
+    g = load_golden(name)
     shapes = {k: tuple(v) for k, v in golden_json(g, "shapes_json").items()}
-    vae = _build_vae(int(g["n_genes"]))
+    vae = _build_vae(int(g["n_genes"]), shared_theta="decoder_head.theta.weight" in shapes)
     ours = {k: tuple(v.shape) for k, v in vae.state_dict().items()}
     assert ours == shapes
     vae.load_state_dict(make_state_dict(shapes, int(g["seed"])), strict=True)

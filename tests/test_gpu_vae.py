@@ -17,7 +17,7 @@ def build(name):
     g = load_golden(name)
     shapes = {k: tuple(v) for k, v in golden_json(g, "shapes_json").items()}
     sd = make_state_dict(shapes, int(g["seed"]))
-    vae = _build_vae(int(g["n_genes"]))
+    vae = _build_vae(int(g["n_genes"]), shared_theta="decoder_head.theta.weight" in shapes)
     vae.load_state_dict(sd, strict=True)
     return g, vae.cuda().eval(), sd, VAEConfig(n_genes=int(g["n_genes"]))
 
@@ -26,7 +26,7 @@ def cu(a):
     return torch.from_numpy(np.asarray(a)).cuda()
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_2000"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_2000", "vae_unshared"])
 def test_encode_decode_match_reference_golden(name):
     g, vae, sd, cfg = build(name)
     z = vae.encode(cu(g["counts"]), cu(g["genes"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
@@ -36,7 +36,10 @@ def test_encode_decode_match_reference_golden(name):
     nb2 = vae.decode(cu(g["zrand"]), cu(g["genes"]), cu(g["library_size"]))
     assert max_abs_rel(nb2.mu.cpu(), g["mu_rand"]) < TOL
     assert torch.allclose(nb.mu.sum(1).cpu(), torch.from_numpy(g["library_size"][:, 0]), rtol=1e-4)
-    params, z2 = vae(cu(g["counts"]), cu(g["genes"]), cu(g["library_size"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
+    import contextlib
+    # (with gradients enabled forward() is the differentiable route, which is built for the shared-theta head only)
+    with torch.no_grad() if name == "vae_unshared" else contextlib.nullcontext():
+        params, z2 = vae(cu(g["counts"]), cu(g["genes"]), cu(g["library_size"]), cu(g["counts_subset"]), cu(g["genes_subset"]))
     assert torch.equal(z2, z) and set(params) == {"mu", "theta"}
 
 
@@ -408,3 +411,26 @@ def test_unknown_vae_precision_raises():
     vae.precision = "bf16x3"       # a DiT-only policy
     with pytest.raises(RuntimeError, match="precision"):
         vae.decode(cu(g["z"]), cu(g["genes"]), cu(g["library_size"]))
+
+
+def test_unshared_theta_head_draw_and_training_guard():
+    """decoder_name negative_binomial_unshared_theta (src/scldm/stochastic_layers.py:94-96,109-112; golden `vae_unshared` from the
+    reference): theta (B, G) = exp of the head's second output in every precision policy; the fused draw uses those per-element
+    dispersions (same counts as NegativeBinomial(mu, theta).sample with the same seed: both are nb_draw(seed, element, mu, theta));
+    training raises (the HIP backward is the shared-theta head's)."""
+    g, vae, sd, cfg = build("vae_unshared")
+    z, genes, lib = cu(g["z"]), cu(g["genes"]), cu(g["library_size"])
+    nb = vae.decode(z, genes, lib)
+    assert max_abs_rel(nb.mu.cpu(), g["mu"]) < TOL and max_abs_rel(nb.theta.cpu(), g["theta"]) < TOL
+    assert float(nb.theta.std()) > 0 and not torch.equal(nb.theta[0], nb.theta[1])      # per cell AND gene
+    for prec, tol in (("fp16", 2e-3), ("bf16", 3e-2)):
+        vae.precision = prec
+        nbp = vae.decode(z, genes, lib)
+        assert max_abs_rel(nbp.theta.cpu(), g["theta"]) < tol and max_abs_rel(nbp.mu.cpu(), g["mu"]) < tol
+    vae.precision = "fp32"
+    c1 = vae.decode_sample(z, genes, lib, seed=11)
+    assert torch.equal(c1, vae.decode_sample(z, genes, lib, seed=11)) and (c1 >= 0).all()
+    assert torch.equal(c1, nb.sample(seed=11))
+    vae.train()
+    with pytest.raises(NotImplementedError, match="shared-theta"):
+        vae(cu(g["counts"]), genes, lib, cu(g["counts_subset"]), cu(g["genes_subset"]))

@@ -14,7 +14,7 @@ def setup(name, dtype=torch.float32):
     return g, VAEConfig(n_genes=int(g["n_genes"])), sd
 
 
-@pytest.mark.parametrize("name", ["vae_small", "vae_2000"])
+@pytest.mark.parametrize("name", ["vae_small", "vae_2000", "vae_unshared"])
 def test_encode_decode_match_reference(name):
     g, cfg, sd = setup(name)
     z = encode(sd, cfg, torch.from_numpy(g["counts_subset"]), torch.from_numpy(g["genes_subset"]))
@@ -24,6 +24,12 @@ def test_encode_decode_match_reference(name):
     mu2, _ = decode(sd, cfg, torch.from_numpy(g["zrand"]), torch.from_numpy(g["genes"]), torch.from_numpy(g["library_size"]))
     assert max_abs_rel(mu2, g["mu_rand"]) < 5e-5
     assert torch.allclose(mu.sum(1, keepdim=True), torch.from_numpy(g["library_size"]), rtol=1e-5)
+
+
+def test_unshared_theta_head_has_no_theta_table():
+    """decoder_name negative_binomial_unshared_theta (stochastic_layers.py:94-96): params is Linear(32, 2) and there is no table."""
+    shapes = golden_json(load_golden("vae_unshared"), "shapes_json")
+    assert "decoder_head.theta.weight" not in shapes and shapes["decoder_head.params.weight"] == [2, 32] and shapes["decoder_head.params.bias"] == [2]
 
 
 def test_state_dict_keys_pin():
