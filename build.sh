@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build libscldm_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.  The six translation units are
+# Build libscldm_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.  The seven translation units are
 # compiled in parallel (objects under build/, git-ignored) and linked into one shared library.
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -30,14 +30,14 @@ stale() {  # $1 = tu
   return 1
 }
 pids=()
-for tu in api vae_api vae_train_api train_api train_fused optim; do
+for tu in api vae_api vae_train_api train_api train_fused optim train_step; do
   if stale "$tu"; then
     hipcc $FLAGS -MD -MF "$OBJ/$tu.d" -c "scldm_amd/csrc/$tu.hip" -o "$OBJ/$tu.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/vae_train_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o" "$OBJ/optim.o"
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/api.o" "$OBJ/vae_api.o" "$OBJ/vae_train_api.o" "$OBJ/train_api.o" "$OBJ/train_fused.o" "$OBJ/optim.o" "$OBJ/train_step.o"
 echo "built $OUT"
 # the stand-alone GEMM harness (tests/perf/gemm_probe.hip: ablation timings + the bitwise kernel-against-kernel check that
 # tests/test_gpu_gemm_probe.py runs); rebuilt when one of its headers is newer

@@ -126,6 +126,32 @@ typedef struct {
 int scldm_adamw_step(const scldm_adamw_entry* entries, int count, float* step, const float* found_inf /* may be NULL */, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int maximize, void* stream);
 
+/* The same step driven by a launch table in DEVICE memory (any number of tensors is one launch), with the per-step hyper-parameters
+ * read from device memory and the exponential moving average of the reference's trainer in the same pass:
+ *   - LatentDiffusion wraps the diffusion model in ema_pytorch.EMA (src/scldm/models.py:446-453; ema-pytorch==0.7.7, pyproject.toml:30)
+ *     and calls ema_model.update() after every optimizer step (models.py:83-87); update() copies the online parameters while
+ *     step <= update_after_step and does `ema.lerp_(online, 1 - decay)` every update_every steps after (ldm_base.yaml:51-55);
+ *   - configure_optimizers attaches a per-step LambdaLR (models.py:603-605).
+ * `hyper` (device float[4], may be NULL): [0] learning rate, [1] weight decay, [2] EMA action of THIS step (0 none, 1 copy, 2 lerp),
+ * [3] lerp weight.  The caller refreshes it before the call (scldm_amd.optim.AdamW: one 16-byte asynchronous copy); a captured HIP
+ * graph therefore follows both schedules.  *found_inf != 0 skips the AdamW update (and the step count) but not the EMA action, as
+ * the reference's hook runs after every batch.  The EMA is torch.lerp's arithmetic bit for bit (Tensor.lerp_ / torch._foreach_lerp_).
+ * scldm_adamw_table_build fills a HOST buffer of scldm_adamw_table_bytes(...) bytes from the entries (+ one EMA tensor per entry, or
+ * NULL); the caller copies it to the device once and passes that copy as `table`. */
+size_t scldm_adamw_table_bytes(const scldm_adamw_entry* entries, int count);
+int scldm_adamw_table_build(const scldm_adamw_entry* entries, float* const* ema /* count pointers or NULL */, int count, void* table_host,
+                            size_t bytes, int* n_blocks);
+typedef struct {
+  const void* table;       /* device copy of the table */
+  int count, n_blocks;
+  float* step;             /* device: steps taken so far */
+  const float* found_inf;  /* device, may be NULL */
+  const float* hyper;      /* device float[4], may be NULL (then lr / weight_decay below, no EMA) */
+  float lr, beta1, beta2, eps, weight_decay;
+  int maximize;
+} scldm_adamw_launch;
+int scldm_adamw_table_step(const scldm_adamw_launch* launch, void* stream);
+
 /* State arithmetic of the adaptive Dormand-Prince 5(4) solver - the reference's DEFAULT sampler (src/scldm/models.py:793 ->
  * transport/transport.py:324-331 -> integrators.py:100-112 -> torchdiffeq.odeint(method="dopri5")) - as four kernels instead of ~40
  * elementwise launches per step; the step-size control stays on the host (scldm_amd/transport: Sampler._sample_dopri5).  All tensors
@@ -317,6 +343,43 @@ int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w, const scl
  *   scldm_fm_loss:     loss[b] = mean_e (pred - ut)^2                              (mean_flat, utils.py:15-17)
  *   scldm_fm_loss_bwd: dpred[b][:] = gloss[b] * 2/e * (pred - ut)                  (its gradient w.r.t. pred) */
 int scldm_fm_mix(const float* x1, const float* x0, const float* t, float* xt, float* ut, int n, int e, void* stream);
+
+/* The same pieces with nothing left to the host (csrc/train_step.hip; round 6):
+ *   scldm_fm_prepare   - Transport.sample + ICPlan.plan + the label dropout of DiT.forward in ONE kernel (transport.py:97-108,
+ *                        path.py:148-151, nnets.py:395-402,440-452): t ~ U[0,1) and a drop decision per row, x0 ~ N(0, I), xt, ut,
+ *                        and labels_out (n_classes, n) = what the model sees (null token where dropped; mutually_exclusive: ONE class
+ *                        drawn per call among the non-NULL labels_in, every other class all-null - the reference draws it on the
+ *                        host, nnets.py:395).  Draws come from Philox4x32-10 keyed by rng_state[0] (seed) at step rng_state[1]
+ *                        (device memory, read only): reproducible, independent of the launch geometry.  x0 may be NULL.
+ *   scldm_fm_loss_grad - loss_rows[b] = mean_e (pred - ut)^2, loss_mean = mean_b, dpred = d loss_mean / d pred, ONE kernel
+ *                        (fixed-order sums); advances rng_state[1] when rng_state is given.  ticket: a zero-initialised device word.
+ * Captured in a HIP graph both follow the device-side step counter: every replay draws a fresh batch. */
+int scldm_fm_prepare(const float* x1, const int64_t* const* labels_in, const int* null_tokens, int n_classes, int strategy /* 0 mutually_exclusive, 1 joint */,
+                     int drop, float p_drop, const unsigned long long* rng_state, int n, int e, float* t, float* x0, float* xt, float* ut,
+                     int64_t* labels_out, void* stream);
+int scldm_fm_loss_grad(const float* pred, const float* ut, int n, int e, float* loss_rows, float* loss_mean, float* dpred, unsigned int* ticket,
+                       unsigned long long* rng_state, void* stream);
+
+/* One optimisation step of LatentDiffusion.training_step on a batch of latents (src/scldm/models.py:628-663 + Lightning's backward
+ * and optimizer.step(), + the EMA hook when `opt` carries one): scldm_fm_prepare -> scldm_dit_train_forward -> scldm_fm_loss_grad ->
+ * scldm_dit_train_backward (every gradient into `grads`) -> scldm_adamw_table_step (skipped when opt is NULL: a data-parallel caller
+ * reduces `grads` first).  Kernel launches and event records only; every per-step decision is read from device memory.  Buffers are
+ * the caller's: */
+typedef struct {
+  int row_elems;            /* seq_len * n_embed_input */
+  float* t;                 /* (n) */
+  float* x0;                /* (n, row_elems) or NULL */
+  float* xt; float* ut; float* pred; float* dpred;   /* (n, row_elems) */
+  int64_t* labels;          /* (n_classes, n) */
+  float* loss_rows;         /* (n) */
+  float* loss_mean;         /* (1): the step's loss */
+  unsigned int* ticket;     /* zero-initialised word */
+  void* saved; void* ws;    /* scldm_dit_train_saved_bytes_for / _workspace_bytes_for */
+} scldm_train_step_buffers;
+int scldm_dit_train_step(scldm_dit* h, const scldm_dit_weights* w, const scldm_dit_grads* grads, const float* x1,
+                         const int64_t* const* labels_in, const int* null_tokens, int n_classes, int strategy, float p_drop,
+                         unsigned long long* rng_state, int n, int precision, const scldm_train_step_buffers* buffers,
+                         const scldm_adamw_launch* opt /* may be NULL */, void* stream);
 int scldm_fm_loss(const float* pred, const float* ut, float* loss, int n, int e, void* stream);
 int scldm_fm_loss_bwd(const float* pred, const float* ut, const float* gloss, float* dpred, int n, int e, void* stream);
 

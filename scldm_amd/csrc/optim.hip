@@ -90,8 +90,146 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
 }
 
 static_assert(sizeof(AdamArgs) <= 4000, "kernel arguments must stay under 4 KB");
+
+// ---- round 6: the launch table in DEVICE memory, the hyper-parameters that change per step in device memory, the EMA of the reference's
+// trainer in the same pass.  (a) Any number of tensors is one launch (the DiT-L shape's ~250 tensors were three); (b) `hyper` is read
+// by the kernel, so a captured HIP graph follows a learning-rate schedule (the reference's LambdaLR, src/scldm/models.py:603-605) and
+// the EMA schedule (ema_pytorch 0.7.7 as LatentDiffusion uses it, models.py:446-453 + on_train_batch_end, models.py:83-87) without
+// re-capture - ADVICE r5: lr was a by-value kernel argument frozen at capture; (c) the EMA's `ema.lerp_(p, 1 - decay)` (or the copy
+// of its warm-up phase) reads p from the registers of the AdamW update instead of a second pass over both models.
+struct TableTensor { float* p; const float* g; float* m; float* v; float* e; long long n; };
+struct TableBlock { int tensor, chunk; };
+struct TableArgs {
+  const TableTensor* tensors;
+  const TableBlock* blocks;
+  const float* step;
+  const float* found_inf;
+  const float* hyper;             // device float[4] or null: lr, weight_decay, EMA mode (0 none | 1 copy | 2 lerp), EMA lerp weight
+  double lr, beta1, beta2, eps, weight_decay;
+  int maximize;
+};
+// torch.lerp (ATen/native/Lerp.h): weight < 0.5 ? start + weight (end - start) : end - (end - start) (1 - weight); ATen's device code is
+// built with floating-point contraction on, so each form is ONE fma (tests/test_gpu_train.py compares the bits with Tensor.lerp_)
+__device__ __forceinline__ float torch_lerp(float start, float end, float w, float omw) {
+  const float d = end - start;
+  return fabsf(w) < 0.5f ? __builtin_fmaf(w, d, start) : __builtin_fmaf(-d, omw, end);
+}
+__global__ __launch_bounds__(256) void adamw_table_kernel(const TableArgs a) {
+  const bool skip = a.found_inf && *a.found_inf != 0.f;
+  const int ema_mode = a.hyper ? (int)a.hyper[2] : 0;
+  if (skip && ema_mode == 0) return;
+  const TableBlock blk = a.blocks[blockIdx.x];
+  const TableTensor tt = a.tensors[blk.tensor];
+  const int base = blk.chunk * kChunk;
+  const long long n = tt.n;
+  float* __restrict__ p = tt.p;
+  const float* __restrict__ g = tt.g;
+  float* __restrict__ m = tt.m;
+  float* __restrict__ v = tt.v;
+  float* __restrict__ ema = ema_mode ? tt.e : nullptr;
+  if (skip && !ema) return;
+  const double lr = a.hyper ? (double)a.hyper[0] : a.lr, wd = a.hyper ? (double)a.hyper[1] : a.weight_decay;
+  const float ew = a.hyper ? a.hyper[3] : 0.f, eomw = 1.0f - ew;
+  const double step = (double)*a.step;
+  const float bc1 = (float)(1.0 - pow(a.beta1, step)), bc2 = (float)(1.0 - pow(a.beta2, step));
+  const float step_size = (float)(lr / (double)bc1), bc2_sqrt = sqrtf(bc2), lr_wd = (float)(lr * wd);
+  const float omb1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
+  auto one = [&](float pv, float gv, float& mv, float& vv) {     // (the arithmetic of adamw_kernel, bit for bit)
+    if (a.maximize) gv = -gv;
+    pv = pv - lr_wd * pv;
+    mv = mv + omb1 * (gv - mv);
+    vv = b2 * vv + omb2 * gv * gv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    return pv - step_size * mv / denom;
+  };
+  auto ema_of = [&](float ev, float pv) { return ema_mode == 1 ? pv : torch_lerp(ev, pv, ew, eomw); };
+  const bool vec = ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v) |
+                     reinterpret_cast<size_t>(ema)) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < kChunk / (256 * 4); ++it) {
+    const long long i = base + (it * 256 + (int)threadIdx.x) * 4;
+    if (i >= n) break;
+    if (vec && i + 4 <= n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+      if (!skip) {
+        f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float me = mv[e], ve = vv[e];
+          pv[e] = one(pv[e], gv[e], me, ve);
+          mv[e] = me;
+          vv[e] = ve;
+        }
+        *reinterpret_cast<f32x4*>(p + i) = pv;
+        *reinterpret_cast<f32x4*>(m + i) = mv;
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+      }
+      if (ema) {
+        f32x4 ev = ema_mode == 1 ? pv : *reinterpret_cast<f32x4*>(ema + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev[e] = ema_of(ev[e], pv[e]);
+        *reinterpret_cast<f32x4*>(ema + i) = ev;
+      }
+    } else {
+      for (long long e = i; e < (i + 4 < n ? i + 4 : n); ++e) {
+        float pe = p[e];
+        if (!skip) {
+          float me = m[e], ve = v[e];
+          pe = one(pe, g[e], me, ve);
+          p[e] = pe;
+          m[e] = me;
+          v[e] = ve;
+        }
+        if (ema) ema[e] = ema_of(ema_mode == 1 ? pe : ema[e], pe);
+      }
+    }
+  }
+}
 }  // namespace optim
 }  // namespace scldm
+
+extern "C" size_t scldm_adamw_table_bytes(const scldm_adamw_entry* e, int count) {
+  using namespace scldm::optim;
+  if (!e || count < 1) return 0;
+  size_t blocks = 0;
+  for (int i = 0; i < count; ++i)
+    if (e[i].n > 0) blocks += (size_t)((e[i].n + kChunk - 1) / kChunk);
+  return sizeof(TableTensor) * (size_t)count + sizeof(TableBlock) * blocks;
+}
+extern "C" int scldm_adamw_table_build(const scldm_adamw_entry* e, float* const* ema, int count, void* table_host, size_t bytes, int* n_blocks) {
+  using namespace scldm::optim;
+  if (!e || count < 1 || !table_host || !n_blocks) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: bad argument");
+  if (bytes < scldm_adamw_table_bytes(e, count)) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: the table buffer is too small");
+  TableTensor* tt = reinterpret_cast<TableTensor*>(table_host);
+  TableBlock* tb = reinterpret_cast<TableBlock*>(tt + count);
+  long long blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    if (e[i].n > 0 && (!e[i].p || !e[i].g || !e[i].m || !e[i].v)) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: tensor %d has a NULL pointer", i);
+    tt[i] = TableTensor{e[i].p, e[i].g, e[i].m, e[i].v, ema ? ema[i] : nullptr, e[i].n};
+    for (long long c = 0; c * kChunk < e[i].n; ++c) tb[blocks++] = TableBlock{i, (int)c};
+  }
+  if (blocks > 0x7fffffffLL) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: too many workgroups");
+  *n_blocks = (int)blocks;
+  return SCLDM_OK;
+}
+extern "C" int scldm_adamw_table_step(const scldm_adamw_launch* l, void* stream_) {
+  using namespace scldm::optim;
+  if (!l || !l->table || !l->step || l->count < 1 || l->n_blocks < 0) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_step: bad argument");
+  hipStream_t st = (hipStream_t)stream_;
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, l->step, l->found_inf);
+  if (l->n_blocks) {
+    TableArgs a{};
+    a.tensors = reinterpret_cast<const TableTensor*>(l->table);
+    a.blocks = reinterpret_cast<const TableBlock*>(a.tensors + l->count);
+    a.step = l->step; a.found_inf = l->found_inf; a.hyper = l->hyper;
+    a.lr = l->lr; a.beta1 = l->beta1; a.beta2 = l->beta2; a.eps = l->eps; a.weight_decay = l->weight_decay; a.maximize = l->maximize;
+    hipLaunchKernelGGL(adamw_table_kernel, dim3(l->n_blocks), dim3(256), 0, st, a);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(SCLDM_ERR_HIP, "scldm_adamw_table_step: %s", hipGetErrorString(err));
+  return SCLDM_OK;
+}
 
 extern "C" int scldm_adamw_step(const scldm_adamw_entry* e, int count, float* step, const float* found_inf, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, int maximize, void* stream_) {

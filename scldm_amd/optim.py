@@ -30,6 +30,47 @@ class AdamW(torch.optim.Optimizer):
                                       capturable=True, fused=True, foreach=None, differentiable=False,
                                       decoupled_weight_decay=True))   # (torch >= 2.6: AdamW is Adam with this flag; kept so a state_dict loads there as AdamW)
 
+    # ---- EMA of the reference's trainer in the same launch (scldm_amd.ema.EMA; models.py:83-87,446-453)
+    def attach_ema(self, ema) -> None:
+        """Fold `ema.update()` into this optimizer's launch: every step() applies the EMA action of that step (copy / lerp / none,
+        ema.next_action()) to the averaged copy of each parameter it updates.  Parameters outside the optimizer (frozen ones: equal to
+        the deep copy EMA made, and lerp(a, a, w) == a) and the model's buffers are left to the host-side copy EMA made at construction."""
+        by_obj = {id(p): n for n, p in ema.model.named_parameters()}
+        avg = dict(ema.ema_model.named_parameters())
+        self._ema, self._ema_of = ema, {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                n = by_obj.get(id(p))
+                if n is None:
+                    raise ValueError("attach_ema: the optimizer holds a parameter that is not one of ema.model's")
+                self._ema_of[id(p)] = avg[n]
+            group.pop("_table", None)
+        ema._fused_by = self
+
+    def _hyper(self, group, dev):
+        h = group.get("_hyper")
+        if h is None or h[0].device != dev:
+            h = group["_hyper"] = (torch.zeros(4, dtype=torch.float32, device=dev), None)
+        return h
+
+    def refresh_hyper(self) -> None:
+        """Stage this step's learning rate, weight decay and EMA action in the device `hyper` vector of every group (asynchronous 16-byte
+        copy on the current stream).  step() calls it; `GraphedTrainStep` calls it before each replay (inside a capture it is skipped)."""
+        ema = getattr(self, "_ema", None)
+        action, w = ema.next_action() if ema is not None else (0, 0.0)
+        if ema is not None:
+            ema._pending += 1
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None] or list(group["params"])
+            if not ps:
+                continue
+            dev_t, _ = self._hyper(group, ps[0].device)
+            # a FRESH pinned staging tensor per step: the host runs several steps ahead of the device (always, when the step is a graph
+            # replay), so a reused staging buffer would be overwritten before the queued copy of an earlier step has read it; torch's
+            # pinned-memory allocator recycles a block only after the copies that read it have completed
+            host_t = torch.tensor([float(group["lr"]), float(group["weight_decay"]), float(action), float(w)], dtype=torch.float32).pin_memory()
+            dev_t.copy_(host_t, non_blocking=True)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -41,6 +82,9 @@ class AdamW(torch.optim.Optimizer):
         if grad_scale is not None:
             raise NotImplementedError("scldm_amd.optim.AdamW takes found_inf only: un-scale the gradients before the step (the fp16 backward does)")
         L = _lib.lib()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.refresh_hyper()
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -52,57 +96,95 @@ class AdamW(torch.optim.Optimizer):
                 prev = next((self.state[p]["step"] for p in ps if "step" in self.state.get(p, {})), None)
                 step_t = group["_step_t"] = torch.zeros((), dtype=torch.float32, device=dev) if prev is None else \
                     torch.as_tensor(float(prev), dtype=torch.float32, device=dev).clone()
-            # the pointer table is rebuilt only when a parameter, gradient or state tensor moved (the HIP backward's flat gradient buffer
-            # usually comes back at the same address every step): one pass of data_ptr() calls instead of 84 x the full checks
-            # (an exact, order-sensitive key: a checksum can collide when the allocator hands equal-sized blocks back in another order)
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
-            cached = group.get("_table")
-            if cached is not None and cached[0] == key and all(
-                    self.state[p]["exp_avg"].data_ptr() == cached[2][i][0] and self.state[p]["exp_avg_sq"].data_ptr() == cached[2][i][1]
-                    for i, p in enumerate(ps)):
-                ent = cached[1]
-                ps_build = ()
-            else:
-                ent = (_lib.AdamwEntry * len(ps))()
-                ps_build = ps
-            keep = []
-            for i, p in enumerate(ps_build):
-                if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
-                    raise RuntimeError("scldm_amd.optim.AdamW: fp32 CUDA (ROCm) parameters with dense fp32 gradients only; there is no CPU path")
+            # the launch table is rebuilt (host build + one host-to-device copy) only when a parameter, gradient, state or EMA tensor
+            # moved - the HIP backward's flat gradient buffer usually comes back at the same address every step.  An exact,
+            # order-sensitive key: a checksum can collide when the allocator hands equal-sized blocks back in another order.
+            ema_of = getattr(self, "_ema_of", None)
+            for p in ps:
                 st = self.state[p]
                 if "exp_avg" not in st:
+                    if not p.is_cuda or p.dtype != torch.float32:
+                        raise RuntimeError("scldm_amd.optim.AdamW: fp32 CUDA (ROCm) parameters with dense fp32 gradients only; there is no CPU path")
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] = step_t          # (shared tensor: torch's per-parameter key, one counter)
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                if not p.is_contiguous() or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
-                    raise RuntimeError("scldm_amd.optim.AdamW: parameters and optimizer state must be contiguous")
-                if g is not p.grad:
-                    key = None                       # a temporary contiguous copy: never cache its address
-                ent[i].p, ent[i].g, ent[i].m, ent[i].v, ent[i].n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                keep.append(g)
-            if ps_build:
-                group["_table"] = (key, ent, [(self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps]) \
-                    if key is not None else None
-            lr = float(group["lr"])
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                         ema_of[id(p)].data_ptr() if ema_of else 0) for p in ps)
+            cached = group.get("_table")
+            if cached is None or cached[0] != key:
+                if capturing:
+                    raise RuntimeError("scldm_amd.optim.AdamW: a tensor moved during HIP-graph capture (run warm-up steps before capturing)")
+                ent = (_lib.AdamwEntry * len(ps))()
+                emas = (C.c_void_p * len(ps))()
+                keep = []
+                cacheable = True
+                for i, p in enumerate(ps):
+                    st = self.state[p]
+                    if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                        raise RuntimeError("scldm_amd.optim.AdamW: fp32 CUDA (ROCm) parameters with dense fp32 gradients only; there is no CPU path")
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    if not p.is_contiguous() or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous():
+                        raise RuntimeError("scldm_amd.optim.AdamW: parameters and optimizer state must be contiguous")
+                    if g is not p.grad:
+                        cacheable = False               # a temporary contiguous copy: never cache its address
+                    ent[i].p, ent[i].g, ent[i].m, ent[i].v, ent[i].n = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                    if ema_of:
+                        e = ema_of[id(p)]
+                        if e.device != p.device or e.dtype != torch.float32 or not e.is_contiguous() or e.shape != p.shape:
+                            raise RuntimeError("attach_ema: the averaged copy of a parameter must be a contiguous fp32 tensor on the parameter's device")
+                        emas[i] = e.data_ptr()
+                    keep.append(g)
+                nbytes = L.scldm_adamw_table_bytes(ent, len(ps))
+                host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+                nblk = C.c_int(0)
+                _lib.check(L.scldm_adamw_table_build(ent, C.cast(emas, C.POINTER(C.c_void_p)) if ema_of else None, len(ps), host.data_ptr(), nbytes,
+                                                     C.byref(nblk)), "scldm_adamw_table_build")
+                table = host.to(dev, non_blocking=True)
+                table.record_stream(torch.cuda.current_stream(dev))
+                cached = (key if cacheable else None, table, nblk.value, host, keep)
+                group["_table"] = cached
+            _, table, nblk, _, _ = cached
+            dev_hyper, _ = self._hyper(group, dev)
             b1, b2 = group["betas"]
+            launch = _lib.AdamwLaunch(table=table.data_ptr(), count=len(ps), n_blocks=nblk, step=step_t.data_ptr(),
+                                      found_inf=None if found_inf is None else found_inf.data_ptr(), hyper=dev_hyper.data_ptr(),
+                                      lr=float(group["lr"]) if not torch.is_tensor(group["lr"]) else 0.0, beta1=float(b1), beta2=float(b2),
+                                      eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])))
             with torch.cuda.device(dev):
-                _lib.check(L.scldm_adamw_step(ent, len(ps), step_t.data_ptr(), None if found_inf is None else found_inf.data_ptr(), lr, float(b1), float(b2),
-                                              float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"])),
-                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "scldm_adamw_step")
+                _lib.check(L.scldm_adamw_table_step(C.byref(launch), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "scldm_adamw_table_step")
         return loss
+
+    def launch_struct(self, group_index: int = 0):
+        """The scldm_adamw_launch of a group whose table is current (after one step()): what `scldm_dit_train_step` takes to run the
+        optimizer inside the fused step (scldm_amd.training.FusedTrainStep)."""
+        group = self.param_groups[group_index]
+        cached, step_t = group.get("_table"), group.get("_step_t")
+        if cached is None or cached[0] is None or step_t is None:
+            raise RuntimeError("AdamW.launch_struct: take one ordinary step() first (it builds the device launch table)")
+        dev_hyper, _ = self._hyper(group, step_t.device)
+        b1, b2 = group["betas"]
+        found_inf = getattr(self, "found_inf", None)
+        return _lib.AdamwLaunch(table=cached[1].data_ptr(), count=len(cached[0]), n_blocks=cached[2], step=step_t.data_ptr(),
+                                found_inf=None if found_inf is None else found_inf.data_ptr(), hyper=dev_hyper.data_ptr(), lr=0.0,
+                                beta1=float(b1), beta2=float(b2), eps=float(group["eps"]), weight_decay=float(group["weight_decay"]),
+                                maximize=int(bool(group["maximize"])))
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         for g in self.param_groups:          # the state tensors were replaced: rebuild the pointer table and the shared step count
             g.pop("_table", None)
             g.pop("_step_t", None)
+            g.pop("_hyper", None)
+            steps = {float(self.state[p]["step"]) for p in g["params"] if "step" in self.state.get(p, {})}
+            if len(steps) > 1:   # (ADVICE r5) one counter per group here: a checkpoint whose parameters took different numbers of steps does not fit
+                raise ValueError(f"scldm_amd.optim.AdamW keeps ONE step count per parameter group; the loaded state has {sorted(steps)}")
 
     def state_dict(self):
         sd = super().state_dict()
         for g in sd["param_groups"]:
             g.pop("_step_t", None)
             g.pop("_table", None)
+            g.pop("_hyper", None)
         # every parameter gets its OWN copy of the step count: torch's optimizers increment the `step` tensor of each parameter, so a
         # shared tensor loaded there would advance once per parameter per step
         sd["state"] = {k: {kk: (vv.clone() if kk == "step" and torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}

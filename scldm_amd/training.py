@@ -273,6 +273,21 @@ class GraphedTrainStep:
             if not g.get("capturable", False):
                 raise ValueError("the optimizer step is captured in a HIP graph: construct it with capturable=True "
                                  "(e.g. torch.optim.AdamW(params, fused=True, capturable=True))")
+        # Host-side decisions a capture would freeze: (1) a multi-class mutually_exclusive model draws the class of a
+        # forward with a CPU randint (nnets.py:395; DiT._label_ptrs) - every replay would train the class drawn at capture;
+        # (2) fp16 with an optimizer that cannot take GradScaler's found_inf would apply an overflowed step (the eager train_step
+        # reads the flag on the host instead).  `FusedTrainStep` has neither restriction (class draw and schedules live on the device).
+        if getattr(dit, "condition_strategy", None) == "mutually_exclusive" and len([c for c in dit._class_names if c in condition]) > 1:
+            raise NotImplementedError("GraphedTrainStep: a mutually_exclusive model with several condition classes draws its class on the host "
+                                      "per forward; a captured graph would freeze it - use FusedTrainStep (device-side draw) or train_step")
+        if getattr(dit, "precision", None) == "fp16" and not getattr(optimizer, "_step_supports_amp_scaling", False):
+            raise NotImplementedError("GraphedTrainStep: fp16 training needs an optimizer that takes GradScaler's found_inf "
+                                      "(scldm_amd.optim.AdamW, torch's fused Adam / AdamW): an overflowed step cannot be skipped on the host inside a graph")
+        if not hasattr(optimizer, "refresh_hyper") and any(torch.is_tensor(g["lr"]) is False for g in optimizer.param_groups):
+            import warnings
+            warnings.warn("GraphedTrainStep: this optimizer passes its learning rate by value into the captured kernels - a per-step LR "
+                          "schedule (models.py:603-605) has no effect on replays; use scldm_amd.optim.AdamW (device-resident hyper-parameters) "
+                          "or a tensor lr", RuntimeWarning, stacklevel=2)
         self.dit, self.transport, self.optimizer = dit, transport, optimizer
         self.x1 = x1.detach().clone()
         self.condition = {k: v.detach().clone() for k, v in condition.items()}
@@ -310,6 +325,226 @@ class GraphedTrainStep:
         self.x1.copy_(x1, non_blocking=True)
         for k, v in condition.items():
             self.condition[k].copy_(v, non_blocking=True)
+        if hasattr(self.optimizer, "refresh_hyper"):
+            self.optimizer.refresh_hyper()       # this step's learning rate / weight decay / EMA action -> the device vector the captured kernel reads
         self.graph.replay()
         self.replays += 1
+        return self.loss
+
+
+class FusedTrainStep:
+    """One optimisation step of `LatentDiffusion.training_step` (src/scldm/models.py:628-663) + Lightning's backward, optimizer step
+    and EMA hook (models.py:83-87) as ONE C call, `scldm_dit_train_step` (include/scldm_hip.h; csrc/train_step.hip):
+
+        [frozen vae.encode of the tokenised batch, models.py:641]  ->  batch preparation (t, x0, xt, ut, label dropout, class draw: one
+        kernel, Philox state on the device)  ->  DiT forward with the training record  ->  loss + d loss (one kernel)  ->  DiT backward
+        ->  AdamW + EMA (one launch, scldm_amd.optim.AdamW with attach_ema)
+
+    No autograd, no Python between the kernels, no decision on the host: the call is captured once in a HIP graph (`graph=True`) and
+    replayed - per replay the host stages 16 bytes (learning rate, weight decay, EMA action) and copies the batch.  Gradients live in
+    one flat fp32 buffer (`.grad` of every parameter is a view), so a data-parallel group reduces it in place between backward and
+    optimizer (`group=`; that variant is not graphed).  Requires the fused training route (base DiT shape, precision bf16 | fp16), the
+    Linear path with velocity prediction (ldm_base.yaml:30-35) and `scldm_amd.optim.AdamW`.
+    `__call__(x1, condition)` or `__call__(condition=..., counts=, genes=, counts_subset=, genes_subset=)` with a frozen `vae`."""
+
+    def __init__(self, dit, transport, optimizer, batch_size: int, condition_keys, ema=None, vae=None, seed: int | None = None,
+                 graph: bool = True, group=None, encode_shape: tuple[int, int] | None = None):
+        from . import _lib
+        from .optim import AdamW
+        if not isinstance(optimizer, AdamW):
+            raise TypeError("FusedTrainStep runs the optimizer inside the step: it needs scldm_amd.optim.AdamW")
+        if len(optimizer.param_groups) != 1:
+            raise NotImplementedError("FusedTrainStep: one parameter group (the reference's configure_optimizers builds one, models.py:598-601)")
+        dev = dit.pos_embed.device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedTrainStep needs the model on a CUDA (ROCm) device; there is no CPU path")
+        self.dit, self.transport, self.optimizer, self.ema, self.vae = dit, transport, optimizer, ema, vae
+        self.n, self.group, self.dev = int(batch_size), group, dev
+        self.keys = [c for c in dit._class_names if c in set(condition_keys)]
+        if not self.keys:
+            raise ValueError("condition_keys holds none of the model's classes")
+        if dit.condition_strategy == "joint" and len(self.keys) != len(dit._class_names):
+            raise KeyError(next(c for c in dit._class_names if c not in self.keys))      # (nnets.py:449 indexes every class)
+        dit._need_null_row("label dropout")
+        if ema is not None and getattr(optimizer, "_ema", None) is not ema:
+            optimizer.attach_ema(ema)
+        L, h = dit._native_handle()
+        self._L, self._h = L, h
+        prec = dit._prec()
+        if prec not in (_lib.PRECISIONS["bf16"], _lib.PRECISIONS["fp16"]) or not dit.fused_shape:
+            raise NotImplementedError("FusedTrainStep serves the fused training route: the reference's DiT shape at precision 'bf16' or 'fp16'")
+        self.prec = prec
+        n, e = self.n, dit.seq_len * dit.n_embed_input
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x1 = torch.zeros(n, dit.seq_len, dit.n_embed_input, **f32)
+        self.labels_in = {k: torch.zeros(n, dtype=torch.long, device=dev) for k in self.keys}
+        self.t, self.loss_rows, self.loss = torch.empty(n, **f32), torch.empty(n, **f32), torch.zeros((), **f32)
+        self.xt, self.ut, self.pred, self.dpred = (torch.empty(n, e, **f32) for _ in range(4))
+        self.labels = torch.empty(len(dit._class_names), n, dtype=torch.long, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        self.rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)         # [0] Philox key, [1] step counter (advanced on the device)
+        self.saved = torch.empty(L.scldm_dit_train_saved_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(L.scldm_dit_train_workspace_bytes_for(h, n, prec), dtype=torch.uint8, device=dev)
+        self.params = tuple(dit.parameters())
+        self._w, self._keep_w = dit._weights_struct(self.params)
+        with torch.cuda.device(dev):
+            _lib.check(L.scldm_dit_train_prepare(h, C.byref(self._w), n, prec, torch.cuda.current_stream(dev).cuda_stream), "scldm_dit_train_prepare")
+        dit.__dict__["_prepared_key"] = (id(self._w), n, prec)
+        offs = dit._grad_offsets
+        self.flat = torch.zeros(dit._grad_numel, **f32)
+        base = self.flat.data_ptr()
+        self._gpos = torch.zeros_like(dit.pos_embed) if dit.pos_embed.requires_grad else None
+        self._g, self._keep_g = dit._param_struct(lambda p: (self._gpos.data_ptr() if self._gpos is not None else None) if p is dit.pos_embed
+                                                  else base + 4 * offs[id(p)])
+        for p in self.params:
+            if p.requires_grad:
+                p.grad = self._gpos if p is dit.pos_embed else self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view(p.shape)
+        names = dit._class_names
+        self._lab_ptrs = _lib.ptr_array([self.labels_in[c].data_ptr() if c in self.labels_in else None for c in names])
+        self._nulls = (C.c_int * len(names))(*[int(dit.class_vocab_sizes[c]) for c in names])
+        self._buf = _lib.TrainStepBuffers(row_elems=e, t=self.t.data_ptr(), x0=None, xt=self.xt.data_ptr(), ut=self.ut.data_ptr(),
+                                          pred=self.pred.data_ptr(), dpred=self.dpred.data_ptr(), labels=self.labels.data_ptr(),
+                                          loss_rows=self.loss_rows.data_ptr(), loss_mean=self.loss.data_ptr(), ticket=self.ticket.data_ptr(),
+                                          saved=self.saved.data_ptr(), ws=self.ws.data_ptr())
+        self.found_inf = dit.found_inf_flag() if dit.precision == "fp16" else None
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.steps = 0
+        # the encode of the tokenised batch (frozen VAE as tokenizer, models.py:641): static inputs when graphed
+        self.enc = None
+        if vae is not None and encode_shape is not None:
+            S = int(encode_shape[1])
+            self.enc = (torch.zeros(n, S, **f32), torch.zeros(n, S, dtype=torch.long, device=dev))
+        # one ordinary optimizer step builds the device launch table against the flat gradient buffer (zero gradients: a no-op update
+        # that still counts as step 1 would shift the bias correction, so its effects are rolled back)
+        self._prime_optimizer()
+        if self.distributed:
+            self._opt = None
+        else:
+            if self.found_inf is not None:
+                optimizer.found_inf = self.found_inf          # (launch_struct reads it: the fp16 backward's overflow flag skips the update on device)
+            try:
+                self._opt = optimizer.launch_struct()
+            finally:
+                if self.found_inf is not None:
+                    del optimizer.found_inf
+        self.graph = None
+        if graph and not self.distributed:
+            self._capture()
+
+    def _prime_optimizer(self) -> None:
+        opt = self.optimizer
+        snap = [p.detach().clone() for p in self.params]
+        ema = getattr(opt, "_ema", None)
+        ema_snap = None if ema is None else ([p.detach().clone() for p in ema.ema_model.parameters()], ema._host_step, ema._host_initted, ema._pending)
+        opt.step()
+        with torch.no_grad():
+            for p, s0 in zip(self.params, snap):
+                p.copy_(s0)
+            g = opt.param_groups[0]
+            g["_step_t"].zero_()
+            for p in g["params"]:
+                st = opt.state.get(p)
+                if st:
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+            if ema_snap is not None:
+                for p, s0 in zip(ema.ema_model.parameters(), ema_snap[0]):
+                    p.copy_(s0)
+                ema._host_step, ema._host_initted, ema._pending = ema_snap[1], ema_snap[2], ema_snap[3]
+
+    def _launch(self) -> None:
+        from . import _lib
+        dit = self.dit
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            if self.enc is not None:
+                z = self.vae.encode(self.enc[0], self.enc[1])
+                self.x1.copy_(z.view_as(self.x1))
+            _lib.check(self._L.scldm_dit_train_step(self._h, C.byref(self._w), C.byref(self._g), self.x1.data_ptr(), C.cast(self._lab_ptrs, _lib.c_void_pp),
+                                                    self._nulls, len(dit._class_names), 1 if dit.condition_strategy == "joint" else 0,
+                                                    float(dit.cfg_dropout_prob), self.rng.data_ptr(), self.n, self.prec, C.byref(self._buf),
+                                                    C.byref(self._opt) if self._opt is not None else None, st), "scldm_dit_train_step")
+
+    def _capture(self) -> None:
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        state = self._snapshot()
+        with torch.cuda.stream(side):            # warm-up: lazy allocations, side streams, pack tables
+            self.optimizer.refresh_hyper()
+            self._launch()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self._restore(state)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._launch()
+
+    def _snapshot(self):
+        opt, ema = self.optimizer, getattr(self.optimizer, "_ema", None)
+        g = opt.param_groups[0]
+        return ([p.detach().clone() for p in self.params], g["_step_t"].clone(),
+                [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if p in opt.state], self.rng.clone(),
+                None if ema is None else ([p.detach().clone() for p in ema.ema_model.parameters()], ema._host_step, ema._host_initted, ema._pending))
+
+    def _restore(self, state) -> None:
+        opt, ema = self.optimizer, getattr(self.optimizer, "_ema", None)
+        g = opt.param_groups[0]
+        with torch.no_grad():
+            for p, s0 in zip(self.params, state[0]):
+                p.copy_(s0)
+            g["_step_t"].copy_(state[1])
+            for p, (m, v) in zip([p for p in g["params"] if p in opt.state], state[2]):
+                opt.state[p]["exp_avg"].copy_(m)
+                opt.state[p]["exp_avg_sq"].copy_(v)
+            self.rng.copy_(state[3])
+            if ema is not None:
+                for p, s0 in zip(ema.ema_model.parameters(), state[4][0]):
+                    p.copy_(s0)
+                ema._host_step, ema._host_initted, ema._pending = state[4][1], state[4][2], state[4][3]
+
+    @torch.no_grad()
+    def __call__(self, x1: torch.Tensor | None = None, condition: dict[str, torch.Tensor] | None = None, *, counts=None, genes=None,
+                 counts_subset=None, genes_subset=None) -> torch.Tensor:
+        if condition is None or any(k not in condition for k in self.keys):
+            raise KeyError(f"FusedTrainStep was built for the condition classes {self.keys}")
+        if x1 is None:
+            if self.vae is None:
+                raise ValueError("FusedTrainStep: pass latents x1, or build it with a frozen vae and pass the tokenised batch")
+            c = counts_subset if counts_subset is not None else counts
+            gs = genes_subset if genes_subset is not None else genes
+            if self.enc is not None:
+                self.enc[0].copy_(c, non_blocking=True)
+                self.enc[1].copy_(gs, non_blocking=True)
+            else:
+                x1 = self.vae.encode(counts, genes, counts_subset, genes_subset)
+        if x1 is not None:
+            if tuple(x1.shape) != tuple(self.x1.shape):
+                raise ValueError(f"FusedTrainStep was built for latents {tuple(self.x1.shape)}, got {tuple(x1.shape)}")
+            self.x1.copy_(x1, non_blocking=True)
+        for k in self.keys:
+            self.labels_in[k].copy_(condition[k], non_blocking=True)
+        if self.distributed:
+            self._launch()                                         # backward only (opt = NULL): gradients in self.flat
+            step = max(1, (128 << 20) // 4)
+            for a in range(0, self.flat.numel(), step):
+                piece = self.flat[a:a + step]
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                piece.div_(dist.get_world_size(self.group))
+            if self.found_inf is not None:
+                dist.all_reduce(self.found_inf, op=dist.ReduceOp.MAX, group=self.group)
+                self.optimizer.found_inf, self.optimizer.grad_scale = self.found_inf, None
+            try:
+                self.optimizer.step()
+            finally:
+                if self.found_inf is not None:
+                    del self.optimizer.found_inf, self.optimizer.grad_scale
+        else:
+            self.optimizer.refresh_hyper()
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._launch()
+        self.steps += 1
         return self.loss

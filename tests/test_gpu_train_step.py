@@ -1,0 +1,274 @@
+"""The whole flow-matching optimisation step as one C call (scldm_dit_train_step, include/scldm_hip.h):
+batch preparation and loss kernels against torch compositions on the SAME draws (bit for bit), the statistics of the device-side
+draws (the reference's are torch.rand / randn / randint: RNG parity is impossible by construction), the AdamW + EMA launch against
+torch's lerp_ (bit for bit) and the oracle's restatement of ema-pytorch's schedule, and FusedTrainStep (eager and HIP-graph replay)
+against the composed autograd route on the same draws."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from scldm_amd import _lib
+from test_gpu_train import build
+
+pytestmark = pytest.mark.gpu
+
+
+def _prepare(x1, labels, nulls, strategy, p_drop, rng, drop=1, want_x0=True):
+    L = _lib.lib()
+    n, e = x1.shape[0], x1[0].numel()
+    f = dict(dtype=torch.float32, device="cuda")
+    t, xt, ut = torch.empty(n, **f), torch.empty(n, e, **f), torch.empty(n, e, **f)
+    x0 = torch.empty(n, e, **f) if want_x0 else None
+    out = torch.empty(len(labels), n, dtype=torch.long, device="cuda")
+    ptrs = _lib.ptr_array([None if l is None else l.data_ptr() for l in labels])
+    nl = (C.c_int * len(labels))(*nulls)
+    _lib.check(L.scldm_fm_prepare(x1.data_ptr(), C.cast(ptrs, _lib.c_void_pp), nl, len(labels), strategy, drop, p_drop, rng.data_ptr(), n, e,
+                                  t.data_ptr(), None if x0 is None else x0.data_ptr(), xt.data_ptr(), ut.data_ptr(), out.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "scldm_fm_prepare")
+    return t, x0, xt, ut, out
+
+
+def test_prepare_kernel_is_the_eager_composition_on_its_own_draws():
+    """transport.py:97-108 + path.py:148-151 + nnets.py:395-402,440-452 in one kernel: xt / ut are the eager expressions of the kernel's
+    own (t, x0) bit for bit; the draws have the right distributions; labels follow one mask per row; the class of a mutually_exclusive
+    model is drawn per call on the device; everything is a function of (seed, step counter) only."""
+    n = 4096
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x1 = torch.randn(n, 16, 16, device="cuda", generator=g)
+    a = torch.randint(0, 4, (n,), device="cuda", generator=g)
+    b = torch.randint(0, 2024, (n,), device="cuda", generator=g)
+    rng = torch.tensor([12345, 7], dtype=torch.int64, device="cuda")
+    t, x0, xt, ut, lab = _prepare(x1, [a, b], [4, 2024], 1, 0.8, rng)
+    x1f = x1.view(n, -1)
+    te = t.view(-1, 1)
+    assert torch.equal(xt, te * x1f + (1 - te) * x0) and torch.equal(ut, x1f - x0)
+    assert float(t.min()) >= 0.0 and float(t.max()) < 1.0
+    assert abs(float(t.mean()) - 0.5) < 0.02 and abs(float(t.var()) - 1 / 12) < 0.005
+    z = x0.double()
+    assert abs(float(z.mean())) < 0.005 and abs(float(z.var()) - 1) < 0.01 and abs(float((z ** 4).mean()) - 3) < 0.05 and abs(float((z ** 3).mean())) < 0.02
+    assert abs(float(torch.corrcoef(torch.stack([z[:, 0], z[:, 1]]))[0, 1])) < 0.06        # neighbours of one Philox call are independent
+    # joint: ONE mask per row over every class (nnets.py:440-443)
+    da, db = lab[0] == 4, lab[1] == 2024
+    assert torch.equal(da, db) and abs(float(da.float().mean()) - 0.8) < 0.03
+    assert torch.equal(lab[0][~da], a[~da]) and torch.equal(lab[1][~db], b[~db])
+    # same state -> same batch; next step -> another one; x0 = NULL changes nothing else
+    t2, _, xt2, ut2, lab2 = _prepare(x1, [a, b], [4, 2024], 1, 0.8, rng, want_x0=False)
+    assert torch.equal(t, t2) and torch.equal(xt, xt2) and torch.equal(ut, ut2) and torch.equal(lab, lab2)
+    rng[1] += 1
+    t3, x03, _, _, lab3 = _prepare(x1, [a, b], [4, 2024], 1, 0.8, rng)
+    assert not torch.equal(t, t3) and not torch.equal(x0, x03) and not torch.equal(lab, lab3)
+    # drop = 0 (eval-mode forward_with_cfg never drops): labels pass through
+    assert torch.equal(_prepare(x1, [a, b], [4, 2024], 1, 0.8, rng, drop=0)[4], torch.stack([a, b]))
+    # mutually_exclusive with two classes: one class per CALL (nnets.py:395), the other all null; both get their turn
+    picks = []
+    for step in range(64):
+        rng[1] = step
+        out = _prepare(x1[:256], [a[:256], b[:256]], [4, 2024], 0, 0.5, rng)[4]
+        live = [bool((out[0] != 4).any()), bool((out[1] != 2024).any())]
+        assert sum(live) == 1
+        picks.append(live.index(True))
+        c = picks[-1]
+        keep = out[c] != [4, 2024][c]
+        assert abs(float(keep.float().mean()) - 0.5) < 0.15 and torch.equal(out[c][keep], [a, b][c][:256][keep])
+    assert 16 <= sum(picks) <= 48
+    # a class missing from `condition`: never chosen, always null
+    out = _prepare(x1[:64], [None, b[:64]], [4, 2024], 0, 0.0, rng)[4]
+    assert bool((out[0] == 4).all()) and torch.equal(out[1], b[:64])
+    with pytest.raises(_lib.ScldmError):
+        _prepare(x1[:64], [None, b[:64]], [4, 2024], 1, 0.0, rng)          # joint needs every class (nnets.py:449)
+
+
+def test_loss_grad_kernel_matches_the_composed_kernels_bit_for_bit():
+    L = _lib.lib()
+    n, e = 1000, 256
+    g = torch.Generator(device="cuda").manual_seed(2)
+    pred, ut = torch.randn(n, e, device="cuda", generator=g), torch.randn(n, e, device="cuda", generator=g)
+    rows, mean, dpred = torch.empty(n, device="cuda"), torch.zeros((), device="cuda"), torch.empty(n, e, device="cuda")
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rng = torch.tensor([5, 41], dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for rep in range(3):
+        _lib.check(L.scldm_fm_loss_grad(pred.data_ptr(), ut.data_ptr(), n, e, rows.data_ptr(), mean.data_ptr(), dpred.data_ptr(), ticket.data_ptr(),
+                                        rng.data_ptr(), st), "scldm_fm_loss_grad")
+        rows_ref, d_ref = torch.empty(n, device="cuda"), torch.empty(n, e, device="cuda")
+        gl = torch.full((n,), 1.0 / n, device="cuda")
+        _lib.check(L.scldm_fm_loss(pred.data_ptr(), ut.data_ptr(), rows_ref.data_ptr(), n, e, st), "scldm_fm_loss")
+        _lib.check(L.scldm_fm_loss_bwd(pred.data_ptr(), ut.data_ptr(), gl.data_ptr(), d_ref.data_ptr(), n, e, st), "scldm_fm_loss_bwd")
+        assert torch.equal(rows, rows_ref) and torch.equal(dpred, d_ref)
+        assert abs(float(mean) - float(rows.double().mean())) <= 2e-6 * float(mean)
+        assert int(ticket) == 0 and int(rng[1]) == 42 + rep                      # the ticket resets itself, the Philox step counter advances
+    m0 = float(mean)
+    _lib.check(L.scldm_fm_loss_grad(pred.data_ptr(), ut.data_ptr(), n, e, rows.data_ptr(), mean.data_ptr(), dpred.data_ptr(), ticket.data_ptr(), None, st), "x")
+    assert float(mean) == m0 and int(rng[1]) == 44                                # fixed-order sums: repeatable; NULL state: no advance
+
+
+def _torch_ema_reference(traj, kw):
+    from oracle.ema import run
+    return run(traj, **kw)
+
+
+def test_adamw_launch_with_ema_is_torch_lerp_bit_for_bit_and_follows_lr():
+    """scldm_adamw_table_step: (a) the parameters follow torch's fused AdamW under a per-step learning-rate schedule read from device
+    memory; (b) the EMA tensors equal `ema.lerp_(p, 1 - decay)` / copies applied by torch on the SAME parameter trajectory, bit for bit,
+    through the copy phase, lerp weights above and below 0.5 (both branches of torch.lerp) and the steps without an update;
+    (c) a found_inf step skips AdamW but not the EMA hook (models.py:83-87 runs after every batch)."""
+    from scldm_amd.ema import EMA
+    from scldm_amd.optim import AdamW
+    torch.manual_seed(0)
+    shapes = [(300, 17), (4096,), (5,), (64, 64), (1, 9000)]
+    net = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes])
+    ref = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in net])
+    kw = dict(beta=0.95, update_every=2, update_after_step=7)
+    ema = EMA(model=net, **kw)
+    opt = AdamW(net.parameters(), lr=1e-2, weight_decay=0.05)
+    opt.attach_ema(ema)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05, fused=True)
+    traj = [[] for _ in shapes]
+    flag = torch.zeros((), device="cuda")
+    for step in range(60):
+        lr = 1e-2 * (0.5 + 0.5 * np.cos(step / 10))                               # LambdaLR-style schedule: a new value every step
+        for g_ in opt.param_groups + topt.param_groups:
+            g_["lr"] = lr
+        grads = [torch.randn_like(p) for p in net]
+        for p, q, g_ in zip(net, ref, grads):
+            p.grad, q.grad = g_.clone(), g_.clone()
+        skip = step == 37
+        flag.fill_(1.0 if skip else 0.0)
+        opt.found_inf, opt.grad_scale = flag, None
+        opt.step()
+        del opt.found_inf, opt.grad_scale
+        ema.update()
+        if not skip:
+            topt.step()
+        for i, p in enumerate(net):
+            traj[i].append(p.detach().clone())
+    for p, q in zip(net, ref):
+        assert float((p - q).detach().abs().max()) <= 2e-6 * float(q.detach().abs().max())         # (torch's kernel forms lr-dependent terms in another order)
+    for i, avg in enumerate(ema.ema_model.parameters()):
+        want = _torch_ema_reference(traj[i], kw)[-1]
+        assert torch.equal(avg, want), i
+    sched = __import__("oracle.ema", fromlist=["schedule"]).schedule(60, **kw)
+    ws = [w for a, w in sched if a == "lerp"]
+    assert min(ws) < 0.5 < max(ws)                                                 # both branches of torch.lerp were exercised
+    with pytest.raises(RuntimeError, match="has not stepped"):
+        ema.update()                                                               # one update() per optimizer step
+
+
+@pytest.mark.parametrize("strategy,vocab,prec", [("joint", {"cell_line": 4, "gene": 2024}, "bf16"), ("mutually_exclusive", {"a": 5, "b": 9}, "bf16"),
+                                                 ("joint", {"cell_line": 4, "gene": 2024}, "fp16")])
+def test_fused_train_step_equals_the_composed_route_and_replays_as_a_graph(strategy, vocab, prec):
+    """FusedTrainStep (one C call per step) against the autograd route (DiT.forward -> _FlowMatchLoss -> backward -> AdamW.step ->
+    EMA) fed the SAME draws: gradients, parameters, optimizer state and EMA bit for bit; then the HIP-graph form against the eager
+    form over several steps (device-side step counter, learning-rate schedule and EMA actions reach the replays)."""
+    from scldm_amd.ema import EMA
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import _FlowMatchLoss, create_transport
+    n = 96
+    m1, _, _ = build(vocab, strategy, 8, 31)
+    m1.precision = prec
+    m1.cfg_dropout_prob = 0.6
+    m2 = copy.deepcopy(m1)
+    m3 = copy.deepcopy(m1)
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    kw = dict(beta=0.9, update_every=2, update_after_step=3)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    batches = [(torch.randn(n, 16, 16, device="cuda", generator=gen), {k: torch.randint(0, v, (n,), device="cuda", generator=gen) for k, v in vocab.items()})
+               for _ in range(6)]
+    lrs = [1e-3 * (1 + s) / 6 for s in range(6)]
+
+    def make(m, graph):
+        opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)
+        ema = EMA(model=m, **kw)
+        return FusedTrainStep(m, tr, opt, n, list(vocab), ema=ema, seed=99, graph=graph), opt, ema
+
+    f1, o1, e1 = make(m1, False)
+    # ---- step 0: fused eager vs composed on the same draws
+    o1.param_groups[0]["lr"] = lrs[0]
+    x1, cond = batches[0]
+    loss1 = f1(x1, cond).clone()
+    e1.update()
+    t, xt, ut, lab = f1.t.clone(), f1.xt.clone(), f1.ut.clone(), f1.labels.clone()
+    g1 = f1.flat.clone()
+    o2 = AdamW([p for p in m2.parameters() if p.requires_grad], lr=lrs[0], weight_decay=0.01)
+    e2 = EMA(model=m2, **kw)
+    m2.cfg_dropout_prob = 0.0                                    # the labels below are already dropped: no second mask
+    names = m2._class_names
+    if strategy == "joint":
+        cond2 = {c: lab[i] for i, c in enumerate(names)}
+    else:                                                        # the class the kernel drew is the only one that is not all-null
+        live = [i for i, c in enumerate(names) if bool((lab[i] != vocab[c]).any())]
+        cond2 = {names[live[0] if live else 0]: lab[live[0] if live else 0]}
+    pred = m2(xt.view(n, 16, 16), t, cond2, force_drop_ids=False)
+    loss2 = _FlowMatchLoss.apply(pred.view(n, -1), ut).mean()
+    loss2.backward()
+    assert abs(float(loss1) - float(loss2)) <= 2e-6 * abs(float(loss2))
+    offs = m1._grad_offsets
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            continue
+        assert torch.equal(g1[offs[id(p1)]:offs[id(p1)] + p1.numel()].view(p1.shape), p2.grad), k
+    if prec == "fp16":
+        o2.found_inf, o2.grad_scale = m2.found_inf_flag(), None
+    o2.step()
+    e2.update()
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p1, p2), k
+    for (k, a), (_, b) in zip(e1.ema_model.named_parameters(), e2.ema_model.named_parameters()):
+        assert torch.equal(a, b), k
+    # ---- steps 1-5 eager on m1; steps 0-5 as graph replays on m3 (same seed, same batches, same schedule): identical models
+    for s in range(1, 6):
+        o1.param_groups[0]["lr"] = lrs[s]
+        f1(*batches[s])
+        e1.update()
+    f3, o3, e3 = make(m3, True)
+    assert f3.graph is not None
+    losses = []
+    for s in range(6):
+        o3.param_groups[0]["lr"] = lrs[s]
+        losses.append(float(f3(*batches[s])))
+        e3.update()
+    assert abs(losses[0] - float(loss1)) <= 2e-6 * abs(float(loss1)) and len(set(losses)) == 6
+    for (k, p1), (_, p3) in zip(m1.named_parameters(), m3.named_parameters()):
+        assert torch.equal(p1, p3), k
+    for (k, a), (_, b) in zip(e1.ema_model.named_parameters(), e3.ema_model.named_parameters()):
+        assert torch.equal(a, b), k
+    assert int(f3.rng[1]) == 6 and float(o3.param_groups[0]["_step_t"]) == 6.0
+    # the EMA model is a working DiT (models.py:690 evaluates it): its packed copies follow the in-place updates
+    e3.ema_model.eval()
+    y = e3(batches[0][0], torch.full((n,), 0.5, device="cuda"), {k: v for k, v in batches[0][1].items()} if strategy == "joint" else
+           {list(vocab)[0]: batches[0][1][list(vocab)[0]]})
+    assert torch.isfinite(y).all()
+
+
+def test_fused_train_step_with_the_frozen_vae_encode_in_the_graph():
+    """models.py:641: every training step encodes the tokenised batch with the frozen VAE; here the encode sits inside the captured
+    step (static token buffers), and the latents it trains on are the ones TransformerVAE.encode returns."""
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    from test_gpu_vae import _fresh_vae
+    n, S, G = 64, 200, 500
+    vae, _, _ = _fresh_vae(G, 5)
+    for p in vae.parameters():
+        p.requires_grad_(False)
+    vae.precision = "fp16"
+    m, _, _ = build({"clusters": 14}, "mutually_exclusive", 8, 32)
+    m.precision = "bf16"
+    m.cfg_dropout_prob = 0.8
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    step = FusedTrainStep(m, tr, opt, n, ["clusters"], vae=vae, seed=3, graph=True, encode_shape=(n, S))
+    rngn = np.random.default_rng(0)
+    p0 = [p.detach().clone() for p in m.parameters()]
+    for it in range(3):
+        genes = torch.from_numpy(np.stack([rngn.permutation(G)[:S] for _ in range(n)])).cuda()
+        counts = torch.from_numpy(rngn.poisson(1.0, (n, S)).astype(np.float32)).cuda()
+        lab = {"clusters": torch.from_numpy(rngn.integers(0, 14, n)).cuda()}
+        loss = float(step(condition=lab, counts_subset=counts, genes_subset=genes))
+        assert np.isfinite(loss)
+        assert torch.equal(step.x1.view(n, 16, 16), vae.encode(counts, genes))
+    assert any(not torch.equal(a, b) for a, b in zip(p0, m.parameters()))
