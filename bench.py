@@ -310,6 +310,19 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world, optimize
     cond = {k: torch.randint(0, v, (wl["B"],), generator=g).to(device) for k, v in wl["vocab"].items()}
     step = lambda: train_step(m, tr, opt, x1, cond)
     time_training.graphed = False
+    if graphed == "fused" and not dist_on:
+        # the product's one-call step (scldm_amd.training.FusedTrainStep -> scldm_dit_train_step, replayed as a HIP graph): batch
+        # preparation, forward, loss, backward, AdamW + EMA; the latents are copied into the graph's static input every step
+        from scldm_amd.ema import EMA
+        from scldm_amd.training import FusedTrainStep
+        ema = EMA(model=m, beta=0.9999, update_every=10, update_after_step=10_000)      # ldm_base.yaml:51-55
+        fstep = FusedTrainStep(m, tr, opt, wl["B"], list(wl["vocab"]), ema=ema, seed=7, graph=True)
+        def step():
+            loss = fstep(x1, cond)
+            ema.update()
+            return loss
+        time_training.graphed = True
+        graphed = False
     if graphed and not dist_on:
         # the product's whole-step HIP graph (scldm_amd.training.GraphedTrainStep): forward, backward and optimizer captured once,
         # one graph launch per mini-batch (the batch is copied into the graph's static inputs every step, as a data loader's would be)
@@ -351,6 +364,57 @@ def time_training(wl, precision, device, steps, warmup, dist_on, world, optimize
         if not time_training.info["replicas_in_sync"]:
             raise SystemExit("bench.py: data-parallel replicas diverged (parameter checksums differ across ranks)")
     return dt, float(loss)
+
+
+def train_end_to_end(wl, precision, device, n_genes=17002, S=6147, steps=20):
+    """The LDM training step as the reference runs it (src/scldm/models.py:628-663 + hooks): tokenised counts of the batch -> frozen
+    VAE encode (models.py:641; fp16 operands = the reference's TF32 class) -> flow-matching step -> AdamW -> EMA hook (models.py:83-87,
+    ldm_base.yaml:51-55), everything inside ONE HIP graph replay per step.  ms per step (wall, 20 replays between synchronisations) and the
+    device time of every stage of one eager step (HIP events between the sub-calls)."""
+    from scldm_amd.ema import EMA
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    B = wl["B"]
+    m = make_model(wl, precision, device).train()
+    vae = make_vae(n_genes, device)
+    for p in vae.parameters():
+        p.requires_grad_(False)
+    vae.precision = "fp16"
+    opt = make_optimizer([p for p in m.parameters() if p.requires_grad], 1e-4, "native")
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    ema = EMA(model=m, beta=0.9999, update_every=10, update_after_step=10_000)
+    g = torch.Generator().manual_seed(5)
+    genes = torch.stack([torch.randperm(n_genes, generator=g)[:S] for _ in range(8)]).repeat(B // 8, 1).to(device)
+    counts = torch.poisson(torch.full((B, S), 1.5), generator=g).to(device)
+    cond = {k: torch.randint(0, v, (B,), generator=g).to(device) for k, v in wl["vocab"].items()}
+    rec = {"workload": f"replogle_train_b{B} from tokenised counts", "cells": B, "tokens_per_cell": S, "n_genes": n_genes, "dtype": precision,
+           "vae_encode_precision": "fp16", "ema": "beta 0.9999, every 10 steps, after 10 000 (ldm_base.yaml:51-55)"}
+    for graph in (True, False):
+        fs = FusedTrainStep(m, tr, opt, B, list(wl["vocab"]), ema=ema, vae=vae, seed=11, graph=graph, encode_shape=(B, S))
+        def step():
+            loss = fs(condition=cond, counts_subset=counts, genes_subset=genes)
+            ema.update()
+            return loss
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        rec["ms_per_step_graph" if graph else "ms_per_step_eager_one_c_call"] = 1e3 * (time.perf_counter() - t0) / steps
+        if not graph:
+            st = [fs.profile_stages() for _ in range(5)]
+            for _ in range(5):
+                ema.update()
+            rec["stage_ms"] = {k: statistics.median(s_[k] for s_ in st) for k in st[0]}
+        del fs
+    rec["ms_per_step"] = rec["ms_per_step_graph"]
+    rec["cells_per_s"] = B / (rec["ms_per_step"] / 1e3)
+    return rec
 
 
 def fused_kernel_roofline(m, blocks, n_fwd, precision, wl, evals_per_step):
@@ -848,6 +912,7 @@ def compact_line(result):
     for prec in ("fp32", "fp16"):
         put(f"mcab_dec_gene_{prec}_frac", "mcab_roofline", prec, "dec_gene", "frac"); put(f"mcab_dec_gene_{prec}_us", "mcab_roofline", prec, "dec_gene", "avg_launch_us")
         put(f"mcab_enc_pool_{prec}_frac", "mcab_roofline", prec, "enc_pool", "frac"); put(f"mcab_enc_pool_{prec}_us", "mcab_roofline", prec, "enc_pool", "avg_launch_us")
+    put("train_e2e_ms", "training_step_end_to_end", "ms_per_step"); put("train_autograd_graph_ms", "training_step_autograd_graph", "ms_per_step")
     put("e2e_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "cells_per_s")
     put("e2e_ms_dentate512", "generation_end_to_end", "dentate_b512_euler50", "ms")
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
@@ -1101,18 +1166,27 @@ def main():
             tw = dict(TRAIN_WORKLOADS["replogle_train_b1024"])
             torch.cuda.empty_cache()
             tprec = "bf16" if args.precision in ("bf16", "fp16") else "fp32"
-            dtt, _ = time_training(tw, tprec, device, 20, 5, False, 1, graphed=True)
+            fused_ok = tprec == "bf16"
+            try:
+                dtt, _ = time_training(tw, tprec, device, 20, 5, False, 1, graphed="fused" if fused_ok else True)
+            except Exception as e:   # the one-call step must not take the line down: fall back to the graphed autograd step, and say so
+                note(f"FusedTrainStep failed ({e!r}): timing GraphedTrainStep")
+                fused_ok = False
+                torch.cuda.synchronize()
+                dtt, _ = time_training(tw, tprec, device, 20, 5, False, 1, graphed=True)
             dtt /= 2
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
-                                       "launch": ("GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph"
+                                       "launch": ("FusedTrainStep: scldm_dit_train_step (batch preparation, forward, loss, backward, AdamW + EMA hook: one C call) "
+                                                  "replayed as one HIP graph" if fused_ok else
+                                                  "GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph"
                                                   if time_training.graphed else "eager train_step (graph capture failed: see stderr)"),
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "
                                                 "per layer (DESIGN 4.5)") if tprec == "bf16" else "generic GEMM path (DESIGN 4.6)"}
             if tprec == "bf16":
                 # the same step at the reference's own training precision class (fp16 operands = TF32's mantissa, loss-scaled backward)
                 torch.cuda.empty_cache()
-                dth, _ = time_training(tw, "fp16", device, 20, 5, False, 1, graphed=True)
+                dth, _ = time_training(tw, "fp16", device, 20, 5, False, 1, graphed="fused" if fused_ok else True)
                 dth /= 2
                 result["training_step_fp16"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dth / 10), "ms_per_step": 1e3 * dth / 10,
                                                 "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dth / 10) / 1e12, "dtype": "fp16",
@@ -1122,7 +1196,15 @@ def main():
             dte, _ = time_training(tw, tprec, device, 10, 5, False, 1)
             result["training_step_eager"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dte / 10, "dtype": tprec,
                                              "launch": "scldm_amd.training.train_step: eager (~100 kernel launches + autograd + optimizer Python per step)"}
-            d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1, graphed=True)   # the small-batch step
+            d256, _ = time_training(dict(tw, B=256), tprec, device, 20, 5, False, 1, graphed="fused" if fused_ok else True)   # the small-batch step
+            dgr, _ = time_training(tw, tprec, device, 20, 5, False, 1, graphed=True)
+            result["training_step_autograd_graph"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dgr / 20, "dtype": tprec,
+                                                      "launch": "GraphedTrainStep: Transport.training_losses -> autograd -> optimizer.step() captured as one HIP graph (round 5's form)"}
+            if fused_ok:
+                try:
+                    result["training_step_end_to_end"] = train_end_to_end(tw, tprec, device)
+                except Exception as e:  # noqa: BLE001
+                    result["training_step_end_to_end"] = {"error": repr(e)}
             torch.cuda.empty_cache()
             dto, _ = time_training(tw, tprec, device, 10, 5, False, 1, optimizer="torch")
             result["training_step_torch_adamw"] = {"workload": "replogle_train_b1024", "ms_per_step": 1e3 * dto / 10, "dtype": tprec,

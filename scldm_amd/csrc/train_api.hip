@@ -1000,6 +1000,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     } else {
       TRY(fused::backward_layers(h, g, s.mod, k.dmod, n, rec, fs, st, precision));
     }
+    if (edge) TRY(fused::join_side(h, st, 0));   // the final layer's weight / bias gradient reduction (side stream 0, fused::final_backward)
     if (!edge || dx_out) TRY(fused::to_plain(fs.dx, k.dx, n, st));
   }
   // bf16-source route: dy, dqkv, da, db (consumed only by GEMMs) are bf16 arrays in their slots of the scratch block

@@ -306,6 +306,26 @@ __global__ void wgrad_reduce_kernel(const ReduceArgs g) {
   }
 }
 
+// The same for up to eight layers in ONE launch (blockIdx.y = layer): at batches whose backward kernel fills the chip the eight
+// per-layer reductions (10 us each + a launch gap, in series between backward layers) leave the layer loop - every layer keeps its
+// own partial block and they are summed behind the last layer (round 6; SCLDM_TRAIN_WGRAD_DEFER=0 restores the per-layer launches).
+struct ReduceAll { ReduceArgs layer[8]; };
+__global__ void wgrad_reduce_all_kernel(const ReduceAll all) {
+  const ReduceArgs& g = all.layer[blockIdx.y];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < g.total; i += (long)gridDim.x * blockDim.x) {
+    int ji = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+      if (k < g.n_jobs && i >= g.job[k].first) ji = k;
+    const ReduceJob& j = g.job[ji];
+    const long e = i - j.first, mn = (long)j.M * j.N;
+    float s = 0.f;
+    for (int z = 0; z < g.splits; ++z) s += g.part[j.part_off + z * mn + e];
+    j.dst[(e / j.N) * j.ldc + (e % j.N)] = s;
+  }
+}
+static_assert(sizeof(ReduceAll) <= 4000, "kernel arguments must stay under 4 KB");
+
 __global__ void iota32_kernel(int32_t* __restrict__ ri, int n) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < n) ri[s] = s;
@@ -424,7 +444,10 @@ __global__ __launch_bounds__(256) void inproj_bwd_kernel(const float* __restrict
 
 // out[j] = sum_p part[p * ld + j] (p ascending), 16 columns x 16 row phases per workgroup; `period` > 0: only rows p with
 // p % period == phase0 contribute (the per-wave position rows of inproj_bwd_kernel)
-__global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restrict__ part, int rows, int ld, int cols, float* __restrict__ out) {
+// (columns >= split go to out2[c - split]: the final layer's weight and bias gradients leave for their two tensors directly - round 5
+// reduced into scratch and issued two device-to-device copies behind it, ~10 us of copy engine + gaps in front of the layer loop)
+__global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restrict__ part, int rows, int ld, int cols, float* __restrict__ out,
+                                                          float* __restrict__ out2 = nullptr, int split = 0) {
   __shared__ float red[16][17];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
   float s = 0.f;
@@ -436,7 +459,8 @@ __global__ __launch_bounds__(256) void edge_reduce_kernel(const float* __restric
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
-    out[c] = t;
+    if (out2 && c >= split) out2[c - split] = t;
+    else out[c] = t;
   }
 }
 // d in_w arrives as [c][f] (the kernel's accumulation order); the parameter is (256, din): out[f * din + c]
@@ -599,7 +623,10 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.e_set_elems = (c.off - set_off0) / sizeof(__bf16);
   s.e_set1 = pad4(n) / 4 <= kOverlapTiles ? c.take<__bf16>(s.e_set_elems) : nullptr;
   s.part_floats = part_floats(h);
-  s.part = c.take<float>(s.part_floats);
+  // one partial block per layer where the per-layer reductions are deferred to the end of the layer loop (no second operand-pair set:
+  // the backward kernel fills the chip), one block otherwise
+  s.part_layers = s.e_set1 ? 1 : h->cfg.n_layer;
+  s.part = c.take<float>(s.part_floats * (size_t)s.part_layers);
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.edge_part = c.take<float>(edge_part_floats(h));
   s.dout_s = c.take<float>(T * 32);
@@ -777,11 +804,13 @@ static int final_backward_t(scldm_dit* h, const float* x_last, const float* mod,
     HIP_TRY(hipMemsetAsync(dx + (size_t)(n / 4) * 64 * kD, 0, (size_t)64 * kD * sizeof(float), st));
   final_bwd_kernel<DIN><<<groups, 256, 0, st>>>(x_last, mod, h->mod_w, of, dout, fin_w, h->cfg.layernorm_eps, n, dx, dmod, part);
   LAUNCH_CHECK();
-  float* red = part + (size_t)rows * ld;   // [DIN*256 + 32] reduced, then split into the two parameters
-  edge_reduce_kernel<<<cdiv(ld, 16), 256, 0, st>>>(part, rows, ld, ld, red);
+  // The reduction of the per-wave partials (d fin_w, d fin_b) feeds nothing in the layer loop: it runs on side stream 0 beside the
+  // first backward layer (round 6; it was 20 us + two copies on the critical path); the caller joins side 0 after the layers.
+  hipStream_t ss = st;
+  const int rc = fork_side(h, st, 0, &ss);
+  if (rc) return rc;
+  edge_reduce_kernel<<<cdiv(DIN * kD + DIN, 16), 256, 0, ss>>>(part, rows, ld, DIN * kD + DIN, gw, gb, DIN * kD);
   LAUNCH_CHECK();
-  HIP_TRY(hipMemcpyAsync(gw, red, (size_t)DIN * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(gb, red + DIN * kD, (size_t)DIN * sizeof(float), hipMemcpyDeviceToDevice, st));
   return SCLDM_OK;
 }
 int final_backward(scldm_dit* h, const float* x_last, const float* mod, const float* dout, const float* fin_w, int n, float* dx,
@@ -887,6 +916,10 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
       if (!h->wg_ev[q]) HIP_TRY(hipEventCreateWithFlags(&h->wg_ev[q], hipEventDisableTiming));
   }
   const ptrdiff_t set_delta = overlap ? s.e_set1 - s.e_h1 : 0;
+  static const bool defer_off = [] { const char* e = getenv("SCLDM_TRAIN_WGRAD_DEFER"); return e && e[0] == '0'; }();
+  const bool defer = !overlap && !defer_off && s.part_layers >= c.n_layer;
+  ReduceAll pending{};
+  int n_pending = 0;
   for (int l = c.n_layer - 1; l >= 0; --l) {
     const int set = overlap ? ((c.n_layer - 1 - l) & 1) : 0;
     const ptrdiff_t sd = set ? set_delta : 0;
@@ -973,7 +1006,8 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     wa.T = T;
     const int splits_req = h->wgrad_splits > 0 ? std::min(kSplits, h->wgrad_splits) : kSplitsDefault;
     wa.kchunk = cdiv(cdiv(T, splits_req), kWK) * kWK;
-    wa.part = s.part;
+    float* part_l = s.part + (defer ? (size_t)l * s.part_floats : 0);
+    wa.part = part_l;
     const int splits = cdiv(T, wa.kchunk);
     wa.splits = splits;
     wgrad_bf16_kernel<BW::kF16><<<tile0 * splits, 256, kWgradLds, sw>>>(wa);
@@ -981,9 +1015,18 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     ra.n_jobs = nr;
     ra.splits = splits;
     ra.total = first;
-    ra.part = s.part;
-    wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, sw>>>(ra);
-    LAUNCH_CHECK();
+    ra.part = part_l;
+    if (defer) {
+      pending.layer[n_pending++] = ra;
+      if (n_pending == 8 || l == 0) {
+        wgrad_reduce_all_kernel<<<dim3((unsigned)std::min<long>(cdiv(first, 256), 1024), n_pending), 256, 0, sw>>>(pending);
+        LAUNCH_CHECK();
+        n_pending = 0;
+      }
+    } else {
+      wgrad_reduce_kernel<<<(unsigned)std::min<long>(cdiv(first, 256), 4096), 256, 0, sw>>>(ra);
+      LAUNCH_CHECK();
+    }
     if (overlap) HIP_TRY(hipEventRecord(h->wg_ev[set], sw));
   }
   if (overlap) {   // every weight gradient is final before the caller's tails / gradient events

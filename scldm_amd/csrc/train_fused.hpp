@@ -34,7 +34,8 @@ struct Scratch {
   float* ada_dw;    // (mod_w, 256) + (mod_w): gradient of the stacked adaLN Linears before it is scattered to the per-layer tensors
   float* edge_part; // per-wave partials of the final-layer / input-projection weight gradients
   float* dout_s;    // fp16 policy: the loss-scaled copy of d loss / d output (n x 16 x n_embed_input)
-  size_t part_floats;   // floats behind `part`
+  size_t part_floats;   // floats of ONE layer's partial block behind `part`
+  int part_layers;      // blocks behind `part`: n_layer where the per-layer reductions are deferred to the end of the layer loop, else 1
   float* scale;     // fp16 policy: the handle's loss-scale state ([0] S, a power of two decided on device from max |dout|, [1] 1 / S, ...)
   size_t bytes;
 };

@@ -98,30 +98,45 @@ __global__ __launch_bounds__(256) void fm_prepare_kernel(const PrepArgs a) {
   }
 }
 
-// One workgroup per batch row: loss_rows[b] = mean_e (pred - ut)^2 (fm_loss_kernel's order), dpred = (1/n) (2/e) (pred - ut) (what
-// autograd hands back through mean() and fm_loss_bwd_kernel: gloss[b] = 1/n); the LAST workgroup to finish (ticket) sums the rows
-// in a fixed order into loss_mean and advances the Philox step counter - deterministic, one launch.
+// One WAVE per batch row, eight rows per workgroup: loss_rows[b] = mean_e (pred - ut)^2 in fm_loss_kernel's summation order (its thread
+// i takes elements i, i + 256, ...; its four waves are summed ((0 + 1) + (2 + 3)): lane l here carries the four partial sums of threads
+// l, 64 + l, 128 + l, 192 + l and reduces each with the same butterfly), dpred = (1/n) (2/e) (pred - ut) (what autograd hands back through
+// mean() and fm_loss_bwd_kernel: gloss[b] = 1/n); the LAST workgroup to finish (ticket) sums the rows in a fixed order into loss_mean and
+// advances the Philox step counter - deterministic, one launch.  (One workgroup per row was 1 024 same-address ticket atomics at ~20 ns
+// each: 26 us for a 1 MB pass, profiles/r6d; eight rows per workgroup: n / 8 of them.)
+constexpr int kLossRows = 8;
 __global__ __launch_bounds__(256) void fm_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ ut, float* __restrict__ loss_rows,
                                                            float* __restrict__ loss_mean, float* __restrict__ dpred, int n, int e,
                                                            unsigned int* __restrict__ ticket, unsigned long long* __restrict__ rng) {
   __shared__ float red[4];
   __shared__ bool last;
-  const long b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float gl = 1.0f / (float)n, k = 2.0f / (float)e;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < e; i += 256) {
-    const float d = pred[b * e + i] - ut[b * e + i];
-    s = fmaf(d, d, s);
-    dpred[b * e + i] = gl * k * d;
-  }
+  for (int r = wave; r < kLossRows; r += 4) {
+    const long b = (long)blockIdx.x * kLossRows + r;
+    if (b >= n) break;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < e; base += 256) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+      for (int q = 0; q < 4; ++q) {
+        const int i = base + 64 * q + lane;
+        if (i < e) {
+          const float d = pred[b * e + i] - ut[b * e + i];
+          s[q] = fmaf(d, d, s[q]);
+          dpred[b * e + i] = gl * k * d;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s[q] += __shfl_xor(s[q], o);
+    if (lane == 0) loss_rows[b] = ((s[0] + s[1]) + (s[2] + s[3])) / (float)e;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    loss_rows[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)e;
     __threadfence();
-    last = atomicAdd(ticket, 1u) == (unsigned)n - 1;
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
   __syncthreads();
   if (!last) return;
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256) void fm_loss_grad_kernel(const float* __restri
   for (int i = threadIdx.x; i < n; i += 256) acc += __builtin_nontemporal_load(loss_rows + i);   // (written by other workgroups: bypass this CU's cache)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  if (lane == 0) red[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     *loss_mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
@@ -168,7 +183,8 @@ extern "C" int scldm_fm_prepare(const float* x1, const int64_t* const* labels_in
 extern "C" int scldm_fm_loss_grad(const float* pred, const float* ut, int n, int e, float* loss_rows, float* loss_mean, float* dpred,
                                   unsigned int* ticket, unsigned long long* rng_state, void* stream_) {
   if (!pred || !ut || !loss_rows || !loss_mean || !dpred || !ticket || n < 1 || e < 1) return fail(SCLDM_ERR_SHAPE, "scldm_fm_loss_grad: bad argument");
-  hipLaunchKernelGGL(fm_loss_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream_, pred, ut, loss_rows, loss_mean, dpred, n, e, ticket, rng_state);
+  hipLaunchKernelGGL(fm_loss_grad_kernel, dim3((n + kLossRows - 1) / kLossRows), dim3(256), 0, (hipStream_t)stream_, pred, ut, loss_rows, loss_mean, dpred, n,
+                     e, ticket, rng_state);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }

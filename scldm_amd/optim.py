@@ -112,8 +112,9 @@ class AdamW(torch.optim.Optimizer):
                          ema_of[id(p)].data_ptr() if ema_of else 0) for p in ps)
             cached = group.get("_table")
             if cached is None or cached[0] != key:
-                if capturing:
-                    raise RuntimeError("scldm_amd.optim.AdamW: a tensor moved during HIP-graph capture (run warm-up steps before capturing)")
+                # (inside a HIP-graph capture - GraphedTrainStep: autograd allocates the flat gradient buffer from the graph's pool, at another
+                # address than in the warm-up steps - the upload below becomes a copy node that re-reads the pinned table at every replay:
+                # the pinned buffer is kept alive and unchanged in the cache entry)
                 ent = (_lib.AdamwEntry * len(ps))()
                 emas = (C.c_void_p * len(ps))()
                 keep = []
@@ -135,12 +136,16 @@ class AdamW(torch.optim.Optimizer):
                         emas[i] = e.data_ptr()
                     keep.append(g)
                 nbytes = L.scldm_adamw_table_bytes(ent, len(ps))
-                host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+                # (pinning memory is not permitted while a stream is capturing: there the pinned buffer of the warm-up steps' table - same
+                # size - is rewritten; the device was synchronised before the capture began, so no earlier copy is still reading it)
+                reuse = capturing and cached is not None and cached[3].numel() == nbytes
+                if capturing and not reuse:
+                    raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+                host = cached[3] if reuse else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
                 nblk = C.c_int(0)
                 _lib.check(L.scldm_adamw_table_build(ent, C.cast(emas, C.POINTER(C.c_void_p)) if ema_of else None, len(ps), host.data_ptr(), nbytes,
                                                      C.byref(nblk)), "scldm_adamw_table_build")
-                table = host.to(dev, non_blocking=True)
-                table.record_stream(torch.cuda.current_stream(dev))
+                table = host.to(dev, non_blocking=True)       # (kept alive by the cache entry, like the pinned source)
                 cached = (key if cacheable else None, table, nblk.value, host, keep)
                 group["_table"] = cached
             _, table, nblk, _, _ = cached

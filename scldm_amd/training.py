@@ -434,25 +434,32 @@ class FusedTrainStep:
             self._capture()
 
     def _prime_optimizer(self) -> None:
+        """One ordinary optimizer.step() on the (zero) flat gradient buffer builds the device launch table; everything it changed -
+        parameters (weight decay), moments, step count, EMA - is put back, so an optimizer that already trained keeps its state."""
         opt = self.optimizer
-        snap = [p.detach().clone() for p in self.params]
-        ema = getattr(opt, "_ema", None)
-        ema_snap = None if ema is None else ([p.detach().clone() for p in ema.ema_model.parameters()], ema._host_step, ema._host_initted, ema._pending)
+        g = opt.param_groups[0]
+        had_state = {id(p) for p in g["params"] if opt.state.get(p)}
+        step_before = g["_step_t"].clone() if g.get("_step_t") is not None else None
+        state = self._snapshot(with_state=False)
+        moments = {id(p): (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if id(p) in had_state}
+        self.flat.zero_()
         opt.step()
+        self._restore(state, with_state=False)
         with torch.no_grad():
-            for p, s0 in zip(self.params, snap):
-                p.copy_(s0)
-            g = opt.param_groups[0]
-            g["_step_t"].zero_()
+            if step_before is not None:
+                g["_step_t"].copy_(step_before)
+            else:
+                g["_step_t"].zero_()
             for p in g["params"]:
                 st = opt.state.get(p)
-                if st:
+                if not st:
+                    continue
+                if id(p) in moments:
+                    st["exp_avg"].copy_(moments[id(p)][0])
+                    st["exp_avg_sq"].copy_(moments[id(p)][1])
+                else:
                     st["exp_avg"].zero_()
                     st["exp_avg_sq"].zero_()
-            if ema_snap is not None:
-                for p, s0 in zip(ema.ema_model.parameters(), ema_snap[0]):
-                    p.copy_(s0)
-                ema._host_step, ema._host_initted, ema._pending = ema_snap[1], ema_snap[2], ema_snap[3]
 
     def _launch(self) -> None:
         from . import _lib
@@ -466,6 +473,42 @@ class FusedTrainStep:
                                                     self._nulls, len(dit._class_names), 1 if dit.condition_strategy == "joint" else 0,
                                                     float(dit.cfg_dropout_prob), self.rng.data_ptr(), self.n, self.prec, C.byref(self._buf),
                                                     C.byref(self._opt) if self._opt is not None else None, st), "scldm_dit_train_step")
+
+    def profile_stages(self) -> dict:
+        """Device time of each stage of ONE (real, eager) step, in ms: the sub-entry points scldm_dit_train_step itself calls, issued one by
+        one with HIP events between them on the current stream (bench.py's `train_e2e` record)."""
+        from . import _lib
+        dit, L, h = self.dit, self._L, self._h
+        names = dit._class_names
+        lab = _lib.ptr_array([self.labels.data_ptr() + 8 * self.n * i for i in range(len(names))])
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        self.optimizer.refresh_hyper()
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            b = self._buf
+            ev[0].record()
+            if self.enc is not None:
+                self.x1.copy_(self.vae.encode(self.enc[0], self.enc[1]).view_as(self.x1))
+            ev[1].record()
+            _lib.check(L.scldm_fm_prepare(self.x1.data_ptr(), C.cast(self._lab_ptrs, _lib.c_void_pp), self._nulls, len(names),
+                                          1 if dit.condition_strategy == "joint" else 0, 1, float(dit.cfg_dropout_prob), self.rng.data_ptr(), self.n,
+                                          b.row_elems, b.t, b.x0, b.xt, b.ut, b.labels, st), "scldm_fm_prepare")
+            ev[2].record()
+            _lib.check(L.scldm_dit_train_forward(h, C.byref(self._w), b.xt, b.t, C.cast(lab, _lib.c_void_pp), self.n, b.pred, self.prec, b.saved, b.ws, st),
+                       "scldm_dit_train_forward")
+            ev[3].record()
+            _lib.check(L.scldm_fm_loss_grad(b.pred, b.ut, self.n, b.row_elems, b.loss_rows, b.loss_mean, b.dpred, b.ticket, self.rng.data_ptr(), st),
+                       "scldm_fm_loss_grad")
+            ev[4].record()
+            _lib.check(L.scldm_dit_train_backward(h, C.byref(self._w), C.byref(self._g), b.xt, C.cast(lab, _lib.c_void_pp), b.dpred, self.n, None, self.prec,
+                                                  b.saved, b.ws, st), "scldm_dit_train_backward")
+            ev[5].record()
+            if self._opt is not None:
+                _lib.check(L.scldm_adamw_table_step(C.byref(self._opt), st), "scldm_adamw_table_step")
+            ev[6].record()
+        torch.cuda.synchronize(self.dev)
+        keys = ("vae_encode", "prepare_batch", "forward_with_record", "loss_and_grad", "backward", "adamw_and_ema")
+        return {k: ev[i].elapsed_time(ev[i + 1]) for i, k in enumerate(keys)}
 
     def _capture(self) -> None:
         side = torch.cuda.Stream(device=self.dev)
@@ -481,23 +524,25 @@ class FusedTrainStep:
         with torch.cuda.graph(self.graph):
             self._launch()
 
-    def _snapshot(self):
+    def _snapshot(self, with_state: bool = True):
         opt, ema = self.optimizer, getattr(self.optimizer, "_ema", None)
         g = opt.param_groups[0]
-        return ([p.detach().clone() for p in self.params], g["_step_t"].clone(),
-                [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if p in opt.state], self.rng.clone(),
+        return ([p.detach().clone() for p in self.params], g["_step_t"].clone() if with_state else None,
+                [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if p in opt.state] if with_state else None,
+                self.rng.clone(),
                 None if ema is None else ([p.detach().clone() for p in ema.ema_model.parameters()], ema._host_step, ema._host_initted, ema._pending))
 
-    def _restore(self, state) -> None:
+    def _restore(self, state, with_state: bool = True) -> None:
         opt, ema = self.optimizer, getattr(self.optimizer, "_ema", None)
         g = opt.param_groups[0]
         with torch.no_grad():
             for p, s0 in zip(self.params, state[0]):
                 p.copy_(s0)
-            g["_step_t"].copy_(state[1])
-            for p, (m, v) in zip([p for p in g["params"] if p in opt.state], state[2]):
-                opt.state[p]["exp_avg"].copy_(m)
-                opt.state[p]["exp_avg_sq"].copy_(v)
+            if with_state:
+                g["_step_t"].copy_(state[1])
+                for p, (m, v) in zip([p for p in g["params"] if p in opt.state], state[2]):
+                    opt.state[p]["exp_avg"].copy_(m)
+                    opt.state[p]["exp_avg_sq"].copy_(v)
             self.rng.copy_(state[3])
             if ema is not None:
                 for p, s0 in zip(ema.ema_model.parameters(), state[4][0]):

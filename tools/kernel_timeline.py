@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the first kernel after the optimizer's launches (torch's multi_tensor_apply group or scldm's adamw_kernel)
-opt = lambda r: "multi_tensor_apply" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"]
+opt = lambda r: "multi_tensor_apply" in r["Kernel_Name"] or "adamw_kernel" in r["Kernel_Name"] or "adamw_table_kernel" in r["Kernel_Name"]
 starts = [i for i, r in enumerate(rows) if opt(r) and (i + 1 < len(rows) and not opt(rows[i + 1]))]
 a, b = starts[-k - 1] + 1, starts[-k] + 1
 step = rows[a:b]
