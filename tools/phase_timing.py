@@ -24,7 +24,8 @@ n_layer = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 m = _random_dit(n_layer=n_layer).cuda()
 m.precision = prec
 L, h = m._native()
-n_blocks = (n_fwd * 16 + 63) // 64  # upper bound (NTT=2)
+n_blocks = (n_fwd * 16 + 31) // 32 + 2  # upper bound: small launches run 32-token tiles (NTT = 1), i.e. twice the workgroups of NTT = 2
+# (round 6: sized for NTT = 2 only, the stamps of a <= 512-sample-forward launch ran past the buffer - a GPU memory fault)
 buf = torch.zeros(n_blocks * 8 * 32, dtype=torch.int64, device="cuda")
 _lib.check(L.scldm_dit_set_debug_buffer(h, buf.data_ptr()), "set_debug_buffer")
 x = torch.randn(n_fwd, 16, 16, device="cuda")
