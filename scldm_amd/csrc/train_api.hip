@@ -13,6 +13,7 @@
 #include "bgemm4.hpp"
 #include "attn_mfma.hpp"
 #include "train_fused.hpp"
+#include "cond_bwd.hpp"
 
 using namespace scldm;
 using namespace scldm::train;
@@ -1279,7 +1280,17 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     TRY(fire(SCLDM_GRAD_ADA, l));
     TRY(linear_dgrad(st, dm, mw, wl, n, width, kD, k.dsc, kD, l > 0, k));
   }
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsc, s.c, k.dc, (long)n * kD);
+  // Fused route (round 6): everything behind d SiLU(c) except the class tables as two exact-fp32 kernels (cond_bwd.hpp) instead of a chain
+  // of nine launches.  MEASURED +-0 to slower (same box, interleaved: 1 024 cells 1.984-1.998 against 1.972 ms per step, 256 cells 1.246
+  // against 1.208): the chain's launches already run on three streams beside the stacked adaLN weight gradient, and the two kernels
+  // (27 + 28 us: 128 workgroups each, latency-bound) share the chip with that product.  Opt-in: SCLDM_TRAIN_COND_BWD=1.
+  static const bool cond_bwd_on = [] { const char* e = getenv("SCLDM_TRAIN_COND_BWD"); return e && e[0] == '1'; }();
+  const bool cond2 = use_fused && cond_bwd_on && kD == kCbD;
+  if (cond2) {
+    hipLaunchKernelGGL(cond_bwd_rows_kernel, dim3(cdiv(n, kCbRows)), dim3(256), 0, st, k.dsc, s.c, s.th, w->t_w2, n, k.dc, k.dth);
+  } else {
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsc, s.c, k.dc, (long)n * kD);
+  }
   LAUNCH_CHECK();
 
   // ---- class embeddings and the timestep MLP (c = temb + sum emb) ----
@@ -1319,11 +1330,20 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
     }
     LAUNCH_CHECK();
   }
-  TRY(linear_wgrad(s_tw2, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k_tw2, g->t_b2));
-  TRY(linear_dgrad(st, k.dc, kD, w->t_w2, n, kD, kD, k.dsth, kD, false, k));
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
-  LAUNCH_CHECK();
-  TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
+  if (cond2) {
+    CondWgradArgs ca{};
+    ca.dy[0] = k.dc; ca.x[0] = s.sth; ca.dW[0] = g->t_w2; ca.db[0] = g->t_b2;
+    ca.dy[1] = k.dth; ca.x[1] = s.freq; ca.dW[1] = g->t_w0; ca.db[1] = g->t_b0;
+    ca.n = n;
+    hipLaunchKernelGGL(cond_bwd_wgrad_kernel, dim3(kCbD / 32, kCbD / 32, 2), dim3(256), 0, st, ca);
+    LAUNCH_CHECK();
+  } else {
+    TRY(linear_wgrad(s_tw2, k.dc, kD, s.sth, kD, n, kD, kD, g->t_w2, k_tw2, g->t_b2));
+    TRY(linear_dgrad(st, k.dc, kD, w->t_w2, n, kD, kD, k.dsth, kD, false, k));
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid((long)n * kD)), dim3(256), 0, st, k.dsth, s.th, k.dth, (long)n * kD);
+    LAUNCH_CHECK();
+    TRY(linear_wgrad(st, k.dth, kD, s.freq, 256, n, kD, 256, g->t_w0, k, g->t_b0));
+  }
   if (s_emb != st && s_emb != s_in) TRY(fused::join_side(h, st, 0));
   if (s_in != st) TRY(fused::join_side(h, st, 0));
   if (s_ada != st) TRY(fused::join_side(h, st, 1));
