@@ -141,6 +141,11 @@ int scldm_adamw_step(const scldm_adamw_entry* entries, int count, float* step, c
 size_t scldm_adamw_table_bytes(const scldm_adamw_entry* entries, int count);
 int scldm_adamw_table_build(const scldm_adamw_entry* entries, float* const* ema /* count pointers or NULL */, int count, void* table_host,
                             size_t bytes, int* n_blocks);
+/* The table is [count tensor records (addresses, size) | workgroup map (sizes only)]: when only addresses changed (autograd handed out
+ * another gradient buffer), scldm_adamw_table_update fills just the records (scldm_adamw_table_records_bytes(count) bytes) for the caller
+ * to copy over the head of the device table. */
+size_t scldm_adamw_table_records_bytes(int count);
+int scldm_adamw_table_update(const scldm_adamw_entry* entries, float* const* ema, int count, void* records_host, size_t bytes);
 typedef struct {
   const void* table;       /* device copy of the table */
   int count, n_blocks;

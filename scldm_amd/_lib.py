@@ -99,6 +99,9 @@ def lib() -> C.CDLL:
     L.scldm_adamw_table_bytes.argtypes = [C.POINTER(AdamwEntry), C.c_int]
     L.scldm_adamw_table_bytes.restype = C.c_size_t
     L.scldm_adamw_table_build.argtypes = [C.POINTER(AdamwEntry), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    L.scldm_adamw_table_records_bytes.argtypes = [C.c_int]
+    L.scldm_adamw_table_records_bytes.restype = C.c_size_t
+    L.scldm_adamw_table_update.argtypes = [C.POINTER(AdamwEntry), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]
     L.scldm_adamw_table_step.argtypes = [C.POINTER(AdamwLaunch), C.c_void_p]
     L.scldm_fm_prepare.argtypes = [C.c_void_p, c_void_pp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -197,7 +200,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
            "scldm_dit_refresh_weights", "scldm_dit_fp16_stats", "scldm_dit_train_fp16_state", "scldm_dit_train_set_found_inf", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_set_option", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
-           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_adamw_step", "scldm_adamw_table_bytes", "scldm_adamw_table_build", "scldm_adamw_table_step", "scldm_fm_prepare", "scldm_fm_loss_grad", "scldm_dit_train_step", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
+           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_adamw_step", "scldm_adamw_table_bytes", "scldm_adamw_table_build", "scldm_adamw_table_records_bytes", "scldm_adamw_table_update", "scldm_adamw_table_step", "scldm_fm_prepare", "scldm_fm_loss_grad", "scldm_dit_train_step", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes", "scldm_dit_train_saved_bytes_for", "scldm_dit_train_workspace_bytes_for",
            "scldm_dit_train_prepare", "scldm_dit_train_set_grad_events", "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_fm_mix", "scldm_fm_loss", "scldm_fm_loss_bwd", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights", "scldm_vae_refresh_weights", "scldm_vae_kernel_timing_enable", "scldm_vae_kernel_timing",
            "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_vae_decode_sample", "scldm_vae_train_saved_bytes", "scldm_vae_train_workspace_bytes", "scldm_vae_train_forward", "scldm_vae_train_backward", "scldm_nb_loglik", "scldm_nb_loglik_bwd", "scldm_nb_sample", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",

@@ -213,6 +213,20 @@ extern "C" int scldm_adamw_table_build(const scldm_adamw_entry* e, float* const*
   *n_blocks = (int)blocks;
   return SCLDM_OK;
 }
+// Only the per-tensor records (the head of the table: count x 48 bytes) depend on addresses; the workgroup map behind them depends on
+// the tensor SIZES alone.  A caller whose gradient buffers move between steps (autograd allocating a fresh flat buffer) re-uploads the
+// records - 12 KB for the DiT-L shape's ~250 tensors - instead of the whole table (0.9 MB of workgroup map at 459 M parameters).
+extern "C" size_t scldm_adamw_table_records_bytes(int count) { return count > 0 ? sizeof(scldm::optim::TableTensor) * (size_t)count : 0; }
+extern "C" int scldm_adamw_table_update(const scldm_adamw_entry* e, float* const* ema, int count, void* records_host, size_t bytes) {
+  using namespace scldm::optim;
+  if (!e || count < 1 || !records_host || bytes < sizeof(TableTensor) * (size_t)count) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_update: bad argument");
+  TableTensor* tt = reinterpret_cast<TableTensor*>(records_host);
+  for (int i = 0; i < count; ++i) {
+    if (e[i].n > 0 && (!e[i].p || !e[i].g || !e[i].m || !e[i].v)) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_update: tensor %d has a NULL pointer", i);
+    tt[i] = TableTensor{e[i].p, e[i].g, e[i].m, e[i].v, ema ? ema[i] : nullptr, e[i].n};
+  }
+  return SCLDM_OK;
+}
 extern "C" int scldm_adamw_table_step(const scldm_adamw_launch* l, void* stream_) {
   using namespace scldm::optim;
   if (!l || !l->table || !l->step || l->count < 1 || l->n_blocks < 0) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_step: bad argument");

@@ -135,20 +135,31 @@ class AdamW(torch.optim.Optimizer):
                             raise RuntimeError("attach_ema: the averaged copy of a parameter must be a contiguous fp32 tensor on the parameter's device")
                         emas[i] = e.data_ptr()
                     keep.append(g)
-                nbytes = L.scldm_adamw_table_bytes(ent, len(ps))
-                # (pinning memory is not permitted while a stream is capturing: there the pinned buffer of the warm-up steps' table - same
-                # size - is rewritten; the device was synchronised before the capture began, so no earlier copy is still reading it)
-                reuse = capturing and cached is not None and cached[3].numel() == nbytes
-                if capturing and not reuse:
-                    raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
-                host = cached[3] if reuse else torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-                nblk = C.c_int(0)
-                _lib.check(L.scldm_adamw_table_build(ent, C.cast(emas, C.POINTER(C.c_void_p)) if ema_of else None, len(ps), host.data_ptr(), nbytes,
-                                                     C.byref(nblk)), "scldm_adamw_table_build")
-                table = host.to(dev, non_blocking=True)       # (kept alive by the cache entry, like the pinned source)
-                cached = (key if cacheable else None, table, nblk.value, host, keep)
+                ema_arg = C.cast(emas, C.POINTER(C.c_void_p)) if ema_of else None
+                sizes = tuple(p.numel() for p in ps)
+                if cached is not None and cached[5] == sizes:
+                    # same tensors at other addresses (autograd handed out another flat gradient buffer - every step on the generic route,
+                    # where a full rebuild of the DiT-L shape's 0.9 MB workgroup map cost 13 ms of a 20 ms step): only the records change.
+                    # A FRESH small pinned staging tensor per update, like refresh_hyper's - except while capturing, where pinning is not
+                    # permitted and the warm-up's staging buffer is rewritten (the device was synchronised before the capture began).
+                    rbytes = L.scldm_adamw_table_records_bytes(len(ps))
+                    stage = cached[3] if capturing else torch.empty(rbytes, dtype=torch.uint8).pin_memory()
+                    if stage.numel() < rbytes:
+                        raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+                    _lib.check(L.scldm_adamw_table_update(ent, ema_arg, len(ps), stage.data_ptr(), rbytes), "scldm_adamw_table_update")
+                    cached[1][:rbytes].copy_(stage[:rbytes], non_blocking=True)
+                    cached = (key if cacheable else None, cached[1], cached[2], stage, keep, sizes)
+                else:
+                    if capturing:
+                        raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+                    nbytes = L.scldm_adamw_table_bytes(ent, len(ps))
+                    host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+                    nblk = C.c_int(0)
+                    _lib.check(L.scldm_adamw_table_build(ent, ema_arg, len(ps), host.data_ptr(), nbytes, C.byref(nblk)), "scldm_adamw_table_build")
+                    table = host.to(dev, non_blocking=True)       # (kept alive by the cache entry, like the pinned source)
+                    cached = (key if cacheable else None, table, nblk.value, host, keep, sizes)
                 group["_table"] = cached
-            _, table, nblk, _, _ = cached
+            table, nblk = cached[1], cached[2]
             dev_hyper, _ = self._hyper(group, dev)
             b1, b2 = group["betas"]
             launch = _lib.AdamwLaunch(table=table.data_ptr(), count=len(ps), n_blocks=nblk, step=step_t.data_ptr(),
