@@ -209,7 +209,12 @@ struct Prefetch {  // k-steps of run-ahead of the weight ring
 #ifdef SCLDM_PF
   static constexpr int PF = OP::kIsBF16 ? SCLDM_PF : OP::kRing;
 #else
-  static constexpr int PF = OP::kRing;
+  // 32-token tiles (launches below one 64-token tile per CU: a single workgroup's walk through the layers IS the launch time) run the
+  // 16-bit policies' ring 8 k-steps ahead instead of 4: with one workgroup per CU nothing else hides the L2 latency of the weight
+  // stream, and the instantiation has the registers (170 -> 216 VGPRs, no spills).  Same box, interleaved, 128 cells x 50 evaluations:
+  // 165.0 -> 150.6 us per launch, 9.24 -> 8.51 ms per trajectory (round 6).  64-token tiles keep 4 (247 VGPRs: 8 would spill; +-0 at
+  // full occupancy, HISTORY).  Results do not depend on the depth.
+  static constexpr int PF = (NTT == 1 && OP::kIsBF16) ? 8 : OP::kRing;
 #endif
 };
 
