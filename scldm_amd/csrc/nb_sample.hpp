@@ -4,6 +4,7 @@
 // (src/scldm/models.py:819 `nb.sample()`; distribution built at src/scldm/vae.py:87).  The reference does it with three
 // eager passes over the (2B, G) mean / dispersion tensors (Gamma sample, clamp, Poisson sample) after writing both; here the
 // pass that normalises the logits draws the count in registers, so neither mu nor theta ever reaches HBM.
+// Transcendentals of the samplers run on the hardware units (v_log / v_exp / v_sqrt / v_cos, ~1 ulp) since round 6.
 // RNG: Philox4x32-10 (Salmon et al., SC'11), counter = (element index, draw index), key = (seed) - a result depends only
 // on (seed, element), not on the launch geometry.  Samplers: Marsaglia-Tsang (2000) for Gamma (shape < 1 through the
 // U^(1/a) boost), inversion by multiplication for Poisson(lambda < 10), Hoermann's PTRS (1993) above.  RNG-dependent by
@@ -44,15 +45,20 @@ struct Philox {
   __device__ __forceinline__ float uniform() { return ((next() >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1), 24 bits
   __device__ __forceinline__ float normal() {   // Box-Muller, one value per call (the sine branch is not kept: registers)
     const float u1 = uniform(), u2 = uniform();
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    // hardware transcendentals (round 6: v_log_f32 / v_sqrt_f32 / v_cos_f32, ~1 ulp; the argument of v_cos_f32 is in revolutions, so
+    // u2 needs no 2 pi and no range reduction) instead of libm's ~30-instruction logf / cosf: the draw was a quarter of decode_sample
+    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);   // -2 ln 2 log2(u1)
   }
 };
+// natural log / exp / power on the hardware units (inputs here are positive and far from the subnormal range)
+__device__ __forceinline__ float nb_log(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float nb_exp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
 
 // Gamma(shape a, scale 1), Marsaglia & Tsang: d = a - 1/3, c = 1 / sqrt(9 d); accept d v when log u < x^2/2 + d - d v + d log v
 __device__ __forceinline__ float gamma_draw(Philox& g, float a) {
   float boost = 1.0f;
   if (a < 1.0f) {
-    boost = powf(g.uniform(), 1.0f / a);
+    boost = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(g.uniform()) * __builtin_amdgcn_rcpf(a));   // u^(1/a)
     a += 1.0f;
   }
   const float d = a - (1.0f / 3.0f), c = rsqrtf(9.0f * d);
@@ -62,7 +68,7 @@ __device__ __forceinline__ float gamma_draw(Philox& g, float a) {
     if (v <= 0.f) continue;
     v = v * v * v;
     const float u = g.uniform();
-    if (u < 1.0f - 0.0331f * (x * x) * (x * x) || logf(u) < 0.5f * x * x + d * (1.0f - v + logf(v))) return d * v * boost;
+    if (u < 1.0f - 0.0331f * (x * x) * (x * x) || nb_log(u) < 0.5f * x * x + d * (1.0f - v + nb_log(v))) return d * v * boost;
   }
   return d * boost;   // 64 rejections in a row: probability < 1e-80
 }
@@ -70,14 +76,14 @@ __device__ __forceinline__ float gamma_draw(Philox& g, float a) {
 __device__ __forceinline__ float poisson_draw(Philox& g, float lam) {
   if (!(lam > 0.f)) return 0.f;
   if (lam < 10.0f) {   // multiply uniforms until the product drops below exp(-lambda)
-    const float L = expf(-lam);
+    const float L = nb_exp(-lam);
     float p = g.uniform();
     int k = 0;
     while (p > L && k < 200) { p *= g.uniform(); ++k; }
     return (float)k;
   }
   // PTRS: transformed rejection with squeeze (Hoermann 1993); the form numpy / torch use for large lambda
-  const float slam = sqrtf(lam), loglam = logf(lam);
+  const float slam = __builtin_amdgcn_sqrtf(lam), loglam = nb_log(lam);
   const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
   const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.0f);
   for (int it = 0; it < 256; ++it) {
@@ -86,7 +92,7 @@ __device__ __forceinline__ float poisson_draw(Philox& g, float lam) {
     const float k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
     if (us >= 0.07f && V <= vr) return k;
     if (k < 0.f || (us < 0.013f && V > us)) continue;
-    if (logf(V) + logf(invalpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;
+    if (nb_log(V * invalpha / (a / (us * us) + b)) <= -lam + k * loglam - lgammaf(k + 1.0f)) return k;   // (the slow path: ~14 % of the large-lambda draws)
   }
   return floorf(lam);
 }

@@ -46,3 +46,13 @@ python tools/train_graph_bench.py 256 bf16 2>&1 | grep cells >> ${o}_train_bench
 cp profiles/bench_last.json ${o}_bench_last.json 2>/dev/null
 timeout 2400 python -m pytest tests -m gpu -q -rP 2>&1 | grep -E "^\[parity\]|^\[dopri5|passed|failed|^E  |^FAILED" | cut -c1-400 > ${o}_gpu_tests.txt; tail -2 ${o}_gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" > ${o}_smoke.txt 2>&1; tail -3 ${o}_smoke.txt
+# round 6: MCAB kernels at the bench shapes (kernel statistics + four PMC passes per precision), the one-call training step (timelines at
+# 1 024 and 256 cells, step times per mode and size), the hand-written GEMM against the vendor library per DiT-L shape, DiT-L step per optimizer
+bash tools/r6_mcab_evidence.sh ${tag} "fp32 fp16 bf16" > ${o}_mcab_evidence.log 2>&1
+for b in 1024 256; do
+  ROCPROF_ROWS=30 bash tools/rocprof_stats.sh ${tag}_stats_fused_b$b tests/perf/train_fused_profile.py $b 20 bf16 1 > ${o}_train_fused_b${b}_kernel_stats.txt 2>&1
+  python3 tools/kernel_timeline.py $(find gpurun_out/${tag}_stats_fused_b$b -name "*kernel_trace.csv" | head -1) 3 > ${o}_train_fused_b${b}_graph_timeline.txt 2>&1
+done
+{ for a in "1024 40 bf16 1" "1024 40 bf16 0" "1024 40 fp16 0" "512 40 bf16 0" "256 40 bf16 1" "256 40 bf16 0" "128 40 bf16 0" "64 40 bf16 0" "1024 40 bf16 1 1" "1024 40 bf16 0 1"; do python tests/perf/train_fused_profile.py $a 2>&1 | tail -1; done; } > ${o}_train_fused_sizes.txt
+bash tools/r6_gemm_vs_vendor.sh ${tag} > /dev/null 2>&1
+python tests/perf/ditl_optimizer_ab.py 2>&1 | grep ms/step > ${o}_ditl_optimizer_ab.txt
