@@ -812,7 +812,7 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     path: size factors drawn on device (SizeFactorSampler) -> noise -> fused CFG ODE -> MCAB decode (fp16 operands beside a 16-bit DiT, else fp32) with the negative-binomial
     draw fused in -> CSR assembly on device -> host arrays (indptr / indices / data of the 2B generated rows + the 2B latents).
     cells/s = requested cells / wall time of the whole chain (median of `reps` after one warm-up), with the device time of each stage."""
-    from scldm_amd.datamodule import dense_to_csr
+    from scldm_amd.datamodule import dense_to_csr, to_host
     from scldm_amd.sampling import SizeFactorSampler, sample_latents
     wl = dict(WORKLOADS[wl_name])
     B = wl["B"]
@@ -840,7 +840,7 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
         rec(3)
         indptr, indices, data = dense_to_csr(counts)
         rec(4)
-        host = (indptr.cpu(), indices.cpu(), data.cpu(), z.cpu())
+        host = to_host(indptr, indices, data, z)     # pinned staging, one synchronisation (scldm_amd.datamodule.to_host)
         rec(5)
         return host
     once()
@@ -862,7 +862,7 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
             "stage_ms": {"size_factors_and_noise": stage[0], "ode": stage[1], "decode_and_nb_draw": stage[2], "csr_assembly": stage[3],
                          "device_to_host": stage[4]},
             "nnz_fraction": nnz / (2 * B * n_genes), "host_bytes": sum(int(t.numel()) * t.element_size() for t in host),
-            "path": "SizeFactorSampler.sample -> sample_latents (scldm_sample_ode) -> TransformerVAE.decode_sample -> dense_to_csr -> .cpu()"}
+            "path": "SizeFactorSampler.sample -> sample_latents (scldm_sample_ode) -> TransformerVAE.decode_sample -> dense_to_csr -> to_host (pinned)"}
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -1182,8 +1182,8 @@ def main():
             dtt /= 2
             result["training_step"] = {"workload": "replogle_train_b1024", "cells_per_s": tw["B"] / (dtt / 10), "ms_per_step": 1e3 * dtt / 10,
                                        "tflops": 3 * FLOPS_PER_SAMPLE_FWD * tw["B"] / (dtt / 10) / 1e12, "dtype": tprec,
-                                       "launch": ("FusedTrainStep: scldm_dit_train_step (batch preparation, forward, loss, backward, AdamW + EMA hook: one C call) "
-                                                  "replayed as one HIP graph" if fused_ok else
+                                       "launch": ("FusedTrainStep: scldm_dit_train_step (batch preparation, forward, loss, backward, AdamW + EMA hook: one C call), "
+                                                  "the faster of a HIP-graph replay and the eager call (fused_step_modes)" if fused_ok else
                                                   "GraphedTrainStep: the whole step (training_losses forward, HIP backward, AdamW) replayed as one HIP graph"
                                                   if time_training.graphed else "eager train_step (graph capture failed: see stderr)"),
                                        "path": ("fused: REC forward + dit_backward_kernel + batched bf16 wgrad, activation record 32 KB per cell "

@@ -74,6 +74,24 @@ def dense_to_csr(dense: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch
     return indptr, indices[:nnz], data[:nnz]
 
 
+def to_host(*tensors: torch.Tensor) -> tuple[torch.Tensor, ...]:
+    """Device tensors -> host tensors through PINNED staging memory: every copy is queued asynchronously on the current stream and the
+    host waits ONCE (the reference's `tree_map(lambda x: x.cpu(), batch)`, src/scldm/models.py:742, is one synchronous copy into
+    pageable memory per tensor: ~19 GB/s on this host against ~45 GB/s pinned).  torch's pinned-memory allocator caches the blocks, so
+    only the first call pays for pinning.  The returned tensors are ordinary CPU tensors (pinned storage)."""
+    outs = []
+    for t in tensors:
+        if not t.is_cuda:
+            outs.append(t)
+            continue
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        outs.append(h)
+    if any(t.is_cuda for t in tensors):
+        torch.cuda.current_stream().synchronize()
+    return tuple(outs)
+
+
 def tokenize_cells(counts: torch.Tensor, gene_idx: torch.Tensor, genes_seq_len: int, sample_genes: str, mask_token_idx: int = 0,
                    gene_means: torch.Tensor | None = None, generator: torch.Generator | None = None) -> dict[str, torch.Tensor]:
     """Device-side `scldm.datamodule.tokenize_cells` for every `sample_genes` mode (src/scldm/datamodule.py:652-805); dict keys as

@@ -157,9 +157,10 @@ def test_adamw_launch_with_ema_is_torch_lerp_bit_for_bit_and_follows_lr():
         ema.update()                                                               # one update() per optimizer step
 
 
-@pytest.mark.parametrize("strategy,vocab,prec", [("joint", {"cell_line": 4, "gene": 2024}, "bf16"), ("mutually_exclusive", {"a": 5, "b": 9}, "bf16"),
-                                                 ("joint", {"cell_line": 4, "gene": 2024}, "fp16")])
-def test_fused_train_step_equals_the_composed_route_and_replays_as_a_graph(strategy, vocab, prec):
+@pytest.mark.parametrize("strategy,vocab,prec,n", [("joint", {"cell_line": 4, "gene": 2024}, "bf16", 96), ("mutually_exclusive", {"a": 5, "b": 9}, "bf16", 96),
+                                                   ("joint", {"cell_line": 4, "gene": 2024}, "fp16", 96),
+                                                   ("joint", {"cell_line": 4, "gene": 2024}, "bf16", 37)])     # ragged: the last 64-token tile is padded
+def test_fused_train_step_equals_the_composed_route_and_replays_as_a_graph(strategy, vocab, prec, n):
     """FusedTrainStep (one C call per step) against the autograd route (DiT.forward -> _FlowMatchLoss -> backward -> AdamW.step ->
     EMA) fed the SAME draws: gradients, parameters, optimizer state and EMA bit for bit; then the HIP-graph form against the eager
     form over several steps (device-side step counter, learning-rate schedule and EMA actions reach the replays)."""
@@ -167,7 +168,6 @@ def test_fused_train_step_equals_the_composed_route_and_replays_as_a_graph(strat
     from scldm_amd.optim import AdamW
     from scldm_amd.training import FusedTrainStep
     from scldm_amd.transport import _FlowMatchLoss, create_transport
-    n = 96
     m1, _, _ = build(vocab, strategy, 8, 31)
     m1.precision = prec
     m1.cfg_dropout_prob = 0.6
