@@ -57,8 +57,10 @@ class AdamW(torch.optim.Optimizer):
         """Stage this step's learning rate, weight decay and EMA action in the device `hyper` vector of every group (asynchronous 16-byte
         copy on the current stream).  step() calls it; `GraphedTrainStep` calls it before each replay (inside a capture it is skipped)."""
         ema = getattr(self, "_ema", None)
-        action, w = ema.next_action() if ema is not None else (0, 0.0)
-        if ema is not None:
+        live = any(p.grad is not None for g in self.param_groups for p in g["params"])
+        # (a step() that will launch nothing - no parameter has a gradient - must not consume the EMA action of a step)
+        action, w = ema.next_action() if (ema is not None and live) else (0, 0.0)
+        if ema is not None and live:
             ema._pending += 1
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None] or list(group["params"])

@@ -345,7 +345,8 @@ class FusedTrainStep:
     one flat fp32 buffer (`.grad` of every parameter is a view), so a data-parallel group reduces it in place between backward and
     optimizer (`group=`; that variant is not graphed).  Requires the fused training route (base DiT shape, precision bf16 | fp16), the
     Linear path with velocity prediction (ldm_base.yaml:30-35) and `scldm_amd.optim.AdamW`.
-    `__call__(x1, condition)` or `__call__(condition=..., counts=, genes=, counts_subset=, genes_subset=)` with a frozen `vae`."""
+    `__call__(x1, condition)` or `__call__(condition=..., counts=, genes=, counts_subset=, genes_subset=)` with a frozen `vae`; returns the
+    step's loss as a STATIC device scalar (overwritten by the next step: `.clone()` or `float()` it to keep a value)."""
 
     def __init__(self, dit, transport, optimizer, batch_size: int, condition_keys, ema=None, vae=None, seed: int | None = None,
                  graph: bool = True, group=None, encode_shape: tuple[int, int] | None = None):

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"libscldm_hip.so does not export {name}"
     assert declared == set(_lib.EXPORTS)
-    assert L.scldm_version() == 3
+    assert L.scldm_version() == 4
 
 
 def test_create_rejects_unsupported_shapes_without_gpu():
