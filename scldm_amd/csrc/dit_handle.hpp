@@ -50,6 +50,7 @@ struct scldm_dit {
   unsigned long long* d_fp_state;  // [0] running accumulator, [1] fingerprint of the packed weights
   int* d_dirty;    // [0] re-pack flag written by the compare kernel, [1] force flag
   hipStream_t side[3];     // secondary streams for tile-group launches (created on first use)
+  bool wgrad_reduce_on_side = false;   // fused training backward: the deferred weight-gradient reduction is in flight on side[2] (joined by scldm_dit_train_backward)
   hipEvent_t fork_ev, join_ev[3];
   hipEvent_t wg_ev[2] = {nullptr, nullptr};   // fused training, small batches: layer l's weight-gradient launches (side stream) are done with operand-pair set l & 1
   hipEvent_t bwd_pack_ev = nullptr;   // the training step's backward weight stream is packed (second pack launch of fused::prepare)

@@ -1312,7 +1312,7 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   }
   if (par_tails) {
     TRY(fused::fork_side(h, st, 1, &s_tw2));
-    k_tw2.part = fs.part;
+    k_tw2.part = fs.part + (fs.part_layers > 1 ? (size_t)fs.part_layers * fs.part_floats : 0);   // (the spare block: the layers' blocks may still be read by the deferred reduction)
     k_tw2.part_floats = fs.part_floats;
   }
   for (int c = 0; c < cfg.n_classes; ++c) {
@@ -1347,6 +1347,10 @@ extern "C" int scldm_dit_train_backward(scldm_dit* h, const scldm_dit_weights* w
   if (s_emb != st && s_emb != s_in) TRY(fused::join_side(h, st, 0));
   if (s_in != st) TRY(fused::join_side(h, st, 0));
   if (s_ada != st) TRY(fused::join_side(h, st, 1));
+  if (h->wgrad_reduce_on_side) {   // the layers' deferred weight-gradient reduction (fused::backward_layers)
+    h->wgrad_reduce_on_side = false;
+    TRY(fused::join_side(h, st, 2));
+  }
   if (f16) TRY(fused::unscale_grads(h, g, dx_out, (long)T * din, fs, st));
   TRY(fire(SCLDM_GRAD_END, 0));
   h->grad_events.clear();

@@ -308,7 +308,7 @@ __global__ void wgrad_reduce_kernel(const ReduceArgs g) {
 
 // The same for up to eight layers in ONE launch (blockIdx.y = layer): at batches whose backward kernel fills the chip the eight
 // per-layer reductions (10 us each + a launch gap, in series between backward layers) leave the layer loop - every layer keeps its
-// own partial block and they are summed behind the last layer (round 6; SCLDM_TRAIN_WGRAD_DEFER=0 restores the per-layer launches).
+// own partial block and they are summed behind the last layer (round 6; opt-in SCLDM_TRAIN_WGRAD_DEFER=1: measured +-0 to slower, below).
 struct ReduceAll { ReduceArgs layer[8]; };
 __global__ void wgrad_reduce_all_kernel(const ReduceAll all) {
   const ReduceArgs& g = all.layer[blockIdx.y];
@@ -625,8 +625,11 @@ Scratch carve_scratch(const scldm_dit* h, int n, void* base) {
   s.part_floats = part_floats(h);
   // one partial block per layer where the per-layer reductions are deferred to the end of the layer loop (no second operand-pair set:
   // the backward kernel fills the chip), one block otherwise
-  s.part_layers = s.e_set1 ? 1 : h->cfg.n_layer;
-  s.part = c.take<float>(s.part_floats * (size_t)s.part_layers);
+  static const bool defer_on = [] { const char* e = getenv("SCLDM_TRAIN_WGRAD_DEFER"); return e && e[0] == '1'; }();
+  s.part_layers = (s.e_set1 || !defer_on) ? 1 : h->cfg.n_layer;
+  // (+ one more block when deferring: the backward's tail borrows a block for the split-K partials of d t_w2 while the deferred
+  // reduction is still reading the layers' blocks on its side stream)
+  s.part = c.take<float>(s.part_floats * (size_t)(s.part_layers + (s.part_layers > 1 ? 1 : 0)));
   s.ada_dw = c.take<float>((size_t)h->mod_w * (kD + 1));
   s.edge_part = c.take<float>(edge_part_floats(h));
   s.dout_s = c.take<float>(T * 32);
@@ -916,8 +919,10 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
       if (!h->wg_ev[q]) HIP_TRY(hipEventCreateWithFlags(&h->wg_ev[q], hipEventDisableTiming));
   }
   const ptrdiff_t set_delta = overlap ? s.e_set1 - s.e_h1 : 0;
-  static const bool defer_off = [] { const char* e = getenv("SCLDM_TRAIN_WGRAD_DEFER"); return e && e[0] == '0'; }();
-  const bool defer = !overlap && !defer_off && s.part_layers >= c.n_layer;
+  // MEASURED (round 6, same box, interleaved, 1 024 cells): one deferred launch on the main stream +-0 (2.019 / 2.000 against 2.013 / 2.015
+  // ms per step), on side stream 2 beside the tail 1.985 / 1.995 against 1.966 / 1.968 - SLOWER: the 200 MB pass competes with the tail's
+  // bandwidth-bound adaLN products.  The per-layer launches stay the default; SCLDM_TRAIN_WGRAD_DEFER=1 selects the deferred form.
+  const bool defer = !overlap && s.part_layers >= c.n_layer && c.n_layer > 1;
   ReduceAll pending{};
   int n_pending = 0;
   for (int l = c.n_layer - 1; l >= 0; --l) {
@@ -1019,8 +1024,14 @@ static int backward_layers_t(scldm_dit* h, const scldm_dit_grads* g, const float
     if (defer) {
       pending.layer[n_pending++] = ra;
       if (n_pending == 8 || l == 0) {
-        wgrad_reduce_all_kernel<<<dim3((unsigned)std::min<long>(cdiv(first, 256), 1024), n_pending), 256, 0, sw>>>(pending);
+        // on side stream 2, behind this layer's weight-gradient launch: nothing in the backward's tails reads a layer weight gradient, so
+        // the 200 MB pass (85 us for eight layers) runs beside them; scldm_dit_train_backward joins side 2 before its gradient events
+        hipStream_t sr = st;
+        const int rc = fork_side(h, st, 2, &sr);
+        if (rc) return rc;
+        wgrad_reduce_all_kernel<<<dim3((unsigned)std::min<long>(cdiv(first, 256), 1024), n_pending), 256, 0, sr>>>(pending);
         LAUNCH_CHECK();
+        h->wgrad_reduce_on_side = true;
         n_pending = 0;
       }
     } else {
