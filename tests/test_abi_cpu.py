@@ -170,3 +170,38 @@ def test_fresh_dit_matches_reference_initialisation():
         elif k != "pos_embed":
             assert abs(float(v.float().std()) - std) < 0.08 * std, k          # same distribution family and scale
             assert float(v.abs().max()) < 1.6 * amax, k                       # xavier-uniform stays bounded, normal(0.02) tails
+
+
+def test_adamw_launch_table_layout_is_built_on_the_host():
+    """scldm_adamw_table_build / _update are host-side (no HIP call): [count x {p, g, m, v, ema, n} (48 B)] then one {tensor, chunk} per
+    4 096-element workgroup; empty tensors own no workgroup; _update rewrites the records only."""
+    import ctypes as C
+    import struct
+    from scldm_amd import _lib
+    L = _lib.lib()
+    sizes = [5, 4096, 0, 4097, 12288]
+    ent = (_lib.AdamwEntry * len(sizes))()
+    for i, n in enumerate(sizes):
+        ent[i].p, ent[i].g, ent[i].m, ent[i].v, ent[i].n = 0x1000 * (i + 1), 0x2000 * (i + 1), 0x3000 * (i + 1), 0x4000 * (i + 1), n
+    ema = (C.c_void_p * len(sizes))(*[0x5000 * (i + 1) for i in range(len(sizes))])
+    nb = L.scldm_adamw_table_bytes(ent, len(sizes))
+    blocks = [1, 1, 0, 2, 3]
+    assert nb == 48 * len(sizes) + 8 * sum(blocks) and L.scldm_adamw_table_records_bytes(len(sizes)) == 48 * len(sizes)
+    buf = (C.c_char * nb)()
+    n_blocks = C.c_int(0)
+    _lib.check(L.scldm_adamw_table_build(ent, C.cast(ema, C.POINTER(C.c_void_p)), len(sizes), buf, nb, C.byref(n_blocks)), "build")
+    assert n_blocks.value == sum(blocks)
+    raw = bytes(buf)
+    for i, n in enumerate(sizes):
+        assert struct.unpack_from("<6q", raw, 48 * i) == (0x1000 * (i + 1), 0x2000 * (i + 1), 0x3000 * (i + 1), 0x4000 * (i + 1), 0x5000 * (i + 1), n)
+    got = [struct.unpack_from("<2i", raw, 48 * len(sizes) + 8 * b) for b in range(n_blocks.value)]
+    assert got == [(i, c) for i, k in enumerate(blocks) for c in range(k)]
+    ent[3].g = 0x7777
+    rec = (C.c_char * (48 * len(sizes)))()
+    _lib.check(L.scldm_adamw_table_update(ent, None, len(sizes), rec, 48 * len(sizes)), "update")
+    assert struct.unpack_from("<6q", bytes(rec), 48 * 3) == (0x4000, 0x7777, 0xC000, 0x10000, 0, 4097)
+    with pytest.raises(_lib.ScldmError):
+        _lib.check(L.scldm_adamw_table_build(ent, None, len(sizes), buf, 8, C.byref(n_blocks)), "too small")
+    ent[1].v = None
+    with pytest.raises(_lib.ScldmError, match="NULL"):
+        _lib.check(L.scldm_adamw_table_build(ent, None, len(sizes), buf, nb, C.byref(n_blocks)), "null")
