@@ -67,11 +67,25 @@ class AdamW(torch.optim.Optimizer):
             if not ps:
                 continue
             dev_t, _ = self._hyper(group, ps[0].device)
-            # a FRESH pinned staging tensor per step: the host runs several steps ahead of the device (always, when the step is a graph
-            # replay), so a reused staging buffer would be overwritten before the queued copy of an earlier step has read it; torch's
-            # pinned-memory allocator recycles a block only after the copies that read it have completed
-            host_t = torch.tensor([float(group["lr"]), float(group["weight_decay"]), float(action), float(w)], dtype=torch.float32).pin_memory()
-            dev_t.copy_(host_t, non_blocking=True)
+            # The host runs several steps ahead of the device (always, when the step is a graph replay), so ONE reused staging buffer would
+            # be overwritten before the queued copy of an earlier step has read it (found as a replay-vs-eager mismatch), and a fresh
+            # pinned tensor per step makes the pinned allocator call hipHostMalloc whenever its cached blocks are still owned by copies
+            # in flight - milliseconds each (found as 3.3 ms steps in a 20-step bench window).  A ring of 64 pinned slots, each guarded
+            # by the event of the copy that last read it, costs neither.
+            ring = group.get("_hyper_ring")
+            if ring is None:
+                ring = group["_hyper_ring"] = {"buf": torch.zeros(64, 4, dtype=torch.float32).pin_memory(), "ev": [None] * 64, "i": 0}
+            slot = ring["i"] % 64
+            ring["i"] += 1
+            if ring["ev"][slot] is not None:
+                ring["ev"][slot].synchronize()        # 64 steps old: long complete
+            else:
+                ring["ev"][slot] = torch.cuda.Event()
+            host_t = ring["buf"][slot]
+            host_t[0], host_t[1], host_t[2], host_t[3] = float(group["lr"]), float(group["weight_decay"]), float(action), float(w)
+            with torch.cuda.device(dev_t.device):
+                dev_t.copy_(host_t, non_blocking=True)
+                ring["ev"][slot].record(torch.cuda.current_stream(dev_t.device))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -145,12 +159,27 @@ class AdamW(torch.optim.Optimizer):
                     # A FRESH small pinned staging tensor per update, like refresh_hyper's - except while capturing, where pinning is not
                     # permitted and the warm-up's staging buffer is rewritten (the device was synchronised before the capture began).
                     rbytes = L.scldm_adamw_table_records_bytes(len(ps))
-                    stage = cached[3] if capturing else torch.empty(rbytes, dtype=torch.uint8).pin_memory()
-                    if stage.numel() < rbytes:
-                        raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+                    if capturing:
+                        stage = cached[3]
+                        if stage.numel() < rbytes:
+                            raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+                    else:      # a ring of 8 pinned staging slots guarded by events (see refresh_hyper: no pinned allocation per step)
+                        ring = group.get("_rec_ring")
+                        if ring is None or ring["buf"].shape[1] < rbytes:
+                            ring = group["_rec_ring"] = {"buf": torch.zeros(8, rbytes, dtype=torch.uint8).pin_memory(), "ev": [None] * 8, "i": 0}
+                        slot = ring["i"] % 8
+                        ring["i"] += 1
+                        if ring["ev"][slot] is not None:
+                            ring["ev"][slot].synchronize()
+                        else:
+                            ring["ev"][slot] = torch.cuda.Event()
+                        stage = ring["buf"][slot]
                     _lib.check(L.scldm_adamw_table_update(ent, ema_arg, len(ps), stage.data_ptr(), rbytes), "scldm_adamw_table_update")
-                    cached[1][:rbytes].copy_(stage[:rbytes], non_blocking=True)
-                    cached = (key if cacheable else None, cached[1], cached[2], stage, keep, sizes)
+                    with torch.cuda.device(dev):
+                        cached[1][:rbytes].copy_(stage[:rbytes], non_blocking=True)
+                        if not capturing:
+                            ring["ev"][slot].record(torch.cuda.current_stream(dev))
+                    cached = (key if cacheable else None, cached[1], cached[2], cached[3] if not capturing else stage, keep, sizes)
                 else:
                     if capturing:
                         raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
@@ -193,6 +222,8 @@ class AdamW(torch.optim.Optimizer):
             g.pop("_table", None)
             g.pop("_step_t", None)
             g.pop("_hyper", None)
+            g.pop("_hyper_ring", None)
+            g.pop("_rec_ring", None)
             steps = {float(self.state[p]["step"]) for p in g["params"] if "step" in self.state.get(p, {})}
             if len(steps) > 1:   #  one counter per group here: a checkpoint whose parameters took different numbers of steps does not fit
                 raise ValueError(f"scldm_amd.optim.AdamW keeps ONE step count per parameter group; the loaded state has {sorted(steps)}")
@@ -203,6 +234,8 @@ class AdamW(torch.optim.Optimizer):
             g.pop("_step_t", None)
             g.pop("_table", None)
             g.pop("_hyper", None)
+            g.pop("_hyper_ring", None)
+            g.pop("_rec_ring", None)
         # every parameter gets its OWN copy of the step count: torch's optimizers increment the `step` tensor of each parameter, so a
         # shared tensor loaded there would advance once per parameter per step
         sd["state"] = {k: {kk: (vv.clone() if kk == "step" and torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}
