@@ -272,3 +272,44 @@ def test_fused_train_step_with_the_frozen_vae_encode_in_the_graph():
         assert np.isfinite(loss)
         assert torch.equal(step.x1.view(n, 16, 16), vae.encode(counts, genes))
     assert any(not torch.equal(a, b) for a, b in zip(p0, m.parameters()))
+
+
+def test_fused_train_step_fp16_overflow_skips_adamw_but_not_the_ema_hook():
+    """fp16 overflow inside the one-call step: the backward raises the device flag, the AdamW part of the launch is skipped (parameters,
+    moments and the step count stay), the EMA action of that step still runs (the reference's hook fires after every batch,
+    models.py:83-87), and the next step backs the loss scale off."""
+    from scldm_amd.ema import EMA
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    vocab = {"cell_line": 4, "gene": 2024}
+    n = 64
+    m, _, _ = build(vocab, "joint", 8, 85)
+    m.precision = "fp16"
+    m.cfg_dropout_prob = 0.5
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    ema = EMA(model=m, beta=0.9, update_every=1, update_after_step=0)
+    step = FusedTrainStep(m, create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5), opt, n, list(vocab), ema=ema, seed=1, graph=False)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x1 = torch.randn(n, 16, 16, device="cuda", generator=gen)
+    cond = {"cell_line": torch.randint(0, 4, (n,), device="cuda", generator=gen), "gene": torch.randint(0, 2024, (n,), device="cuda", generator=gen)}
+    step(x1, cond); ema.update()
+    assert float(m.found_inf_flag()) == 0.0 and float(opt.param_groups[0]["_step_t"]) == 1.0
+    for _ in range(8):          # grow weights (inside the fp16 range themselves) until a product of the backward leaves it
+        with torch.no_grad():
+            for blk in m.blocks:
+                blk.mlp.c_proj.weight.mul_(10.0)
+                blk.mlp.w1.weight.mul_(3.0)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        ema_before = [p.detach().clone() for p in ema.ema_model.parameters()]
+        t_before = float(opt.param_groups[0]["_step_t"])
+        step(x1, cond); ema.update()
+        if float(m.found_inf_flag()) == 1.0:
+            break
+    assert float(m.found_inf_flag()) == 1.0
+    assert all(torch.equal(before[k], p.detach()) for k, p in m.named_parameters()), "AdamW must skip a step whose gradients are not finite"
+    assert float(opt.param_groups[0]["_step_t"]) == t_before
+    moved = [not torch.equal(a, b) for a, b in zip(ema_before, ema.ema_model.parameters())]
+    assert any(moved), "the EMA hook runs after every batch, also after a skipped optimizer step"
+    step(x1, cond); ema.update()
+    assert m.fp16_train_state()["headroom"] <= -1

@@ -434,3 +434,35 @@ def test_unshared_theta_head_draw_and_training_guard():
     vae.train()
     with pytest.raises(NotImplementedError, match="shared-theta"):
         vae(cu(g["counts"]), genes, lib, cu(g["counts_subset"]), cu(g["genes_subset"]))
+
+
+@pytest.mark.parametrize("B,S,G", [(1, 1, 1), (3, 31, 33), (2, 64, 1025), (5, 100, 4099)])
+def test_fp16_policy_ragged_sizes_vs_oracle(B, S, G):
+    """The 16-bit operand policy at sizes that do not fill 32-gene tiles / 1 024-gene chunks (S = 1, G = 1 included): finite, inside the
+    TF32-operand oracle's class (<= 2e-3 of the exact oracle: the oracle with 10-bit operands reads 1.5-6e-4 on the goldens), rows
+    sum to the library size."""
+    g, vae, sd, cfg = build("vae_2000")
+    vae.precision = "fp16"
+    rng = np.random.default_rng(B * 1000 + S + G)
+    genes_s = rng.integers(0, 2000, (B, S)).astype(np.int64)
+    counts_s = rng.poisson(1.5, (B, S)).astype(np.float32)
+    genes = np.stack([rng.permutation(2001)[:G] if G <= 2001 else rng.integers(0, 2001, G) for _ in range(B)]).astype(np.int64)
+    lib = rng.uniform(100, 2000, (B, 1)).astype(np.float32)
+    zr = rng.standard_normal((B, 16, 16)).astype(np.float32)
+    z = vae.encode(cu(counts_s), cu(genes_s))
+    assert torch.isfinite(z).all() and max_abs_rel(z.cpu(), encode(sd, cfg, torch.from_numpy(counts_s), torch.from_numpy(genes_s))) < 2e-3
+    mu_ref, th_ref = decode(sd, cfg, torch.from_numpy(zr), torch.from_numpy(genes), torch.from_numpy(lib))
+    nb = vae.decode(cu(zr), cu(genes), cu(lib))
+    assert max_abs_rel(nb.mu.cpu(), mu_ref) < 2e-3 and max_abs_rel(nb.theta.cpu(), th_ref) < 1e-5
+    assert torch.allclose(nb.mu.sum(1, keepdim=True).cpu(), torch.from_numpy(lib), rtol=1e-4)
+
+
+def test_to_host_matches_cpu_copies():
+    from scldm_amd.datamodule import dense_to_csr, to_host
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dense = torch.poisson(torch.full((33, 517), 0.2, device="cuda"), generator=g)
+    indptr, indices, data = dense_to_csr(dense)
+    h = to_host(indptr, indices, data, dense)
+    assert all(not t.is_cuda and t.is_pinned() for t in h)
+    for a, b in zip(h, (indptr, indices, data, dense)):
+        assert torch.equal(a, b.cpu()) and a.dtype == b.dtype
