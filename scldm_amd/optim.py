@@ -156,8 +156,9 @@ class AdamW(torch.optim.Optimizer):
                 if cached is not None and cached[5] == sizes:
                     # same tensors at other addresses (autograd handed out another flat gradient buffer - every step on the generic route,
                     # where a full rebuild of the DiT-L shape's 0.9 MB workgroup map cost 13 ms of a 20 ms step): only the records change.
-                    # A FRESH small pinned staging tensor per update, like refresh_hyper's - except while capturing, where pinning is not
-                    # permitted and the warm-up's staging buffer is rewritten (the device was synchronised before the capture began).
+                    # Staged through a ring of pinned slots like refresh_hyper's - except while capturing, where the pinned buffer of the
+                    # initial build is rewritten (the device was synchronised before the capture began) and the upload becomes a copy node
+                    # that re-reads it at every replay: that buffer is never written again afterwards.
                     rbytes = L.scldm_adamw_table_records_bytes(len(ps))
                     if capturing:
                         stage = cached[3]
