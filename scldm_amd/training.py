@@ -439,7 +439,7 @@ class FusedTrainStep:
         parameters (weight decay), moments, step count, EMA - is put back, so an optimizer that already trained keeps its state."""
         opt = self.optimizer
         g = opt.param_groups[0]
-        had_state = {id(p) for p in g["params"] if opt.state.get(p)}
+        had_state = {id(p) for p in g["params"] if "exp_avg" in (opt.state.get(p) or {})}
         step_before = g["_step_t"].clone() if g.get("_step_t") is not None else None
         state = self._snapshot(with_state=False)
         moments = {id(p): (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if id(p) in had_state}
