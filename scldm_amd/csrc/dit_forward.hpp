@@ -575,8 +575,11 @@ __device__ __forceinline__ void ln_modulate_store(const float (&v)[FT][NTT][16],
   }
 }
 
+#ifndef SCLDM_FWD_ONE_WG
+#define SCLDM_FWD_ONE_WG 0    // experiment builds: 1 = compile every instantiation for ONE wave per SIMD (up to 512 registers: room for -DSCLDM_PF=8 -DSCLDM_W12_PAIR=1)
+#endif
 template <typename OP, int NTT, int FT, bool REC = false>
-__global__ __launch_bounds__(64 * (8 / FT), ((OP::kTwoWG && NTT <= 2) || NTT == 1) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(64 * (8 / FT), (!SCLDM_FWD_ONE_WG && ((OP::kTwoWG && NTT <= 2) || NTT == 1)) ? 2 : 1) void dit_forward_kernel(const FwdArgs a) {
   using L = FwdLayout<OP, NTT, FT>;
   using E = typename OP::E;
   using Frag = typename OP::Frag;
