@@ -573,11 +573,10 @@ class FusedTrainStep:
             self.labels_in[k].copy_(condition[k], non_blocking=True)
         if self.distributed:
             self._launch()                                         # backward only (opt = NULL): gradients in self.flat
-            step = max(1, (128 << 20) // 4)
-            for a in range(0, self.flat.numel(), step):
-                piece = self.flat[a:a + step]
-                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
-                piece.div_(dist.get_world_size(self.group))
+            # in-place, in slices of <= 128 MB of the flat buffer the .grad views share (the path the gloo tests exercise)
+            allreduce_gradients([p for p in self.params if p.requires_grad and p is not self.dit.pos_embed], self.group)
+            if self._gpos is not None:
+                allreduce_gradients([self.dit.pos_embed], self.group)
             if self.found_inf is not None:
                 dist.all_reduce(self.found_inf, op=dist.ReduceOp.MAX, group=self.group)
                 self.optimizer.found_inf, self.optimizer.grad_scale = self.found_inf, None
