@@ -206,6 +206,7 @@ extern "C" int scldm_adamw_table_build(const scldm_adamw_entry* e, float* const*
   long long blocks = 0;
   for (int i = 0; i < count; ++i) {
     if (e[i].n > 0 && (!e[i].p || !e[i].g || !e[i].m || !e[i].v)) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: tensor %d has a NULL pointer", i);
+    if (e[i].n > 0x7fffffffLL) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_build: tensor %d has more than 2^31 elements", i);
     tt[i] = TableTensor{e[i].p, e[i].g, e[i].m, e[i].v, ema ? ema[i] : nullptr, e[i].n};
     for (long long c = 0; c * kChunk < e[i].n; ++c) tb[blocks++] = TableBlock{i, (int)c};
   }
@@ -223,6 +224,7 @@ extern "C" int scldm_adamw_table_update(const scldm_adamw_entry* e, float* const
   TableTensor* tt = reinterpret_cast<TableTensor*>(records_host);
   for (int i = 0; i < count; ++i) {
     if (e[i].n > 0 && (!e[i].p || !e[i].g || !e[i].m || !e[i].v)) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_update: tensor %d has a NULL pointer", i);
+    if (e[i].n > 0x7fffffffLL) return fail(SCLDM_ERR_SHAPE, "scldm_adamw_table_update: tensor %d has more than 2^31 elements", i);
     tt[i] = TableTensor{e[i].p, e[i].g, e[i].m, e[i].v, ema ? ema[i] : nullptr, e[i].n};
   }
   return SCLDM_OK;
