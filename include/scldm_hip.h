@@ -462,9 +462,10 @@ int scldm_vae_encode(scldm_vae* h, const float* counts, const int64_t* genes, in
 /* precision (encode, decode, decode_sample): SCLDM_PREC_FP32 = exact-fp32 MFMA chain (parity path, <= 1e-4);
  * SCLDM_PREC_FP16 = fp16 operands for the per-gene MCAB / SwiGLU contractions (10 mantissa bits = TF32, the arithmetic class the
  * reference runs CrossAttention / MLP in under set_float32_matmul_precision("high"): experiments/scripts/inference.py:26,
- * src/scldm/layers.py:248-264,305-330), fp32 accumulate / softmax / LayerNorm / NB head, operands saturated at +-65 504;
+ * src/scldm/layers.py:248-264,305-330), fp32 accumulate / softmax / LayerNorm / NB head, weights saturated at +-65 504;
  * SCLDM_PREC_BF16 = the same with bf16 operands (8 bits: narrower than the reference).  Both 16-bit policies run about 3x the fp32
- * decode rate; the 16-token cell trunks stay exact fp32 in every policy.  Other values: SCLDM_ERR_SHAPE. */
+ * decode rate; the Linears of the 16-token cell trunks take the policy's operand type too (the reference runs them in TF32 as well;
+ * their 16 x 16 attention stays fp32 on the VALU).  Other values: SCLDM_ERR_SHAPE. */
 int scldm_vae_decode(scldm_vae* h, const float* z, const int64_t* genes, const float* library_size, int B, int G, float* mu,
                      float* theta, int precision, void* ws, void* stream);
 

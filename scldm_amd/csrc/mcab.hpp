@@ -33,8 +33,8 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-// Operand policy of the per-gene contractions (common.hpp): OpF32 = the exact chain; OpBF16 / OpFP16 = 16-bit operands, fp32
-// accumulate.  OpFP16 carries TF32's 10 mantissa bits - the arithmetic class the reference runs MCAB in
+// Operand policy of the per-gene contractions and of the trunks' Linears (common.hpp): OpF32 = the exact chain; OpBF16 / OpFP16 = 16-bit
+// operands, fp32 accumulate.  OpFP16 carries TF32's 10 mantissa bits - the arithmetic class the reference runs MCAB in
 // (torch.set_float32_matmul_precision("high"): experiments/scripts/inference.py:26, train.py:18) - at the bf16 MFMA rate.
 // What fp16 gives up against TF32 is exponent range.  Weights and the per-cell K / V fragments are converted once per workgroup
 // and SATURATE at +-65 504 (mcab_pack8_sat); the per-tile activation operands (LayerNorm outputs, softmax probabilities, attention
@@ -246,25 +246,37 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 // acc += W-tile (16 steps = K 32, fragments from global memory) x[16] (accumulator-order registers)
+// OP = OpF32: sixteen (eight) exact-fp32 MFMA steps.  OP = OpFP16 / OpBF16 (round 6: the 16-token trunks of the 16-bit policies - the
+// reference runs these Linears in TF32 too, and a trunk is a chain of DEPENDENT products: 13 of them per layer at 16 x 64 cycles each in
+// fp32): eight consecutive fp32 steps are the 16 k-values of one 16-bit MFMA in the same (step, half-wave) order, so the fp32 fragments
+// are converted four at a time (weights saturating) and the chain is two (one) MFMAs.
+template <class OP>
+__device__ __forceinline__ f32x16 chain_w8(const f32x4& wa, const f32x4& wb, const float* x, f32x16 acc) {   // steps [s0, s0 + 8)
+  if constexpr (McabOp<OP>::k16) {
+    const float w8[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+    return OP::mma(mcab_pack8_sat<OP>(w8), mcab_pack8<OP>(x), acc);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma2(wa[i], x[i], acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = mfma2(wb[i], x[4 + i], acc);
+    return acc;
+  }
+}
+template <class OP = OpF32>
 __device__ __forceinline__ f32x16 chain16(const float* __restrict__ frag, const float (&x)[16], f32x16 acc, int lane) {
   const f32x4* F = reinterpret_cast<const f32x4*>(frag);
   f32x4 w[4];
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) w[g4] = F[g4 * 64 + lane];
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma2(w[g4][i], x[g4 * 4 + i], acc);
-  return acc;
+  acc = chain_w8<OP>(w[0], w[1], x, acc);
+  return chain_w8<OP>(w[2], w[3], x + 8, acc);
 }
+template <class OP = OpF32>
 __device__ __forceinline__ f32x16 chain8(const float* __restrict__ frag, const float (&x)[8], f32x16 acc, int lane) {
   const f32x4* F = reinterpret_cast<const f32x4*>(frag);
   const f32x4 w0 = F[lane], w1 = F[64 + lane];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc = mfma2(w0[i], x[i], acc);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc = mfma2(w1[i], x[4 + i], acc);
-  return acc;
+  return chain_w8<OP>(w0, w1, x, acc);
 }
 
 // The same with the fragments already in registers: inside the trunk the NEXT tile's fragments are requested before the
@@ -285,19 +297,14 @@ __device__ __forceinline__ Frag8 load8(const float* __restrict__ frag, int lane)
   f.w[1] = F[64 + lane];
   return f;
 }
+template <class OP = OpF32>
 __device__ __forceinline__ f32x16 chain16(const Frag16& f, const float (&x)[16], f32x16 acc) {
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma2(f.w[g4][i], x[g4 * 4 + i], acc);
-  return acc;
+  acc = chain_w8<OP>(f.w[0], f.w[1], x, acc);
+  return chain_w8<OP>(f.w[2], f.w[3], x + 8, acc);
 }
+template <class OP = OpF32>
 __device__ __forceinline__ f32x16 chain8(const Frag8& f, const float (&x)[8], f32x16 acc) {
-#pragma unroll
-  for (int g4 = 0; g4 < 2; ++g4)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma2(f.w[g4][i], x[g4 * 4 + i], acc);
-  return acc;
+  return chain_w8<OP>(f.w[0], f.w[1], x, acc);
 }
 
 // LayerNorm over the first `width` features of every token (registers beyond `width` must be zero); affine if w != nullptr
@@ -359,16 +366,17 @@ __device__ __forceinline__ void tile_ln(const float (&x)[16], float (&y)[16], co
 }
 
 // SwiGLU MLP on a normalised tile: x += c_proj( silu(w1 yn) * (w2 yn) ), six 16-unit hidden tiles (88 padded to 96 with zeros)
+template <class OP = OpF32>
 __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const float* __restrict__ wc, const float (&yn)[16],
                                             float (&x)[16], int lane) {
   f32x16 mo = zero16();
 #pragma unroll 1
   for (int u = 0; u < kHTiles; ++u) {
-    const f32x16 ht = chain16(w12 + u * 1024, yn, zero16(), lane);   // rows 0-15 = w1 units, 16-31 = the matching w2 units
+    const f32x16 ht = chain16<OP>(w12 + u * 1024, yn, zero16(), lane);   // rows 0-15 = w1 units, 16-31 = the matching w2 units
     float hv[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];
-    mo = chain8(wc + u * 512, hv, mo, lane);
+    mo = chain8<OP>(wc + u * 512, hv, mo, lane);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) x[r] += mo[r];
@@ -385,6 +393,7 @@ __device__ __forceinline__ void tile_swiglu(const float* __restrict__ w12, const
 // same-box A/B at 1 024 / 2 048 / 4 096 cells: decoder trunk 110 / 139 / 259 -> 108 / 126 / 225 us, encoder tail 114 / 143 / 281
 // -> 113 / 136 / 260 us (three waves per SIMD spill and lose 10 %; unbounded - 305 registers, one wave - is 22 % faster at
 // 1 024 cells and 10 % slower at 4 096).
+template <class OP = OpF32>
 __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__ S, float* __restrict__ X, const float* __restrict__ wts,
                                              int n_layer, float eps, int lane, int hw) {
   const int c32 = lane & 31, hh = lane >> 5;
@@ -406,14 +415,14 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
     if (hw == 0) {
       Frag16 cur = nxt;
       nxt = load16(w + T_QKV + 1024, lane);
-      put_tile(chain16(cur, yn, zero16()), 0);
+      put_tile(chain16<OP>(cur, yn, zero16()), 0);
       cur = nxt;
       nxt = load16(w + T_PROJ, lane);
-      put_tile(chain16(cur, yn, zero16()), 1);
+      put_tile(chain16<OP>(cur, yn, zero16()), 1);
     } else {
       const Frag16 cur = nxt;
       nxt = load16(w + T_PROJ, lane);
-      put_tile(chain16(cur, yn, zero16()), 2);
+      put_tile(chain16<OP>(cur, yn, zero16()), 2);
     }
     __syncthreads();
     // attention: 8 heads x 16 queries of cell `hw` = 128 (head, query) pairs, two per lane; the output replaces q in place
@@ -454,7 +463,7 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
     {
       const Frag16 cur = nxt;                     // proj (both waves: each needs the new state)
       nxt = load16(w + T_W12 + hw * 1024, lane);
-      const f32x16 po = chain16(cur, ao, zero16());
+      const f32x16 po = chain16<OP>(cur, ao, zero16());
 #pragma unroll
       for (int r = 0; r < 16; ++r) x[r] += po[r];
     }
@@ -469,11 +478,11 @@ __device__ __forceinline__ void trunk_blocks(float (&x)[16], float* __restrict__
       const Frag8 wcf = load8(w + T_WC + u * 512, lane);
       if (uu + 1 < kHTiles / 2) nxt = load16(w + T_W12 + (u + 2) * 1024, lane);
       else if (!last) nxt = load16(w + kTrunkLayerFloats + T_QKV + (hw ? 2 * 1024 : 0), lane);
-      const f32x16 ht = chain16(cur, yn, zero16());   // rows 0-15 = w1 units, 16-31 = the matching w2 units
+      const f32x16 ht = chain16<OP>(cur, yn, zero16());   // rows 0-15 = w1 units, 16-31 = the matching w2 units
       float hv[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) hv[r] = silu_f(ht[r]) * ht[r + 8];
-      mo = chain8(wcf, hv, mo);
+      mo = chain8<OP>(wcf, hv, mo);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) X[hw * kTrunkXchg + r * 64 + lane] = mo[r];
@@ -504,8 +513,9 @@ struct DecCellArgs {
   int B, n_lat, n_layer;
   float eps;
 };
-template <bool PLAIN>
+template <class OP>
 __global__ __launch_bounds__(64 * kTrunkWaves, 2) void dec_cell_kernel(const DecCellArgs a) {
+  constexpr bool PLAIN = !McabOp<OP>::k16;   // fp32 policy: K | V rows for the VALU attention of dec_gene_kernel<OpF32>; 16-bit policies: MFMA fragments
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
   const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
   const int c32 = lane & 31, hh = lane >> 5;
@@ -523,17 +533,17 @@ __global__ __launch_bounds__(64 * kTrunkWaves, 2) void dec_cell_kernel(const Dec
   }
   tile_ln(zr, zn, nullptr, nullptr, a.n_lat, a.eps, hh);
   {
-    const f32x16 h0 = chain16(a.lat_frag, zn, zero16(), lane);
+    const f32x16 h0 = chain16<OP>(a.lat_frag, zn, zero16(), lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = h0[r];
   }
-  trunk_blocks(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
+  trunk_blocks<OP>(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
   if (hw) return;   // the tail (no workgroup barrier below) is wave 0's
   float yn[16];
   tile_ln(x, yn, a.ca_ln1_w, a.ca_ln1_b, kE, a.eps, hh);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {   // scratch rows [token][K 32 | V 32]
-    const f32x16 o = chain16(a.kv_frag + t * 1024, yn, zero16(), lane);
+    const f32x16 o = chain16<OP>(a.kv_frag + t * 1024, yn, zero16(), lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<f32x4*>(S + c32 * kTrunkLd + t * 32 + q * 8 + hh * 4) = f32x4{o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
@@ -1212,6 +1222,7 @@ struct EncCellArgs {
   int B, n_lat, n_layer;
   float eps;
 };
+template <class OP>
 __global__ __launch_bounds__(64 * kTrunkWaves, 2) void enc_cell_kernel(const EncCellArgs a) {
   __shared__ __attribute__((aligned(16))) float SM[kTrunkSmemFloats];
   const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;   // both waves carry the workgroup's cell pair (trunk_blocks)
@@ -1229,12 +1240,12 @@ __global__ __launch_bounds__(64 * kTrunkWaves, 2) void enc_cell_kernel(const Enc
     for (int i = 0; i < 4; ++i) { att[q * 4 + i] = p4[i]; x[q * 4 + i] = i4[i]; }
   }
   {
-    const f32x16 po = chain16(a.proj_frag, att, zero16(), lane);   // h = inducing + c_proj(att): the residual is the QUERY (layers.py:327)
+    const f32x16 po = chain16<OP>(a.proj_frag, att, zero16(), lane);   // h = inducing + c_proj(att): the residual is the QUERY (layers.py:327)
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] += po[r];
   }
   tile_ln(x, yn, a.ca_ln2_w, a.ca_ln2_b, kE, a.eps, hh);
-  tile_swiglu(a.w12_frag, a.wc_frag, yn, x, lane);
+  tile_swiglu<OP>(a.w12_frag, a.wc_frag, yn, x, lane);
   if (a.pos) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1243,10 +1254,10 @@ __global__ __launch_bounds__(64 * kTrunkWaves, 2) void enc_cell_kernel(const Enc
       for (int i = 0; i < 4; ++i) x[q * 4 + i] += p4[i];
     }
   }
-  trunk_blocks(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
+  trunk_blocks<OP>(x, S, X, a.trunk, a.n_layer, a.eps, lane, hw);
   if (hw) return;
   // latent head: Linear 32 -> n_lat (no bias; fragment rows >= n_lat are zero), LN without affine over the n_lat channels
-  const f32x16 lt = chain16(a.lat_frag, x, zero16(), lane);
+  const f32x16 lt = chain16<OP>(a.lat_frag, x, zero16(), lane);
   float lv[16], ln[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) lv[r] = lt[r];

@@ -300,7 +300,12 @@ int scldm_vae_encode_ex(scldm_vae* h, const float* counts, const int64_t* genes,
   e.pos = c.positional_encoding ? h->small + S_ENC_POS : nullptr;
   e.trunk = h->enc_trunk; e.lat_frag = h->frag_cell + F_ENC_LAT; e.z = z;
   e.B = B; e.n_lat = c.n_embed_latent; e.n_layer = c.n_layer; e.eps = c.layernorm_eps;
-  { KernelTimer kt(h, SCLDM_VAE_K_ENC_CELL, st); enc_cell_kernel<<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e); }
+  {
+    KernelTimer kt(h, SCLDM_VAE_K_ENC_CELL, st);
+    if (precision == SCLDM_PREC_FP16) enc_cell_kernel<OpFP16><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
+    else if (precision == SCLDM_PREC_BF16) enc_cell_kernel<OpBF16><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
+    else enc_cell_kernel<OpF32><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(e);
+  }
   LAUNCH_CHECK();
   return SCLDM_OK;
 }
@@ -329,8 +334,9 @@ static int vae_decode_impl(scldm_vae* h, const float* z, const int64_t* genes, c
   d.kvfrag = kv; d.B = B; d.n_lat = c.n_embed_latent; d.n_layer = c.n_layer; d.eps = c.layernorm_eps;
   {
     KernelTimer kt(h, SCLDM_VAE_K_DEC_CELL, st);
-    if (precision != SCLDM_PREC_FP32) dec_cell_kernel<false><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
-    else dec_cell_kernel<true><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+    if (precision == SCLDM_PREC_FP16) dec_cell_kernel<OpFP16><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+    else if (precision == SCLDM_PREC_BF16) dec_cell_kernel<OpBF16><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
+    else dec_cell_kernel<OpF32><<<cdiv(B, 2), 64 * kTrunkWaves, 0, st>>>(d);
   }
   LAUNCH_CHECK();
   const int nch = dec_chunks(G);

@@ -95,9 +95,10 @@ class TransformerVAE(nn.Module):
         self.decoder_head = decoder_head
         self.input_layer = input_layer
         self._handle = None
-        # operand policy of the per-gene contractions of encode / decode / decode_sample (the cell trunks, LayerNorms, softmax and
-        # the NB head are fp32 in every policy): "fp32" = exact (parity path); "fp16" = TF32's mantissa, the arithmetic class the
-        # reference itself runs MCAB in (set_float32_matmul_precision("high"), experiments/scripts/inference.py:26); "bf16" = 8 bits
+        # operand policy of the contractions of encode / decode / decode_sample - the per-gene MCAB / SwiGLU products and the Linears of
+        # the 16-token trunks (LayerNorms, softmax, the trunks' 16 x 16 attention and the NB head are fp32 in every policy): "fp32" =
+        # exact (parity path); "fp16" = TF32's mantissa, the arithmetic class the reference itself runs the VAE in
+        # (set_float32_matmul_precision("high"), experiments/scripts/inference.py:26); "bf16" = 8 bits
         self.precision = "fp32"
         self._weights_key = None
         self._weights_fp = None
