@@ -560,7 +560,7 @@ def mcab_roofline(device, rows=8192, cells=4096, n_genes=17002, S=6147, calls=6)
             fl, by = work[k]
             us = 1e3 * ms / n
             hbm_bound = k == "dec_finalize"
-            peak = 8000.0 if hbm_bound else PEAK[prec if k in ("dec_gene", "enc_pool") else "fp32"] / 1e12   # the cell trunks are exact fp32 in every policy
+            peak = 8000.0 if hbm_bound else PEAK[prec] / 1e12   # (the trunks' Linears take the policy's operand type too)
             ach = by / (us * 1e-6) / 1e9 if hbm_bound else fl / (us * 1e-6) / 1e12
             traffic = (pmc.get(prec, {}).get(k, {}) or {}).get("hbm_bytes_per_launch")
             out[k] = {"bound": "hbm" if hbm_bound else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
