@@ -14,6 +14,10 @@ schemes and pin them with an analytic known-answer test (tests/test_oracle_trans
 (the same form as the reference's own SDE Heun step without noise, integrators.py:39-48).
 The grid is th.linspace(0, 1, num_steps) (integrators.py:95): num_steps points ->
 num_steps-1 steps; the model sees t broadcast to a (B,) vector (:103-104).
+Third-party anchor available in this image: SciPy's independent `scipy.integrate.RK45` implements the same Dormand-Prince pair
+and starting-step rule - `dopri5_step` / `dopri5_initial_step` below are checked against it to rounding (stage points, slopes,
+5th-order solution, the error estimate as Shampine's 2/3 multiple, the starting step).  Unpinned after that: torchdiffeq's
+accept / grow rule and its interpolation at the save times.
 """
 from __future__ import annotations
 
@@ -109,6 +113,34 @@ def _rms64(a: "_np.ndarray") -> float:
     return float(_np.sqrt(_np.mean(_np.square(_np.abs(a)))))
 
 
+def dopri5_step(f, ta: float, dt: float, y0: "_np.ndarray", f0: "_np.ndarray"):
+    """One attempted Dormand-Prince step from (ta, y0) with f0 = f(ta, y0): returns (y1, error estimate, the 7 stage slopes).
+    The stage arithmetic (alpha / beta / 5th-order weights) is the classic DP5(4) pair - tests/test_oracle_transport.py checks
+    it stage by stage against SciPy's independent `scipy.integrate.RK45` (`rk_step`); the embedded error weights are
+    Shampine's (torchdiffeq's `c_error`), 2/3 of the classic pair's, checked there as that multiple."""
+    k = _np.empty((7, y0.size))
+    k[0] = f0
+    yi = y0
+    for i, (alpha, beta) in enumerate(zip(_DP_ALPHA, _DP_BETA)):
+        ti = ta + dt if alpha == 1.0 else ta + alpha * dt
+        yi = y0 + (beta * dt) @ k[:i + 1]
+        k[i + 1] = f(ti, yi)
+    # c_sol == beta[-1] and c_sol[-1] == 0: the last stage point IS y1
+    return yi, (dt * _DP_C_ERROR) @ k, k
+
+
+def dopri5_initial_step(f, t0: float, y0: "_np.ndarray", f0: "_np.ndarray", atol: float, rtol: float) -> float:
+    """Hairer-Norsett-Wanner II.4 starting step with the rms norm and exponent 1/5 (pinned to SciPy's `select_initial_step`
+    in tests/test_oracle_transport.py: the same published algorithm, an independent implementation)."""
+    scale = atol + _np.abs(y0) * rtol
+    d0, d1 = _rms64(y0 / scale), _rms64(f0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    f1 = f(t0 + h0, y0 + h0 * f0)
+    d2 = _rms64((f1 - f0) / scale) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+    return min(100 * h0, h1)
+
+
 def sample_ode_dopri5(x: torch.Tensor, model_fn, num_steps: int = 50, atol: float = 1e-5, rtol: float = 1e-5,
                       safety: float = 0.9, ifactor: float = 10.0, dfactor: float = 0.2, max_num_steps: int = 100000,
                       return_stats: bool = False):
@@ -132,14 +164,7 @@ def sample_ode_dopri5(x: torch.Tensor, model_fn, num_steps: int = 50, atol: floa
     ts = torch.linspace(0.0, 1.0, num_steps).to(torch.float64).numpy()     # integrators.py:95, cast as the solver does
     y0 = x.detach().to(torch.float64).numpy().reshape(-1).copy()
     f0 = f(ts[0], y0)
-    # initial step
-    scale = atol + _np.abs(y0) * rtol
-    d0, d1 = _rms64(y0 / scale), _rms64(f0 / scale)
-    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
-    f1 = f(ts[0] + h0, y0 + h0 * f0)
-    d2 = _rms64((f1 - f0) / scale) / h0
-    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
-    dt = min(100 * h0, h1)
+    dt = dopri5_initial_step(f, float(ts[0]), y0, f0, atol, rtol)
 
     t0 = t1 = float(ts[0])
     coeff = [y0] * 5
@@ -151,15 +176,7 @@ def sample_ode_dopri5(x: torch.Tensor, model_fn, num_steps: int = 50, atol: floa
             assert n_steps < max_num_steps, "max_num_steps exceeded"
             assert t1 + dt > t1, "underflow in dt"
             ta, tb = t1, t1 + dt
-            k = _np.empty((7, y0.size))
-            k[0] = f0
-            yi = y0
-            for i, (alpha, beta) in enumerate(zip(_DP_ALPHA, _DP_BETA)):
-                ti = tb if alpha == 1.0 else ta + alpha * dt
-                yi = y0 + (beta * dt) @ k[:i + 1]
-                k[i + 1] = f(ti, yi)
-            y1 = yi                                           # c_sol == beta[-1] and c_sol[-1] == 0: the last stage point IS y1
-            err = (dt * _DP_C_ERROR) @ k
+            y1, err, k = dopri5_step(f, ta, dt, y0, f0)
             ratio = _rms64(err / (atol + rtol * _np.maximum(_np.abs(y0), _np.abs(y1))))
             ok = ratio <= 1
             if ok:

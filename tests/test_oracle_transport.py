@@ -150,3 +150,40 @@ def test_host_dopri5_reproduces_the_oracle_step_sequence():
         for (ta, ha), (tb, hb) in zip(ls["accepted_steps"] + ls["rejected_steps"], st["accepted"] + st["rejected"]):
             assert abs(ta - tb) <= 1e-6 * max(1.0, abs(tb)) and abs(ha - hb) <= 1e-6 * hb
         assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-9 * max(1.0, float(ref.abs().max()))
+
+
+def test_dopri5_step_arithmetic_matches_scipy_rk45():
+    """torchdiffeq is absent, but SciPy ships an independent implementation of the same published pair (Dormand & Prince 1980;
+    `scipy.integrate.RK45`) and of the same starting-step rule (Hairer-Norsett-Wanner II.4): the oracle's stage points, stage slopes
+    and 5th-order solution agree with `rk_step` to rounding, its error estimate is Shampine's 2/3 multiple of the classic embedded
+    difference (torchdiffeq's `c_error`), its starting step equals `select_initial_step`, and the mid-point weights are 5th-order.
+    What stays unpinned after this: the accept / grow rule and the interpolation at the save times (torchdiffeq-specific)."""
+    import numpy as np
+    from scipy.integrate._ivp.common import select_initial_step
+    from scipy.integrate._ivp.rk import RK45, rk_step
+    from oracle.transport import dopri5_initial_step, dopri5_step
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((12, 12)) * 0.7
+    f = lambda t, y: np.tanh(W @ y) * (1.0 + 0.5 * np.sin(3.0 * t)) - 0.3 * y
+    for ta, dt in ((0.0, 0.05), (0.31, 0.2), (0.9, 0.4)):
+        y0 = rng.standard_normal(12)
+        f0 = f(ta, y0)
+        y1, err, k = dopri5_step(f, ta, dt, y0, f0)
+        K = np.empty((7, 12))
+        y1_s, f1_s = rk_step(f, ta, y0, f0, dt, RK45.A, RK45.B, RK45.C, K)
+        assert np.abs(y1 - y1_s).max() < 1e-14 and np.abs(k - K).max() < 1e-13
+        assert np.abs(k[6] - f1_s).max() < 1e-13                                   # FSAL: the 7th slope is f(t1, y1)
+        assert np.abs(err - (-2.0 / 3.0) * dt * (K.T @ RK45.E)).max() < 1e-15
+        for atol, rtol in ((1e-5, 1e-5), (1e-8, 1e-3)):
+            h_s = select_initial_step(f, ta, y0, np.inf, np.inf, f0, 1, RK45.error_estimator_order, rtol, atol)
+            assert abs(dopri5_initial_step(f, ta, y0, f0, atol, rtol) - h_s) <= 1e-15 * h_s
+    # mid-point weights: y0 + dt * (c_mid . k) is the solution at ta + dt / 2 to O(dt^5) (halving dt shrinks the defect ~ 32 x)
+    from oracle.transport import _DP_C_MID
+    g = lambda t, y: np.array([y[1], -y[0]])                                      # (cos t, -sin t)
+    defect = []
+    for dt in (0.2, 0.1, 0.05):
+        y0 = np.array([1.0, 0.0])
+        _, _, k = dopri5_step(g, 0.0, dt, y0, g(0.0, y0))
+        ym = y0 + (dt * _DP_C_MID) @ k
+        defect.append(np.abs(ym - np.array([np.cos(dt / 2), -np.sin(dt / 2)])).max())
+    assert defect[0] / defect[1] > 20 and defect[1] / defect[2] > 20 and defect[2] < 1e-9
