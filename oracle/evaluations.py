@@ -7,7 +7,9 @@ formulas).  Pinned against matrices and MMD values produced by the reference cla
 installed here): PARITY UNPINNED.  `wasserstein_sinkhorn` below restates the PUBLISHED algorithm behind the call the reference
 makes (models.py:47-48: method="sinkhorn", power 1 / 2, reg 0.05): Sinkhorn-Knopp matrix scaling (Cuturi, NIPS 2013) with the
 iteration order, the every-10th-iteration marginal-error test (stopThr 1e-9) and the keep-previous-scalings exit on a singular
-update that POT's `sinkhorn_knopp` documents; anchored on closed-form cases in tests/test_wasserstein.py.
+update that POT's `sinkhorn_knopp` documents; anchored on closed-form cases in tests/test_wasserstein.py and on an independent
+SciPy solve (L-BFGS on the semi-dual, `linear_sum_assignment` for the reg -> 0 limit) of the optimisation problem the call is
+published to solve: the VALUE is third-party-checked, POT's iteration count / stopping details stay unpinned.
 """
 from __future__ import annotations
 

@@ -1,5 +1,6 @@
 """Entropic OT (Sinkhorn) for the Wasserstein generation metrics (reference src/scldm/evaluations.py:85-108 -> third-party POT,
-not vendored: parity unpinned).  CPU part: the oracle's restatement against closed-form cases.  GPU part: the HIP iteration
+not vendored: parity unpinned).  CPU part: the oracle's restatement against closed-form cases and against an independent SciPy
+solve of the same published optimisation problem.  GPU part: the HIP iteration
 against the oracle."""
 import math
 
@@ -39,6 +40,41 @@ def test_oracle_singular_update_keeps_previous_scalings():
     x0, x1 = torch.randn(8, 3, generator=g) * 50, torch.randn(8, 3, generator=g) * 50
     d, it, status = wasserstein_sinkhorn(x0, x1, reg=1e-3, power=2, dtype=torch.float32)   # exp(-M/reg) underflows: K has zero columns
     assert status == 2 and it == 0 and (math.isnan(d) or d >= 0)
+
+
+@pytest.mark.parametrize("n,m,D,power,reg,scale", [(7, 9, 3, 2, 0.05, 0.3), (12, 12, 4, 1, 0.05, 0.5), (20, 11, 6, 2, 0.5, 1.0)])
+def test_oracle_value_equals_an_independent_solve_of_the_entropic_problem(n, m, D, power, reg, scale):
+    """POT is absent; the PROBLEM `ot.sinkhorn2` solves is published (Cuturi 2013): min_P <P, M> - reg H(P) over the couplings of
+    (a, b), returned as <P*, M>.  SciPy solves its concave semi-dual here with L-BFGS in float64 (no Sinkhorn iteration involved):
+    the restated iteration's value must be that optimum's transport cost; and for n = m uniform weights the reg -> 0 limit is the
+    assignment problem `scipy.optimize.linear_sum_assignment` solves exactly (`ot.emd2`'s value)."""
+    from scipy.optimize import linear_sum_assignment, minimize
+    from scipy.special import logsumexp
+    g = torch.Generator().manual_seed(n * 100 + m)
+    x0, x1 = torch.randn(n, D, generator=g) * scale, torch.randn(m, D, generator=g) * scale + 0.2
+    M = torch.cdist(x0.double(), x1.double()).numpy() ** power
+    a, b = np.full(n, 1.0 / n), np.full(m, 1.0 / m)
+
+    def neg_semidual(f):
+        lse = logsumexp((f[:, None] - M) / reg, axis=0)                      # (m,)
+        gdual = reg * (np.log(b) - lse)
+        P = np.exp((f[:, None] + gdual[None, :] - M) / reg)                   # columns sum to b by construction
+        return -(a @ f + b @ gdual), -(a - P.sum(1))
+    r = minimize(neg_semidual, np.zeros(n), jac=True, method="L-BFGS-B", options={"maxiter": 20000, "ftol": 1e-16, "gtol": 1e-12})
+    f = r.x
+    gdual = reg * (np.log(b) - logsumexp((f[:, None] - M) / reg, axis=0))
+    P = np.exp((f[:, None] + gdual[None, :] - M) / reg)
+    assert np.abs(P.sum(1) - a).max() < 1e-8 and np.abs(P.sum(0) - b).max() < 1e-12
+    cost = float((P * M).sum())
+    d, it, status = wasserstein_sinkhorn(x0, x1, reg=reg, power=power)
+    assert status == 0
+    assert abs(d - (math.sqrt(cost) if power == 2 else cost)) < 2e-6 * max(1.0, d)
+    if n == m:
+        ri, ci = linear_sum_assignment(M)
+        emd = float(M[ri, ci].mean())
+        d_small, _, st = wasserstein_sinkhorn(x0, x1, reg=0.002 * float(M.max()), power=power, num_iter_max=200_000)
+        val = d_small ** 2 if power == 2 else d_small
+        assert st in (0, 1) and emd - 1e-9 <= val <= emd * 1.05               # entropic plans are feasible couplings: cost >= the optimum
 
 
 @pytest.mark.gpu
