@@ -485,7 +485,7 @@ def decode_inclusive(m, wl, device, n_genes=17002):
     when the DiT runs a 16-bit policy, exact fp32 otherwise."""
     vae = make_vae(n_genes, device)
     vae.precision = chain_prec = "fp16" if m.precision in ("bf16", "fp16") else "fp32"
-    B = min(wl["B"], 1024)  # (2B, G) fp32 mu + theta outputs: 2 x 139 MB at B=1024
+    B = min(wl["B"], 4096)  # the headline's own batch: (2B, G) fp32 mu + theta outputs are 2 x 557 MB at B = 4 096 (round 5 capped this at 1 024 cells)
     w2 = dict(wl); w2["B"] = B
     z2, cond2, scales = make_inputs(w2, B, device, seed=7)
     genes = torch.arange(n_genes, device=device).repeat(2 * B, 1)
@@ -862,7 +862,25 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     torch.cuda.synchronize()
     stage = [ev[i].elapsed_time(ev[i + 1]) for i in range(5)]
     nnz = int(host[2].numel())
-    return {"workload": wl_name, "cells": B, "generated_rows": 2 * B, "n_genes": n_genes, "cfg_evaluations": wl["evals"], "method": wl["method"],
+    # the same chain over K consecutive batches as the two-stream pipeline (scldm_amd.sampling.generate_cells_stream: batch i's decode /
+    # draw / CSR / host copies beside batch i + 1's ODE) - the reference's prediction loop is a loop over batches (models.py:707-764)
+    from scldm_amd.sampling import generate_cells_stream
+    K = 8
+    genes1 = genes2[:B]
+    def run_stream():
+        return sum(int(out[2].numel()) for out in generate_cells_stream(m, vae, [cond] * K, scales, genes1, steps, wl["method"], size_factor_sampler=smp))
+    run_stream()
+    torch.cuda.synchronize()
+    tp = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run_stream()
+        torch.cuda.synchronize()
+        tp.append((time.perf_counter() - t0) / K)
+    dtp = statistics.median(tp)
+    pipelined = {"batches": K, "cells_per_s": B / dtp, "ms_per_batch": 1e3 * dtp,
+                 "path": "generate_cells_stream: ODE of batch i+1 on the caller's stream || decode_sample + dense_to_csr + to_host of batch i on a second stream"}
+    return {"workload": wl_name, "pipelined": pipelined, "cells": B, "generated_rows": 2 * B, "n_genes": n_genes, "cfg_evaluations": wl["evals"], "method": wl["method"],
             "dit_precision": precision, "decode_precision": vae.precision, "cells_per_s": B / dt, "ms": 1e3 * dt, "ms_each": [round(1e3 * t, 3) for t in ts],
             "stage_ms": {"size_factors_and_noise": stage[0], "ode": stage[1], "decode_and_nb_draw": stage[2], "csr_assembly": stage[3],
                          "device_to_host": stage[4]},
@@ -920,6 +938,8 @@ def compact_line(result):
     put("train_e2e_ms", "training_step_end_to_end", "ms_per_step"); put("train_autograd_graph_ms", "training_step_autograd_graph", "ms_per_step")
     put("e2e_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "cells_per_s")
     put("e2e_ms_dentate512", "generation_end_to_end", "dentate_b512_euler50", "ms")
+    put("e2e_pipelined_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "pipelined", "cells_per_s")
+    put("e2e_pipelined_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "pipelined", "cells_per_s")
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
     put("e2e_ms_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "ms")
     put("train_ms", "training_step", "ms_per_step"); put("train_cells_per_s", "training_step", "cells_per_s"); put("train_tflops", "training_step", "tflops")

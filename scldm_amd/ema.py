@@ -137,4 +137,5 @@ class EMA(nn.Module):
     def load_state_dict(self, state_dict, *args, **kwargs):
         out = super().load_state_dict(state_dict, *args, **kwargs)
         self._host_step, self._host_initted = int(self.step), bool(self.initted)
+        self._pending = 0
         return out

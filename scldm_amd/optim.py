@@ -29,6 +29,9 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize,
                                       capturable=True, fused=True, foreach=None, differentiable=False,
                                       decoupled_weight_decay=True))   # (torch >= 2.6: AdamW is Adam with this flag; kept so a state_dict loads there as AdamW)
+        # bumped whenever the device launch table / step counter / hyper vector of a group are dropped (load_state_dict, attach_ema):
+        # holders of raw pointers into them (FusedTrainStep's launch struct, a captured HIP graph) compare it before every step
+        self._generation = 0
 
     # ---- EMA of the reference's trainer in the same launch (scldm_amd.ema.EMA; models.py:83-87,446-453)
     def attach_ema(self, ema) -> None:
@@ -46,6 +49,7 @@ class AdamW(torch.optim.Optimizer):
                 self._ema_of[id(p)] = avg[n]
             group.pop("_table", None)
         ema._fused_by = self
+        self._generation = getattr(self, "_generation", 0) + 1
 
     def _hyper(self, group, dev):
         h = group.get("_hyper")
@@ -219,6 +223,7 @@ class AdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._generation = getattr(self, "_generation", 0) + 1
         for g in self.param_groups:          # the state tensors were replaced: rebuild the pointer table and the shared step count
             g.pop("_table", None)
             g.pop("_step_t", None)

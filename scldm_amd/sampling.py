@@ -37,10 +37,11 @@ def sample_latents(dit, z0: torch.Tensor, condition: dict[str, torch.Tensor] | N
 @torch.no_grad()
 def sample_cells(dit, vae, condition, guidance_weight, batch_size: int, genes: torch.Tensor, size_factors: torch.Tensor | None,
                  num_steps: int = 101, sampling_method: str = "euler", z0: torch.Tensor | None = None, draw_counts: bool = True,
-                 size_factor_sampler: "SizeFactorSampler | None" = None):
+                 size_factor_sampler: "SizeFactorSampler | None" = None, seed: int | None = None):
     """Reference `LatentDiffusion.sample` (models.py:766-819): returns (counts or NB distribution, latents) with
     2*batch_size rows, unconditional first.  Log size factors are either given or drawn on device by a
-    `SizeFactorSampler` (models.py:785 -> _sample_log_size_factors)."""
+    `SizeFactorSampler` (models.py:785 -> _sample_log_size_factors).  `seed`: the negative-binomial draw's (default: from torch's
+    host generator)."""
     if size_factors is None:
         if size_factor_sampler is None:
             raise ValueError("pass size_factors or a size_factor_sampler")
@@ -55,8 +56,61 @@ def sample_cells(dit, vae, condition, guidance_weight, batch_size: int, genes: t
     lib = torch.exp(size_factors).view(-1, 1)
     lib2 = torch.cat([lib, lib], dim=0)
     if draw_counts:   # models.py:819 `nb.sample()`: fused into the decoder's normalisation pass (mu / theta stay on chip)
-        return vae.decode_sample(z, genes2, lib2), z
+        return vae.decode_sample(z, genes2, lib2, seed=seed), z
     return vae.decode(z, genes2, lib2), z
+
+
+def generate_cells_stream(dit, vae, batches, guidance_weight, genes: torch.Tensor, num_steps: int = 101, sampling_method: str = "euler",
+                          size_factor_sampler: "SizeFactorSampler | None" = None, seeds=None):
+    """The reference's prediction loop (`trainer.predict` -> `predict_step` per batch -> `.cpu()`, src/scldm/models.py:707-764,742)
+    as a two-stage pipeline over an iterable of batches: while batch i + 1's CFG ODE runs on the caller's stream, batch i's MCAB
+    decode + negative-binomial draw, CSR assembly and pinned device-to-host copies run on a second HIP stream - the ODE kernel is
+    matrix-pipe-bound and (below ~700 cells) leaves CU slots empty, the decode is VALU-bound: they share the chip.
+
+    `batches` yields `condition` dicts, or `(condition, log_size_factors)` / `(condition, log_size_factors, z0)` tuples (size
+    factors None -> drawn by `size_factor_sampler`, models.py:785); `genes` is the (B, G) gene-index matrix of a batch (every batch
+    has B cells).  Yields per batch, in order, `(indptr, indices, data, latents)` as HOST tensors for the 2B generated rows
+    (unconditional first): exactly what `sample_cells(..., draw_counts=True)` -> `dense_to_csr` -> `to_host` returns for that batch -
+    same kernels, same seeds (`seeds`: optional iterable of draw seeds, one per batch), only the streams differ."""
+    from .datamodule import dense_to_csr, to_host
+    dev = dit.pos_embed.device
+    if dev.type != "cuda":
+        raise RuntimeError("generate_cells_stream needs the model on a CUDA (ROCm) device; there is no CPU path")
+    # (normal priority: a lowest-priority HIP stream starves batch i's decode until batch i + 1's ODE has drained, and the host - blocked in
+    # finish(i) - then queues batch i + 2 too late: 20.45 against 19.55 ms per batch, profiles/r6_gen_stream_ab.txt)
+    side = torch.cuda.Stream(device=dev)
+    genes2 = torch.cat([genes, genes], dim=0)
+    seeds = iter(seeds) if seeds is not None else None
+
+    def finish(item):
+        z, sf, ready, seed = item
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            lib = torch.exp(sf).view(-1, 1)
+            counts = vae.decode_sample(z, genes2, torch.cat([lib, lib], dim=0), seed=seed)
+            indptr, indices, data = dense_to_csr(counts)          # (its one host wait - nnz sizes the arrays - waits for `side` only)
+            return to_host(indptr, indices, data, z)              # z, sf stay referenced by `item` until `side` has drained
+
+    pending = None
+    # (no torch.no_grad() around the loop: a context held across `yield` would leak into the consumer's code; nothing here records a graph)
+    for batch in batches:
+        cond, sf, z0 = (tuple(batch) + (None, None))[:3] if isinstance(batch, (tuple, list)) else (batch, None, None)
+        B = genes.shape[0]
+        if sf is None:
+            if size_factor_sampler is None:
+                raise ValueError("pass log size factors with each batch or a size_factor_sampler")
+            sf = size_factor_sampler.sample(cond, B)
+        if z0 is None:
+            z0 = torch.randn((B, dit.seq_len, vae.encoder.latent_embedding), device=dev)
+        z = sample_latents(dit, z0, cond, guidance_weight, num_steps, sampling_method)      # queued; the host does not wait
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        seed = int(next(seeds)) if seeds is not None else int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
+        if pending is not None:
+            yield finish(pending)
+        pending = (z, sf, ready, seed)
+    if pending is not None:
+        yield finish(pending)
 
 
 @torch.no_grad()

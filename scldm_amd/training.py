@@ -304,6 +304,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
         self.replays = 0
+        self._generation = getattr(optimizer, "_generation", None)
 
     def _body(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -322,6 +323,9 @@ class GraphedTrainStep:
     def __call__(self, x1: torch.Tensor, condition: dict[str, torch.Tensor]) -> torch.Tensor:
         if x1.shape != self.x1.shape or set(condition) != set(self.condition):
             raise ValueError(f"GraphedTrainStep was captured for x1 {tuple(self.x1.shape)} and labels {sorted(self.condition)}")
+        if getattr(self.optimizer, "_generation", None) != self._generation:
+            raise RuntimeError("GraphedTrainStep: the optimizer's device state was replaced after the capture (optimizer.load_state_dict / attach_ema): "
+                               "the graph holds the old tensors' addresses - load checkpoints first, then build GraphedTrainStep")
         self.x1.copy_(x1, non_blocking=True)
         for k, v in condition.items():
             self.condition[k].copy_(v, non_blocking=True)
@@ -399,9 +403,6 @@ class FusedTrainStep:
         self._gpos = torch.zeros_like(dit.pos_embed) if dit.pos_embed.requires_grad else None
         self._g, self._keep_g = dit._param_struct(lambda p: (self._gpos.data_ptr() if self._gpos is not None else None) if p is dit.pos_embed
                                                   else base + 4 * offs[id(p)])
-        for p in self.params:
-            if p.requires_grad:
-                p.grad = self._gpos if p is dit.pos_embed else self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view(p.shape)
         names = dit._class_names
         self._lab_ptrs = _lib.ptr_array([self.labels_in[c].data_ptr() if c in self.labels_in else None for c in names])
         self._nulls = (C.c_int * len(names))(*[int(dit.class_vocab_sizes[c]) for c in names])
@@ -417,6 +418,23 @@ class FusedTrainStep:
         if vae is not None and encode_shape is not None:
             S = int(encode_shape[1])
             self.enc = (torch.zeros(n, S, **f32), torch.zeros(n, S, dtype=torch.long, device=dev))
+        self._want_graph = bool(graph) and not self.distributed
+        self._grad_probe = next(p for p in self.params if p.requires_grad)
+        self._bind_optimizer()
+
+    def _attach_grads(self) -> None:
+        offs = self.dit._grad_offsets
+        for p in self.params:
+            if p.requires_grad:
+                p.grad = self._gpos if p is self.dit.pos_embed else self.flat[offs[id(p)]:offs[id(p)] + p.numel()].view(p.shape)
+
+    def _bind_optimizer(self) -> None:
+        """Everything that holds raw addresses of the optimizer's device state - the launch struct and the captured graph.  Runs at
+        construction and again when the optimizer dropped that state (`optimizer.load_state_dict` on resume, `attach_ema`:
+        AdamW._generation) - a replay of the old graph would update freed moment tensors."""
+        optimizer = self.optimizer
+        self.graph = None
+        self._attach_grads()                      # (optimizer.zero_grad(set_to_none=True) by a caller detaches the views)
         # one ordinary optimizer step builds the device launch table against the flat gradient buffer (zero gradients: a no-op update
         # that still counts as step 1 would shift the bias correction, so its effects are rolled back)
         self._prime_optimizer()
@@ -430,8 +448,8 @@ class FusedTrainStep:
             finally:
                 if self.found_inf is not None:
                     del optimizer.found_inf
-        self.graph = None
-        if graph and not self.distributed:
+        self._bound_generation = optimizer._generation
+        if self._want_graph:
             self._capture()
 
     def _prime_optimizer(self) -> None:
@@ -441,6 +459,9 @@ class FusedTrainStep:
         g = opt.param_groups[0]
         had_state = {id(p) for p in g["params"] if "exp_avg" in (opt.state.get(p) or {})}
         step_before = g["_step_t"].clone() if g.get("_step_t") is not None else None
+        if step_before is None:    # after optimizer.load_state_dict the counter lives only in the per-parameter state: step() re-creates it from there
+            prev = next((opt.state[p]["step"] for p in g["params"] if "step" in (opt.state.get(p) or {})), None)
+            step_before = None if prev is None else torch.as_tensor(float(prev), dtype=torch.float32, device=self.dev)
         state = self._snapshot(with_state=False)
         moments = {id(p): (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in g["params"] if id(p) in had_state}
         self.flat.zero_()
@@ -571,6 +592,10 @@ class FusedTrainStep:
             self.x1.copy_(x1, non_blocking=True)
         for k in self.keys:
             self.labels_in[k].copy_(condition[k], non_blocking=True)
+        if self.optimizer._generation != self._bound_generation:
+            self._bind_optimizer()                                 # the optimizer's device state was replaced (checkpoint resume)
+        elif self._grad_probe.grad is None:
+            self._attach_grads()                                   # zero_grad(set_to_none=True) by the caller
         if self.distributed:
             self._launch()                                         # backward only (opt = NULL): gradients in self.flat
             # in-place, in slices of <= 128 MB of the flat buffer the .grad views share (the path the gloo tests exercise)

@@ -313,3 +313,58 @@ def test_fused_train_step_fp16_overflow_skips_adamw_but_not_the_ema_hook():
     assert any(moved), "the EMA hook runs after every batch, also after a skipped optimizer step"
     step(x1, cond); ema.update()
     assert m.fp16_train_state()["headroom"] <= -1
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_fused_train_step_follows_a_checkpoint_resume(graph):
+    """optimizer.load_state_dict replaces the moment tensors and drops the device launch table: the step's launch struct and captured
+    graph hold their addresses (a replay would update freed memory).  FusedTrainStep re-binds itself (AdamW._generation), keeps the
+    loaded step count, and a run resumed from a checkpoint after 3 steps ends where the uninterrupted 6-step run ends, bit for bit;
+    zero_grad(set_to_none=True) by the caller is survived; GraphedTrainStep refuses to replay after such a load."""
+    from scldm_amd.ema import EMA
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep, GraphedTrainStep
+    from scldm_amd.transport import create_transport
+    vocab, n = {"cell_line": 4, "gene": 2024}, 64
+    m, _, _ = build(vocab, "joint", 8, 47)
+    m.precision = "bf16"
+    m.cfg_dropout_prob = 0.5
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)
+    ema = EMA(model=m, beta=0.9, update_every=2, update_after_step=1)
+    fs = FusedTrainStep(m, tr, opt, n, list(vocab), ema=ema, seed=5, graph=graph)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    batches = [(torch.randn(n, 16, 16, device="cuda", generator=gen), {k: torch.randint(0, v, (n,), device="cuda", generator=gen) for k, v in vocab.items()})
+               for _ in range(6)]
+    for s in range(3):
+        fs(*batches[s]); ema.update()
+    ck = copy.deepcopy({"opt": opt.state_dict(), "ema": ema.state_dict(), "rng": fs.rng.clone()})     # (ema's state holds the online model too)
+    for s in range(3, 6):
+        fs(*batches[s]); ema.update()
+    want = [p.detach().clone() for p in m.parameters()], [p.detach().clone() for p in ema.ema_model.parameters()]
+    want_m = [opt.state[p]["exp_avg"].clone() for p in opt.param_groups[0]["params"]]
+    # resume into the SAME objects (the trainer's flow: build everything, then load the checkpoint)
+    ema.load_state_dict(ck["ema"])
+    opt.load_state_dict(ck["opt"])
+    fs.rng.copy_(ck["rng"])
+    opt.zero_grad(set_to_none=True)
+    for s in range(3, 6):
+        fs(*batches[s]); ema.update()
+    assert float(opt.param_groups[0]["_step_t"]) == 6.0
+    for a, b in zip(want[0], m.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(want[1], ema.ema_model.parameters()):
+        assert torch.equal(a, b)
+    for a, p in zip(want_m, opt.param_groups[0]["params"]):
+        assert torch.equal(a, opt.state[p]["exp_avg"])
+    if graph:
+        assert fs.graph is not None
+        m2, _, _ = build({"clusters": 14}, "mutually_exclusive", 8, 48)
+        m2.precision = "bf16"
+        o2 = AdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-3)
+        x1, cond = torch.randn(32, 16, 16, device="cuda"), {"clusters": torch.randint(0, 14, (32,), device="cuda")}
+        gs = GraphedTrainStep(m2, tr, o2, x1, cond)
+        gs(x1, cond)
+        o2.load_state_dict(copy.deepcopy(o2.state_dict()))
+        with pytest.raises(RuntimeError, match="load checkpoints first"):
+            gs(x1, cond)

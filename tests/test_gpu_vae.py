@@ -183,6 +183,52 @@ def test_generation_chain_with_device_size_factors_matches_oracle_chain():
     assert np.array_equal(data.cpu().numpy(), ref.data) and counts.shape == (2 * B, G) and (counts >= 0).all()
 
 
+def test_generate_cells_stream_equals_the_serial_chain_batch_by_batch():
+    """The two-stream prediction loop (sampling.generate_cells_stream: batch i's decode / draw / CSR / host copies beside batch i + 1's
+    ODE) returns, batch by batch and in order, exactly the host arrays of the serial chain sample_cells -> dense_to_csr -> to_host with
+    the same noise, size factors and draw seeds; the consumer's grad mode is untouched between yields."""
+    from scldm_amd.datamodule import dense_to_csr, to_host
+    from scldm_amd.nnets import DiT
+    from scldm_amd.sampling import generate_cells_stream, sample_cells
+    g, vae, sd_v, cfg_v = build("vae_2000")
+    vae.precision = "fp16"
+    gd = load_golden("dit_base")
+    kw = golden_json(gd, "kwargs_json")
+    shapes = {k: tuple(v) for k, v in golden_json(gd, "shapes_json").items()}
+    dit = DiT(**kw)
+    dit.load_state_dict(make_state_dict(shapes, int(gd["seed"])), strict=True)
+    dit = dit.cuda().eval()
+    dit.precision = "bf16"
+    rng = np.random.default_rng(23)
+    B, G, K = 24, 300, 4
+    genes = cu(np.stack([rng.permutation(2000)[:G] for _ in range(B)]).astype(np.int64))
+    scales = {"clusters": 1.5}
+    items = [({"clusters": cu(rng.integers(0, 13, B))}, cu((6.0 + rng.standard_normal(B) * 0.3).astype(np.float32)),
+              cu(rng.standard_normal((B, 16, 16)).astype(np.float32))) for _ in range(K)]
+    seeds = [101, 202, 303, 404]
+    serial = []
+    for (cond, sf, z0), seed in zip(items, seeds):
+        counts, z = sample_cells(dit, vae, cond, scales, B, genes, sf, num_steps=5, sampling_method="heun", z0=z0, seed=seed)
+        serial.append(to_host(*dense_to_csr(counts), z))
+    got = []
+    for out in generate_cells_stream(dit, vae, items, scales, genes, num_steps=5, sampling_method="heun", seeds=seeds):
+        assert torch.is_grad_enabled()
+        got.append(out)
+    assert len(got) == K
+    for a, b in zip(serial, got):
+        assert all(not t.is_cuda for t in b) and len(b) == 4
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and torch.equal(x, y)
+    assert not torch.equal(got[0][2], got[1][2])
+    # size factors drawn by the sampler when a batch carries none; a generator (lazy) source works
+    from types import SimpleNamespace
+    smp = SimpleNamespace(sample=lambda c, b: torch.full((b,), 6.0, device="cuda"))
+    outs = list(generate_cells_stream(dit, vae, (it[0] for it in items[:2]), scales, genes, num_steps=3, size_factor_sampler=smp))
+    assert len(outs) == 2 and outs[0][0].shape == (2 * B + 1,) and int(outs[0][0][-1]) == outs[0][2].numel()
+    with pytest.raises(ValueError, match="size_factor_sampler"):
+        next(generate_cells_stream(dit, vae, [items[0][0]], scales, genes, num_steps=3))
+
+
 def test_bf16_decode_close_to_fp32():
     """decode with bf16 operands in the per-gene contractions (vae.precision = "bf16"): mu within bf16 noise of the fp32 path,
     rows still sum to the library size, theta identical."""
