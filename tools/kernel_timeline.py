@@ -17,7 +17,7 @@ print(f"{'start us':>9} {'dur us':>8} {'gap us':>7} {'queue':>6}  kernel")
 for r in step:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     g = max(0, s - end_prev)
-    name = r["Kernel_Name"].split("(")[0].replace("scldm::", "").replace("void ", "")[:70]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("scldm::", "").replace("void ", "")[:70]
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {g / 1e3:7.1f} {r.get('Queue_Id', '?'):>6}  {name}")
     gap += g
     end_prev = max(end_prev, e)
