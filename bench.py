@@ -704,6 +704,9 @@ def mfma_ceiling_record():
         v = C.c_double()
         _lib.check(L.scldm_mfma_sustained_tflops(fill, 12000, C.byref(v)), "scldm_mfma_sustained_tflops")
         rec[name + "_tflops"] = v.value
+    v = C.c_double()
+    _lib.check(L.scldm_mfma_sustained_tflops(2 | 4, 12000, C.byref(v)), "scldm_mfma_sustained_tflops")
+    rec["normal_fp16_tflops"] = v.value      # the same loop on v_mfma_f32_32x32x16_f16: the fp16 policy's ceiling on this box
     rec["note"] = ("register-only v_mfma_f32_32x32x16_bf16 loop, 2 waves per SIMD, ~0.6 s per fill; identical instruction stream - the "
                    "difference between fills is clock (power budget)")
     return rec
@@ -950,6 +953,8 @@ def compact_line(result):
     put("vae_train_b32_ms", "vae_training_step", "b32", "ms_per_step"); put("vae_train_b512_ms", "vae_training_step", "b512", "ms_per_step")
     put("guidance1_direct_cells_per_s", "guidance1_direct", "cells_per_s")
     put("mfma_sustained_normal_tflops", "mfma_sustained_ceiling", "normal_tflops")
+    put("mfma_sustained_normal_fp16_tflops", "mfma_sustained_ceiling", "normal_fp16_tflops")
+    put("fp16_frac_of_sustained", "reference_class_path", "roofline", "frac_of_sustained_normal")
     put("strong_scaling_cells_per_s", "strong_scaling", "cells_per_s"); put("strong_scaling_ms", "strong_scaling", "ms_per_step")
     out.update(sc)
     out["details"] = "profiles/bench_last.json (every record behind these scalars; written by this run)"
@@ -1137,6 +1142,10 @@ def main():
                 note("parity path done")
             if args.precision != "fp16":
                 result["reference_class_path"] = precision_path(wl, device, "fp16", args.steps, args.warmup)
+                c16 = _dig(result, "mfma_sustained_ceiling", "normal_fp16_tflops")
+                a16 = _dig(result, "reference_class_path", "roofline", "achieved")
+                if c16 and a16:   # the fp16 policy against what a bare fp16 MFMA loop sustains on this box in this run
+                    result["reference_class_path"]["roofline"]["frac_of_sustained_normal"] = a16 / c16
                 note("reference-class (fp16) path done")
             if args.precision != "bf16":
                 result["throughput_path"] = precision_path(wl, device, "bf16", args.steps, args.warmup)

@@ -261,7 +261,8 @@ int scldm_dit_set_option(scldm_dit* h, int option, int value);
 int scldm_dit_layers_per_launch(const scldm_dit* h);
 
 /* Measurement aid (bench.py): TFLOP/s a register-only v_mfma_f32_32x32x16_bf16 loop sustains on the current device for about
- * `iters` x 5 x 16 MFMAs per wave (fill 0: zero operands, 1: uniform [-1, 1), 2: N(0, 1)); same instruction stream for every fill -
+ * `iters` x 5 x 16 MFMAs per wave (fill 0: zero operands, 1: uniform [-1, 1), 2: N(0, 1); fill | 4: the same loop and values on
+ * v_mfma_f32_32x32x16_f16 - the ceiling of the fp16 policy); same instruction stream for every fill -
  * the part clocks to its power budget, so the figure for realistic operands is the ceiling an MFMA-bound kernel can reach on this
  * device, below the nominal 2.5 PFLOP/s.  Synchronises the device. */
 int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops);

@@ -1030,9 +1030,12 @@ extern "C" int scldm_dit_block_timing(scldm_dit* h, int* n_launches, double* tot
 // fragments of a given fill.  The instruction stream is the same for every fill; the rate differs because the part clocks to its
 // power budget (MI355X_MICROARCH.md "DVFS give-back"): zero operands run near the nominal 2.5 PFLOP/s, N(0,1) operands at about half
 // of it (profiles/r4c_mfma_power_ceiling.txt).  bench.py reports the figure beside roofline.frac, whose denominator stays nominal.
-__global__ __launch_bounds__(256, 2) void mfma_ceiling_kernel(const bf16x8* __restrict__ frags, float* __restrict__ out, int iters) {
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void mfma_ceiling_kernel(const bf16x8* __restrict__ frags_, float* __restrict__ out, int iters) {
+  using Frag = typename std::conditional<F16, f16x8, bf16x8>::type;
+  const Frag* __restrict__ frags = reinterpret_cast<const Frag*>(frags_);
   const int lane = threadIdx.x & 63;
-  bf16x8 a[4], b[4];
+  Frag a[4], b[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     a[i] = frags[(i * 2 + 0) * 64 + lane];
@@ -1047,7 +1050,10 @@ __global__ __launch_bounds__(256, 2) void mfma_ceiling_kernel(const bf16x8* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[(i + 2 * u + 1) & 3], acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (F16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + u) & 3], b[(i + 2 * u + 1) & 3], acc[i], 0, 0, 0);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + u) & 3], b[(i + 2 * u + 1) & 3], acc[i], 0, 0, 0);
+      }
   }
   float s = 0.f;
 #pragma unroll
@@ -1110,6 +1116,8 @@ extern "C" int scldm_rk_poly(float* out, const float* c0, const float* c1, const
 }
 
 extern "C" int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops) {
+  const bool f16 = (fill & 4) != 0;   // fill | 4: the same loop on v_mfma_f32_32x32x16_f16 (fp16 fragments of the same values)
+  fill &= ~4;
   if (!tflops || fill < 0 || fill > 2 || iters < 1) return fail(SCLDM_ERR_SHAPE, "scldm_mfma_sustained_tflops: bad argument");
   const int blocks = 512, launches = 5;   // 2 workgroups of 4 waves per CU
   std::vector<__bf16> hfr(8 * 64 * 8);
@@ -1126,7 +1134,8 @@ extern "C" int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops) 
     float x = 0.f;
     if (fill == 1) x = (float)(2.0 * u01() - 1.0);
     if (fill == 2) x = (float)(sqrt(-2.0 * log(u01())) * cos(6.283185307179586 * u01()));
-    v = (__bf16)x;
+    if (f16) { const _Float16 hx = (_Float16)x; memcpy(&v, &hx, 2); }
+    else v = (__bf16)x;
   }
   bf16x8* d_fr = nullptr;
   float* d_out = nullptr;
@@ -1139,10 +1148,11 @@ extern "C" int scldm_mfma_sustained_tflops(int fill, int iters, double* tflops) 
     HIP_TRY(hipMemcpy(d_fr, hfr.data(), hfr.size() * sizeof(__bf16), hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    mfma_ceiling_kernel<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters / 8 + 1);   // warm-up
+    auto kern = f16 ? mfma_ceiling_kernel<true> : mfma_ceiling_kernel<false>;
+    kern<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters / 8 + 1);   // warm-up
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipEventRecord(e0, 0));
-    for (int k = 0; k < launches; ++k) mfma_ceiling_kernel<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters);
+    for (int k = 0; k < launches; ++k) kern<<<blocks, 256, 0, 0>>>(d_fr, d_out, iters);
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0;

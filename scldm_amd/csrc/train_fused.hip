@@ -648,6 +648,19 @@ bool eligible(const scldm_dit* h, int n, int precision) {
          h->cfg.hidden_dim <= kHP && h->cfg.hidden_dim % 2 == 0 && h->lpl >= 1 && h->cfg.n_layer <= kMaxScatterLayers;
 }
 
+// side streams of the training step (experiment switch SCLDM_TRAIN_SIDE_PRIO=low: lowest HIP priority, so that what is queued on the
+// caller's stream - the step's critical path - wins the dispatcher when both have workgroups ready)
+static int make_side_stream(hipStream_t* s) {
+  static const bool low = [] { const char* e = getenv("SCLDM_TRAIN_SIDE_PRIO"); return e && e[0] == 'l'; }();
+  if (low) {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(s, hipStreamNonBlocking, least));
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+  }
+  return SCLDM_OK;
+}
 // everything of a step that is not a kernel launch or an event: the pack-job tables of the live parameters, the side streams
 // and their events (scldm_dit_train_prepare calls it ahead of the first step; prepare() re-checks it per step for free)
 int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
@@ -655,7 +668,7 @@ int prepare_tables(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st) {
   if (rc) return rc;
   for (int k = 0; k < 3; ++k)
     if (!h->side[k]) {
-      HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+      { const int rc_s = make_side_stream(&h->side[k]); if (rc_s) return rc_s; }
       HIP_TRY(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming));
     }
   if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -686,7 +699,7 @@ int prepare(scldm_dit* h, const scldm_dit_weights* w, hipStream_t st, int precis
 // side stream k (created on first use) ordered after everything queued on `st` so far / `st` ordered after side stream k
 int fork_side(scldm_dit* h, hipStream_t st, int k, hipStream_t* out) {
   if (!h->side[k]) {
-    HIP_TRY(hipStreamCreateWithFlags(&h->side[k], hipStreamNonBlocking));
+    { const int rc_s = make_side_stream(&h->side[k]); if (rc_s) return rc_s; }
     HIP_TRY(hipEventCreateWithFlags(&h->join_ev[k], hipEventDisableTiming));
   }
   if (!h->fork_ev) HIP_TRY(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
