@@ -396,9 +396,10 @@ def train_end_to_end(wl, precision, device, n_genes=17002, S=6147, steps=20):
     counts = torch.poisson(torch.full((B, S), 1.5), generator=g).to(device)
     cond = {k: torch.randint(0, v, (B,), generator=g).to(device) for k, v in wl["vocab"].items()}
     rec = {"workload": f"replogle_train_b{B} from tokenised counts", "cells": B, "tokens_per_cell": S, "n_genes": n_genes, "dtype": precision,
-           "vae_encode_precision": "fp16", "ema": "beta 0.9999, every 10 steps, after 10 000 (ldm_base.yaml:51-55)"}
+           "vae_encode_precision": "fp16", "ema": "beta 0.9999, every 10 steps, after 10 000 (ldm_base.yaml:51-55)",
+           "gradient_clip": "global norm 10.0 inside the optimizer launch (training/default.yaml:15-16: gradient_clip_val 10, algorithm norm)"}
     for graph in (True, False):
-        fs = FusedTrainStep(m, tr, opt, B, list(wl["vocab"]), ema=ema, vae=vae, seed=11, graph=graph, encode_shape=(B, S))
+        fs = FusedTrainStep(m, tr, opt, B, list(wl["vocab"]), ema=ema, vae=vae, seed=11, graph=graph, encode_shape=(B, S), grad_clip_norm=10.0)
         def step():
             loss = fs(condition=cond, counts_subset=counts, genes_subset=genes)
             ema.update()
@@ -419,6 +420,7 @@ def train_end_to_end(wl, precision, device, n_genes=17002, S=6147, steps=20):
         del fs
     rec["ms_per_step"] = rec["ms_per_step_graph"]
     rec["cells_per_s"] = B / (rec["ms_per_step"] / 1e3)
+    rec["last_grad_norm"] = float(opt.last_grad_norm)
     return rec
 
 

@@ -64,7 +64,7 @@ class AdamwLaunch(C.Structure):
     """scldm_adamw_launch (include/scldm_hip.h)."""
     _fields_ = [("table", C.c_void_p), ("count", C.c_int), ("n_blocks", C.c_int), ("step", C.c_void_p), ("found_inf", C.c_void_p),
                 ("hyper", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("maximize", C.c_int)]
+                ("weight_decay", C.c_float), ("maximize", C.c_int), ("max_grad_norm", C.c_float), ("clip_ws", C.c_void_p)]
 
 
 class TrainStepBuffers(C.Structure):
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
     L.scldm_adamw_table_build.argtypes = [C.POINTER(AdamwEntry), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
     L.scldm_adamw_table_records_bytes.argtypes = [C.c_int]
     L.scldm_adamw_table_records_bytes.restype = C.c_size_t
+    L.scldm_adamw_clip_workspace_bytes.argtypes = [C.c_int]
+    L.scldm_adamw_clip_workspace_bytes.restype = C.c_size_t
     L.scldm_adamw_table_update.argtypes = [C.POINTER(AdamwEntry), C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t]
     L.scldm_adamw_table_step.argtypes = [C.POINTER(AdamwLaunch), C.c_void_p]
     L.scldm_fm_prepare.argtypes = [C.c_void_p, c_void_pp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int,
@@ -200,7 +202,7 @@ def lib() -> C.CDLL:
 
 EXPORTS = ["scldm_last_error", "scldm_version", "scldm_dit_create", "scldm_dit_destroy", "scldm_dit_load_weights",
            "scldm_dit_refresh_weights", "scldm_dit_fp16_stats", "scldm_dit_train_fp16_state", "scldm_dit_train_set_found_inf", "scldm_dit_label_errors", "scldm_dit_mod_width", "scldm_dit_layers_per_launch", "scldm_dit_set_option", "scldm_dit_workspace_bytes", "scldm_dit_cond_rows", "scldm_dit_forward_rows",
-           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_adamw_step", "scldm_adamw_table_bytes", "scldm_adamw_table_build", "scldm_adamw_table_records_bytes", "scldm_adamw_table_update", "scldm_adamw_table_step", "scldm_fm_prepare", "scldm_fm_loss_grad", "scldm_dit_train_step", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
+           "scldm_dit_forward", "scldm_dit_forward_cfg", "scldm_sample_ode", "scldm_adamw_step", "scldm_adamw_table_bytes", "scldm_adamw_table_build", "scldm_adamw_table_records_bytes", "scldm_adamw_clip_workspace_bytes", "scldm_adamw_table_update", "scldm_adamw_table_step", "scldm_fm_prepare", "scldm_fm_loss_grad", "scldm_dit_train_step", "scldm_rk_combine", "scldm_rk_error", "scldm_rk_dense", "scldm_rk_poly", "scldm_mfma_sustained_tflops", "scldm_dit_block_timing_enable",
            "scldm_dit_block_timing", "scldm_dit_set_debug_buffer", "scldm_dit_train_saved_bytes", "scldm_dit_train_workspace_bytes", "scldm_dit_train_saved_bytes_for", "scldm_dit_train_workspace_bytes_for",
            "scldm_dit_train_prepare", "scldm_dit_train_set_grad_events", "scldm_dit_train_forward", "scldm_dit_train_backward", "scldm_fm_mix", "scldm_fm_loss", "scldm_fm_loss_bwd", "scldm_vae_create", "scldm_vae_destroy", "scldm_vae_load_weights", "scldm_vae_refresh_weights", "scldm_vae_kernel_timing_enable", "scldm_vae_kernel_timing",
            "scldm_vae_workspace_bytes", "scldm_vae_encode", "scldm_vae_decode", "scldm_vae_decode_sample", "scldm_vae_train_saved_bytes", "scldm_vae_train_workspace_bytes", "scldm_vae_train_forward", "scldm_vae_train_backward", "scldm_nb_loglik", "scldm_nb_loglik_bwd", "scldm_nb_sample", "scldm_tokenize_expressed", "scldm_csr_count", "scldm_csr_fill", "scldm_mmd_workspace_bytes",

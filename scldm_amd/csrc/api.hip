@@ -32,7 +32,7 @@ extern "C" const char* scldm_last_error(void) { return g_err; }
 // 3: SCLDM_PREC_FP16, scldm_dit_fp16_stats, scldm_dit_train_prepare, forward_cfg t_stride 2
 // 4 (round 6): SCLDM_PREC_FP16 on the scldm_vae_* entry points, unshared-theta head (theta == NULL), scldm_dit_train_step / scldm_fm_prepare /
 //    scldm_fm_loss_grad, the scldm_adamw_table_* family, scldm_vae_kernel_timing
-extern "C" int scldm_version(void) { return 4; }
+extern "C" int scldm_version(void) { return 5; }
 //   // 2: has_null_row in scldm_dit_config, SCLDM_PREC_BF16X3, refresh_weights / label_errors
 
 static size_t esize(int prec) { return (prec == SCLDM_PREC_BF16 || prec == SCLDM_PREC_FP16) ? 2 : 4; }  // bytes per packed weight element (split-bf16: hi + lo)

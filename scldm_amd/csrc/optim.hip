@@ -107,7 +107,66 @@ struct TableArgs {
   const float* hyper;             // device float[4] or null: lr, weight_decay, EMA mode (0 none | 1 copy | 2 lerp), EMA lerp weight
   double lr, beta1, beta2, eps, weight_decay;
   int maximize;
+  const float* clip_coef;         // device, or null: every gradient is read times *clip_coef (clip_grad_norm_'s clip_coef_clamped)
 };
+// Total L2 norm of every gradient of the table and the clipping coefficient torch.nn.utils.clip_grad_norm_ derives from it
+// (torch/nn/utils/clip_grad.py: clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1; error_if_nonfinite = False).  One workgroup
+// per 4 096-element chunk (the update's own map); ws = [norm, coef, ticket (as int), pad | one partial per workgroup]; the last
+// workgroup to finish (ticket) sums the partials in index order - the result does not depend on which workgroup that is.
+__global__ __launch_bounds__(256) void grad_norm_table_kernel(const TableArgs a, float* __restrict__ ws, int n_blocks, float max_norm) {
+  __shared__ float red[256];
+  __shared__ int last;
+  const TableBlock blk = a.blocks[blockIdx.x];
+  const TableTensor tt = a.tensors[blk.tensor];
+  const float* __restrict__ g = tt.g;
+  const long long n = tt.n;
+  const int base = blk.chunk * kChunk;
+  float s = 0.f;
+  const bool vec = (reinterpret_cast<size_t>(g) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < kChunk / (256 * 4); ++it) {
+    const long long i = base + (it * 256 + (int)threadIdx.x) * 4;
+    if (i >= n) break;
+    if (vec && i + 4 <= n) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+      s += gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2] + gv[3] * gv[3];
+    } else {
+      for (long long e = i; e < (i + 4 < n ? i + 4 : n); ++e) s += g[e] * g[e];
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  float* part = ws + 4;
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = red[0];
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<int*>(ws) + 2, 1) == n_blocks - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;     // (partials are fp32 sums of 4 096 squares; their sum in double: 2 400 terms for the base DiT, 112 000 for DiT-L)
+  for (int i = threadIdx.x; i < n_blocks; i += 256) t += (double)__builtin_nontemporal_load(part + i);
+  __shared__ double redd[256];
+  redd[threadIdx.x] = t;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) redd[threadIdx.x] += redd[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(redd[0]);
+    const float coef = max_norm / (norm + 1e-6f);
+    ws[0] = norm;
+    ws[1] = coef < 1.0f ? coef : 1.0f;      // (a NaN norm - non-finite gradients - gives a NaN coefficient, as torch's clamp does)
+    if (coef != coef) ws[1] = coef;
+    reinterpret_cast<int*>(ws)[2] = 0;      // ready for the next step
+  }
+}
 // torch.lerp (ATen/native/Lerp.h): weight < 0.5 ? start + weight (end - start) : end - (end - start) (1 - weight); ATen's device code is
 // built with floating-point contraction on, so each form is ONE fma (tests/test_gpu_train.py compares the bits with Tensor.lerp_)
 __device__ __forceinline__ float torch_lerp(float start, float end, float w, float omw) {
@@ -134,7 +193,10 @@ __global__ __launch_bounds__(256) void adamw_table_kernel(const TableArgs a) {
   const float bc1 = (float)(1.0 - pow(a.beta1, step)), bc2 = (float)(1.0 - pow(a.beta2, step));
   const float step_size = (float)(lr / (double)bc1), bc2_sqrt = sqrtf(bc2), lr_wd = (float)(lr * wd);
   const float omb1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, omb2 = (float)(1.0 - a.beta2), eps = (float)a.eps;
+  const bool clip = a.clip_coef != nullptr;
+  const float cc = clip ? *a.clip_coef : 1.0f;
   auto one = [&](float pv, float gv, float& mv, float& vv) {     // (the arithmetic of adamw_kernel, bit for bit)
+    if (clip) gv = gv * cc;      // clip_grad_norm_ multiplies every gradient by the clamped coefficient, 1.0 included
     if (a.maximize) gv = -gv;
     pv = pv - lr_wd * pv;
     mv = mv + omb1 * (gv - mv);
@@ -217,6 +279,7 @@ extern "C" int scldm_adamw_table_build(const scldm_adamw_entry* e, float* const*
 // Only the per-tensor records (the head of the table: count x 48 bytes) depend on addresses; the workgroup map behind them depends on
 // the tensor SIZES alone.  A caller whose gradient buffers move between steps (autograd allocating a fresh flat buffer) re-uploads the
 // records - 12 KB for the DiT-L shape's ~250 tensors - instead of the whole table (0.9 MB of workgroup map at 459 M parameters).
+extern "C" size_t scldm_adamw_clip_workspace_bytes(int n_blocks) { return n_blocks > 0 ? sizeof(float) * (4 + (size_t)n_blocks) : 0; }
 extern "C" size_t scldm_adamw_table_records_bytes(int count) { return count > 0 ? sizeof(scldm::optim::TableTensor) * (size_t)count : 0; }
 extern "C" int scldm_adamw_table_update(const scldm_adamw_entry* e, float* const* ema, int count, void* records_host, size_t bytes) {
   using namespace scldm::optim;
@@ -240,6 +303,10 @@ extern "C" int scldm_adamw_table_step(const scldm_adamw_launch* l, void* stream_
     a.blocks = reinterpret_cast<const TableBlock*>(a.tensors + l->count);
     a.step = l->step; a.found_inf = l->found_inf; a.hyper = l->hyper;
     a.lr = l->lr; a.beta1 = l->beta1; a.beta2 = l->beta2; a.eps = l->eps; a.weight_decay = l->weight_decay; a.maximize = l->maximize;
+    if (l->max_grad_norm > 0.f && l->clip_ws) {
+      hipLaunchKernelGGL(grad_norm_table_kernel, dim3(l->n_blocks), dim3(256), 0, st, a, l->clip_ws, l->n_blocks, l->max_grad_norm);
+      a.clip_coef = l->clip_ws + 1;
+    }
     hipLaunchKernelGGL(adamw_table_kernel, dim3(l->n_blocks), dim3(256), 0, st, a);
   }
   hipError_t err = hipGetLastError();

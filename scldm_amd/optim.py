@@ -21,11 +21,18 @@ class AdamW(torch.optim.Optimizer):
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, amsgrad: bool = False,
                  *, maximize: bool = False, capturable: bool = True, fused: bool | None = True, foreach: bool | None = None,
-                 differentiable: bool = False):
+                 differentiable: bool = False, max_grad_norm: float | None = None):
         if amsgrad or differentiable:
             raise NotImplementedError("scldm_amd.optim.AdamW: amsgrad / differentiable are not provided (no caller in the reference)")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or not 0.0 <= weight_decay:
             raise ValueError("invalid AdamW hyper-parameter")
+        if max_grad_norm is not None and not max_grad_norm > 0.0:
+            raise ValueError("max_grad_norm must be positive (or None: no clipping)")
+        # max_grad_norm (an extension of torch's signature): the reference's trainer clips the global gradient norm between backward and
+        # optimizer.step (experiments/configs/training/default.yaml:15-16 -> Lightning -> torch.nn.utils.clip_grad_norm_(parameters, 10.0));
+        # here the norm is one more launch over the same table and the update reads g * clip_coef - no pass that rewrites the gradients.
+        # `.grad` itself is left unscaled.  `last_grad_norm` is the device scalar clip_grad_norm_ would have returned.
+        self.max_grad_norm = None if max_grad_norm is None else float(max_grad_norm)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize,
                                       capturable=True, fused=True, foreach=None, differentiable=False,
                                       decoupled_weight_decay=True))   # (torch >= 2.6: AdamW is Adam with this flag; kept so a state_dict loads there as AdamW)
@@ -56,6 +63,27 @@ class AdamW(torch.optim.Optimizer):
         if h is None or h[0].device != dev:
             h = group["_hyper"] = (torch.zeros(4, dtype=torch.float32, device=dev), None)
         return h
+
+    def _clip_args(self, group, n_blocks: int, dev, capturing: bool = False):
+        """(max_grad_norm, device workspace pointer) of a group's launch: (0.0, None) without clipping."""
+        if self.max_grad_norm is None:
+            return 0.0, None
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("scldm_amd.optim.AdamW: max_grad_norm is the GLOBAL norm over every parameter - one parameter group only")
+        need = 4 + n_blocks
+        ws = group.get("_clip_ws")
+        if ws is None or ws.numel() < need or ws.device != dev:
+            if capturing:
+                raise RuntimeError("scldm_amd.optim.AdamW: run at least one ordinary step() before capturing it in a HIP graph")
+            ws = group["_clip_ws"] = torch.zeros(need, dtype=torch.float32, device=dev)
+        return self.max_grad_norm, ws.data_ptr()
+
+    @property
+    def last_grad_norm(self):
+        """Total gradient norm of the last step() (before clipping) as a device scalar - what clip_grad_norm_ returns; None without
+        max_grad_norm or before the first step."""
+        ws = self.param_groups[0].get("_clip_ws")
+        return None if ws is None else ws[0]
 
     def refresh_hyper(self) -> None:
         """Stage this step's learning rate, weight decay and EMA action in the device `hyper` vector of every group (asynchronous 16-byte
@@ -198,10 +226,12 @@ class AdamW(torch.optim.Optimizer):
             table, nblk = cached[1], cached[2]
             dev_hyper, _ = self._hyper(group, dev)
             b1, b2 = group["betas"]
+            max_norm, clip_ws = self._clip_args(group, nblk, dev, capturing)
             launch = _lib.AdamwLaunch(table=table.data_ptr(), count=len(ps), n_blocks=nblk, step=step_t.data_ptr(),
                                       found_inf=None if found_inf is None else found_inf.data_ptr(), hyper=dev_hyper.data_ptr(),
                                       lr=float(group["lr"]) if not torch.is_tensor(group["lr"]) else 0.0, beta1=float(b1), beta2=float(b2),
-                                      eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])))
+                                      eps=float(group["eps"]), weight_decay=float(group["weight_decay"]), maximize=int(bool(group["maximize"])),
+                                      max_grad_norm=max_norm, clip_ws=clip_ws)
             with torch.cuda.device(dev):
                 _lib.check(L.scldm_adamw_table_step(C.byref(launch), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "scldm_adamw_table_step")
         return loss
@@ -216,10 +246,11 @@ class AdamW(torch.optim.Optimizer):
         dev_hyper, _ = self._hyper(group, step_t.device)
         b1, b2 = group["betas"]
         found_inf = getattr(self, "found_inf", None)
+        max_norm, clip_ws = self._clip_args(group, cached[2], step_t.device)
         return _lib.AdamwLaunch(table=cached[1].data_ptr(), count=len(cached[0]), n_blocks=cached[2], step=step_t.data_ptr(),
                                 found_inf=None if found_inf is None else found_inf.data_ptr(), hyper=dev_hyper.data_ptr(), lr=0.0,
                                 beta1=float(b1), beta2=float(b2), eps=float(group["eps"]), weight_decay=float(group["weight_decay"]),
-                                maximize=int(bool(group["maximize"])))
+                                maximize=int(bool(group["maximize"])), max_grad_norm=max_norm, clip_ws=clip_ws)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -230,6 +261,7 @@ class AdamW(torch.optim.Optimizer):
             g.pop("_hyper", None)
             g.pop("_hyper_ring", None)
             g.pop("_rec_ring", None)
+            g.pop("_clip_ws", None)
             steps = {float(self.state[p]["step"]) for p in g["params"] if "step" in self.state.get(p, {})}
             if len(steps) > 1:   #  one counter per group here: a checkpoint whose parameters took different numbers of steps does not fit
                 raise ValueError(f"scldm_amd.optim.AdamW keeps ONE step count per parameter group; the loaded state has {sorted(steps)}")
@@ -242,6 +274,7 @@ class AdamW(torch.optim.Optimizer):
             g.pop("_hyper", None)
             g.pop("_hyper_ring", None)
             g.pop("_rec_ring", None)
+            g.pop("_clip_ws", None)
         # every parameter gets its OWN copy of the step count: torch's optimizers increment the `step` tensor of each parameter, so a
         # shared tensor loaded there would advance once per parameter per step
         sd["state"] = {k: {kk: (vv.clone() if kk == "step" and torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()}

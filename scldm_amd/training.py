@@ -347,19 +347,26 @@ class FusedTrainStep:
     No autograd, no Python between the kernels, no decision on the host: the call is captured once in a HIP graph (`graph=True`) and
     replayed - per replay the host stages 16 bytes (learning rate, weight decay, EMA action) and copies the batch.  Gradients live in
     one flat fp32 buffer (`.grad` of every parameter is a view), so a data-parallel group reduces it in place between backward and
-    optimizer (`group=`; that variant is not graphed).  Requires the fused training route (base DiT shape, precision bf16 | fp16), the
+    optimizer (`group=`; that variant is not graphed).  `grad_clip_norm=` = the trainer's `gradient_clip_val` (global-norm clipping inside
+    the optimizer's launch; `optimizer.last_grad_norm` is the step's norm).  Requires the fused training route (base DiT shape, precision bf16 | fp16), the
     Linear path with velocity prediction (ldm_base.yaml:30-35) and `scldm_amd.optim.AdamW`.
     `__call__(x1, condition)` or `__call__(condition=..., counts=, genes=, counts_subset=, genes_subset=)` with a frozen `vae`; returns the
     step's loss as a STATIC device scalar (overwritten by the next step: `.clone()` or `float()` it to keep a value)."""
 
     def __init__(self, dit, transport, optimizer, batch_size: int, condition_keys, ema=None, vae=None, seed: int | None = None,
-                 graph: bool = True, group=None, encode_shape: tuple[int, int] | None = None):
+                 graph: bool = True, group=None, encode_shape: tuple[int, int] | None = None, grad_clip_norm: float | None = None):
         from . import _lib
         from .optim import AdamW
         if not isinstance(optimizer, AdamW):
             raise TypeError("FusedTrainStep runs the optimizer inside the step: it needs scldm_amd.optim.AdamW")
         if len(optimizer.param_groups) != 1:
             raise NotImplementedError("FusedTrainStep: one parameter group (the reference's configure_optimizers builds one, models.py:598-601)")
+        if grad_clip_norm is not None:
+            # the trainer's gradient_clip_val (experiments/configs/training/default.yaml:15-16: 10.0, algorithm "norm"): inside the optimizer's
+            # launch (AdamW.max_grad_norm), between the backward and the update like Lightning's clip_grad_norm_ call
+            if not grad_clip_norm > 0.0:
+                raise ValueError("grad_clip_norm must be positive (or None: no clipping)")
+            optimizer.max_grad_norm = float(grad_clip_norm)
         dev = dit.pos_embed.device
         if dev.type != "cuda":
             raise RuntimeError("FusedTrainStep needs the model on a CUDA (ROCm) device; there is no CPU path")
@@ -449,6 +456,7 @@ class FusedTrainStep:
                 if self.found_inf is not None:
                     del optimizer.found_inf
         self._bound_generation = optimizer._generation
+        self._bound_clip = optimizer.max_grad_norm
         if self._want_graph:
             self._capture()
 
@@ -592,7 +600,7 @@ class FusedTrainStep:
             self.x1.copy_(x1, non_blocking=True)
         for k in self.keys:
             self.labels_in[k].copy_(condition[k], non_blocking=True)
-        if self.optimizer._generation != self._bound_generation:
+        if self.optimizer._generation != self._bound_generation or self.optimizer.max_grad_norm != self._bound_clip:
             self._bind_optimizer()                                 # the optimizer's device state was replaced (checkpoint resume)
         elif self._grad_probe.grad is None:
             self._attach_grads()                                   # zero_grad(set_to_none=True) by the caller

@@ -368,3 +368,91 @@ def test_fused_train_step_follows_a_checkpoint_resume(graph):
         o2.load_state_dict(copy.deepcopy(o2.state_dict()))
         with pytest.raises(RuntimeError, match="load checkpoints first"):
             gs(x1, cond)
+
+
+def test_adamw_gradient_norm_clipping_is_torchs_clip_grad_norm():
+    """The trainer's gradient_clip_val (experiments/configs/training/default.yaml:15-16 -> Lightning -> torch.nn.utils.clip_grad_norm_) inside
+    the AdamW launch: the norm equals clip_grad_norm_'s return value, the parameters follow torch's clip + fused AdamW over steps whose
+    gradient scale varies by 10^4 (Adam alone is scale-invariant: a constant clip would be invisible), `.grad` stays unscaled, a threshold
+    above every norm is the unclipped optimizer bit for bit, and a captured graph follows the per-step coefficient."""
+    from scldm_amd.optim import AdamW
+    torch.manual_seed(1)
+    shapes = [(300, 17), (4096,), (5,), (64, 64), (1, 9000), (37,)]
+    mk = lambda: torch.nn.ParameterList([torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).cuda()) for i, s in enumerate(shapes)])
+    net, ref, free, big = mk(), mk(), mk(), mk()
+    opt = AdamW(net.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=10.0)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05, fused=True)
+    fopt = AdamW(free.parameters(), lr=1e-2, weight_decay=0.05)
+    bopt = AdamW(big.parameters(), lr=1e-2, weight_decay=0.05, max_grad_norm=1e9)
+    scales = [1.0, 100.0, 0.01, 3.0, 0.05, 40.0, 1.0, 0.2]
+    clipped = 0
+    for step, sc in enumerate(scales):
+        grads = [torch.randn(s, generator=torch.Generator().manual_seed(100 * step + i)).cuda() * sc for i, s in enumerate(shapes)]
+        for ps in (net, ref, free, big):
+            for p, g_ in zip(ps, grads):
+                p.grad = g_.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        topt.step()
+        opt.step(); fopt.step(); bopt.step()
+        got = float(opt.last_grad_norm)
+        assert abs(got - float(want_norm)) <= 2e-6 * float(want_norm), (step, got, float(want_norm))
+        assert abs(float(opt.param_groups[0]["_clip_ws"][1]) - min(1.0, 10.0 / (float(want_norm) + 1e-6))) < 1e-6
+        clipped += float(want_norm) > 10.0
+        for p, g_ in zip(net, grads):
+            assert torch.equal(p.grad, g_)                                          # the clip is applied in registers, not to .grad
+    assert 2 <= clipped <= len(scales) - 2
+    for p, q in zip(net, ref):
+        assert float((p - q).detach().abs().max()) <= 4e-6 * float(q.detach().abs().max())
+    for p, q in zip(big, free):
+        assert torch.equal(p, q)                                                    # coefficient 1.0: g * 1.0 is g
+    assert any(not torch.equal(p, q) for p, q in zip(net, free))
+    with pytest.raises(ValueError):
+        AdamW(mk().parameters(), max_grad_norm=0.0)
+    two = mk()
+    o2 = AdamW([{"params": list(two)[:3]}, {"params": list(two)[3:]}], lr=1e-2, max_grad_norm=1.0)
+    for p in two:
+        p.grad = torch.ones_like(p)
+    with pytest.raises(NotImplementedError, match="one parameter group"):
+        o2.step()
+
+
+def test_fused_train_step_clips_the_gradient_norm_in_the_graph():
+    """FusedTrainStep(grad_clip_norm=...): last_grad_norm is the norm of the step's gradients; a threshold above it is the unclipped step
+    bit for bit; a threshold far below changes the trajectory, and the HIP-graph replay follows the eager call bit for bit (the coefficient
+    is computed on the device per replay)."""
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    vocab, n = {"cell_line": 4, "gene": 2024}, 64
+    tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    batches = [(torch.randn(n, 16, 16, device="cuda", generator=gen) * (1.0 + 3.0 * (s % 2)),
+                {k: torch.randint(0, v, (n,), device="cuda", generator=gen) for k, v in vocab.items()}) for s in range(4)]
+    m0, _, _ = build(vocab, "joint", 8, 61)
+    m0.precision = "bf16"
+    m0.cfg_dropout_prob = 0.5
+
+    def run(clip, graph):
+        m = copy.deepcopy(m0)
+        opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)
+        fs = FusedTrainStep(m, tr, opt, n, list(vocab), seed=5, graph=graph, grad_clip_norm=clip)
+        norms = []
+        for b in batches:
+            fs(*b)
+            if clip is not None:
+                flat = torch.cat([fs.flat] + ([fs._gpos.reshape(-1)] if fs._gpos is not None else []))
+                want = float(torch.linalg.vector_norm(flat.double()))
+                norms.append((float(opt.last_grad_norm), want))
+        return [p.detach().clone() for p in m.parameters()], norms
+    free, _ = run(None, False)
+    big, norms = run(1e9, False)
+    for a, b in zip(free, big):
+        assert torch.equal(a, b)
+    for got, want in norms:
+        assert abs(got - want) <= 2e-6 * want
+    thr = 0.5 * min(w for _, w in norms)
+    eager, _ = run(thr, False)
+    graph, _ = run(thr, True)
+    for a, b in zip(eager, graph):
+        assert torch.equal(a, b)
+    assert any(not torch.equal(a, b) for a, b in zip(eager, free))
