@@ -156,10 +156,11 @@ typedef struct {
   int maximize;
   /* Gradient-norm clipping of the reference's trainer (experiments/configs/training/default.yaml:15-16: gradient_clip_val 10,
    * gradient_clip_algorithm norm -> Lightning calls torch.nn.utils.clip_grad_norm_(parameters, 10.0) between backward and
-   * optimizer.step): max_grad_norm > 0 runs one more launch over the same table ahead of the update - sum of squares of every gradient,
-   * block partials summed in a fixed order - and the update then reads g * min(1, max_grad_norm / (norm + 1e-6)), torch's
-   * clip_coef_clamped.  clip_ws: device memory of scldm_adamw_clip_workspace_bytes(n_blocks) bytes, zero-initialised once by the
-   * caller; afterwards clip_ws[0] = the step's total gradient norm (before clipping), clip_ws[1] = the coefficient applied.
+   * optimizer.step): max_grad_norm > 0 runs two more launches over the same table ahead of the update - the sum of squares of every
+   * 4 096-element chunk, then one workgroup summing those partials in a fixed order - and the update reads
+   * g * min(1, max_grad_norm / (norm + 1e-6)), torch's clip_coef_clamped.  clip_ws: device memory of
+   * scldm_adamw_clip_workspace_bytes(n_blocks) bytes; afterwards clip_ws[0] = the step's total gradient norm (before clipping),
+   * clip_ws[1] = the coefficient applied.
    * max_grad_norm <= 0 or clip_ws == NULL: no clipping (the struct of version 4 zero-extended). */
   float max_grad_norm;
   float* clip_ws;

@@ -110,12 +110,14 @@ struct TableArgs {
   const float* clip_coef;         // device, or null: every gradient is read times *clip_coef (clip_grad_norm_'s clip_coef_clamped)
 };
 // Total L2 norm of every gradient of the table and the clipping coefficient torch.nn.utils.clip_grad_norm_ derives from it
-// (torch/nn/utils/clip_grad.py: clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1; error_if_nonfinite = False).  One workgroup
-// per 4 096-element chunk (the update's own map); ws = [norm, coef, ticket (as int), pad | one partial per workgroup]; the last
-// workgroup to finish (ticket) sums the partials in index order - the result does not depend on which workgroup that is.
-__global__ __launch_bounds__(256) void grad_norm_table_kernel(const TableArgs a, float* __restrict__ ws, int n_blocks, float max_norm) {
+// (torch/nn/utils/clip_grad.py: clip_coef = max_norm / (total_norm + 1e-6), clamped to <= 1; error_if_nonfinite = False), as TWO plain
+// launches: one workgroup per 4 096-element chunk (the update's own map) writes its sum of squares, one workgroup sums the partials in a
+// fixed order.  ws = [norm, coef, -, - | one partial per chunk].  Measured inside the step at 1 024 cells (2 400 chunks): a single kernel
+// with a last-workgroup ticket costs 68 us (one same-address atomic and two agent-scope fences per workgroup), <= 512 striding workgroups
+// 27 us (three dependent round trips per chunk with little occupancy to hide them), two-level tickets 95 us; two launches without
+// atomics or fences are the cheapest form.
+__global__ __launch_bounds__(256) void grad_sq_partials_kernel(const TableArgs a, float* __restrict__ part) {
   __shared__ float red[256];
-  __shared__ int last;
   const TableBlock blk = a.blocks[blockIdx.x];
   const TableTensor tt = a.tensors[blk.tensor];
   const float* __restrict__ g = tt.g;
@@ -140,18 +142,14 @@ __global__ __launch_bounds__(256) void grad_norm_table_kernel(const TableArgs a,
     if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
     __syncthreads();
   }
-  float* part = ws + 4;
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = red[0];
-    __threadfence();
-    last = atomicAdd(reinterpret_cast<int*>(ws) + 2, 1) == n_blocks - 1;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  double t = 0.0;     // (partials are fp32 sums of 4 096 squares; their sum in double: 2 400 terms for the base DiT, 112 000 for DiT-L)
-  for (int i = threadIdx.x; i < n_blocks; i += 256) t += (double)__builtin_nontemporal_load(part + i);
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+// ONE workgroup: the partials summed in double (thread-strided, then a fixed tree) -> ws[0] = norm, ws[1] = clip_coef_clamped
+__global__ __launch_bounds__(256) void grad_norm_final_kernel(float* __restrict__ ws, int n_blocks, float max_norm) {
   __shared__ double redd[256];
+  const float* part = ws + 4;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n_blocks; i += 256) t += (double)part[i];
   redd[threadIdx.x] = t;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
@@ -162,9 +160,7 @@ __global__ __launch_bounds__(256) void grad_norm_table_kernel(const TableArgs a,
     const float norm = (float)sqrt(redd[0]);
     const float coef = max_norm / (norm + 1e-6f);
     ws[0] = norm;
-    ws[1] = coef < 1.0f ? coef : 1.0f;      // (a NaN norm - non-finite gradients - gives a NaN coefficient, as torch's clamp does)
-    if (coef != coef) ws[1] = coef;
-    reinterpret_cast<int*>(ws)[2] = 0;      // ready for the next step
+    ws[1] = coef != coef ? coef : (coef < 1.0f ? coef : 1.0f);   // (a NaN norm - non-finite gradients - gives a NaN coefficient, as torch's clamp does)
   }
 }
 // torch.lerp (ATen/native/Lerp.h): weight < 0.5 ? start + weight (end - start) : end - (end - start) (1 - weight); ATen's device code is
@@ -304,7 +300,8 @@ extern "C" int scldm_adamw_table_step(const scldm_adamw_launch* l, void* stream_
     a.step = l->step; a.found_inf = l->found_inf; a.hyper = l->hyper;
     a.lr = l->lr; a.beta1 = l->beta1; a.beta2 = l->beta2; a.eps = l->eps; a.weight_decay = l->weight_decay; a.maximize = l->maximize;
     if (l->max_grad_norm > 0.f && l->clip_ws) {
-      hipLaunchKernelGGL(grad_norm_table_kernel, dim3(l->n_blocks), dim3(256), 0, st, a, l->clip_ws, l->n_blocks, l->max_grad_norm);
+      hipLaunchKernelGGL(grad_sq_partials_kernel, dim3(l->n_blocks), dim3(256), 0, st, a, l->clip_ws + 4);
+      hipLaunchKernelGGL(grad_norm_final_kernel, dim3(1), dim3(256), 0, st, l->clip_ws, l->n_blocks, l->max_grad_norm);
       a.clip_coef = l->clip_ws + 1;
     }
     hipLaunchKernelGGL(adamw_table_kernel, dim3(l->n_blocks), dim3(256), 0, st, a);

@@ -70,7 +70,7 @@ class AdamW(torch.optim.Optimizer):
             return 0.0, None
         if len(self.param_groups) != 1:
             raise NotImplementedError("scldm_amd.optim.AdamW: max_grad_norm is the GLOBAL norm over every parameter - one parameter group only")
-        need = 4 + n_blocks
+        need = _lib.lib().scldm_adamw_clip_workspace_bytes(n_blocks) // 4
         ws = group.get("_clip_ws")
         if ws is None or ws.numel() < need or ws.device != dev:
             if capturing:

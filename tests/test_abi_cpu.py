@@ -187,7 +187,7 @@ def test_adamw_launch_table_layout_is_built_on_the_host():
     nb = L.scldm_adamw_table_bytes(ent, len(sizes))
     blocks = [1, 1, 0, 2, 3]
     assert nb == 48 * len(sizes) + 8 * sum(blocks) and L.scldm_adamw_table_records_bytes(len(sizes)) == 48 * len(sizes)
-    # gradient-norm clipping (version 5): [norm, coefficient, ticket, pad | one partial per workgroup]; the launch struct grew by two fields
+    # gradient-norm clipping (version 5): [norm, coefficient, -, - | one partial per workgroup]; the launch struct grew by two fields
     assert L.scldm_adamw_clip_workspace_bytes(sum(blocks)) == 4 * (4 + sum(blocks)) and L.scldm_adamw_clip_workspace_bytes(0) == 0
     assert C.sizeof(_lib.AdamwLaunch) == 80 and _lib.AdamwLaunch.max_grad_norm.offset == 64 and _lib.AdamwLaunch.clip_ws.offset == 72
     buf = (C.c_char * nb)()
