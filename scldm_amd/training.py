@@ -625,4 +625,5 @@ class FusedTrainStep:
             else:
                 self._launch()
         self.steps += 1
+        self.optimizer._opt_called = True      # (torch's LR schedulers warn when scheduler.step() is not preceded by an optimizer.step(): the fused call is that step)
         return self.loss
