@@ -285,13 +285,13 @@ def time_allgather(out, B, device, world, reps=5):
     return (time.perf_counter() - t0) / reps
 
 
-def make_optimizer(params, lr, kind="native"):
+def make_optimizer(params, lr, kind="native", max_grad_norm=None):
     """AdamW as the reference's trainer configures it (src/scldm/models.py configure_optimizers): `native` = scldm_amd.optim.AdamW (the
     same arithmetic in one HIP launch per step), `torch` = torch.optim.AdamW(fused=True)."""
     if kind == "torch":
         return torch.optim.AdamW(params, lr=lr, fused=True)
     from scldm_amd.optim import AdamW
-    return AdamW(params, lr=lr)
+    return AdamW(params, lr=lr, max_grad_norm=max_grad_norm)
 
 
 def time_training(wl, precision, device, steps, warmup, dist_on, world, optimizer="native", graphed=False):
@@ -759,7 +759,7 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
         gs = torch.stack([torch.sort(torch.randperm(n_genes, generator=g)[:S]).values for _ in range(B)]).to(device)
         cs = counts.gather(1, gs)
         lib = counts.sum(1, keepdim=True)
-        opt = make_optimizer(vae.parameters(), 1e-3)
+        opt = make_optimizer(vae.parameters(), 1e-3, max_grad_norm=10.0)     # the trainer's gradient_clip_val (training/default.yaml:15-16)
 
         def step(ev=None):
             opt.zero_grad(set_to_none=True)
@@ -792,7 +792,8 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
         flops = 3 * B * (S * MCAB_ENCODE_FLOPS_PER_GENE + 1.5e6 + n_genes * MCAB_DECODE_FLOPS_PER_GENE + 3.3e6)
         rec[f"b{B}"] = {"cells": B, "n_genes": n_genes, "tokens_per_cell": S, "ms_per_step": 1e3 * dt, "cells_per_s": B / dt,
                         "forward_and_loss_ms": fwd_ms, "backward_ms": bwd_ms, "backward_over_forward": bwd_ms / fwd_ms,
-                        "tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / PEAK["fp32"], "final_loss": float(loss.detach())}
+                        "tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / PEAK["fp32"], "final_loss": float(loss.detach()),
+                        "gradient_clip": "global norm 10.0 inside the optimizer launch", "last_grad_norm": float(opt.last_grad_norm)}
         del vae, opt
         torch.cuda.empty_cache()
     return rec
