@@ -422,6 +422,7 @@ class FusedTrainStep:
         self.steps = 0
         # the encode of the tokenised batch (frozen VAE as tokenizer, models.py:641): static inputs when graphed
         self.enc = None
+        self._vae_frozen = vae is not None and not any(p.requires_grad for p in vae.parameters())
         if vae is not None and encode_shape is not None:
             S = int(encode_shape[1])
             self.enc = (torch.zeros(n, S, **f32), torch.zeros(n, S, dtype=torch.long, device=dev))
@@ -497,7 +498,16 @@ class FusedTrainStep:
         with torch.cuda.device(self.dev):
             st = torch.cuda.current_stream(self.dev).cuda_stream
             if self.enc is not None:
-                z = self.vae.encode(self.enc[0], self.enc[1])
+                # a frozen tokenizer (models.py:432-435: requires_grad False on every VAE parameter): its packed weight copies are checked
+                # through the version counters only - the device-side fingerprint pass (five small launches per encode, there for EMA-style
+                # `.data` updates) is skipped inside the step
+                keep = self.vae.check_weight_fingerprint
+                if self._vae_frozen:
+                    self.vae.check_weight_fingerprint = False
+                try:
+                    z = self.vae.encode(self.enc[0], self.enc[1])
+                finally:
+                    self.vae.check_weight_fingerprint = keep
                 self.x1.copy_(z.view_as(self.x1))
             _lib.check(self._L.scldm_dit_train_step(self._h, C.byref(self._w), C.byref(self._g), self.x1.data_ptr(), C.cast(self._lab_ptrs, _lib.c_void_pp),
                                                     self._nulls, len(dit._class_names), 1 if dit.condition_strategy == "joint" else 0,
