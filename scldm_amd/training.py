@@ -418,7 +418,8 @@ class FusedTrainStep:
                                           loss_rows=self.loss_rows.data_ptr(), loss_mean=self.loss.data_ptr(), ticket=self.ticket.data_ptr(),
                                           saved=self.saved.data_ptr(), ws=self.ws.data_ptr())
         self.found_inf = dit.found_inf_flag() if dit.precision == "fp16" else None
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (an explicit group selects the exchange path even with one rank: the collectives are identities, the plumbing is the multi-GPU one)
+        self.distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size(group) > 1)
         self.steps = 0
         # the encode of the tokenised batch (frozen VAE as tokenizer, models.py:641): static inputs when graphed
         self.enc = None

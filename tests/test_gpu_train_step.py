@@ -456,3 +456,50 @@ def test_fused_train_step_clips_the_gradient_norm_in_the_graph():
     for a, b in zip(eager, graph):
         assert torch.equal(a, b)
     assert any(not torch.equal(a, b) for a, b in zip(eager, free))
+
+
+def test_fused_train_step_data_parallel_branch_on_a_one_rank_rccl_group():
+    """FusedTrainStep(group=...): the call stops after the backward, the flat gradient buffer (and pos_embed's) is all-reduced in place over
+    RCCL, then optimizer.step() applies clipping, AdamW and the EMA action.  With a one-rank group the collectives are identities, so the
+    result must be the single-process fused step bit for bit - the plumbing (NULL optimizer launch, in-place slices of the flat buffer,
+    table built against the views, EMA schedule through step()) is the multi-GPU one; >= 2 ranks never ran on this pool."""
+    import os, socket
+    import torch.distributed as dist
+    from scldm_amd.ema import EMA
+    from scldm_amd.optim import AdamW
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        vocab, n = {"cell_line": 4, "gene": 2024}, 64
+        tr = create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5)
+        gen = torch.Generator(device="cuda").manual_seed(12)
+        batches = [(torch.randn(n, 16, 16, device="cuda", generator=gen), {k: torch.randint(0, v, (n,), device="cuda", generator=gen) for k, v in vocab.items()})
+                   for _ in range(4)]
+        m0, _, _ = build(vocab, "joint", 8, 71)
+        m0.precision = "bf16"
+        m0.cfg_dropout_prob = 0.5
+        out = {}
+        for name, group in (("single", None), ("group", dist.group.WORLD)):
+            m = copy.deepcopy(m0)
+            opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.01)
+            ema = EMA(model=m, beta=0.9, update_every=2, update_after_step=1)
+            fs = FusedTrainStep(m, tr, opt, n, list(vocab), ema=ema, seed=5, graph=False, group=group, grad_clip_norm=0.5)
+            assert fs.distributed == (group is not None) and (fs._opt is None) == (group is not None)
+            losses = []
+            for b in batches:
+                losses.append(float(fs(*b)))
+                ema.update()
+            out[name] = ([p.detach().clone() for p in m.parameters()], [p.detach().clone() for p in ema.ema_model.parameters()], losses,
+                         float(opt.last_grad_norm))
+        assert out["single"][2] == out["group"][2] and out["single"][3] == out["group"][3]
+        for a, b in zip(out["single"][0], out["group"][0]):
+            assert torch.equal(a, b)
+        for a, b in zip(out["single"][1], out["group"][1]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
