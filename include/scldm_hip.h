@@ -174,7 +174,7 @@ int scldm_adamw_table_step(const scldm_adamw_launch* launch, void* stream);
  * fp32, contiguous, `n` elements on the device; `k` / `coef` are HOST arrays of n_k <= 7 device pointers / h-scaled tableau weights.
  *   scldm_rk_combine: out = y0 + sum_j coef_j k_j (left to right; y0 may be NULL)                      - stage points
  *   scldm_rk_error:   ws[1022] (double) = mean((sum_j coef_j k_j / (atol + rtol max(|y0|, |y1|)))^2)    - error ratio^2; ws = 8 KB of
- *                     zero-initialised device memory (block partials + a ticket), summed in a fixed order
+ *                     device memory (block partials, summed in block order by a second one-workgroup launch)
  *   scldm_rk_dense:   coefficients c1..c4 of the quartic interpolant of an accepted step (c0 = y0)
  *   scldm_rk_poly:    out = c0 + s1 c1 + s2 c2 + s3 c3 + s4 c4                                           - a save point */
 int scldm_rk_combine(float* out, const float* y0, const float* const* k, const float* coef, int n_k, long long n, void* stream);

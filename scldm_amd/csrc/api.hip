@@ -1088,10 +1088,10 @@ extern "C" int scldm_rk_error(const float* y0, const float* y1, const float* con
   scldm::rk::CombArgs a{};
   int rc = rk_args(&a, k, coef, n_k, "scldm_rk_error");
   if (rc) return rc;
-  double* w = reinterpret_cast<double*>(ws);     // [0, 1022) block partials | [1022] mean of squared ratios | [1023] ticket (zero at first use)
+  double* w = reinterpret_cast<double*>(ws);     // [0, 1022) block partials | [1022] mean of squared ratios | [1023] unused since round 6
   const unsigned blocks = (unsigned)std::min<long long>(cdiv(n, 256 * 8), 1022);
-  hipLaunchKernelGGL(scldm::rk::error_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, y0, y1, a, (long)n, atol, rtol, w,
-                     reinterpret_cast<unsigned*>(w + 1023), w + 1022);
+  hipLaunchKernelGGL(scldm::rk::error_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, y0, y1, a, (long)n, atol, rtol, w);
+  hipLaunchKernelGGL(scldm::rk::error_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, w, blocks, (long)n, w + 1022);
   LAUNCH_CHECK();
   return SCLDM_OK;
 }

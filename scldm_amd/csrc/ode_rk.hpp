@@ -35,12 +35,13 @@ __global__ __launch_bounds__(256) void combine_kernel(float* __restrict__ out, c
   reinterpret_cast<f32x4*>(out)[i] = acc;
 }
 
-// err = sum_j c_j k_j;  q = err / (atol + rtol * max(|y0|, |y1|));  partial[block] = sum q^2 (double);  the LAST block adds the
-// partials in block order and writes mean(q^2) to *out (deterministic: no floating-point atomics)
+// err = sum_j c_j k_j;  q = err / (atol + rtol * max(|y0|, |y1|));  partial[block] = sum q^2 (double); error_final_kernel (ONE workgroup,
+// the next launch) adds the partials in block order and writes mean(q^2) to *out (deterministic: no floating-point atomics).  Round 6:
+// two plain launches instead of a last-block ticket - the ticket cost an agent-scope fence per workgroup and the last workgroup's thread 0
+// fetched up to 1 022 partials one after the other: 150 us per step of the default sampler (profiles/r6_dopri5_*).
 __global__ __launch_bounds__(256) void error_kernel(const float* __restrict__ y0, const float* __restrict__ y1, const CombArgs a, long n, float atol,
-                                                    float rtol, double* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ out) {
+                                                    float rtol, double* __restrict__ partial) {
   __shared__ double red[4];
-  __shared__ bool last;
   double s = 0.0;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float e = 0.f;
@@ -58,18 +59,17 @@ __global__ __launch_bounds__(256) void error_kernel(const float* __restrict__ y0
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    __threadfence();
-    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// the partials fetched by the whole workgroup at once, then added one after the other in block order (the order of the one-kernel form: same bits)
+__global__ __launch_bounds__(256) void error_final_kernel(const double* __restrict__ partial, unsigned n_part, long n, double* __restrict__ out) {
+  __shared__ double p[1024];
+  for (unsigned b = threadIdx.x; b < n_part; b += 256) p[b] = partial[b];
   __syncthreads();
-  if (last && threadIdx.x == 0) {
-    __threadfence();
+  if (threadIdx.x == 0) {
     double t = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(partial + b);
+    for (unsigned b = 0; b < n_part; ++b) t += p[b];
     *out = t / (double)n;
-    *ticket = 0u;
   }
 }
 

@@ -7,6 +7,8 @@ through libscldm_hip.so (include/scldm_hip.h); there is no eager/CPU fallback.
 """
 from __future__ import annotations
 
+import contextlib
+
 import ctypes as C
 import os
 from typing import Literal
@@ -159,6 +161,22 @@ class _DiTTrainFn(torch.autograd.Function):
                 o = offs[id(p)]
                 out.append(flat[o:o + p.numel()].view(p.shape))
         return (None, dx, None, None, None, *out)
+
+
+_ASSUME_WEIGHTS_UNCHANGED = [0]
+
+
+@contextlib.contextmanager
+def weights_unchanged():
+    """Inside this block a DiT trusts its packed weight copies whenever parameter storages and torch version counters are unchanged: the
+    per-call device-side fingerprint pass (there for in-place `.data` updates, which those counters do not see) is skipped.  For loops that
+    call the model many times with no parameter update in between - `scldm_amd.transport.Sampler`'s evaluation loops use it after their
+    first evaluation (the reference's default dopri5 solve: 110 calls of forward_with_cfg)."""
+    _ASSUME_WEIGHTS_UNCHANGED[0] += 1
+    try:
+        yield
+    finally:
+        _ASSUME_WEIGHTS_UNCHANGED[0] -= 1
 
 
 class DiT(nn.Module):
@@ -327,9 +345,10 @@ class DiT(nn.Module):
         if key != self._weights_key:
             self._load_weights(L)
             self._weights_key = key
-        else:
+        elif not _ASSUME_WEIGHTS_UNCHANGED[0]:
             # same storages and version counters: `.data` updates (EMA) are invisible to both, so the C side compares a
-            # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation)
+            # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation).
+            # Skipped inside `weights_unchanged()` (the samplers' evaluation loops: 25 + 5 + 10 us of launches per call).
             with torch.cuda.device(self.pos_embed.device):
                 _lib.check(L.scldm_dit_refresh_weights(self._handle, _stream_ptr()), "scldm_dit_refresh_weights")
         _lib.check(L.scldm_dit_set_option(self._handle, _lib.OPT_CFG1_DIRECT, int(bool(getattr(self, "guidance1_direct", False)))), "scldm_dit_set_option")

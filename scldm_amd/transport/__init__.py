@@ -263,6 +263,14 @@ class Sampler:
             ts = [float(v) for v in torch.linspace(0.0, 1.0, num_steps).double()]   # integrators.py:95, cast as the solver does
             y0 = x
             f0 = f(y0, ts[0])
+            # (the first evaluation checked the packed weights against the parameters; no parameter changes inside a solve, so the
+            # remaining ~110 evaluations skip the device-side fingerprint pass: scldm_amd.nnets.weights_unchanged)
+            from ..nnets import weights_unchanged
+            with weights_unchanged():
+                return _solve(f, comb, error_ratio, dense_fit, dense_eval, ts, x, y0, f0, lambda: n_eval)
+
+        def _solve(f, comb, error_ratio, dense_fit, dense_eval, ts, x, y0, f0, n_eval_now):
+            dev = x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0
             # initial step (Hairer / Norsett / Wanner II.4, rms norm, exponent 1 / 5)
             scale = atol + rtol * y0.abs()
             d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
@@ -276,7 +284,7 @@ class Sampler:
             accepted, rejected = [], []
             for next_t in ts[1:]:
                 while next_t > t1:            # advance until the save time lies inside the last accepted step
-                    if not (t1 + h > t1) or n_eval > 100000:
+                    if not (t1 + h > t1) or n_eval_now() > 100000:
                         raise RuntimeError("dopri5: step size underflow / too many evaluations")
                     ta = t1
                     ks = [f0]
@@ -298,7 +306,7 @@ class Sampler:
                     else:
                         h = h * min(10.0, max(0.9 / ratio ** 0.2, 1.0 if ratio < 1.0 else 0.2))
                 out.append(dense_eval(coeff, (next_t - t0) / (t1 - t0)))
-            _sample.last_stats = {"evaluations": n_eval, "rejected": len(rejected), "accepted_steps": accepted, "rejected_steps": rejected}
+            _sample.last_stats = {"evaluations": n_eval_now(), "rejected": len(rejected), "accepted_steps": accepted, "rejected_steps": rejected}
             return torch.stack(out)
 
         return _sample
@@ -330,15 +338,20 @@ class Sampler:
                 tv = torch.full((), float(tval), device=xc.device, dtype=torch.float32).expand(xc.shape[0])
                 return drift(xc, tv, model, **model_kwargs)
 
-            for i in range(num_steps - 1):
-                h = float(ts[i + 1] - ts[i])
-                k1 = f(x, ts[i])
-                if method == "euler":
-                    x = x + h * k1
-                else:
-                    k2 = f(x + h * k1, ts[i + 1])
-                    x = x + (0.5 * h) * (k1 + k2)
-                traj.append(x)
+            from ..nnets import weights_unchanged
+            import contextlib
+            with contextlib.ExitStack() as stack:
+                for i in range(num_steps - 1):
+                    h = float(ts[i + 1] - ts[i])
+                    k1 = f(x, ts[i])
+                    if i == 0:    # the first evaluation checked the packed weights against the parameters: the rest of the loop skips that pass
+                        stack.enter_context(weights_unchanged())
+                    if method == "euler":
+                        x = x + h * k1
+                    else:
+                        k2 = f(x + h * k1, ts[i + 1])
+                        x = x + (0.5 * h) * (k1 + k2)
+                    traj.append(x)
             return torch.stack(traj)
 
         return _sample
