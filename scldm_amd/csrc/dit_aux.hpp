@@ -417,14 +417,26 @@ __global__ __launch_bounds__(256) void t_embed_kernel(const float* __restrict__ 
     te[n] = (n < 128) ? cosf(arg) : sinf(arg);
   }
   __syncthreads();
+  // (64 weight loads requested together, the additions in k order as before: with 8 in flight the two loops were 64 dependent L2 round
+  // trips - 22 us per evaluation of a host-driven solver, profiles/r6_dopri5_before_kernel_stats.txt)
   float s = b0[n];
-#pragma unroll 8
-  for (int k = 0; k < 256; ++k) s += w0t[k * 256 + n] * te[k];
+  for (int k0 = 0; k0 < 256; k0 += 64) {
+    float wv[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wv[j] = w0t[(k0 + j) * 256 + n];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) s += wv[j] * te[k0 + j];
+  }
   h1[n] = silu_f(s);
   __syncthreads();
   float c = b2[n];
-#pragma unroll 8
-  for (int k = 0; k < 256; ++k) c += w2t[k * 256 + n] * h1[k];
+  for (int k0 = 0; k0 < 256; k0 += 64) {
+    float wv[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wv[j] = w2t[(k0 + j) * 256 + n];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) c += wv[j] * h1[k0 + j];
+  }
   temb[n] = c;
 }
 
