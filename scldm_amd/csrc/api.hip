@@ -100,6 +100,7 @@ extern "C" int scldm_dit_create(const scldm_dit_config* cfg, scldm_dit** out) {
   if (const char* e = getenv("SCLDM_ADALN_EXACT")) h->adaln_exact = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_ADALN_ROWTILE")) h->adaln_rowtile = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_COND_AHEAD")) h->cond_ahead = atoi(e) != 0;
+  if (const char* e = getenv("SCLDM_COND_ALL")) h->cond_all_on = atoi(e) != 0;
   if (const char* e = getenv("SCLDM_GROUPS")) h->groups = std::min(4, std::max(1, atoi(e)));
   if (const char* e = getenv("SCLDM_TAIL_SPLIT")) h->tail_split = atoi(e) != 0;
   {
@@ -201,6 +202,7 @@ extern "C" void scldm_dit_destroy(scldm_dit* h) {
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->bwd_pack_ev) (void)hipEventDestroy(h->bwd_pack_ev);
   if (h->cond_stream) (void)hipStreamDestroy(h->cond_stream);
+  if (h->cond_all) (void)hipFree(h->cond_all);
   for (hipEvent_t ev : {h->ev_cond[0], h->ev_cond[1], h->ev_free[0], h->ev_free[1], h->ev_ready})
     if (ev) (void)hipEventDestroy(ev);
   delete h;
@@ -780,6 +782,25 @@ __global__ void set_scalar_kernel(float* p, float v) { *p = v; }
 
 // The conditioning of one CFG evaluation (timestep rows, class embeddings, adaLN projection -> w.mod): depends on t and the labels
 // only, never on the state.
+static CondRowsArgs cond_rows_args(const scldm_dit* h, const CfgPlan& pl, const float* temb, float* silu_c, const int* gate) {
+  CondRowsArgs ca;
+  ca.temb = temb;
+  ca.emb = h->emb;
+  ca.n_classes = h->cfg.n_classes;
+  ca.U = pl.U > 0 ? pl.U : 1;
+  ca.rows = pl.n_rows;
+  for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
+    ca.emb_row0[c] = c < ca.n_classes ? h->emb_row0[c] : 0;
+    ca.null_tok[c] = c < ca.n_classes ? h->cfg.class_vocab[c] : 0;
+    ca.tab_rows[c] = c < ca.n_classes ? h->tab_rows[c] : 1;
+    ca.labels[c] = (c < ca.n_classes && pl.ulabels && pl.ulabels[c]) ? pl.ulabels[c] : nullptr;
+    ca.mask[c] = c < pl.P ? pl.mask[c] : 0u;
+  }
+  ca.silu_c = silu_c;
+  ca.label_err = h->label_err;
+  ca.gate = gate;
+  return ca;
+}
 static int cfg_cond(scldm_dit* h, const CfgPlan& pl, const float* t_dev, int t_stride, const Ws& w, int prec, hipStream_t st,
                     const float* temb_pre = nullptr) {
   int rc;
@@ -792,22 +813,7 @@ static int cfg_cond(scldm_dit* h, const CfgPlan& pl, const float* t_dev, int t_s
       t_embed_kernel<<<1, 256, 0, st>>>(t_dev, h->w0t, h->b0, h->w2t, h->b2, w.temb);
       temb = w.temb;
     }
-    CondRowsArgs ca;
-    ca.temb = temb;
-    ca.emb = h->emb;
-    ca.n_classes = h->cfg.n_classes;
-    ca.U = pl.U > 0 ? pl.U : 1;
-    ca.rows = pl.n_rows;
-    for (int c = 0; c < SCLDM_MAX_CLASSES; ++c) {
-      ca.emb_row0[c] = c < ca.n_classes ? h->emb_row0[c] : 0;
-      ca.null_tok[c] = c < ca.n_classes ? h->cfg.class_vocab[c] : 0;
-      ca.tab_rows[c] = c < ca.n_classes ? h->tab_rows[c] : 1;
-      ca.labels[c] = (c < ca.n_classes && pl.ulabels && pl.ulabels[c]) ? pl.ulabels[c] : nullptr;
-      ca.mask[c] = c < pl.P ? pl.mask[c] : 0u;
-    }
-    ca.silu_c = w.silu;
-    ca.label_err = h->label_err;
-    ca.gate = gate;
+    CondRowsArgs ca = cond_rows_args(h, pl, temb, w.silu, gate);
     cond_rows_kernel<<<t_stride == 2 ? rows_u : pl.n_rows, 256, 0, st>>>(ca);
     LAUNCH_CHECK();
   }
@@ -966,10 +972,45 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
     HIP_TRY(hipStreamWaitEvent(h->cond_stream, h->ev_ready, 0));
     if ((rc = cfg_cond(h, pl, tscal, 0, wb[0], precision, st, w.temb))) return rc;   // evaluation 0: in line
   }
+  // Conditioning of the whole solve up front (round 6): the adaLN vectors depend on t and the labels only, so every evaluation's rows go
+  // through ONE timestep-embedding launch (above), ONE row launch and ONE adaLN projection over n_evals x n_rows rows instead of two
+  // launches per evaluation on the critical path (4.7 + 8.2 us of a 174 us evaluation at 128 cells: profiles/r6_small_batch_trace.txt).
+  // Same kernels, same per-row arithmetic: bit-identical (tested).  Budget 512 MB (15 rows x 100 evaluations = 83 MB for the dentate
+  // vocabulary; a batch of 1 024 distinct joint labels would need 5.7 GB and keeps the per-evaluation launches).
+  float* mod_all = nullptr;
+  if (pre && !ahead && h->cond_all_on && n_evals > 1) {
+    const size_t rows_all = (size_t)n_evals * pl.n_rows;
+    const size_t b_mod = align256(rows_all * h->mod_w * 4), b_silu = align256((rows_all + 1) * 256 * 4), b_split = align256((rows_all + 31) / 32 * 32 * 256 * 4);
+    if (b_mod <= ((size_t)512 << 20)) {
+      const size_t need = b_mod + b_silu + b_split;
+      if (h->cond_all_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(st));     // (an earlier solve on this stream may still read the buffer that is replaced)
+        if (h->cond_all) (void)hipFree(h->cond_all);
+        h->cond_all = nullptr;
+        h->cond_all_bytes = 0;
+        if (hipMalloc(&h->cond_all, need) == hipSuccess) h->cond_all_bytes = need;
+        else (void)hipGetLastError();          // no room: the per-evaluation launches
+      }
+      if (h->cond_all_bytes >= need) {
+        mod_all = reinterpret_cast<float*>(h->cond_all);
+        float* silu_all = reinterpret_cast<float*>(reinterpret_cast<char*>(h->cond_all) + b_mod);
+        void* split_all = reinterpret_cast<char*>(h->cond_all) + b_mod + b_silu;
+        CondRowsArgs ca = cond_rows_args(h, pl, w.temb, silu_all, nullptr);
+        cond_rows_kernel<<<dim3(pl.n_rows, n_evals), 256, 0, st>>>(ca);
+        LAUNCH_CHECK();
+        if ((rc = launch_adaln(h, silu_all, mod_all, (int)rows_all, st, nullptr, precision, split_all))) return rc;
+      }
+    }
+  }
   int e_idx = 0;   // running evaluation index
   // one evaluation: (ahead) queue the conditioning of the next one on the second stream, wait for this one's, run the trunk
   auto eval = [&](const float* zin, float tval, float* dz, float* euler_z, float euler_h) -> int {
     const int e = e_idx++;
+    if (mod_all) {
+      Ws we = w;
+      we.mod = mod_all + (size_t)e * pl.n_rows * h->mod_w;
+      return cfg_trunk(h, pl, zin, we, dz, precision, st, euler_z, euler_h);
+    }
     if (!ahead) {
       if (!pre) set_scalar_kernel<<<1, 1, 0, st>>>(tscal, tval);
       return cfg_eval(h, pl, zin, tscal, 0, w, dz, precision, st, pre ? w.temb + (size_t)e * 256 : nullptr, euler_z, euler_h);

@@ -487,15 +487,16 @@ struct CondRowsArgs {
 };
 __global__ __launch_bounds__(256) void cond_rows_kernel(const CondRowsArgs a) {
   if (a.gate && *a.gate != 1) return;
+  // blockIdx.y = evaluation of a whole-solve launch (its timestep embedding and its block of output rows); 0 for the per-evaluation launch
   const int r = blockIdx.x, n = threadIdx.x;
-  float c = a.temb[n];
+  float c = a.temb[(size_t)blockIdx.y * 256 + n];
   const int p = r > 0 ? (r - 1) / a.U : 0, u = r > 0 ? (r - 1) % a.U : 0;
   for (int ci = 0; ci < a.n_classes; ++ci) {
     int tok = a.null_tok[ci];
     if (r > 0 && a.labels[ci] != nullptr && ((a.mask[p] >> ci) & 1u)) tok = checked_label(a.labels[ci], u, a.tab_rows[ci], a.label_err, n == 0);
     c += a.emb[(size_t)(a.emb_row0[ci] + tok) * 256 + n];
   }
-  a.silu_c[(size_t)r * 256 + n] = silu_f(c);
+  a.silu_c[((size_t)blockIdx.y * a.rows + r) * 256 + n] = silu_f(c);
 }
 
 // mod[u][n] = bias[n] + sum_k wt[k][n] * silu_c[u][k] for ALL layers at once (n < mod_w).

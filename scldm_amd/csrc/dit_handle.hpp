@@ -58,6 +58,11 @@ struct scldm_dit {
   // stream beside the trunk of evaluation e, into the other of two buffer sets (scldm_sample_ode)
   hipStream_t cond_stream = nullptr;
   hipEvent_t ev_cond[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_ready = nullptr;
+  // round 6: the adaLN vectors of EVERY evaluation of a fixed-grid solve in one batched pass ahead of the loop (they depend on t and the
+  // labels only): SCLDM_COND_ALL=0 switches it off; cond_all = [mod | silu | split rows] for n_evals x n_rows rows, grown on demand
+  bool cond_all_on = true;
+  void* cond_all = nullptr;
+  size_t cond_all_bytes = 0;
   bool cond_ahead = false;  // SCLDM_COND_AHEAD=1: opt-in (measured +0.5 % at 1 024 joint-conditioned cells, -0.8 % at 512, -0.2 % at 4 096: off)
   int force_ft, force_x3_ft, force_x3_ntt;
   bool small_ntt = true;   // 32-token tiles for launches of at most 256 of them (SCLDM_SMALL_NTT=0: off)

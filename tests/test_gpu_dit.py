@@ -755,6 +755,29 @@ def test_tile_group_launches_are_bit_identical(monkeypatch):
             assert torch.equal(y, ref), (knob, val)
 
 
+@pytest.mark.parametrize("case,precision", [("dit_base", "bf16"), ("dit_base", "fp32"), ("dit_joint", "bf16"), ("dit_me2_256", "fp16")])
+def test_whole_solve_conditioning_is_bit_identical_to_per_evaluation_conditioning(case, precision, monkeypatch):
+    """scldm_sample_ode prepares the adaLN vectors of EVERY evaluation of a fixed-grid solve in one batched pass ahead of the loop (they
+    depend on t and the labels only) instead of two launches per evaluation: same kernels over more rows, so the trajectories must be the
+    per-evaluation path's (SCLDM_COND_ALL=0) bit for bit - Euler and Heun, few rows (<= 128: row-tile projection) and many distinct label
+    tuples (the 128 x 128-block projection), single evaluation (nothing to batch)."""
+    g, m, cfg, sd = build(case, precision)
+    monkeypatch.setenv("SCLDM_COND_ALL", "0")                # (read once, when the native handle is created)
+    _, m0, _, _ = build(case, precision)
+    monkeypatch.delenv("SCLDM_COND_ALL")
+    vocab = cfg.class_vocab_sizes
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for B, steps, method in ((40, 7, "euler"), (40, 5, "heun"), (300, 4, "euler"), (3, 2, "euler")):
+            z0 = torch.randn(B, 16, 16, device="cuda", generator=gen)
+            z2 = torch.cat([z0, z0])
+            cond = {k: torch.randint(0, v, (B,), device="cuda", generator=gen).repeat(2) for k, v in vocab.items()}
+            scales = {k: 1.5 for k in vocab}
+            a = m.sample_ode_cfg(z2, cond, scales, steps, method)
+            b = m0.sample_ode_cfg(z2, cond, scales, steps, method)
+            assert torch.isfinite(a).all() and torch.equal(a, b), (B, steps, method)
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 def test_small_launches_on_32_token_tiles_are_bit_identical(precision, monkeypatch):
     """Launches of at most 256 32-token tiles (512 samples) run the 32-token-tile instantiation of the fused kernel (a shorter walk
