@@ -774,12 +774,18 @@ def vae_training_record(device, batches=(32, 512), n_genes=17002, S=6147):
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        n = 10 if B <= 64 else 5
-        t0 = time.perf_counter()
-        for _ in range(n):
-            loss = step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        n = 20 if B <= 64 else 5
+        import gc
+        gc.collect()
+        gc.disable()         # (a full collection of the bench process is ~70 ms: one of them inside ten 2.5 ms steps read 6.3 ms per step)
+        try:
+            t0 = time.perf_counter()
+            for _ in range(n):
+                loss = step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+        finally:
+            gc.enable()
         # device time of the forward (+ loss) and of the backward, medians of separately recorded steps
         fwd, bwd = [], []
         for _ in range(5):
