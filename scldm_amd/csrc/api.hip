@@ -983,7 +983,9 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
     const size_t b_mod = align256(rows_all * h->mod_w * 4), b_silu = align256((rows_all + 1) * 256 * 4), b_split = align256((rows_all + 31) / 32 * 32 * 256 * 4);
     if (b_mod <= ((size_t)512 << 20)) {
       const size_t need = b_mod + b_silu + b_split;
-      if (h->cond_all_bytes < need) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cap);
+      if (h->cond_all_bytes < need && cap == hipStreamCaptureStatusNone) {   // (no allocation inside a stream capture: the per-evaluation launches)
         HIP_TRY(hipStreamSynchronize(st));     // (an earlier solve on this stream may still read the buffer that is replaced)
         if (h->cond_all) (void)hipFree(h->cond_all);
         h->cond_all = nullptr;
