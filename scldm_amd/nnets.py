@@ -248,6 +248,10 @@ class DiT(nn.Module):
         self._weights_key = None
         self._ws = None
         self._dedup_cache = {}
+        # True: the CFG plan of the samplers never waits for the host (dense label-tuple rows instead of torch.unique); out-of-range labels
+        # are then clamped and reported by check_labels() instead of raising at once.  scldm_amd.sampling.generate_cells_stream sets it
+        # for the duration of its loop.
+        self.deferred_label_check = False
         self.initialize_weights()
 
     # ------------------------------------------------------------------ init (nnets.py:458-492)
@@ -392,8 +396,10 @@ class DiT(nn.Module):
         n = C.c_int(0)
         with torch.cuda.device(self.pos_embed.device):
             _lib.check(_lib.lib().scldm_dit_label_errors(self._handle, C.byref(n), _stream_ptr()), "scldm_dit_label_errors")
-        if n.value:
-            raise IndexError(f"{n.value} condition label(s) were outside their class vocabulary (index out of range in self)")
+        deferred = self.__dict__.pop("_label_bad", None)        # (labels clamped by the sync-free CFG plan, `deferred_label_check`)
+        total = n.value + (int(deferred) if deferred is not None else 0)
+        if total:
+            raise IndexError(f"{total} condition label(s) were outside their class vocabulary (index out of range in self)")
         return 0
 
     # ------------------------------------------------------------------ copies / pickling: the native handle never travels
@@ -401,13 +407,13 @@ class DiT(nn.Module):
         state = self.__dict__.copy()
         state.update(_handle=None, _weights_key=None, _ws=None, _dedup_cache={})
         for k in ("_wstruct_cache", "_grad_offsets", "_grad_numel", "_grad_segs", "_pos_idx", "_param_list", "_prepared_key", "_grad_sync",
-                  "_train_step_sync", "_fp16_checked", "_found_inf", "_found_inf_handle"):   # (_found_inf is registered with the handle that does not travel)
+                  "_train_step_sync", "_fp16_checked", "_found_inf", "_found_inf_handle", "_dense_rows", "_label_bad"):   # (_found_inf is registered with the handle that does not travel)
             state.pop(k, None)
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for k, v in (("_handle", None), ("_weights_key", None), ("_ws", None), ("_dedup_cache", {})):
+        for k, v in (("_handle", None), ("_weights_key", None), ("_ws", None), ("_dedup_cache", {}), ("deferred_label_check", False)):
             self.__dict__.setdefault(k, v)
 
     def _param_struct(self, dp):
@@ -691,7 +697,39 @@ class DiT(nn.Module):
         cell_row_ptr = None
         n_u = B
         cols = {c: half[c].contiguous() for c in used}
-        if dedup and used:
+        dense_total = 1
+        for c in used:
+            dense_total *= int(self.class_vocab_sizes[c]) + 1
+        if dedup and used and self.deferred_label_check and dense_total < B and dense_total <= 4096:
+            # Sync-free plan (opt-in, `deferred_label_check`): one conditioning row per POSSIBLE label tuple (15 for the dentate vocabulary)
+            # instead of per tuple present in this batch - no torch.unique, hence no host wait for the stream's earlier work (the prediction
+            # loop queues batch i + 1's solve while batch i's is still running).  Out-of-range labels are clamped and counted on the
+            # device like the plain forward's; `check_labels()` raises for them.
+            sizes = [int(self.class_vocab_sizes[c]) + 1 for c in used]
+            dkey = (tuple(used), str(self.pos_embed.device))
+            dense = self.__dict__.setdefault("_dense_rows", {}).get(dkey)
+            if dense is None:
+                idx = torch.arange(dense_total, device=self.pos_embed.device, dtype=torch.long)
+                strides, acc = [], 1
+                for sz in reversed(sizes):
+                    strides.append(acc)
+                    acc *= sz
+                strides = strides[::-1]
+                dense = ({c: ((idx // st) % sz).contiguous() for c, st, sz in zip(used, strides, sizes)}, strides)
+                self.__dict__["_dense_rows"][dkey] = dense
+            ucols, strides = dense
+            inv = torch.zeros(B, dtype=torch.long, device=self.pos_embed.device)
+            bad = torch.zeros((), dtype=torch.long, device=self.pos_embed.device)
+            for c, st, sz in zip(used, strides, sizes):
+                col = cols[c]
+                bad = bad + ((col < 0) | (col >= sz)).sum()
+                inv = inv + col.clamp(0, sz - 1) * st
+            acc_bad = self.__dict__.get("_label_bad")
+            self.__dict__["_label_bad"] = bad if acc_bad is None else acc_bad + bad
+            inv = inv.to(torch.int32).contiguous()
+            cols, n_u, cell_row_ptr = ucols, dense_total, inv.data_ptr()
+            keep.append(inv)
+        elif dedup and used:
             key = tuple((c, cols[c].data_ptr(), cols[c]._version, B) for c in used)
             hit = self._dedup_cache.get(key)
             if hit is None:

@@ -91,6 +91,21 @@ def generate_cells_stream(dit, vae, batches, guidance_weight, genes: torch.Tenso
             indptr, indices, data = dense_to_csr(counts)          # (its one host wait - nnz sizes the arrays - waits for `side` only)
             return to_host(indptr, indices, data, z)              # z, sf stay referenced by `item` until `side` has drained
 
+    # The CFG plan of a solve must not wait for the host (torch.unique does: behind the PREVIOUS batch's solve, which is what the pipeline wants
+    # to run ahead of): dense label-tuple rows, out-of-range labels clamped on the device and raised by check_labels() after the loop.
+    had_flag = getattr(dit, "deferred_label_check", None)
+    if had_flag is not None:
+        dit.deferred_label_check = True
+    try:
+        yield from _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_method, size_factor_sampler, seeds, dev, finish)
+    finally:
+        if had_flag is not None:
+            dit.deferred_label_check = had_flag
+    if hasattr(dit, "check_labels"):
+        dit.check_labels()
+
+
+def _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_method, size_factor_sampler, seeds, dev, finish):
     pending = None
     # (no torch.no_grad() around the loop: a context held across `yield` would leak into the consumer's code; nothing here records a graph)
     for batch in batches:

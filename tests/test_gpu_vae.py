@@ -227,6 +227,12 @@ def test_generate_cells_stream_equals_the_serial_chain_batch_by_batch():
     assert len(outs) == 2 and outs[0][0].shape == (2 * B + 1,) and int(outs[0][0][-1]) == outs[0][2].numel()
     with pytest.raises(ValueError, match="size_factor_sampler"):
         next(generate_cells_stream(dit, vae, [items[0][0]], scales, genes, num_steps=3))
+    # inside the loop the CFG plan is sync-free (dense label-tuple rows): out-of-range labels are clamped on the device and raised after the loop
+    assert dit.deferred_label_check is False
+    bad = ({"clusters": torch.full((B,), 99, dtype=torch.long, device="cuda")}, items[0][1], items[0][2])
+    with pytest.raises(IndexError):
+        list(generate_cells_stream(dit, vae, [items[0], bad], scales, genes, num_steps=3, seeds=[1, 2]))
+    assert dit.deferred_label_check is False and dit.check_labels() == 0
 
 
 def test_bf16_decode_close_to_fp32():
