@@ -460,14 +460,25 @@ __global__ __launch_bounds__(256) void t_embed_all_kernel(int steps, int heun, c
     te[n] = (n < 128) ? cosf(arg) : sinf(arg);
   }
   __syncthreads();
+  // (64 weight loads requested together, additions in k order: as t_embed_kernel)
   float s = b0[n];
-#pragma unroll 8
-  for (int k = 0; k < 256; ++k) s += w0t[k * 256 + n] * te[k];
+  for (int k0 = 0; k0 < 256; k0 += 64) {
+    float wv[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wv[j] = w0t[(k0 + j) * 256 + n];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) s += wv[j] * te[k0 + j];
+  }
   h1[n] = silu_f(s);
   __syncthreads();
   float c = b2[n];
-#pragma unroll 8
-  for (int k = 0; k < 256; ++k) c += w2t[k * 256 + n] * h1[k];
+  for (int k0 = 0; k0 < 256; k0 += 64) {
+    float wv[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) wv[j] = w2t[(k0 + j) * 256 + n];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) c += wv[j] * h1[k0 + j];
+  }
   temb_all[(size_t)e * 256 + n] = c;
 }
 
