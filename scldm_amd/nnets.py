@@ -700,11 +700,12 @@ class DiT(nn.Module):
         dense_total = 1
         for c in used:
             dense_total *= int(self.class_vocab_sizes[c]) + 1
-        if dedup and used and self.deferred_label_check and dense_total < B and dense_total <= 4096:
-            # Sync-free plan (opt-in, `deferred_label_check`): one conditioning row per POSSIBLE label tuple (15 for the dentate vocabulary)
-            # instead of per tuple present in this batch - no torch.unique, hence no host wait for the stream's earlier work (the prediction
-            # loop queues batch i + 1's solve while batch i's is still running).  Out-of-range labels are clamped and counted on the
-            # device like the plain forward's; `check_labels()` raises for them.
+        if dedup and used and dense_total < B and dense_total <= 4096:
+            # Dense plan (round 6): one conditioning row per POSSIBLE label tuple (15 for the dentate vocabulary) instead of per tuple
+            # present in this batch - no torch.unique (a sort, a scan and a dozen small launches per call).  With `deferred_label_check`
+            # it is also sync-free (the prediction loop queues batch i + 1's solve while batch i's is still running): out-of-range labels
+            # are clamped and counted on the device like the plain forward's and `check_labels()` raises for them; otherwise the count is
+            # read here and raises at once, as the torch.unique path below does.
             sizes = [int(self.class_vocab_sizes[c]) + 1 for c in used]
             dkey = (tuple(used), str(self.pos_embed.device))
             dense = self.__dict__.setdefault("_dense_rows", {}).get(dkey)
@@ -718,15 +719,27 @@ class DiT(nn.Module):
                 dense = ({c: ((idx // st) % sz).contiguous() for c, st, sz in zip(used, strides, sizes)}, strides)
                 self.__dict__["_dense_rows"][dkey] = dense
             ucols, strides = dense
-            inv = torch.zeros(B, dtype=torch.long, device=self.pos_embed.device)
-            bad = torch.zeros((), dtype=torch.long, device=self.pos_embed.device)
-            for c, st, sz in zip(used, strides, sizes):
-                col = cols[c]
-                bad = bad + ((col < 0) | (col >= sz)).sum()
-                inv = inv + col.clamp(0, sz - 1) * st
-            acc_bad = self.__dict__.get("_label_bad")
-            self.__dict__["_label_bad"] = bad if acc_bad is None else acc_bad + bad
-            inv = inv.to(torch.int32).contiguous()
+            # (same label tensors as the last call - a host-driven solver evaluating forward_with_cfg again and again: the row map is
+            # reused, nothing is launched and nothing is read back; the entry keeps the label tensors alive so that their addresses
+            # cannot be handed to other tensors)
+            key = ("dense",) + tuple((c, cols[c].data_ptr(), cols[c]._version, B) for c in used)
+            hit = self._dedup_cache.get(key)
+            if hit is None:
+                inv = torch.zeros(B, dtype=torch.long, device=self.pos_embed.device)
+                bad = torch.zeros((), dtype=torch.long, device=self.pos_embed.device)
+                for c, st, sz in zip(used, strides, sizes):
+                    col = cols[c]
+                    bad = bad + ((col < 0) | (col >= sz)).sum()
+                    inv = inv + col.clamp(0, sz - 1) * st
+                if self.deferred_label_check:
+                    acc_bad = self.__dict__.get("_label_bad")
+                    self.__dict__["_label_bad"] = bad if acc_bad is None else acc_bad + bad
+                elif int(bad):      # (the one host read of a call with new labels)
+                    raise IndexError(f"{int(bad)} condition label(s) were outside their class vocabulary (index out of range in self)")
+                hit = (inv.to(torch.int32).contiguous(), [cols[c] for c in used])
+                self._dedup_cache.clear()
+                self._dedup_cache[key] = hit
+            inv = hit[0]
             cols, n_u, cell_row_ptr = ucols, dense_total, inv.data_ptr()
             keep.append(inv)
         elif dedup and used:
