@@ -82,12 +82,24 @@ def generate_cells_stream(dit, vae, batches, guidance_weight, genes: torch.Tenso
     genes2 = torch.cat([genes, genes], dim=0)
     seeds = iter(seeds) if seeds is not None else None
 
+    first = [True]
+
     def finish(item):
         z, sf, ready, seed = item
         with torch.cuda.stream(side):
             side.wait_event(ready)
             lib = torch.exp(sf).view(-1, 1)
-            counts = vae.decode_sample(z, genes2, torch.cat([lib, lib], dim=0), seed=seed)
+            # (after the first batch the VAE's packed weight copies are checked through the version counters only: the device-side
+            # fingerprint pass - five small launches per decode - is for `.data` updates, which do not happen inside this loop)
+            keep_fp = getattr(vae, "check_weight_fingerprint", None)
+            if keep_fp is not None and not first[0]:
+                vae.check_weight_fingerprint = False
+            try:
+                counts = vae.decode_sample(z, genes2, torch.cat([lib, lib], dim=0), seed=seed)
+            finally:
+                if keep_fp is not None:
+                    vae.check_weight_fingerprint = keep_fp
+                first[0] = False
             indptr, indices, data = dense_to_csr(counts)          # (its one host wait - nnz sizes the arrays - waits for `side` only)
             return to_host(indptr, indices, data, z)              # z, sf stay referenced by `item` until `side` has drained
 
@@ -106,6 +118,8 @@ def generate_cells_stream(dit, vae, batches, guidance_weight, genes: torch.Tenso
 
 
 def _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_method, size_factor_sampler, seeds, dev, finish):
+    import contextlib
+    from .nnets import weights_unchanged
     pending = None
     # (no torch.no_grad() around the loop: a context held across `yield` would leak into the consumer's code; nothing here records a graph)
     for batch in batches:
@@ -117,7 +131,8 @@ def _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_
             sf = size_factor_sampler.sample(cond, B)
         if z0 is None:
             z0 = torch.randn((B, dit.seq_len, vae.encoder.latent_embedding), device=dev)
-        z = sample_latents(dit, z0, cond, guidance_weight, num_steps, sampling_method)      # queued; the host does not wait
+        with (weights_unchanged() if pending is not None else contextlib.nullcontext()):   # (the first batch checked the DiT's packed weights)
+            z = sample_latents(dit, z0, cond, guidance_weight, num_steps, sampling_method)  # queued; the host does not wait
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         seed = int(next(seeds)) if seeds is not None else int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
