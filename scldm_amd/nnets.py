@@ -8,6 +8,7 @@ through libscldm_hip.so (include/scldm_hip.h); there is no eager/CPU fallback.
 from __future__ import annotations
 
 import contextlib
+import threading
 
 import ctypes as C
 import os
@@ -163,7 +164,11 @@ class _DiTTrainFn(torch.autograd.Function):
         return (None, dx, None, None, None, *out)
 
 
-_ASSUME_WEIGHTS_UNCHANGED = [0]
+class _PerThreadDepth(threading.local):
+    depth = 0
+
+
+_ASSUME_WEIGHTS_UNCHANGED = _PerThreadDepth()      # (per thread: another thread's sampler loop says nothing about this thread's updates)
 
 
 @contextlib.contextmanager
@@ -172,11 +177,11 @@ def weights_unchanged():
     per-call device-side fingerprint pass (there for in-place `.data` updates, which those counters do not see) is skipped.  For loops that
     call the model many times with no parameter update in between - `scldm_amd.transport.Sampler`'s evaluation loops use it after their
     first evaluation (the reference's default dopri5 solve: 110 calls of forward_with_cfg)."""
-    _ASSUME_WEIGHTS_UNCHANGED[0] += 1
+    _ASSUME_WEIGHTS_UNCHANGED.depth += 1
     try:
         yield
     finally:
-        _ASSUME_WEIGHTS_UNCHANGED[0] -= 1
+        _ASSUME_WEIGHTS_UNCHANGED.depth -= 1
 
 
 class DiT(nn.Module):
@@ -349,7 +354,7 @@ class DiT(nn.Module):
         if key != self._weights_key:
             self._load_weights(L)
             self._weights_key = key
-        elif not _ASSUME_WEIGHTS_UNCHANGED[0]:
+        elif not _ASSUME_WEIGHTS_UNCHANGED.depth:
             # same storages and version counters: `.data` updates (EMA) are invisible to both, so the C side compares a
             # device-side fingerprint of the parameters and re-packs in stream order if it moved (no host synchronisation).
             # Skipped inside `weights_unchanged()` (the samplers' evaluation loops: 25 + 5 + 10 us of launches per call).

@@ -208,3 +208,21 @@ def test_adamw_launch_table_layout_is_built_on_the_host():
     ent[1].v = None
     with pytest.raises(_lib.ScldmError, match="NULL"):
         _lib.check(L.scldm_adamw_table_build(ent, None, len(sizes), buf, nb, C.byref(n_blocks)), "null")
+
+
+def test_weights_unchanged_context_nests_and_is_per_thread():
+    """scldm_amd.nnets.weights_unchanged (the samplers' evaluation loops skip the device-side weight fingerprint pass inside it): a depth
+    counter, restored on exit and on exceptions, private to the thread that entered it."""
+    import threading
+    from scldm_amd.nnets import _ASSUME_WEIGHTS_UNCHANGED as A, weights_unchanged
+    assert A.depth == 0
+    with weights_unchanged():
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(A.depth)); t.start(); t.join()
+        assert A.depth == 1 and seen == [0]
+        with pytest.raises(RuntimeError):
+            with weights_unchanged():
+                assert A.depth == 2
+                raise RuntimeError("x")
+        assert A.depth == 1
+    assert A.depth == 0
