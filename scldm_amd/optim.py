@@ -130,6 +130,9 @@ class AdamW(torch.optim.Optimizer):
         if grad_scale is not None:
             raise NotImplementedError("scldm_amd.optim.AdamW takes found_inf only: un-scale the gradients before the step (the fp16 backward does)")
         L = _lib.lib()
+        first = next((p for g in self.param_groups for p in g["params"] if p.grad is not None), None)
+        if first is not None and not first.is_cuda:
+            raise RuntimeError("scldm_amd.optim.AdamW: fp32 CUDA (ROCm) parameters with dense fp32 gradients only; there is no CPU path")
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         if not capturing:
             self.refresh_hyper()

@@ -226,3 +226,28 @@ def test_weights_unchanged_context_nests_and_is_per_thread():
                 raise RuntimeError("x")
         assert A.depth == 1
     assert A.depth == 0
+
+
+def test_round6_host_faces_fail_loudly_without_gpu():
+    """The round-6 host entry points on CPU modules: the prediction loop and the fused training step refuse to run (no CPU path), the
+    optimizer's extension of torch's signature validates its argument, and an optimizer on CPU parameters raises at step()."""
+    from scldm_amd.nnets import DiT
+    from scldm_amd.optim import AdamW
+    from scldm_amd.sampling import generate_cells_stream
+    from scldm_amd.training import FusedTrainStep
+    from scldm_amd.transport import create_transport
+    dit = DiT(n_embed=256, n_embed_input=16, n_layer=1, n_head=8, seq_len=16, dropout=0.0, bias=True, norm_layer="layernorm", multiple_of=4,
+              layernorm_eps=1e-8, class_vocab_sizes={"clusters": 14}, cfg_dropout_prob=0.8)
+    assert dit.deferred_label_check is False
+    with pytest.raises(RuntimeError, match="CUDA"):
+        next(generate_cells_stream(dit, None, [{"clusters": torch.zeros(4, dtype=torch.long)}], {"clusters": 1.0}, torch.zeros(4, 8, dtype=torch.long)))
+    with pytest.raises(ValueError):
+        AdamW(dit.parameters(), max_grad_norm=-1.0)
+    opt = AdamW(dit.parameters(), lr=1e-3, max_grad_norm=10.0)
+    assert opt.max_grad_norm == 10.0 and opt.last_grad_norm is None
+    with pytest.raises(RuntimeError, match="CUDA"):
+        FusedTrainStep(dit, create_transport("Linear", "velocity", "velocity", 1e-5, 1e-5), opt, 8, ["clusters"])
+    for p in dit.parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        opt.step()
