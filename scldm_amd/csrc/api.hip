@@ -975,13 +975,14 @@ extern "C" int scldm_sample_ode(scldm_dit* h, float* z, const int64_t* const* ul
   // Conditioning of the whole solve up front (round 6): the adaLN vectors depend on t and the labels only, so every evaluation's rows go
   // through ONE timestep-embedding launch (above), ONE row launch and ONE adaLN projection over n_evals x n_rows rows instead of two
   // launches per evaluation on the critical path (4.7 + 8.2 us of a 174 us evaluation at 128 cells: profiles/r6_small_batch_trace.txt).
-  // Same kernels, same per-row arithmetic: bit-identical (tested).  Budget 512 MB (15 rows x 100 evaluations = 83 MB for the dentate
-  // vocabulary; a batch of 1 024 distinct joint labels would need 5.7 GB and keeps the per-evaluation launches).
+  // Same kernels, same per-row arithmetic: bit-identical (tested).  Budget 1 GB (15 rows x 100 evaluations = 83 MB for the dentate
+  // vocabulary, 51 rows x 200 Heun evaluations = 564 MB for hlca; a batch of 1 024 distinct joint labels would need 5.7 GB and keeps the
+  // per-evaluation launches).
   float* mod_all = nullptr;
   if (pre && !ahead && h->cond_all_on && n_evals > 1) {
     const size_t rows_all = (size_t)n_evals * pl.n_rows;
     const size_t b_mod = align256(rows_all * h->mod_w * 4), b_silu = align256((rows_all + 1) * 256 * 4), b_split = align256((rows_all + 31) / 32 * 32 * 256 * 4);
-    if (b_mod <= ((size_t)512 << 20)) {
+    if (b_mod <= ((size_t)1 << 30)) {
       const size_t need = b_mod + b_silu + b_split;
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(st, &cap);
