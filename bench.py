@@ -879,19 +879,24 @@ def generation_end_to_end(wl_name, n_genes, device, precision, reps=5):
     from scldm_amd.sampling import generate_cells_stream
     K = 8
     genes1 = genes2[:B]
-    def run_stream():
-        return sum(int(out[2].numel()) for out in generate_cells_stream(m, vae, [cond] * K, scales, genes1, steps, wl["method"], size_factor_sampler=smp))
-    run_stream()
-    torch.cuda.synchronize()
-    tp = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        run_stream()
+    def run_stream(merge=1):
+        return sum(int(out[2].numel()) for out in generate_cells_stream(m, vae, [cond] * K, scales, genes1, steps, wl["method"], size_factor_sampler=smp,
+                                                                        merge_batches=merge))
+    def time_stream(merge):
+        run_stream(merge)
         torch.cuda.synchronize()
-        tp.append((time.perf_counter() - t0) / K)
-    dtp = statistics.median(tp)
+        tp = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run_stream(merge)
+            torch.cuda.synchronize()
+            tp.append((time.perf_counter() - t0) / K)
+        return statistics.median(tp)
+    dtp, dtm = time_stream(1), time_stream(4)
     pipelined = {"batches": K, "cells_per_s": B / dtp, "ms_per_batch": 1e3 * dtp,
-                 "path": "generate_cells_stream: ODE of batch i+1 on the caller's stream || decode_sample + dense_to_csr + to_host of batch i on a second stream"}
+                 "path": "generate_cells_stream: ODE of batch i+1 on the caller's stream || decode_sample + dense_to_csr + to_host of batch i on a second stream",
+                 "four_batches_per_solve": {"cells_per_s": B / dtm, "ms_per_batch": 1e3 * dtm,
+                                            "note": "merge_batches=4: four consecutive batches share one solve (bit-identical arrays per batch; a cell's trajectory does not depend on its batch)"}}
     return {"workload": wl_name, "pipelined": pipelined, "cells": B, "generated_rows": 2 * B, "n_genes": n_genes, "cfg_evaluations": wl["evals"], "method": wl["method"],
             "dit_precision": precision, "decode_precision": vae.precision, "cells_per_s": B / dt, "ms": 1e3 * dt, "ms_each": [round(1e3 * t, 3) for t in ts],
             "stage_ms": {"size_factors_and_noise": stage[0], "ode": stage[1], "decode_and_nb_draw": stage[2], "csr_assembly": stage[3],
@@ -951,6 +956,10 @@ def compact_line(result):
     put("e2e_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "cells_per_s")
     put("e2e_ms_dentate512", "generation_end_to_end", "dentate_b512_euler50", "ms")
     put("e2e_pipelined_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "pipelined", "cells_per_s")
+    put("e2e_merged4_cells_per_s_dentate512", "generation_end_to_end", "dentate_b512_euler50", "pipelined", "four_batches_per_solve", "cells_per_s")
+    put("e2e_cells_per_s_dentate128", "generation_end_to_end", "dentate_b128_euler50", "cells_per_s")
+    put("e2e_pipelined_cells_per_s_dentate128", "generation_end_to_end", "dentate_b128_euler50", "pipelined", "cells_per_s")
+    put("e2e_merged4_cells_per_s_dentate128", "generation_end_to_end", "dentate_b128_euler50", "pipelined", "four_batches_per_solve", "cells_per_s")
     put("e2e_pipelined_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "pipelined", "cells_per_s")
     put("e2e_cells_per_s_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "cells_per_s")
     put("e2e_ms_parse1m1024", "generation_end_to_end", "parse1m_b1024_euler100", "ms")
@@ -1200,6 +1209,7 @@ def main():
             note("mcab roofline done")
             try:   # configs[1] as the reference's predict_step delivers it, and the configs[3] per-GPU shard
                 result["generation_end_to_end"] = {
+                    "dentate_b128_euler50": generation_end_to_end("dentate_b128_euler50", 17002, device, args.precision),     # the reference's generation batch size (generation.yaml:16)
                     "dentate_b512_euler50": generation_end_to_end("dentate_b512_euler50", 17002, device, args.precision),
                     "parse1m_b1024_euler100": generation_end_to_end("parse1m_b1024_euler100", 2000, device, args.precision)}
             except Exception as e:   # an extra: never takes the headline line down

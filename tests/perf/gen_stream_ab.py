@@ -31,14 +31,15 @@ def serial():
         lib = torch.exp(sf).view(-1, 1)
         to_host(*dense_to_csr(vae.decode_sample(z, genes2, torch.cat([lib, lib]))), z)
 
-def piped():
-    for _ in generate_cells_stream(m, vae, [cond] * K, scales, genes, steps, wl["method"], size_factor_sampler=smp):
+def piped(merge=1):
+    for _ in generate_cells_stream(m, vae, [cond] * K, scales, genes, steps, wl["method"], size_factor_sampler=smp, merge_batches=merge):
         pass
 
-for name, fn in (("serial", serial), ("pipeline", piped), ("serial", serial), ("pipeline", piped)):
+for name, fn in (("serial", serial), ("pipeline", piped), ("pipeline, 2 batches per solve", lambda: piped(2)), ("pipeline, 4 batches per solve", lambda: piped(4)),
+                 ("serial", serial), ("pipeline", piped), ("pipeline, 2 batches per solve", lambda: piped(2)), ("pipeline, 4 batches per solve", lambda: piped(4))):
     fn(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / K)
     dt = statistics.median(ts)
-    print(f"{wl_name} {name:28s} {1e3 * dt:7.3f} ms per batch  {B / dt:9.0f} cells/s   ({', '.join(f'{1e3 * t:.2f}' for t in ts)})")
+    print(f"{wl_name} {name:32s} {1e3 * dt:7.3f} ms per batch  {B / dt:9.0f} cells/s   ({', '.join(f'{1e3 * t:.2f}' for t in ts)})")

@@ -220,6 +220,14 @@ def test_generate_cells_stream_equals_the_serial_chain_batch_by_batch():
         for x, y in zip(a, b):
             assert x.dtype == y.dtype and torch.equal(x, y)
     assert not torch.equal(got[0][2], got[1][2])
+    # k consecutive batches sharing ONE solve (a cell's trajectory does not depend on its batch): the same arrays batch by batch, also when
+    # the last group is short
+    for k in (2, 3, 8):
+        merged = list(generate_cells_stream(dit, vae, items, scales, genes, num_steps=5, sampling_method="heun", seeds=seeds, merge_batches=k))
+        assert len(merged) == K
+        for a, b in zip(serial, merged):
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and torch.equal(x, y), k
     # size factors drawn by the sampler when a batch carries none; a generator (lazy) source works
     from types import SimpleNamespace
     smp = SimpleNamespace(sample=lambda c, b: torch.full((b,), 6.0, device="cuda"))
