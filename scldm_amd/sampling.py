@@ -109,15 +109,9 @@ def generate_cells_stream(dit, vae, batches, guidance_weight, genes: torch.Tenso
 
     # The CFG plan of a solve must not wait for the host (torch.unique does: behind the PREVIOUS batch's solve, which is what the pipeline wants
     # to run ahead of): dense label-tuple rows, out-of-range labels clamped on the device and raised by check_labels() after the loop.
-    had_flag = getattr(dit, "deferred_label_check", None)
-    if had_flag is not None:
-        dit.deferred_label_check = True
-    try:
-        yield from _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_method, size_factor_sampler, seeds, dev, finish,
-                                max(1, int(merge_batches)))
-    finally:
-        if had_flag is not None:
-            dit.deferred_label_check = had_flag
+    # (the flag is set around each solve only - not across `yield`, where it would change the consumer's own calls)
+    yield from _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_method, size_factor_sampler, seeds, dev, finish,
+                            max(1, int(merge_batches)))
     if hasattr(dit, "check_labels"):
         dit.check_labels()
 
@@ -138,8 +132,15 @@ def _stream_loop(dit, vae, batches, guidance_weight, genes, num_steps, sampling_
         nb = len(group)
         cond = None if conds[0] is None else {k: torch.cat([c[k] for c in conds], dim=0) for k in conds[0]}
         z0 = z0s[0] if nb == 1 else torch.cat(z0s, dim=0)
-        with (weights_unchanged() if solved_any else contextlib.nullcontext()):   # (the first solve checked the DiT's packed weights)
-            z = sample_latents(dit, z0, cond, guidance_weight, num_steps, sampling_method)      # queued; the host does not wait
+        had_flag = getattr(dit, "deferred_label_check", None)
+        if had_flag is not None:
+            dit.deferred_label_check = True
+        try:
+            with (weights_unchanged() if solved_any else contextlib.nullcontext()):   # (the first solve checked the DiT's packed weights)
+                z = sample_latents(dit, z0, cond, guidance_weight, num_steps, sampling_method)      # queued; the host does not wait
+        finally:
+            if had_flag is not None:
+                dit.deferred_label_check = had_flag
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         Bt = nb * B
